@@ -1,0 +1,202 @@
+/* =============================================================================
+ * dbg_mi355x.h -- C ABI of the MI355X-native k-mer hot path of the `debruijn`
+ * crate (10XGenomics/rust-debruijn): k-mer extraction -> MSP shard ->
+ * count/filter -> path compression.
+ *
+ * The reference has no FFI: its boundary is the pair of generic Rust functions
+ * `filter_kmers` (src/filter.rs:139-148) and `compress_kmers_with_hash`
+ * (src/compression.rs:588-594) plus the sibling `msp_sequence`
+ * (src/msp.rs:279-288).  Traits and closures cannot cross a C ABI, so this
+ * header monomorphises over a closed set:
+ *   K   : VarIntKmer<u64|u128, K> with run-time k, 4 <= k <= 64; every key
+ *         crosses the ABI as a (hi, lo) u64 pair, right-aligned in 2k bits,
+ *         base 0 most significant (src/kmer.rs:429-437).
+ *   V   : any Vmer, flattened to PackedDnaStringSet layout
+ *         (src/dna_string.rs:762-767): one packed u64 stream (32 bases/word,
+ *         base i at bits [63-2(i%32), 62-2(i%32)] of word i/32,
+ *         src/dna_string.rs:383-399) + start[] (BASE offsets) + length[].
+ *   D1  : none | u8 | u16 | u32 (values must be < 2^24).
+ *   S   : CountFilter (src/filter.rs:40-63) | CountFilterSet (:68-101).
+ *   spec: SimpleCompress with saturating_add / (a+b)%65535 / max / wrapping add,
+ *         or ScmapCompress (src/compression.rs:40-98).
+ *
+ * Conventions: every function returns 0 on success; non-zero means "the
+ * reference would have panicked / invalid argument / device error" and
+ * dbg_last_error(ctx) holds the message.  The library allocates outputs; the
+ * caller releases them with the matching dbg_free_* call.  One ctx per host
+ * thread; no hidden globals (the reference functions are re-entrant).
+ * Functions suffixed _dev take and return DEVICE pointers (HBM-resident, the
+ * configuration the benchmark times); the unsuffixed ones take HOST pointers
+ * exactly like the Rust call sites and stage through PCIe.
+ * ========================================================================== */
+#ifndef DBG_MI355X_H
+#define DBG_MI355X_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dbg_ctx dbg_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+int         dbg_ctx_create(int device, dbg_ctx** out);
+void        dbg_ctx_destroy(dbg_ctx* ctx);
+const char* dbg_last_error(dbg_ctx* ctx);        /* ctx may be NULL: last create error */
+const char* dbg_version(void);
+/* use an externally owned hipStream_t (e.g. torch's current stream); NULL = ctx's own stream */
+int         dbg_ctx_set_stream(dbg_ctx* ctx, void* hip_stream);
+/* scratch budget in bytes for intermediate k-mer records (0 = 60% of free HBM) */
+int         dbg_ctx_set_scratch_budget(dbg_ctx* ctx, uint64_t bytes);
+
+/* ---- input: &[(V, Exts, D1)]  (src/filter.rs:140) flattened -------------- */
+typedef struct {
+    const uint64_t* words;      /* packed bases; n_words >= ceil(max(start+length)/32) */
+    uint64_t        n_words;
+    const uint64_t* start;      /* [n_seqs] base offset of each sequence (not word aligned) */
+    const uint32_t* length;     /* [n_seqs] bases */
+    const uint8_t*  exts;       /* [n_seqs] Exts byte of each sequence; NULL = Exts::empty() */
+    const void*     data;       /* [n_seqs] D1 values, width data_width bytes; NULL = unit */
+    uint32_t        data_width; /* 0, 1, 2 or 4 */
+    uint64_t        n_seqs;
+} dbg_seqset;
+
+/* ---- filter_kmers (src/filter.rs:139-231) -------------------------------- */
+enum { DBG_COUNT_FILTER = 0, DBG_COUNT_FILTER_SET = 1 };
+
+typedef struct {
+    uint32_t k;                 /* K::k() */
+    int32_t  stranded;          /* filter.rs:142 */
+    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min) */
+    uint64_t min_kmer_obs;      /* filter.rs:41,69 */
+    int32_t  report_all_kmers;  /* filter.rs:143 */
+    uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero) */
+} dbg_filter_params;
+
+/* The vectors the reference hands to BoomHashMap2::new (filter.rs:227-230), i.e. ascending
+ * k-mer order, as struct-of-arrays.  Host or device pointers depending on the call. */
+typedef struct {
+    uint64_t  n;                /* valid k-mers */
+    uint64_t* key_hi;           /* [n] zero when k <= 32 */
+    uint64_t* key_lo;           /* [n] */
+    uint8_t*  exts;             /* [n] accumulated Exts */
+    uint16_t* count;            /* [n] CountFilter DS = u16 (saturating); NULL for CountFilterSet */
+    uint64_t* set_off;          /* [n+1] CountFilterSet DS = Vec<D1> as CSR; NULL for CountFilter */
+    uint32_t* set_val;          /* [set_off[n]] sorted, de-duplicated D1 values */
+    uint64_t  n_set_val;
+    uint64_t  n_all;            /* all_kmers (second tuple element), 0 unless report_all_kmers */
+    uint64_t* all_hi;
+    uint64_t* all_lo;
+    uint64_t  n_kmer_instances; /* input_kmers (filter.rs:152-155) */
+    uint32_t  n_passes;         /* bucket-range passes actually run on the device */
+    int32_t   on_device;        /* 1 when the arrays are device pointers */
+} dbg_kmer_table;
+
+int  dbg_filter_kmers(dbg_ctx* ctx, const dbg_seqset* host_seqs, const dbg_filter_params* p, dbg_kmer_table* out_host);
+int  dbg_filter_kmers_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, const dbg_filter_params* p, dbg_kmer_table* out_dev);
+void dbg_free_table(dbg_ctx* ctx, dbg_kmer_table* t);
+/* copy a device table to freshly allocated host arrays */
+int  dbg_table_to_host(dbg_ctx* ctx, const dbg_kmer_table* dev, dbg_kmer_table* out_host);
+
+/* remove_censored_exts_sharded / remove_censored_exts (src/filter.rs:238-306): rewrites
+ * table->exts in place; all_* may be NULL for the non-sharded form. */
+int  dbg_remove_censored_exts(dbg_ctx* ctx, uint32_t k, int stranded, dbg_kmer_table* table, int sharded);
+
+/* ---- msp_sequence (src/msp.rs:279-324), batched over many sequences ------- */
+typedef struct {
+    uint32_t k;
+    uint32_t p;                 /* P::k(), 1 <= p <= 16, p <= k */
+    const uint32_t* permutation;/* [4^p] or NULL = identity (msp.rs:298-303) */
+    int32_t  rc;                /* msp.rs:283 */
+    uint32_t lmer_words;        /* V = Lmer<[u64; lmer_words]> (vmer.rs:32-47); 0 = do not emit packed pieces.
+                                   The reference asserts V::max_len() = (64*lmer_words-8)/2 >= 2k-p (msp.rs:292) */
+} dbg_msp_params;
+
+/* Vec<(u32, Exts, V)> of every input sequence, concatenated in input order; piece_off[i]..piece_off[i+1]
+ * are the pieces of sequence i (empty when its length < k, msp.rs:294-296). */
+typedef struct {
+    uint64_t  n_pieces;
+    uint64_t* piece_off;        /* [n_seqs+1] */
+    uint32_t* bucket;           /* [n_pieces] MspIntervalP::bucket() = canonical minimizer (msp.rs:115-117) */
+    uint8_t*  exts;             /* [n_pieces] Exts::from_slice_bounds (lib.rs:645-660) */
+    uint32_t* start;            /* [n_pieces] MspIntervalP.start */
+    uint16_t* len;              /* [n_pieces] MspIntervalP.len */
+    uint32_t* minimizer_pos;    /* [n_pieces] MspIntervalP.minimizer_pos */
+    uint64_t* lmer;             /* [n_pieces * lmer_words] V::from_slice(piece) or NULL */
+    int32_t   on_device;
+} dbg_msp_pieces;
+
+int  dbg_msp_sequence(dbg_ctx* ctx, const dbg_seqset* host_seqs, const dbg_msp_params* p, dbg_msp_pieces* out_host);
+int  dbg_msp_sequence_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, const dbg_msp_params* p, dbg_msp_pieces* out_dev);
+void dbg_free_pieces(dbg_ctx* ctx, dbg_msp_pieces* pc);
+
+/* ---- compress_kmers_with_hash (src/compression.rs:588-594) ---------------- */
+enum {
+    DBG_SPEC_SIMPLE_SAT_ADD_U16 = 0,   /* SimpleCompress(|a,b| a.saturating_add(*b))  (test.rs:383) */
+    DBG_SPEC_SIMPLE_ADD_MOD_U16 = 1,   /* SimpleCompress(|a,b| (a+b) % 65535)          (test.rs:247) */
+    DBG_SPEC_SIMPLE_MAX_U16     = 2,   /* SimpleCompress(|a,b| max(a,*b))              (test.rs:469) */
+    DBG_SPEC_SCMAP_EQ           = 3,   /* ScmapCompress                                (compression.rs:68-98) */
+    DBG_SPEC_SIMPLE_WRAP_ADD_U16= 4    /* SimpleCompress(|a,b| a+b), release build     (test.rs:265) */
+};
+
+/* BaseGraph<K,D> (src/graph.rs:43-50): sequences = PackedDnaStringSet (dna_string.rs:762-767) */
+typedef struct {
+    uint64_t  n_nodes;
+    uint64_t* seq_words;        /* sequences.sequence.storage */
+    uint64_t  n_seq_words;
+    uint64_t  seq_len_bases;    /* sequences.sequence.len */
+    uint64_t* start;            /* [n_nodes] sequences.start */
+    uint32_t* length;           /* [n_nodes] sequences.length */
+    uint8_t*  exts;             /* [n_nodes] */
+    uint32_t* data;             /* [n_nodes] D */
+    int32_t   stranded;
+} dbg_graph;
+
+/* index: the BoomHashMap2<K,Exts,D> contents as SoA (any key order).  data: u32 per k-mer or NULL
+ * (treated as 0).  seed_order: [n] permutation giving the id visited at each step of the reference's
+ * `for kmer_counter in 0..n` loop (compression.rs:574), i.e. the MPHF slot order supplied by the Rust
+ * shim; NULL = ascending key order.  index arrays are HOST pointers; the graph is returned on the host. */
+int  dbg_compress_kmers_with_hash(dbg_ctx* ctx, uint32_t k, int stranded, int spec,
+                                  uint64_t n, const uint64_t* key_hi, const uint64_t* key_lo,
+                                  const uint8_t* exts, const uint32_t* data,
+                                  const uint64_t* seed_order, dbg_graph* out);
+void dbg_free_graph(dbg_ctx* ctx, dbg_graph* g);
+
+/* ---- synthetic reads: splitmix64, deterministic ----- */
+typedef struct {
+    uint64_t n_reads;
+    uint32_t read_len;          /* L */
+    uint64_t genome_len;        /* G; 0 = n_reads*read_len/30 */
+    uint64_t genome_seed;       /* 0xDB60001 */
+    uint64_t read_seed;         /* 0xDB60002 */
+    double   error_rate;        /* substitution probability per base */
+    int32_t  stranded;          /* 0: reverse-complement each read with prob 1/2 */
+    uint32_t n_colours;         /* D1 = read_index % n_colours as u8; 0 = no data */
+    uint64_t first_read;        /* index of the first read to generate (shards a stream across ranks) */
+} dbg_synth_params;
+
+/* n_words needed for n_reads reads back-to-back + 2 words of tail padding */
+uint64_t dbg_synth_words(const dbg_synth_params* p);
+/* fill caller-allocated device buffers: words[dbg_synth_words], start[n], length[n], data[n] (u8, may be NULL) */
+int  dbg_synth_reads_dev(dbg_ctx* ctx, const dbg_synth_params* p, uint64_t* words, uint64_t* start,
+                         uint32_t* length, uint8_t* data);
+/* same stream generated on the host (no GPU needed) */
+int  dbg_synth_reads_host(const dbg_synth_params* p, uint64_t* words, uint64_t* start,
+                          uint32_t* length, uint8_t* data);
+
+/* ---- timing hook for bench.py: per-kernel HIP-event time of the last call --- */
+typedef struct {
+    char     name[48];
+    double   ms;                /* summed over launches in the last API call */
+    uint32_t launches;
+    uint64_t units;             /* k-mer instances (or records) the launches processed */
+} dbg_kernel_time;
+int  dbg_ctx_enable_timing(dbg_ctx* ctx, int on);
+int  dbg_ctx_get_timings(dbg_ctx* ctx, dbg_kernel_time* out, uint32_t cap, uint32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBG_MI355X_H */

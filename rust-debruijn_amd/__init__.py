@@ -1,0 +1,458 @@
+"""MI355X-native k-mer hot path of the `debruijn` crate (10XGenomics/rust-debruijn).
+
+Host-side mirror of the reference's interface for this path, over the C ABI in
+include/dbg_mi355x.h (hand-written HIP kernels for gfx950 behind it):
+
+    filter_kmers(seqs, summarizer, stranded, report_all_kmers, memory_size)   src/filter.rs:139-148
+    msp_sequence(k, seq, permutation, rc)                                      src/msp.rs:279-288
+    compress_kmers_with_hash(stranded, spec, index)                            src/compression.rs:588-594
+
+plus the plain-data types those functions exchange (Exts, PackedDnaStringSet, BaseGraph, the
+BoomHashMap2 contents as sorted struct-of-arrays).  K (k) and P (p) are type parameters in the
+reference and ordinary arguments here.  Everything computes on the GPU: there is no CPU fallback,
+and importing works without a GPU only so that the boundary itself can be inspected.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _capi
+from ._capi import SeqSet as _SeqSet
+
+__all__ = ["Context", "Exts", "CountFilter", "CountFilterSet", "SimpleCompress", "ScmapCompress",
+           "PackedDnaStringSet", "KmerTable", "BaseGraph", "filter_kmers", "msp_sequence",
+           "compress_kmers_with_hash", "remove_censored_exts", "remove_censored_exts_sharded",
+           "synth_reads_host", "pack_bases", "unpack_bases", "DbgError", "LEFT", "RIGHT"]
+
+LEFT, RIGHT = 0, 1
+M64 = (1 << 64) - 1
+
+
+class DbgError(RuntimeError):
+    """Raised where the reference would panic (assert!/panic!) or on a device error."""
+
+
+# ------------------------------------------------------------------------------------------------
+# plain-data mirrors
+# ------------------------------------------------------------------------------------------------
+class Exts:
+    """1-byte neighbour bitmap (src/lib.rs:577-749): low nibble = left A,C,G,T; high nibble = right."""
+    __slots__ = ("val",)
+
+    def __init__(self, val=0):
+        self.val = int(val) & 0xFF
+
+    @staticmethod
+    def empty():
+        return Exts(0)
+
+    def has_ext(self, direction, base):
+        return bool((self.val >> (4 * direction + base)) & 1)
+
+    def get(self, direction):
+        return [b for b in range(4) if self.has_ext(direction, b)]
+
+    def num_ext_dir(self, direction):
+        return bin((self.val >> (4 * direction)) & 0xF).count("1")
+
+    def rc(self):
+        l, r = self.val & 0xF, self.val >> 4
+        rev4 = lambda x: ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3)
+        return Exts((rev4(l) << 4) | rev4(r))
+
+    def __eq__(self, o):
+        return isinstance(o, Exts) and o.val == self.val
+
+    def __hash__(self):
+        return self.val
+
+    def __int__(self):
+        return self.val
+
+    def __repr__(self):
+        s = lambda d: "".join("ACGT"[b] for b in self.get(d))
+        return "%s|%s" % (s(LEFT), s(RIGHT))
+
+
+class CountFilter:
+    """KmerSummarizer: u16 saturating count, valid iff count >= min_kmer_obs (src/filter.rs:40-63)."""
+    kind = 0
+
+    def __init__(self, min_kmer_obs):
+        self.min_kmer_obs = int(min_kmer_obs)
+
+
+class CountFilterSet:
+    """KmerSummarizer: sorted de-duplicated label list, valid iff nobs >= min_kmer_obs (src/filter.rs:68-101)."""
+    kind = 1
+
+    def __init__(self, min_kmer_obs):
+        self.min_kmer_obs = int(min_kmer_obs)
+
+
+class SimpleCompress:
+    """CompressionSpec with join_test = true and a reduce closure from a closed set
+    (src/compression.rs:40-65): 'saturating_add', 'add_mod_65535', 'max', 'wrapping_add'."""
+    _KINDS = {"saturating_add": 0, "add_mod_65535": 1, "max": 2, "wrapping_add": 4}
+
+    def __init__(self, func="saturating_add"):
+        if func not in self._KINDS:
+            raise ValueError("reduce must be one of %s" % sorted(self._KINDS))
+        self.kind = self._KINDS[func]
+
+
+class ScmapCompress:
+    """CompressionSpec joining only equal data (src/compression.rs:68-98)."""
+    kind = 3
+
+
+def pack_bases(b):
+    """0-3 bases -> packed u64 words, base i at bits [63-2(i%32), 62-2(i%32)] of word i/32
+    (src/dna_string.rs:383-399)."""
+    b = np.asarray(b, dtype=np.uint64)
+    n = len(b)
+    nw = (n + 31) // 32
+    pad = np.zeros(nw * 32, dtype=np.uint64)
+    pad[:n] = b
+    shifts = (62 - 2 * np.arange(32)).astype(np.uint64)
+    if nw == 0:
+        return np.zeros(0, dtype=np.uint64)
+    return np.bitwise_or.reduce(pad.reshape(nw, 32) << shifts, axis=1).astype(np.uint64)
+
+
+def unpack_bases(words, start, length):
+    idx = np.arange(start, start + length, dtype=np.uint64)
+    w = np.asarray(words, dtype=np.uint64)[(idx >> np.uint64(5)).astype(np.int64)]
+    sh = (np.uint64(62) - np.uint64(2) * (idx & np.uint64(31))).astype(np.uint64)
+    return ((w >> sh) & np.uint64(3)).astype(np.uint8)
+
+
+class PackedDnaStringSet:
+    """Concatenated 2-bit store: sequence words + start (base offsets) + length
+    (src/dna_string.rs:762-822)."""
+
+    def __init__(self, words=None, start=None, length=None, n_bases=None):
+        self.words = np.zeros(0, np.uint64) if words is None else np.ascontiguousarray(words, np.uint64)
+        self.start = np.zeros(0, np.uint64) if start is None else np.ascontiguousarray(start, np.uint64)
+        self.length = np.zeros(0, np.uint32) if length is None else np.ascontiguousarray(length, np.uint32)
+        self.n_bases = int(n_bases) if n_bases is not None else (
+            int(self.start[-1] + self.length[-1]) if len(self.start) else 0)
+
+    @staticmethod
+    def from_seqs(seqs):
+        """PackedDnaStringSet::add for each sequence (back-to-back, not word aligned)."""
+        starts, lens, pos, parts = [], [], 0, []
+        for s in seqs:
+            s = np.asarray(s, dtype=np.uint8)
+            starts.append(pos)
+            lens.append(len(s))
+            parts.append(s)
+            pos += len(s)
+        cat = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        return PackedDnaStringSet(pack_bases(cat), starts, lens, pos)
+
+    def __len__(self):
+        return len(self.start)
+
+    def get(self, i):
+        return unpack_bases(self.words, int(self.start[i]), int(self.length[i]))
+
+
+class KmerTable:
+    """The BoomHashMap2<K, Exts, DS> contents as ascending-key struct-of-arrays (the vectors the
+    reference hands to BoomHashMap2::new, src/filter.rs:227-230)."""
+
+    def __init__(self, k):
+        self.k = k
+        self.key_hi = self.key_lo = self.exts = self.count = self.set_off = self.set_val = None
+        self.n_kmer_instances = 0
+        self.n_passes = 0
+
+    def __len__(self):
+        return len(self.key_lo)
+
+    def keys(self):
+        return [(int(h) << 64) | int(l) for h, l in zip(self.key_hi, self.key_lo)]
+
+    def data(self, i):
+        if self.count is not None:
+            return int(self.count[i])
+        return [int(x) for x in self.set_val[int(self.set_off[i]):int(self.set_off[i + 1])]]
+
+    def __iter__(self):
+        for i, kmer in enumerate(self.keys()):
+            yield kmer, Exts(self.exts[i]), self.data(i)
+
+
+class BaseGraph:
+    """BaseGraph<K, D> (src/graph.rs:43-50)."""
+
+    def __init__(self, k, sequences, exts, data, stranded):
+        self.k = k
+        self.sequences = sequences
+        self.exts = exts
+        self.data = data
+        self.stranded = stranded
+
+    def __len__(self):
+        return len(self.sequences)
+
+    def arrays(self):
+        return dict(words=self.sequences.words, start=self.sequences.start, length=self.sequences.length,
+                    exts=self.exts, data=self.data, n_bases=self.sequences.n_bases)
+
+
+# ------------------------------------------------------------------------------------------------
+# context
+# ------------------------------------------------------------------------------------------------
+class Context:
+    """One dbg_ctx: device, stream, pooled scratch.  One per host thread."""
+
+    def __init__(self, device=0):
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        r = self.lib.dbg_ctx_create(device, C.byref(h))
+        if r:
+            raise DbgError(self.lib.dbg_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dbg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, r):
+        if r:
+            raise DbgError(self.lib.dbg_last_error(self.h).decode())
+
+    def enable_timing(self, on=True):
+        self.check(self.lib.dbg_ctx_enable_timing(self.h, int(on)))
+
+    def timings(self):
+        arr = (_capi.KernelTime * 64)()
+        n = C.c_uint32()
+        self.check(self.lib.dbg_ctx_get_timings(self.h, arr, 64, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, units=arr[i].units)
+                for i in range(min(n.value, 64))]
+
+    def set_stream(self, hip_stream_ptr):
+        self.check(self.lib.dbg_ctx_set_stream(self.h, C.c_void_p(hip_stream_ptr)))
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HostSeqs:
+    """&[(V, Exts, D1)] flattened to the C-ABI's dbg_seqset (host arrays)."""
+
+    def __init__(self, words, start, length, exts=None, data=None, data_width=0):
+        self.words = np.ascontiguousarray(words, np.uint64)
+        self.start = np.ascontiguousarray(start, np.uint64)
+        self.length = np.ascontiguousarray(length, np.uint32)
+        self.exts = None if exts is None else np.ascontiguousarray(exts, np.uint8)
+        self.data_width = data_width if data is not None else 0
+        dt = {0: None, 1: np.uint8, 2: np.uint16, 4: np.uint32}[self.data_width]
+        self.data = None if data is None else np.ascontiguousarray(data, dt)
+
+    @staticmethod
+    def from_tuples(seqs, data_width=None):
+        """seqs: iterable of (bases, Exts|int, d) like the reference's &[(V, Exts, D1)]; d may be None/()."""
+        seqs = list(seqs)
+        ps = PackedDnaStringSet.from_seqs([s[0] for s in seqs])
+        exts = np.array([int(s[1]) for s in seqs], dtype=np.uint8)
+        has_d = any(not (s[2] is None or s[2] == ()) for s in seqs)
+        if has_d:
+            dv = [int(s[2]) for s in seqs]
+            if data_width is None:
+                mx = max(dv) if dv else 0
+                data_width = 1 if mx < 256 else (2 if mx < 65536 else 4)
+            return HostSeqs(ps.words, ps.start, ps.length, exts, dv, data_width)
+        return HostSeqs(ps.words, ps.start, ps.length, exts)
+
+    def c_struct(self):
+        s = _SeqSet()
+        s.words = _np_ptr(self.words)
+        s.n_words = len(self.words)
+        s.start = _np_ptr(self.start)
+        s.length = _np_ptr(self.length)
+        s.exts = _np_ptr(self.exts)
+        s.data = _np_ptr(self.data)
+        s.data_width = self.data_width
+        s.n_seqs = len(self.start)
+        return s
+
+
+def _copy(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
+
+
+def _table_from_c(t, k):
+    out = KmerTable(k)
+    n = t.n
+    out.key_hi = _copy(t.key_hi, n, np.uint64)
+    out.key_lo = _copy(t.key_lo, n, np.uint64)
+    out.exts = _copy(t.exts, n, np.uint8)
+    out.count = _copy(t.count, n, np.uint16) if t.count else None
+    out.set_off = _copy(t.set_off, n + 1, np.uint64) if t.set_off else None
+    out.set_val = _copy(t.set_val, t.n_set_val, np.uint32) if t.set_off else None
+    out.all_hi = _copy(t.all_hi, t.n_all, np.uint64)
+    out.all_lo = _copy(t.all_lo, t.n_all, np.uint64)
+    out.n_kmer_instances = t.n_kmer_instances
+    out.n_passes = t.n_passes
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's functions
+# ------------------------------------------------------------------------------------------------
+def filter_kmers(seqs, summarizer, stranded, report_all_kmers, memory_size, k, ctx=None):
+    """filter_kmers::<K, V, D1, DS, S> (src/filter.rs:139-231).
+
+    seqs: HostSeqs or an iterable of (bases, Exts, d).  Returns (KmerTable, all_kmers) where
+    all_kmers is the list of every observed k-mer (ascending) iff report_all_kmers, else []."""
+    ctx = ctx or default_context()
+    hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples(seqs)
+    p = _capi.FilterParams(k, int(bool(stranded)), summarizer.kind, summarizer.min_kmer_obs,
+                           int(bool(report_all_kmers)), int(memory_size))
+    cs = hs.c_struct()
+    t = _capi.KmerTable()
+    ctx.check(ctx.lib.dbg_filter_kmers(ctx.h, C.byref(cs), C.byref(p), C.byref(t)))
+    try:
+        out = _table_from_c(t, k)
+    finally:
+        ctx.lib.dbg_free_table(ctx.h, C.byref(t))
+    all_kmers = [(int(h) << 64) | int(l) for h, l in zip(out.all_hi, out.all_lo)]
+    return out, all_kmers
+
+
+def msp_sequence(k, seq, permutation=None, rc=True, p=8, lmer_words=0, ctx=None):
+    """msp_sequence::<P, V> (src/msp.rs:279-324) for one 0-3 byte sequence.
+    Returns [(bucket, Exts, piece_bases)]; with lmer_words > 0 the third element is the packed
+    Lmer<[u64; lmer_words]> words instead (src/vmer.rs:32-47)."""
+    res = msp_sequence_batch(k, [seq], permutation, rc, p, lmer_words, ctx)
+    seq = np.asarray(seq, dtype=np.uint8)
+    out = []
+    for i in range(len(res["bucket"])):
+        s, l = int(res["start"][i]), int(res["len"][i])
+        v = res["lmer"][i] if lmer_words else seq[s:s + l]
+        out.append((int(res["bucket"][i]), Exts(res["exts"][i]), v))
+    return out
+
+
+def msp_sequence_batch(k, seqs, permutation=None, rc=True, p=8, lmer_words=0, ctx=None):
+    """Batched msp_sequence over many sequences -> dict of arrays (+ piece_off per sequence)."""
+    ctx = ctx or default_context()
+    hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples([(s, 0, None) for s in seqs])
+    perm = None if permutation is None else np.ascontiguousarray(permutation, np.uint32)
+    mp = _capi.MspParams(k, p, _np_ptr(perm), int(bool(rc)), lmer_words)
+    cs = hs.c_struct()
+    pc = _capi.MspPieces()
+    ctx.check(ctx.lib.dbg_msp_sequence(ctx.h, C.byref(cs), C.byref(mp), C.byref(pc)))
+    try:
+        n = pc.n_pieces
+        res = dict(piece_off=_copy(pc.piece_off, len(hs.start) + 1, np.uint64), bucket=_copy(pc.bucket, n, np.uint32),
+                   exts=_copy(pc.exts, n, np.uint8), start=_copy(pc.start, n, np.uint32),
+                   len=_copy(pc.len, n, np.uint16), minimizer_pos=_copy(pc.minimizer_pos, n, np.uint32))
+        res["lmer"] = _copy(pc.lmer, n * lmer_words, np.uint64).reshape(n, lmer_words) if lmer_words else None
+    finally:
+        ctx.lib.dbg_free_pieces(ctx.h, C.byref(pc))
+    return res
+
+
+def compress_kmers_with_hash(stranded, spec, index, k=None, seed_order=None, data=None, ctx=None):
+    """compress_kmers_with_hash::<K, D, S> (src/compression.rs:588-594).
+
+    index: KmerTable (its count column is D unless `data` is given).  seed_order: optional
+    permutation standing in for the MPHF slot order the reference iterates in
+    (compression.rs:574); None = ascending key order."""
+    ctx = ctx or default_context()
+    k = k or index.k
+    n = len(index)
+    key_hi = np.ascontiguousarray(index.key_hi, np.uint64)
+    key_lo = np.ascontiguousarray(index.key_lo, np.uint64)
+    exts = np.ascontiguousarray(index.exts, np.uint8)
+    if data is None:
+        data = index.count if index.count is not None else np.zeros(n, np.uint32)
+    data = np.ascontiguousarray(data, np.uint32)
+    so = None if seed_order is None else np.ascontiguousarray(seed_order, np.uint64)
+    g = _capi.Graph()
+    ctx.check(ctx.lib.dbg_compress_kmers_with_hash(ctx.h, k, int(bool(stranded)), spec.kind, n, _np_ptr(key_hi),
+                                                   _np_ptr(key_lo), _np_ptr(exts), _np_ptr(data), _np_ptr(so),
+                                                   C.byref(g)))
+    try:
+        seqs = PackedDnaStringSet(_copy(g.seq_words, g.n_seq_words, np.uint64), _copy(g.start, g.n_nodes, np.uint64),
+                                  _copy(g.length, g.n_nodes, np.uint32), g.seq_len_bases)
+        out = BaseGraph(k, seqs, _copy(g.exts, g.n_nodes, np.uint8), _copy(g.data, g.n_nodes, np.uint32),
+                        bool(g.stranded))
+    finally:
+        ctx.lib.dbg_free_graph(ctx.h, C.byref(g))
+    return out
+
+
+def _censor(stranded, table, all_kmers, sharded, ctx):
+    ctx = ctx or default_context()
+    t = _capi.KmerTable()
+    key_hi = np.ascontiguousarray(table.key_hi, np.uint64)
+    key_lo = np.ascontiguousarray(table.key_lo, np.uint64)
+    exts = np.ascontiguousarray(table.exts, np.uint8).copy()
+    t.n = len(key_lo)
+    t.key_hi, t.key_lo, t.exts = _np_ptr(key_hi), _np_ptr(key_lo), _np_ptr(exts)
+    if sharded:
+        ah = np.array([v >> 64 for v in all_kmers], dtype=np.uint64)
+        al = np.array([v & M64 for v in all_kmers], dtype=np.uint64)
+        t.n_all, t.all_hi, t.all_lo = len(al), _np_ptr(ah), _np_ptr(al)
+    ctx.check(ctx.lib.dbg_remove_censored_exts(ctx.h, table.k, int(bool(stranded)), C.byref(t), int(sharded)))
+    table.exts = exts
+    return table
+
+
+def remove_censored_exts_sharded(stranded, table, all_kmers, ctx=None):
+    """src/filter.rs:238-276 on the sorted table (in place on table.exts)."""
+    return _censor(stranded, table, all_kmers, True, ctx)
+
+
+def remove_censored_exts(stranded, table, ctx=None):
+    """src/filter.rs:280-306."""
+    return _censor(stranded, table, None, False, ctx)
+
+
+def synth_params(n_reads, read_len=150, genome_len=0, error_rate=0.001, stranded=False, n_colours=4,
+                 first_read=0, genome_seed=0xDB60001, read_seed=0xDB60002):
+    return _capi.SynthParams(n_reads, read_len, genome_len, genome_seed, read_seed, error_rate, int(stranded),
+                             n_colours, first_read)
+
+
+def synth_reads_host(**kw):
+    """Deterministic synthetic reads generated on the host (no GPU): -> HostSeqs."""
+    lib = _capi.load()
+    p = synth_params(**kw)
+    nw = lib.dbg_synth_words(C.byref(p))
+    words = np.zeros(nw, np.uint64)
+    start = np.zeros(p.n_reads, np.uint64)
+    length = np.zeros(p.n_reads, np.uint32)
+    data = np.zeros(p.n_reads, np.uint8) if p.n_colours else None
+    r = lib.dbg_synth_reads_host(C.byref(p), _np_ptr(words), _np_ptr(start), _np_ptr(length), _np_ptr(data))
+    if r:
+        raise DbgError("synthetic genome shorter than a read")
+    return HostSeqs(words, start, length, None, data, 1 if p.n_colours else 0)

@@ -1,0 +1,68 @@
+"""Builds libdbg_mi355x.so (hand-written HIP kernels for gfx950 + the C ABI) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU; the built .so travels to the GPU box with the
+repository snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libdbg_mi355x.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result", "-ffp-contract=off"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "dbg_mi355x.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src[:-4] + ".o")
+    if _stale(obj, [os.path.join(CSRC, src)] + _headers()):
+        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = _sources()
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

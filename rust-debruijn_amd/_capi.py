@@ -1,0 +1,115 @@
+"""ctypes binding of include/dbg_mi355x.h (the C-ABI drop-in boundary).  No torch types cross it."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdbg_mi355x.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+u8p = C.POINTER(C.c_uint8)
+
+
+class SeqSet(C.Structure):
+    _fields_ = [("words", C.c_void_p), ("n_words", C.c_uint64), ("start", C.c_void_p), ("length", C.c_void_p),
+                ("exts", C.c_void_p), ("data", C.c_void_p), ("data_width", C.c_uint32), ("n_seqs", C.c_uint64)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("stranded", C.c_int32), ("summarizer", C.c_int32), ("min_kmer_obs", C.c_uint64),
+                ("report_all_kmers", C.c_int32), ("memory_size", C.c_uint64)]
+
+
+class KmerTable(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("key_hi", C.c_void_p), ("key_lo", C.c_void_p), ("exts", C.c_void_p),
+                ("count", C.c_void_p), ("set_off", C.c_void_p), ("set_val", C.c_void_p), ("n_set_val", C.c_uint64),
+                ("n_all", C.c_uint64), ("all_hi", C.c_void_p), ("all_lo", C.c_void_p),
+                ("n_kmer_instances", C.c_uint64), ("n_passes", C.c_uint32), ("on_device", C.c_int32)]
+
+
+class MspParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("p", C.c_uint32), ("permutation", C.c_void_p), ("rc", C.c_int32),
+                ("lmer_words", C.c_uint32)]
+
+
+class MspPieces(C.Structure):
+    _fields_ = [("n_pieces", C.c_uint64), ("piece_off", C.c_void_p), ("bucket", C.c_void_p), ("exts", C.c_void_p),
+                ("start", C.c_void_p), ("len", C.c_void_p), ("minimizer_pos", C.c_void_p), ("lmer", C.c_void_p),
+                ("on_device", C.c_int32)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("seq_words", C.c_void_p), ("n_seq_words", C.c_uint64),
+                ("seq_len_bases", C.c_uint64), ("start", C.c_void_p), ("length", C.c_void_p), ("exts", C.c_void_p),
+                ("data", C.c_void_p), ("stranded", C.c_int32)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("genome_len", C.c_uint64),
+                ("genome_seed", C.c_uint64), ("read_seed", C.c_uint64), ("error_rate", C.c_double),
+                ("stranded", C.c_int32), ("n_colours", C.c_uint32), ("first_read", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32), ("units", C.c_uint64)]
+
+
+# every symbol include/dbg_mi355x.h declares
+EXPORTS = [
+    "dbg_ctx_create", "dbg_ctx_destroy", "dbg_last_error", "dbg_version", "dbg_ctx_set_stream",
+    "dbg_ctx_set_scratch_budget", "dbg_filter_kmers", "dbg_filter_kmers_dev", "dbg_free_table", "dbg_table_to_host",
+    "dbg_remove_censored_exts", "dbg_msp_sequence", "dbg_msp_sequence_dev", "dbg_free_pieces",
+    "dbg_compress_kmers_with_hash", "dbg_free_graph", "dbg_synth_words", "dbg_synth_reads_dev",
+    "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
+]
+
+_lib = None
+
+
+def load():
+    """Load the HIP library.  There is no CPU fallback: a missing library is a hard error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libdbg_mi355x.so is not built (run `python __graft_entry__.py` / _build.build()); "
+                          "the MI355X hot path has no CPU fallback")
+    # torch bundles its own libamdhip64.so.7; two HIP runtimes in one process cannot both drive the
+    # GPU, so let torch's copy load first and satisfy this library's DT_NEEDED by SONAME.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.dbg_last_error.restype = C.c_char_p
+    lib.dbg_last_error.argtypes = [C.c_void_p]
+    lib.dbg_version.restype = C.c_char_p
+    lib.dbg_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.dbg_ctx_destroy.argtypes = [C.c_void_p]
+    lib.dbg_ctx_destroy.restype = None
+    lib.dbg_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dbg_ctx_set_scratch_budget.argtypes = [C.c_void_p, C.c_uint64]
+    lib.dbg_filter_kmers.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(FilterParams), C.POINTER(KmerTable)]
+    lib.dbg_filter_kmers_dev.argtypes = lib.dbg_filter_kmers.argtypes
+    lib.dbg_free_table.argtypes = [C.c_void_p, C.POINTER(KmerTable)]
+    lib.dbg_free_table.restype = None
+    lib.dbg_table_to_host.argtypes = [C.c_void_p, C.POINTER(KmerTable), C.POINTER(KmerTable)]
+    lib.dbg_remove_censored_exts.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(KmerTable), C.c_int]
+    lib.dbg_msp_sequence.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(MspParams), C.POINTER(MspPieces)]
+    lib.dbg_msp_sequence_dev.argtypes = lib.dbg_msp_sequence.argtypes
+    lib.dbg_free_pieces.argtypes = [C.c_void_p, C.POINTER(MspPieces)]
+    lib.dbg_free_pieces.restype = None
+    lib.dbg_compress_kmers_with_hash.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Graph)]
+    lib.dbg_free_graph.argtypes = [C.c_void_p, C.POINTER(Graph)]
+    lib.dbg_free_graph.restype = None
+    lib.dbg_synth_words.argtypes = [C.POINTER(SynthParams)]
+    lib.dbg_synth_words.restype = C.c_uint64
+    lib.dbg_synth_reads_dev.argtypes = [C.c_void_p, C.POINTER(SynthParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
+    lib.dbg_synth_reads_host.argtypes = [C.POINTER(SynthParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dbg_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.dbg_ctx_get_timings.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_uint32, C.POINTER(C.c_uint32)]
+    _lib = lib
+    return lib

@@ -1,0 +1,237 @@
+// extern "C" boundary: context management and filter_kmers (src/filter.rs:139-231).
+#include "dbg_internal.hpp"
+#include <algorithm>
+#include <cstdlib>
+
+static thread_local std::string g_create_err;
+
+extern "C" const char* dbg_version(void) { return "dbg_mi355x 0.1 (gfx950)"; }
+
+extern "C" int dbg_ctx_create(int device, dbg_ctx** out) {
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        (void)hipGetLastError();
+        g_create_err = "no HIP device available (the MI355X path has no CPU fallback)";
+        return 1;
+    }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return 2; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return 3; }
+    dbg_ctx* c = new dbg_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c; g_create_err = "hipStreamCreate failed"; return 4;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->t_clear();
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+    for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* dbg_last_error(dbg_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int dbg_ctx_set_stream(dbg_ctx* c, void* s) {
+    (void)hipStreamSynchronize(c->stream);
+    if (s) {
+        if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+        c->stream = (hipStream_t)s; c->own_stream = false;
+    } else if (!c->own_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return 0;
+}
+
+extern "C" int dbg_ctx_set_scratch_budget(dbg_ctx* c, uint64_t bytes) { c->scratch_budget = bytes; return 0; }
+
+extern "C" int dbg_ctx_enable_timing(dbg_ctx* c, int on) { c->timing = on != 0; c->t_clear(); return 0; }
+
+extern "C" int dbg_ctx_get_timings(dbg_ctx* c, dbg_kernel_time* out, uint32_t cap, uint32_t* n_out) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<dbg_kernel_time> agg;
+    for (auto& r : c->trecs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { (void)hipGetLastError(); continue; }
+        size_t i = 0;
+        for (; i < agg.size(); i++) if (!strcmp(agg[i].name, r.name)) break;
+        if (i == agg.size()) {
+            dbg_kernel_time t; memset(&t, 0, sizeof(t));
+            strncpy(t.name, r.name, sizeof(t.name) - 1);
+            agg.push_back(t);
+        }
+        agg[i].ms += ms; agg[i].launches += 1; agg[i].units += r.units;
+    }
+    uint32_t n = (uint32_t)std::min<size_t>(agg.size(), cap);
+    for (uint32_t i = 0; i < n; i++) out[i] = agg[i];
+    *n_out = (uint32_t)agg.size();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+static int validate_filter(dbg_ctx* c, const dbg_seqset* s, const dbg_filter_params* p) {
+    if (!s || !p) return c->fail(10, "null argument");
+    if (p->k < 4 || p->k > 64) return c->fail(11, "k must be in 4..=64 (filter.rs:18-23 reads the first 4 bases)");
+    if (p->memory_size == 0) return c->fail(12, "attempt to divide by zero: memory_size = 0 (filter.rs:158)");
+    if (p->summarizer != DBG_COUNT_FILTER && p->summarizer != DBG_COUNT_FILTER_SET) return c->fail(13, "unknown summarizer");
+    if (s->data && !(s->data_width == 1 || s->data_width == 2 || s->data_width == 4)) return c->fail(14, "data_width must be 1, 2 or 4");
+    if (s->n_seqs && (!s->words || !s->start || !s->length)) return c->fail(15, "null sequence arrays");
+    return 0;
+}
+
+static void table_from_reduce(const ReduceOut& r, uint64_t n_inst, dbg_kmer_table* t) {
+    memset(t, 0, sizeof(*t));
+    t->n = r.n_valid; t->key_hi = r.key_hi; t->key_lo = r.key_lo; t->exts = r.exts; t->count = r.count;
+    t->set_off = r.set_off; t->set_val = r.set_val; t->n_set_val = r.n_set_val;
+    t->n_all = r.n_all; t->all_hi = r.all_hi; t->all_lo = r.all_lo;
+    t->n_kmer_instances = n_inst; t->n_passes = 1; t->on_device = 1;
+}
+
+// Generic path: extract every k-mer instance -> global radix sort -> segmented reduce.
+extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out) {
+    DBG_TRY(validate_filter(c, ds, p));
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    memset(out, 0, sizeof(*out));
+    const int k = (int)p->k;
+    const bool has_hi = k > 32;
+    const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+
+    DBuf<uint32_t> kcount;
+    DBuf<uint64_t> koff;
+    ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
+    ALLOC_OR_FAIL(c, koff, s.n + 1);
+    DBG_TRY(kmer_counts(c, s, k, kcount.p));
+    DBG_TRY(scan_exclusive_u32_u64(c, kcount.p, koff.p, s.n));
+    uint64_t n_kmers = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_kmers, koff.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_kmers >= (1ull << 32)) return c->fail(20, "generic path: more than 2^32-1 k-mer instances in one call");
+
+    DBuf<uint64_t> a_hi, a_lo, b_hi, b_lo;
+    DBuf<uint32_t> a_pay, b_pay;
+    size_t nalloc = std::max<uint64_t>(n_kmers, 1);
+    if (has_hi) { ALLOC_OR_FAIL(c, a_hi, nalloc); ALLOC_OR_FAIL(c, b_hi, nalloc); }
+    ALLOC_OR_FAIL(c, a_lo, nalloc); ALLOC_OR_FAIL(c, b_lo, nalloc);
+    ALLOC_OR_FAIL(c, a_pay, nalloc); ALLOC_OR_FAIL(c, b_pay, nalloc);
+    RecArrays A{a_hi.p, a_lo.p, a_pay.p}, B{b_hi.p, b_lo.p, b_pay.p};
+    DBG_TRY(extract_kmers(c, s, koff.p, n_kmers, k, p->stranded != 0, A));
+    bool in_b = false;
+    // CountFilterSet needs (key, D1) order so distinct labels are adjacent; D1 < 2^24
+    int pay_bits = is_set && s.data ? (s.data_width == 1 ? 8 : (s.data_width == 2 ? 16 : 24)) : 0;
+    DBG_TRY(radix_sort_records(c, n_kmers, A, B, 2 * k, 8, pay_bits, &in_b));
+    ReduceOut r;
+    DBG_TRY(reduce_sorted_records(c, n_kmers, in_b ? B : A, has_hi, p->summarizer, p->min_kmer_obs,
+                                  p->report_all_kmers != 0, &r));
+    if (!has_hi && r.n_valid) HIP_TRY(c, hipMemsetAsync(r.key_hi, 0, r.n_valid * 8, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    table_from_reduce(r, n_kmers, out);
+    return 0;
+}
+
+static void* xmalloc(size_t n) { return malloc(n ? n : 1); }
+
+extern "C" int dbg_table_to_host(dbg_ctx* c, const dbg_kmer_table* d, dbg_kmer_table* h) {
+    *h = *d;
+    h->on_device = 0;
+    h->key_hi = h->key_lo = h->set_off = h->all_hi = h->all_lo = nullptr;
+    h->exts = nullptr; h->count = nullptr; h->set_val = nullptr;
+#define CP(field, T, cnt)                                                                             \
+    if (d->field) {                                                                                   \
+        h->field = (T*)xmalloc((size_t)(cnt) * sizeof(T));                                            \
+        if ((cnt)) HIP_TRY(c, hipMemcpyAsync(h->field, d->field, (size_t)(cnt) * sizeof(T), hipMemcpyDeviceToHost, c->stream)); \
+    }
+    CP(key_hi, uint64_t, d->n) CP(key_lo, uint64_t, d->n) CP(exts, uint8_t, d->n) CP(count, uint16_t, d->n)
+    CP(set_off, uint64_t, d->n + 1) CP(set_val, uint32_t, d->n_set_val) CP(all_hi, uint64_t, d->n_all) CP(all_lo, uint64_t, d->n_all)
+#undef CP
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" void dbg_free_table(dbg_ctx* c, dbg_kmer_table* t) {
+    if (!t) return;
+    void* ptrs[] = {t->key_hi, t->key_lo, t->exts, t->count, t->set_off, t->set_val, t->all_hi, t->all_lo};
+    for (void* p : ptrs) {
+        if (!p) continue;
+        if (t->on_device) { if (c) c->dfree(p); } else free(p);
+    }
+    memset(t, 0, sizeof(*t));
+}
+
+// host-pointer form: the Rust call site's shape (filter.rs:139-148); stages through PCIe
+struct DevSeqSet {
+    DBuf<uint64_t> words, start;
+    DBuf<uint32_t> length;
+    DBuf<uint8_t> exts, data;
+    dbg_seqset view;
+};
+int upload_seqset(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d) {
+    uint64_t n = hs->n_seqs;
+    // the device kernels never read past the last word a sequence touches, so n_words suffices
+    ALLOC_OR_FAIL(c, d->words, std::max<uint64_t>(hs->n_words, 1));
+    ALLOC_OR_FAIL(c, d->start, std::max<uint64_t>(n, 1));
+    ALLOC_OR_FAIL(c, d->length, std::max<uint64_t>(n, 1));
+    if (hs->n_words) HIP_TRY(c, hipMemcpyAsync(d->words.p, hs->words, hs->n_words * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(d->start.p, hs->start, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d->length.p, hs->length, n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    d->view = *hs;
+    d->view.words = d->words.p; d->view.start = d->start.p; d->view.length = d->length.p;
+    d->view.exts = nullptr; d->view.data = nullptr;
+    if (hs->exts) {
+        ALLOC_OR_FAIL(c, d->exts, std::max<uint64_t>(n, 1));
+        if (n) HIP_TRY(c, hipMemcpyAsync(d->exts.p, hs->exts, n, hipMemcpyHostToDevice, c->stream));
+        d->view.exts = d->exts.p;
+    }
+    if (hs->data && hs->data_width) {
+        ALLOC_OR_FAIL(c, d->data, std::max<uint64_t>(n * hs->data_width, 1));
+        if (n) HIP_TRY(c, hipMemcpyAsync(d->data.p, hs->data, n * hs->data_width, hipMemcpyHostToDevice, c->stream));
+        d->view.data = d->data.p;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs) {
+    // bounds + D1 range checks that would be undefined behaviour on the device
+    for (uint64_t i = 0; i < hs->n_seqs; i++) {
+        uint64_t end = hs->start[i] + hs->length[i];
+        if ((end + 31) / 32 > hs->n_words && hs->length[i]) return c->fail(16, "sequence runs past n_words");
+        if (hs->data && hs->data_width == 4 && ((const uint32_t*)hs->data)[i] >= (1u << 24))
+            return c->fail(17, "D1 values must be < 2^24");
+    }
+    return 0;
+}
+
+extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filter_params* p, dbg_kmer_table* out) {
+    DBG_TRY(validate_filter(c, hs, p));
+    DBG_TRY(check_host_seqset(c, hs));
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevSeqSet d;
+    DBG_TRY(upload_seqset(c, hs, &d));
+    dbg_kmer_table dev;
+    DBG_TRY(dbg_filter_kmers_dev(c, &d.view, p, &dev));
+    int r = dbg_table_to_host(c, &dev, out);
+    dbg_free_table(c, &dev);
+    return r;
+}
+
+extern "C" int dbg_synth_reads_dev(dbg_ctx* c, const dbg_synth_params* p, uint64_t* words, uint64_t* start,
+                                   uint32_t* length, uint8_t* data) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    DBG_TRY(synth_reads_dev(c, p, words, start, length, data));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}

@@ -1,0 +1,287 @@
+// Path compression: compress_kmers_with_hash (src/compression.rs:355-594) and the neighbour-probe
+// clean-up remove_censored_exts(_sharded) (src/filter.rs:238-306).
+//
+// Device: for every k-mer and both directions, one thread evaluates everything in
+// CompressFromHash::try_extend_kmer (compression.rs:382-444) that does not depend on the greedy
+// `available_kmers` state -- unique extension, canonicalisation + direction flip, presence of the
+// neighbour (binary search in the ascending key array replaces the BoomHashMap2 probe), its incoming
+// extension count, join_test and the palindrome rules -- and stores the result as a 32-bit link
+// ("GPU-resident neighbour bitmaps").  Host: the branchy greedy walk (extend_kmer / build_node /
+// compress_kmers, compression.rs:450-583) follows those links in the reference's seed order.
+#include "dbg_internal.hpp"
+#include <algorithm>
+#include <numeric>
+#include <deque>
+
+namespace {
+constexpr uint32_t LINK_TERM = 0xFFFFFFFFu;     // ExtMode::Terminal regardless of availability
+constexpr uint32_t LINK_PANIC = 0x80000000u;    // incoming_count == 0 && !palindrome (compression.rs:428-434) if reached
+// otherwise: (neighbour id << 1) | next_dir   (0 = Left, 1 = Right)
+
+struct KeysDev {
+    const uint64_t* hi;     // null when k <= 32
+    const uint64_t* lo;
+    uint64_t n;
+};
+
+__device__ __forceinline__ K128 key_at(const KeysDev& t, uint64_t i) { return K128{t.hi ? t.hi[i] : 0ull, t.lo[i]}; }
+
+// index of `q` in the ascending key array, or -1
+__device__ __forceinline__ int64_t find_key(const KeysDev& t, K128 q) {
+    uint64_t lo = 0, hi = t.n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        K128 m = key_at(t, mid);
+        if (k128_lt(m, q)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < t.n && k128_eq(key_at(t, lo), q)) return (int64_t)lo;
+    return -1;
+}
+
+__device__ __forceinline__ bool is_palindrome(K128 a, int k) { return (k & 1) == 0 && k128_eq(a, kmer_rc(a, k)); }   // lib.rs:244-246
+__device__ __forceinline__ uint32_t num_ext_dir(uint32_t e, int dir) { return __popc((e >> (4 * dir)) & 0xfu); }      // lib.rs:687-690
+__device__ __forceinline__ bool join_test(int spec, uint32_t a, uint32_t b) { return spec == DBG_SPEC_SCMAP_EQ ? a == b : true; }
+
+__global__ void link_kernel(KeysDev t, const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data, int k,
+                            int stranded, int spec, uint32_t* __restrict__ link /* [2][n] */) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n) return;
+    K128 kmer = key_at(t, i);
+    uint32_t e = exts[i];
+    bool self_pal = !stranded && is_palindrome(kmer, k);
+    for (int dir = 0; dir < 2; dir++) {
+        uint32_t out = LINK_TERM;
+        if (num_ext_dir(e, dir) == 1 && !self_pal) {                                   // compression.rs:386
+            uint32_t bits = (e >> (4 * dir)) & 0xfu;
+            uint32_t base = 31 - __clz(bits);                                          // get_unique_extension (lib.rs:704-717)
+            K128 next = dir == 0 ? kmer_extend_left(kmer, k, base) : kmer_extend_right(kmer, k, base);   // :392
+            bool flip = false;
+            if (!stranded) {                                                           // :396-400
+                K128 rc = kmer_rc(next, k);
+                if (!k128_lt(next, rc)) { next = rc; flip = true; }
+            }
+            int next_dir = flip ? 1 - dir : dir;                                       // :402
+            bool pal = !stranded && is_palindrome(next, k);                            // :403
+            int64_t nid = find_key(t, next);                                           // :410
+            if (nid >= 0) {
+                int new_incoming_dir = flip ? dir : 1 - dir;                           // dir.flip().cond_flip(flip) :419
+                uint32_t ne = exts[nid];
+                uint32_t incoming = num_ext_dir(ne, new_incoming_dir);                 // :422
+                bool can_join = join_test(spec, data ? data[i] : 0u, data ? data[nid] : 0u);   // :426
+                if (incoming == 0 && !pal) out = LINK_PANIC | ((uint32_t)nid << 1) | (uint32_t)next_dir;
+                else if (can_join && incoming == 1 && !pal) out = ((uint32_t)nid << 1) | (uint32_t)next_dir;   // :435-437
+            }
+        }
+        link[(uint64_t)dir * t.n + i] = out;
+    }
+}
+
+// remove_censored_exts(_sharded) (filter.rs:238-306)
+__global__ void censor_kernel(KeysDev valid, KeysDev all, uint8_t* __restrict__ exts, int k, int stranded, int sharded) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= valid.n) return;
+    K128 kmer = key_at(valid, i);
+    uint32_t e = exts[i], ne = 0;
+    for (int dir = 0; dir < 2; dir++) {
+        for (uint32_t b = 0; b < 4; b++) {
+            if (!((e >> (4 * dir + b)) & 1u)) continue;
+            K128 x = dir == 0 ? kmer_extend_left(kmer, k, b) : kmer_extend_right(kmer, k, b);
+            if (!stranded) { K128 rc = kmer_rc(x, k); if (!k128_lt(x, rc)) x = rc; }   // min_rc (lib.rs:234-241)
+            bool is_valid = find_key(valid, x) >= 0;
+            bool keep = sharded ? (is_valid || find_key(all, x) < 0) : is_valid;       // filter.rs:259-269 / :295-299
+            if (keep) ne |= 1u << (4 * dir + b);
+        }
+    }
+    exts[i] = (uint8_t)ne;
+}
+
+// ---- host side -----------------------------------------------------------------------------
+inline uint32_t spec_reduce(int spec, uint32_t a, uint32_t b, bool* panic) {
+    switch (spec) {
+        case DBG_SPEC_SIMPLE_SAT_ADD_U16: { uint32_t s = a + b; return s > 65535u ? 65535u : s; }
+        case DBG_SPEC_SIMPLE_ADD_MOD_U16: return (a + b) % 65535u;
+        case DBG_SPEC_SIMPLE_MAX_U16: return std::max(a, b);
+        case DBG_SPEC_SCMAP_EQ: if (a != b) *panic = true; return a;                  // compression.rs:88-93
+        case DBG_SPEC_SIMPLE_WRAP_ADD_U16: return (a + b) & 0xFFFFu;
+    }
+    return a;
+}
+
+struct BitPusher {          // DnaString::push (dna_string.rs:303-310) into a growing word vector
+    std::vector<uint64_t> words;
+    uint64_t len = 0;
+    inline void push(uint32_t b) {
+        if ((len & 31) == 0) words.push_back(0);
+        words.back() |= (uint64_t)(b & 3u) << (62 - 2 * (len & 31));
+        len++;
+    }
+};
+}  // namespace
+
+extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int stranded, int spec, uint64_t n,
+                                            const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
+                                            const uint32_t* data, const uint64_t* seed_order, dbg_graph* out) {
+    const int k = (int)k_;
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (spec < 0 || spec > 4) return c->fail(41, "unknown CompressionSpec");
+    if (n >= (1ull << 30)) return c->fail(42, "compress: at most 2^30-1 k-mers per call in this build");
+    if (n && (!key_lo || !exts)) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    memset(out, 0, sizeof(*out));
+    out->stranded = stranded ? 1 : 0;
+    const bool has_hi = k > 32;
+
+    // ids are positions in ascending key order; map the caller's ids when its arrays are not sorted
+    auto key_of = [&](uint64_t i) { return K128{has_hi && key_hi ? key_hi[i] : 0ull, key_lo[i]}; };
+    bool sorted = true;
+    for (uint64_t i = 1; i < n && sorted; i++) sorted = k128_lt(key_of(i - 1), key_of(i));
+    std::vector<uint64_t> s_hi, s_lo; std::vector<uint8_t> s_exts; std::vector<uint32_t> s_data;
+    std::vector<uint32_t> order;        // sorted position -> caller id
+    std::vector<uint32_t> rank;         // caller id -> sorted position
+    if (!sorted) {
+        order.resize(n); std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k128_lt(key_of(a), key_of(b)); });
+        for (uint64_t i = 1; i < n; i++)
+            if (k128_eq(key_of(order[i - 1]), key_of(order[i]))) return c->fail(43, "duplicate k-mer in index");
+        rank.resize(n); s_hi.resize(n); s_lo.resize(n); s_exts.resize(n); if (data) s_data.resize(n);
+        for (uint64_t i = 0; i < n; i++) {
+            uint32_t o = order[i]; rank[o] = (uint32_t)i;
+            s_hi[i] = has_hi && key_hi ? key_hi[o] : 0; s_lo[i] = key_lo[o]; s_exts[i] = exts[o];
+            if (data) s_data[i] = data[o];
+        }
+        key_hi = s_hi.data(); key_lo = s_lo.data(); exts = s_exts.data(); if (data) data = s_data.data();
+    }
+
+    // ---- device: neighbour links ----
+    std::vector<uint32_t> link(2 * n);
+    if (n) {
+        DBuf<uint64_t> d_hi, d_lo; DBuf<uint8_t> d_exts; DBuf<uint32_t> d_data, d_link;
+        if (has_hi) { ALLOC_OR_FAIL(c, d_hi, n); HIP_TRY(c, hipMemcpyAsync(d_hi.p, key_hi, n * 8, hipMemcpyHostToDevice, c->stream)); }
+        ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n); ALLOC_OR_FAIL(c, d_link, 2 * n);
+        HIP_TRY(c, hipMemcpyAsync(d_lo.p, key_lo, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_exts.p, exts, n, hipMemcpyHostToDevice, c->stream));
+        if (data) { ALLOC_OR_FAIL(c, d_data, n); HIP_TRY(c, hipMemcpyAsync(d_data.p, data, n * 4, hipMemcpyHostToDevice, c->stream)); }
+        KeysDev t{has_hi ? d_hi.p : nullptr, d_lo.p, n};
+        c->t_begin("compress_links", n);
+        link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "link_kernel");
+        HIP_TRY(c, hipMemcpyAsync(link.data(), d_link.p, 2 * n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+
+    // ---- host: greedy walk in seed order (compression.rs:545-583) ----
+    std::vector<uint8_t> available(n, 1);
+    auto first_base = [&](uint32_t id) { return kmer_get(K128{has_hi ? key_hi[id] : 0ull, key_lo[id]}, k, 0); };
+    auto last_base = [&](uint32_t id) { return (uint32_t)(key_lo[id] & 3ull); };
+    auto single_dir = [&](uint32_t id, int dir) -> uint32_t { return dir ? (exts[id] >> 4) : (exts[id] & 0xfu); };   // lib.rs:719-726
+    BitPusher seq;
+    std::vector<uint64_t> g_start; std::vector<uint32_t> g_len, g_data; std::vector<uint8_t> g_exts;
+    std::vector<std::pair<uint32_t, int>> path;
+    std::deque<uint8_t> edge;
+    bool spec_panic = false;
+    // extend_kmer (compression.rs:450-479) over precomputed links; returns the terminal Exts nibble
+    auto extend = [&](uint32_t seed, int start_dir, int* err) -> uint32_t {
+        path.clear();
+        uint32_t cur = seed; int dir = start_dir;
+        available[seed] = 0;                                                           // :458
+        for (;;) {
+            uint32_t L = link[(uint64_t)dir * n + cur];
+            if (L == LINK_TERM) return single_dir(cur, dir);
+            uint32_t nid = (L & 0x7FFFFFFFu) >> 1; int ndir = (int)(L & 1u);
+            if (!available[nid]) return single_dir(cur, dir);                          // :410-415
+            if (L & LINK_PANIC) { *err = 1; return 0; }                                // :428-434
+            path.push_back({nid, ndir});
+            available[nid] = 0;                                                        // :467
+            cur = nid; dir = ndir;
+        }
+    };
+    for (uint64_t cidx = 0; cidx < n; cidx++) {
+        uint64_t sid = seed_order ? seed_order[cidx] : cidx;
+        if (sid >= n) return c->fail(44, "seed_order entry out of range");
+        uint32_t seed = sorted ? (uint32_t)sid : rank[sid];
+        if (!available[seed]) continue;                                                // :575
+        K128 sk{has_hi ? key_hi[seed] : 0ull, key_lo[seed]};
+        edge.clear();
+        for (int i = 0; i < k; i++) edge.push_back((uint8_t)kmer_get(sk, k, i));       // :491-493
+        uint32_t node_data = data ? data[seed] : 0u;                                   // :495
+        int err = 0;
+        uint32_t l_ext = extend(seed, 0, &err);                                        // :497
+        if (err) return c->fail(45, "unreachable (compression.rs:434)");
+        for (auto& pr : path) {                                                        // :500-511
+            uint32_t b = pr.second == 0 ? first_base(pr.first) : 3u - last_base(pr.first);
+            edge.push_front((uint8_t)b);
+            node_data = spec_reduce(spec, node_data, data ? data[pr.first] : 0u, &spec_panic);
+        }
+        uint32_t left_extend = (!path.empty() && path.back().second == 1) ? exts_complement(l_ext) & 0xfu : l_ext;   // :513-517
+        uint32_t r_ext = extend(seed, 1, &err);                                        // :519
+        if (err) return c->fail(45, "unreachable (compression.rs:434)");
+        for (auto& pr : path) {                                                        // :522-532
+            uint32_t b = pr.second == 0 ? 3u - first_base(pr.first) : last_base(pr.first);
+            edge.push_back((uint8_t)b);
+            node_data = spec_reduce(spec, node_data, data ? data[pr.first] : 0u, &spec_panic);
+        }
+        uint32_t right_extend = (!path.empty() && path.back().second == 0) ? exts_complement(r_ext) & 0xfu : r_ext;  // :534-538
+        if (spec_panic) return c->fail(46, "ScmapCompress::reduce on unequal data: Should not happen (compression.rs:90)");
+        g_start.push_back(seq.len);                                                    // graph.rs:104-113, dna_string.rs:811-821
+        for (uint8_t b : edge) seq.push(b);
+        g_len.push_back((uint32_t)edge.size());
+        g_exts.push_back((uint8_t)(((right_extend & 0xfu) << 4) | (left_extend & 0xfu)));   // from_single_dirs (lib.rs:591-595)
+        g_data.push_back(node_data);
+    }
+
+    auto dup = [](const void* p, size_t bytes) { void* q = malloc(bytes ? bytes : 1); if (bytes) memcpy(q, p, bytes); return q; };
+    out->n_nodes = g_start.size();
+    out->n_seq_words = seq.words.size();
+    out->seq_len_bases = seq.len;
+    out->seq_words = (uint64_t*)dup(seq.words.data(), seq.words.size() * 8);
+    out->start = (uint64_t*)dup(g_start.data(), g_start.size() * 8);
+    out->length = (uint32_t*)dup(g_len.data(), g_len.size() * 4);
+    out->exts = (uint8_t*)dup(g_exts.data(), g_exts.size());
+    out->data = (uint32_t*)dup(g_data.data(), g_data.size() * 4);
+    return 0;
+}
+
+extern "C" void dbg_free_graph(dbg_ctx*, dbg_graph* g) {
+    if (!g) return;
+    free(g->seq_words); free(g->start); free(g->length); free(g->exts); free(g->data);
+    memset(g, 0, sizeof(*g));
+}
+
+extern "C" int dbg_remove_censored_exts(dbg_ctx* c, uint32_t k_, int stranded, dbg_kmer_table* t, int sharded) {
+    const int k = (int)k_;
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (!t) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool has_hi = k > 32;
+    uint64_t n = t->n, na = sharded ? t->n_all : 0;
+    if (n == 0) return 0;
+    DBuf<uint64_t> d_hi, d_lo, a_hi, a_lo; DBuf<uint8_t> d_exts;
+    KeysDev valid{nullptr, nullptr, n}, all{nullptr, nullptr, na};
+    uint8_t* ex = t->exts;
+    if (t->on_device) {
+        valid.hi = has_hi ? t->key_hi : nullptr; valid.lo = t->key_lo;
+        all.hi = has_hi ? t->all_hi : nullptr; all.lo = t->all_lo;
+    } else {
+        ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n);
+        HIP_TRY(c, hipMemcpyAsync(d_lo.p, t->key_lo, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_exts.p, t->exts, n, hipMemcpyHostToDevice, c->stream));
+        if (has_hi) { ALLOC_OR_FAIL(c, d_hi, n); HIP_TRY(c, hipMemcpyAsync(d_hi.p, t->key_hi, n * 8, hipMemcpyHostToDevice, c->stream)); }
+        if (na) {
+            ALLOC_OR_FAIL(c, a_lo, na);
+            HIP_TRY(c, hipMemcpyAsync(a_lo.p, t->all_lo, na * 8, hipMemcpyHostToDevice, c->stream));
+            if (has_hi) { ALLOC_OR_FAIL(c, a_hi, na); HIP_TRY(c, hipMemcpyAsync(a_hi.p, t->all_hi, na * 8, hipMemcpyHostToDevice, c->stream)); }
+        }
+        valid.hi = has_hi ? d_hi.p : nullptr; valid.lo = d_lo.p;
+        all.hi = has_hi ? a_hi.p : nullptr; all.lo = a_lo.p;
+        ex = d_exts.p;
+    }
+    c->t_begin("remove_censored_exts", n);
+    censor_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(valid, all, ex, k, stranded, sharded);
+    c->t_end();
+    LAUNCH_CHECK(c, "censor_kernel");
+    if (!t->on_device) HIP_TRY(c, hipMemcpyAsync(t->exts, d_exts.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}

@@ -1,0 +1,136 @@
+// Host-side context: device, stream, pooled device memory, error string, per-kernel HIP-event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdio>
+#include <cstring>
+#include "../../include/dbg_mi355x.h"
+
+struct dbg_timing_rec {
+    const char* name;
+    hipEvent_t a, b;
+    uint64_t units;
+};
+
+struct dbg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    uint64_t scratch_budget = 0;
+    bool timing = false;
+    std::vector<dbg_timing_rec> trecs;
+    std::vector<hipEvent_t> event_pool;
+    // pooled device allocations: free blocks by size; live blocks by pointer
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live_blocks;
+    size_t pooled_bytes = 0;
+
+    int fail(int code, const std::string& msg) { err = msg; return code; }
+
+    void* dalloc(size_t bytes) {
+        if (bytes == 0) bytes = 256;
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+            void* p = it->second;
+            live_blocks[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        live_blocks[p] = bytes;
+        pooled_bytes += bytes;
+        return p;
+    }
+    void dfree(void* p) {
+        if (!p) return;
+        auto it = live_blocks.find(p);
+        if (it == live_blocks.end()) { (void)hipFree(p); return; }
+        free_blocks.insert({it->second, p});
+        live_blocks.erase(it);
+    }
+    void trim() {
+        (void)hipStreamSynchronize(stream);
+        for (auto& kv : free_blocks) { (void)hipFree(kv.second); pooled_bytes -= kv.first; }
+        free_blocks.clear();
+    }
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void t_begin(const char* name, uint64_t units) {
+        if (!timing) return;
+        dbg_timing_rec r{name, get_event(), get_event(), units};
+        (void)hipEventRecord(r.a, stream);
+        trecs.push_back(r);
+    }
+    void t_end() {
+        if (!timing) return;
+        (void)hipEventRecord(trecs.back().b, stream);
+    }
+    void t_clear() {
+        for (auto& r : trecs) { event_pool.push_back(r.a); event_pool.push_back(r.b); }
+        trecs.clear();
+    }
+};
+
+// RAII device buffer drawn from the ctx pool
+template <class T>
+struct DBuf {
+    dbg_ctx* ctx = nullptr;
+    T* p = nullptr;
+    size_t n = 0;
+    DBuf() {}
+    DBuf(dbg_ctx* c, size_t count) { alloc(c, count); }
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    DBuf(DBuf&& o) noexcept : ctx(o.ctx), p(o.p), n(o.n) { o.p = nullptr; }
+    DBuf& operator=(DBuf&& o) noexcept { release(); ctx = o.ctx; p = o.p; n = o.n; o.p = nullptr; return *this; }
+    bool alloc(dbg_ctx* c, size_t count) {
+        release();
+        ctx = c; n = count;
+        p = (T*)c->dalloc(count * sizeof(T));
+        return p != nullptr;
+    }
+    void release() { if (p && ctx) ctx->dfree(p); p = nullptr; }
+    T* take() { T* q = p; p = nullptr; return q; }      // ownership leaves the RAII wrapper (stays a live pool block)
+    ~DBuf() { release(); }
+};
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            char _b[512];                                                                       \
+            snprintf(_b, sizeof(_b), "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+            return (ctx)->fail(100, _b);                                                        \
+        }                                                                                       \
+    } while (0)
+
+#define DBG_TRY(expr)                 \
+    do {                              \
+        int _r = (expr);              \
+        if (_r) return _r;            \
+    } while (0)
+
+#define ALLOC_OR_FAIL(ctx, buf, count)                                                          \
+    do {                                                                                        \
+        if (!(buf).alloc((ctx), (count))) {                                                     \
+            char _b[256];                                                                       \
+            snprintf(_b, sizeof(_b), "device allocation of %zu bytes failed at %s:%d",          \
+                     (size_t)(count) * sizeof(*(buf).p), __FILE__, __LINE__);                   \
+            return (ctx)->fail(101, _b);                                                        \
+        }                                                                                       \
+    } while (0)
+
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }

@@ -1,0 +1,69 @@
+// Internal host-side interfaces between the translation units of libdbg_mi355x.so.
+#pragma once
+#include "dbg_ctx.hpp"
+#include "dbg_device.hpp"
+
+// device view of &[(V, Exts, D1)] in PackedDnaStringSet layout
+struct SeqDev {
+    const uint64_t* words;
+    const uint64_t* start;
+    const uint32_t* length;
+    const uint8_t* exts;        // may be null
+    const void* data;           // may be null
+    uint32_t data_width;        // 0,1,2,4
+    uint64_t n;
+};
+
+// k-mer records in HBM: struct-of-arrays, key (hi, lo) + payload (Exts | D1 << 8)
+struct RecArrays {
+    uint64_t* hi;               // null when k <= 32
+    uint64_t* lo;
+    uint32_t* pay;
+};
+
+// ---- scan.hip : exclusive prefix sums, out has n+1 entries (out[n] = total) ----------------
+int scan_exclusive_u32(dbg_ctx* ctx, const uint32_t* in, uint32_t* out, uint64_t n);
+int scan_exclusive_u32_u64(dbg_ctx* ctx, const uint32_t* in, uint64_t* out, uint64_t n);
+int scan_exclusive_u64(dbg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t n);
+
+// ---- extract.hip : iter_kmer_exts + min_rc_flip + Exts::rc fused (lib.rs:812-841, filter.rs:190-196)
+// kcount[i] = len_i.saturating_sub(k-1) (filter.rs:154)
+int kmer_counts(dbg_ctx* ctx, const SeqDev& s, int k, uint32_t* kcount);
+// writes records of sequence i at koff[i] .. koff[i+1]
+int extract_kmers(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uint64_t n_kmers, int k, bool stranded,
+                  RecArrays out);
+
+// ---- radix.hip : stable LSD radix sort of records by (key, selected payload bits) -----------
+// Sorts n (< 2^32) records.  key_bits = 2k significant key bits; pay_shift/pay_bits select payload
+// bits that act as the least-significant sort digits (CountFilterSet needs (key, D1) order).
+// a = input (clobbered), b = scratch; *result_in_b tells where the sorted records ended up.
+int radix_sort_records(dbg_ctx* ctx, uint64_t n, RecArrays a, RecArrays b, int key_bits, int pay_shift,
+                       int pay_bits, bool* result_in_b);
+
+// ---- reduce.hip : group_by key + KmerSummarizer::summarize (filter.rs:53-62, :85-100) -------
+struct ReduceOut {
+    uint64_t n_valid = 0, n_all = 0, n_set_val = 0;
+    uint64_t *key_hi = nullptr, *key_lo = nullptr;
+    uint8_t* exts = nullptr;
+    uint16_t* count = nullptr;
+    uint64_t* set_off = nullptr;
+    uint32_t* set_val = nullptr;
+    uint64_t *all_hi = nullptr, *all_lo = nullptr;
+};
+int reduce_sorted_records(dbg_ctx* ctx, uint64_t n, RecArrays sorted, bool has_hi, int summarizer, uint64_t min_obs,
+                          bool report_all, ReduceOut* out);
+
+// ---- synth.hip ----------------------------------------------------------------------------
+int synth_reads_dev(dbg_ctx* ctx, const dbg_synth_params* p, uint64_t* words, uint64_t* start, uint32_t* length,
+                    uint8_t* data);
+
+// ---- launch helpers -----------------------------------------------------------------------
+#define LAUNCH_CHECK(ctx, name)                                                                 \
+    do {                                                                                        \
+        hipError_t _e = hipGetLastError();                                                      \
+        if (_e != hipSuccess) {                                                                 \
+            char _b[256];                                                                       \
+            snprintf(_b, sizeof(_b), "kernel launch %s failed: %s", name, hipGetErrorString(_e)); \
+            return (ctx)->fail(102, _b);                                                        \
+        }                                                                                       \
+    } while (0)

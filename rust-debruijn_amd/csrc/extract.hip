@@ -1,0 +1,81 @@
+// K-mer extraction from packed sequences: the fused GPU form of
+//   Vmer::iter_kmer_exts / KmerExtsIter::next      (lib.rs:408-422, :812-841)
+//   Kmer::min_rc_flip + Exts::rc when !stranded    (filter.rs:190-196, lib.rs:224-231, :729-748)
+// One wavefront walks one sequence 64 k-mers at a time; each lane materialises its k-mer from
+// <= 3 consecutive packed words (dna_string.rs:123-153) and writes one (key, payload) record.
+#include "dbg_internal.hpp"
+#include <algorithm>
+
+namespace {
+
+__global__ void kmer_counts_kernel(const uint32_t* __restrict__ length, uint64_t n, int k, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint32_t len = length[i];
+        out[i] = len >= (uint32_t)(k - 1) ? len - (uint32_t)(k - 1) : 0u;      // saturating_sub (filter.rs:154)
+    }
+}
+
+__device__ __forceinline__ uint32_t load_d1(const void* data, uint32_t width, uint64_t i) {
+    if (!data) return 0;
+    if (width == 1) return ((const uint8_t*)data)[i];
+    if (width == 2) return ((const uint16_t*)data)[i];
+    return ((const uint32_t*)data)[i];
+}
+
+template <bool STRANDED, bool HAS_HI>
+__global__ void __launch_bounds__(256) extract_kernel(SeqDev s, const uint64_t* __restrict__ koff, int k,
+                                                      uint64_t* __restrict__ out_hi, uint64_t* __restrict__ out_lo,
+                                                      uint32_t* __restrict__ out_pay) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t si = wave; si < s.n; si += n_waves) {
+        const uint32_t len = s.length[si];
+        if (len < (uint32_t)k) continue;                                       // lib.rs:813 with pos = k
+        const uint64_t st = s.start[si];
+        const uint32_t nk = len - (uint32_t)k + 1;
+        const uint32_t sexts = s.exts ? s.exts[si] : 0u;
+        const uint32_t d1 = load_d1(s.data, s.data_width, si);
+        const uint64_t obase = koff[si];
+        for (uint32_t j = lane; j < nk; j += 64) {
+            K128 km = packed_get_kmer(s.words, st + j, k);
+            // lib.rs:820-832: interior exts from the neighbouring bases, boundary exts from seq_exts
+            uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << packed_get(s.words, st + j - 1));
+            uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << packed_get(s.words, st + j + k));
+            uint32_t ex = left | right;
+            if (!STRANDED) {
+                K128 rc = kmer_rc(km, k);
+                if (!k128_lt(km, rc)) { km = rc; ex = exts_rc(ex); }             // ties flip (lib.rs:226-230)
+            }
+            uint64_t o = obase + j;
+            if (HAS_HI) out_hi[o] = km.hi;
+            out_lo[o] = km.lo;
+            out_pay[o] = pay_make(ex, d1);
+        }
+    }
+}
+}  // namespace
+
+int kmer_counts(dbg_ctx* ctx, const SeqDev& s, int k, uint32_t* kcount) {
+    if (s.n == 0) return 0;
+    kmer_counts_kernel<<<cdiv(s.n, 256), 256, 0, ctx->stream>>>(s.length, s.n, k, kcount);
+    LAUNCH_CHECK(ctx, "kmer_counts");
+    return 0;
+}
+
+int extract_kmers(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uint64_t n_kmers, int k, bool stranded,
+                  RecArrays out) {
+    if (s.n == 0 || n_kmers == 0) return 0;
+    uint64_t waves_needed = s.n;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((waves_needed + 3) / 4, 256ull * 16);
+    ctx->t_begin("extract_kmers", n_kmers);
+    bool has_hi = out.hi != nullptr;
+#define GO(ST, HH) extract_kernel<ST, HH><<<blocks, 256, 0, ctx->stream>>>(s, koff, k, out.hi, out.lo, out.pay)
+    if (stranded) { if (has_hi) GO(true, true); else GO(true, false); }
+    else          { if (has_hi) GO(false, true); else GO(false, false); }
+#undef GO
+    ctx->t_end();
+    LAUNCH_CHECK(ctx, "extract_kmers");
+    return 0;
+}

@@ -1,0 +1,122 @@
+"""GPU parity: dbg_msp_sequence (HIP scanner, through the C ABI) vs the CPU oracle's restatement of
+Scanner::scan / msp_sequence (src/msp.rs:207-324), bit-exact including the tie rule."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import refgen as R
+from pkg import dbg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dbg.Context(0)
+    yield c
+    c.close()
+
+
+def check_batch(ctx, seqs, k, p, perm=None, rc=True, lmer_words=0):
+    res = dbg.msp_sequence_batch(k, seqs, perm, rc, p, lmer_words, ctx)
+    off = res["piece_off"]
+    assert len(off) == len(seqs) + 1 and off[0] == 0
+    perm64 = None if perm is None else np.asarray(perm, dtype=np.uint64)
+    for i, s in enumerate(seqs):
+        a, b = int(off[i]), int(off[i + 1])
+        if len(s) < k:
+            assert a == b                                   # msp.rs:294-296
+            continue
+        mi, st, ln, mp = O.msp_scan(s, k, p, perm64, rc=rc)
+        want = O.msp_sequence(s, k, p, perm64, rc=rc, lmer_words=lmer_words)
+        assert b - a == len(st), (i, b - a, len(st))
+        assert np.array_equal(res["start"][a:b], st)
+        assert np.array_equal(res["len"][a:b], ln)
+        assert np.array_equal(res["minimizer_pos"][a:b], mp)
+        assert np.array_equal(res["bucket"][a:b], want[0])
+        assert np.array_equal(res["exts"][a:b], want[1])
+        if lmer_words:
+            assert np.array_equal(res["lmer"][a:b], want[4])
+    return res
+
+
+@pytest.mark.parametrize("k,p", [(47, 8), (31, 6), (35, 5), (63, 8), (50, 8), (16, 5), (21, 10), (47, 12), (64, 16),
+                                 (33, 15), (47, 14)])
+def test_msp_random_reads(ctx, k, p):
+    rng = np.random.default_rng(k * 100 + p)
+    seqs = [R.random_dna(rng, int(n)) for n in rng.integers(0, 400, size=150)]
+    seqs += [R.random_dna(rng, k), R.random_dna(rng, k + 1), R.random_dna(rng, k - 1), np.zeros(0, np.uint8)]
+    check_batch(ctx, seqs, k, p, None, True)
+    check_batch(ctx, seqs, k, p, None, False)
+
+
+def test_msp_low_complexity_ties(ctx):
+    """All-A, dinucleotide and short-period repeats exercise the rightmost-min / strict-entry tie rule."""
+    rng = np.random.default_rng(4)
+    seqs = [np.zeros(n, np.uint8) for n in (47, 48, 100, 150, 300)]
+    seqs += [np.tile(np.array([0, 3], np.uint8), 100), np.tile(np.array([0, 1, 2], np.uint8), 80),
+             np.tile(R.random_dna(rng, 7), 40), R.from_ascii(R.DEGEN)]
+    for k, p in ((31, 6), (47, 8), (21, 5)):
+        check_batch(ctx, seqs, k, p, None, True)
+        check_batch(ctx, seqs, k, p, None, False)
+
+
+def test_msp_permutation(ctx):
+    rng = np.random.default_rng(8)
+    p = 6
+    perm = rng.permutation(1 << (2 * p)).astype(np.uint32)
+    seqs = [R.random_dna(rng, 150) for _ in range(200)]
+    check_batch(ctx, seqs, 31, p, perm, True)
+    check_batch(ctx, seqs, 31, p, perm, False)
+
+
+def test_msp_lmer_words(ctx):
+    rng = np.random.default_rng(12)
+    seqs = [R.random_dna(rng, 150) for _ in range(100)]
+    check_batch(ctx, seqs, 47, 8, None, True, lmer_words=3)          # Lmer3: max_len 92 >= 2*47-8 = 86
+    check_batch(ctx, seqs, 63, 8, None, True, lmer_words=4)          # Lmer4: max_len 124 >= 118
+    with pytest.raises(dbg.DbgError):                                # msp.rs:292 assertion
+        dbg.msp_sequence_batch(63, seqs, None, True, 8, 3, ctx)
+
+
+def test_msp_reference_sample_vectors(ctx):                         # msp.rs:551-581 inputs
+    from golden_inputs import MSP_V1, MSP_V2
+    seqs = [np.array(MSP_V1, np.uint8), np.array(MSP_V2, np.uint8)]
+    check_batch(ctx, seqs, 35, 5, None, True)
+
+
+def test_msp_single_sequence_api(ctx):
+    """msp_sequence::<Kmer8, _>(k, seq, None, true) for one read, like src/test.rs:436."""
+    rng = np.random.default_rng(2)
+    dna = R.random_dna(rng, 150)
+    pieces = dbg.msp_sequence(50, dna, None, True, p=8, ctx=ctx)
+    want = set(R.kmers_of(dna, 50))
+    got = set()
+    for bucket, exts, v in pieces:
+        got.update(R.kmers_of(v, 50))
+        assert bucket == min(R.canon(8, x) for x in R.kmers_of(v, 8))
+    assert want == got                                               # msp.rs:340-355
+
+
+def test_msp_then_filter_equals_direct_filter(ctx):
+    """Per-k-mer results are independent of the MSP sharding: feeding the pieces (with their boundary
+    Exts) to filter_kmers gives exactly the table of the whole reads (src/test.rs:326-355)."""
+    rng = np.random.default_rng(31)
+    genome = R.random_dna(rng, 2000)
+    reads = []
+    for _ in range(300):
+        st = int(rng.integers(0, 1850))
+        s = genome[st:st + 150].copy()
+        reads.append(R.revcomp_bytes(s) if rng.random() < 0.5 else s)
+    k, p = 47, 8
+    res = dbg.msp_sequence_batch(k, reads, None, True, p, 0, ctx)
+    pieces, pexts = [], []
+    for i, r in enumerate(reads):
+        for j in range(int(res["piece_off"][i]), int(res["piece_off"][i + 1])):
+            s, l = int(res["start"][j]), int(res["len"][j])
+            pieces.append(r[s:s + l])
+            pexts.append(int(res["exts"][j]))
+    a, _ = dbg.filter_kmers([(s, e, None) for s, e in zip(pieces, pexts)], dbg.CountFilter(2), False, False, 4, k=k, ctx=ctx)
+    b, _ = dbg.filter_kmers([(s, 0, None) for s in reads], dbg.CountFilter(2), False, False, 4, k=k, ctx=ctx)
+    assert a.keys() == b.keys()
+    assert np.array_equal(a.exts, b.exts) and np.array_equal(a.count, b.count)
