@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mer extract -> MSP shard -> count/filter throughput on MI355X.
+
+One "step" = one pass of the hot path (dbg_filter_kmers_dev, device-resident in and out) over one
+batch of synthetic reads already in HBM (SURVEY.md section 8d stream: splitmix64 genome at 30x,
+150-bp reads, substitution rate 0.001, random strand).  Metric: k-mer instances per second
+(BASELINE.json: "Gkmer/s extracted+counted (k=47, 150 bp synthetic reads)").
+
+    python bench.py --gpus N --steps K --warmup W [--reads R] [--k 47]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU; see DESIGN.md (multi-GPU).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_kmer(k, read_len, is_set, u_over_n):
+    """SURVEY.md section 8(d) two-touch model: B_in + 2R + (U/N) B_out."""
+    key = 8 if k <= 32 else 16
+    b_in = (read_len / 4.0) / (read_len - k + 1)
+    r = key + 1 + (1 if is_set else 0)
+    b_out = key + 1 + 2
+    return b_in + 2 * r + u_over_n * b_out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("DBG_BENCH_READS", 0)))
+    ap.add_argument("--k", type=int, default=47)
+    ap.add_argument("--summarizer", default="set", choices=["set", "count"])
+    ap.add_argument("--min-obs", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    dbg = importlib.import_module("rust-debruijn_amd")
+    capi = importlib.import_module("rust-debruijn_amd._capi")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = dbg.Context(local_rank)
+    lib = ctx.lib
+
+    k, L = args.k, 150
+    reads_per_gpu = args.reads or 100_000_000          # BASELINE configs[1]: 100M x 150 bp, k=47, CountFilterSet
+    is_set = args.summarizer == "set"
+    n_reads_total = reads_per_gpu * world               # weak scaling: fixed reads per GPU
+    genome_len = n_reads_total * L // 30
+
+    # ---- synthetic input, generated directly in HBM ----
+    p = dbg.synth_params(n_reads=reads_per_gpu, read_len=L, genome_len=genome_len, error_rate=0.001,
+                         stranded=False, n_colours=4, first_read=rank * reads_per_gpu)
+    nw = lib.dbg_synth_words(C.byref(p))
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    start = torch.empty(reads_per_gpu, dtype=torch.int64, device=dev)
+    length = torch.empty(reads_per_gpu, dtype=torch.int32, device=dev)
+    colour = torch.empty(reads_per_gpu, dtype=torch.uint8, device=dev)
+    ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), words.data_ptr(), start.data_ptr(), length.data_ptr(),
+                                      colour.data_ptr()))
+    ss = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None,
+                     colour.data_ptr() if is_set else None, 1 if is_set else 0, reads_per_gpu)
+    fp = capi.FilterParams(k, 0, 1 if is_set else 0, args.min_obs, 0, 4)
+
+    def step():
+        t = capi.KmerTable()
+        ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+        res = (t.n, t.n_kmer_instances)
+        lib.dbg_free_table(ctx.h, C.byref(t))
+        return res
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    n_valid = n_inst = 0
+    ktimes = {}
+    for _ in range(args.steps):
+        n_valid, n_inst = step()
+        for kt in ctx.timings():
+            a = ktimes.setdefault(kt["name"], dict(ms=0.0, launches=0, units=0))
+            a["ms"] += kt["ms"]; a["launches"] += kt["launches"]; a["units"] += kt["units"]
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.enable_timing(False)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        cnt = torch.tensor([n_inst], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        n_inst_total = int(cnt.item())
+    else:
+        n_inst_total = n_inst
+    ms_per_step = dt / args.steps * 1e3
+    value = n_inst_total * args.steps / dt / 1e9
+
+    out = None
+    if rank == 0:
+        u_over_n = n_valid / max(n_inst, 1)
+        b_alg = alg_bytes_per_kmer(k, L, is_set, u_over_n)
+        # dominant kernel = largest share of measured HIP-event time
+        dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"]) if ktimes else None
+        roof = None
+        if dom:
+            name, a = dom
+            avg_ms = a["ms"] / a["launches"]
+            units_per_launch = a["units"] / a["launches"]
+            key = 8 if k <= 32 else 16
+            rbytes = key + 4                                   # record = key + 4-byte payload in this build
+            per_unit = {"extract_kmers": (L / 4.0) / (L - k + 1) + rbytes, "radix_scatter": 2 * rbytes,
+                        "radix_hist": 8, "reduce_groups": rbytes + u_over_n * (key + 3)}.get(name, 2 * rbytes)
+            ach = per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "alg_bytes_per_unit": round(per_unit, 2), "units_per_launch": units_per_launch,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": a["launches"] / args.steps,
+                    "whole_path_alg_frac": round(value * b_alg / HBM_PEAK_GBS, 4),
+                    "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle_lib as O
+            n_s = 60000                                        # ~6.2M k-mer instances: 10-30 s of single-thread CPU work
+            hs = dbg.synth_reads_host(n_reads=n_s, read_len=L, genome_len=n_s * L // 30, error_rate=0.001,
+                                      stranded=False, n_colours=4)
+            so = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if is_set else None, 1 if is_set else 0)
+            sec, nv = O.time_filter_kmers(so, k, O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER, args.min_obs, False)
+            cpu = {"value": round(n_s * (L - k + 1) / sec / 1e9, 5), "unit": "Gkmer/s", "cores": 1, "kind": "port",
+                   "sample": "first %d reads of an equally-parameterised stream (%.1fM k-mer instances), "
+                             "oracle filter_kmers single thread, %.1f s" % (n_s, n_s * (L - k + 1) / 1e6, sec),
+                   "host_cores_available": os.cpu_count()}
+        out = {
+            "metric": "Gkmer/s extracted+counted (k=%d, 150 bp synthetic reads)" % k, "value": round(value, 4),
+            "unit": "Gkmer/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=0.001"
+                                   % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs),
+                       "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid,
+                       "path": "generic (extract -> global LSD radix sort -> segmented reduce)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

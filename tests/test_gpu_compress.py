@@ -1,0 +1,156 @@
+"""GPU parity: dbg_compress_kmers_with_hash (device link builder + host greedy walk) and
+dbg_remove_censored_exts vs the CPU oracle's restatement of src/compression.rs:355-594 and
+src/filter.rs:238-306.  With the same seed order the BaseGraph must be literally identical
+(packed words, start, length, exts, data); the reference's own invariants (test.rs:386-413,
+:248-254) are re-checked on the GPU result."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import refgen as R
+from graph_canon import canonical_nodes, graph_kmer_set, graphs_equal, node_bases
+from pkg import dbg
+
+pytestmark = pytest.mark.gpu
+
+SPECS = [(dbg.SimpleCompress("saturating_add"), O.SPEC_SAT_ADD), (dbg.SimpleCompress("add_mod_65535"), O.SPEC_ADD_MOD),
+         (dbg.SimpleCompress("max"), O.SPEC_MAX), (dbg.SimpleCompress("wrapping_add"), O.SPEC_WRAP_ADD)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dbg.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_table(ctx, contigs, k, min_obs, stranded, dup=1):
+    seqs = []
+    for c in contigs:
+        seqs.extend([(c, 0, None)] * dup)
+    t, _ = dbg.filter_kmers(seqs, dbg.CountFilter(min_obs), stranded, False, 4, k=k, ctx=ctx)
+    return t
+
+
+def compare(ctx, t, k, stranded, spec_pair, seed_order=None, data=None):
+    spec, ospec = spec_pair
+    d = t.count if data is None else data
+    got = dbg.compress_kmers_with_hash(stranded, spec, t, k=k, seed_order=seed_order, data=d, ctx=ctx)
+    want = O.compress_kmers(k, stranded, ospec, t.key_hi, t.key_lo, t.exts, d, seed_order)
+    wa = want.arrays()
+    assert graphs_equal(got.arrays(), wa), "BaseGraph differs from the oracle"
+    return got, want
+
+
+@pytest.mark.parametrize("k,stranded", [(32, False), (31, False), (31, True), (47, False), (63, False), (64, False), (16, False)])
+def test_compress_parity_random_contigs(ctx, k, stranded):
+    rng = np.random.default_rng(k + 7 * stranded)
+    for trial in range(3):
+        contigs = R.random_contigs(rng) if trial else R.simple_random_contigs(rng)
+        t = gpu_table(ctx, contigs, k, 1, stranded)
+        got, want = compare(ctx, t, k, stranded, SPECS[trial % len(SPECS)])
+        # reference invariants on the GPU result (test.rs:386-413, :248-254)
+        ga = got.arrays()
+        truth = set(t.keys())
+        assert graph_kmer_set(ga, k, stranded) == truth
+        assert sum(int(x) - k + 1 for x in ga["length"]) == len(truth)
+        og = O.graph_from_arrays(k, stranded, ga["words"], ga["start"], ga["length"], ga["exts"], ga["data"])
+        assert og.is_compressed(SPECS[trial % len(SPECS)][1]) is None
+
+
+def test_compress_seed_order_policy_a(ctx):
+    """A caller-supplied seed order (the MPHF slot order in a real deployment) is honoured literally."""
+    rng = np.random.default_rng(123)
+    contigs = R.random_contigs(rng)
+    t = gpu_table(ctx, contigs, 31, 1, False)
+    base = None
+    for _ in range(4):
+        perm = rng.permutation(len(t)).astype(np.uint64)
+        got, _ = compare(ctx, t, 31, False, SPECS[0], seed_order=perm)
+        canon = canonical_nodes(got.arrays(), 31, False)
+        assert base is None or canon == base          # policy B: canonical form is seed-order independent
+        base = canon
+
+
+def test_compress_unsorted_index(ctx):
+    """index arrays may arrive in any key order (a BoomHashMap2 is in slot order)."""
+    rng = np.random.default_rng(5)
+    t = gpu_table(ctx, R.random_contigs(rng), 31, 1, False)
+    perm = rng.permutation(len(t))
+    import copy
+    u = copy.copy(t)
+    u.key_hi, u.key_lo, u.exts, u.count = t.key_hi[perm], t.key_lo[perm], t.exts[perm], t.count[perm]
+    got = dbg.compress_kmers_with_hash(False, SPECS[0][0], u, k=31, ctx=ctx)
+    want = O.compress_kmers(31, False, SPECS[0][1], u.key_hi, u.key_lo, u.exts, u.count, None)
+    assert graphs_equal(got.arrays(), want.arrays())
+
+
+def test_compress_degenerate_and_palindromes(ctx):
+    seq = R.from_ascii(R.DEGEN)                                      # test.rs:170-193
+    t = gpu_table(ctx, [seq, seq], 31, 2, False)
+    compare(ctx, t, 31, False, SPECS[0])
+    rng = np.random.default_rng(17)                                  # even k: palindromic k-mers are terminal
+    half = R.random_dna(rng, 16)
+    pal = np.concatenate([R.random_dna(rng, 40), half, R.revcomp_bytes(half), R.random_dna(rng, 40)])
+    t = gpu_table(ctx, [pal], 32, 1, False)
+    got, _ = compare(ctx, t, 32, False, SPECS[0])
+    assert any(int(l) == 32 for l in got.arrays()["length"])         # the palindrome sits alone in its node
+
+
+def test_compress_cycle(ctx):
+    """An isolated cycle is cut at the first-visited k-mer and keeps its hanging exts."""
+    rng = np.random.default_rng(3)
+    k = 21
+    c = R.random_dna(rng, 60)
+    circ = np.concatenate([c, c[:k]])                                # covers every k-mer of the circular string once
+    for stranded in (True, False):
+        t = gpu_table(ctx, [circ], k, 1, stranded)
+        got, _ = compare(ctx, t, k, stranded, SPECS[0])
+        ga = got.arrays()
+        assert len(ga["start"]) == 1 and int(ga["length"][0]) == 60 + k - 1
+
+
+def test_compress_hanging_exts_after_filter(ctx):
+    """k-mers below min_obs are dropped but exts towards them stay (filter.rs never prunes); compression
+    then ends the unitig there (compression.rs:386, :410-415)."""
+    rng = np.random.default_rng(29)
+    g = R.random_dna(rng, 400)
+    err = g[100:250].copy()
+    err[75] = (err[75] + 1) % 4
+    reads = [g[i:i + 150] for i in range(0, 250, 10)] * 2 + [err]
+    k = 31
+    t, allk = dbg.filter_kmers([(r, 0, None) for r in reads], dbg.CountFilter(2), False, True, 4, k=k, ctx=ctx)
+    compare(ctx, t, k, False, SPECS[0])
+    # remove_censored_exts_sharded / remove_censored_exts (filter.rs:238-306)
+    ah = np.array([v >> 64 for v in allk], np.uint64)
+    al = np.array([v & O.M64 for v in allk], np.uint64)
+    want_s = O.remove_censored_exts(k, False, t.key_hi, t.key_lo, t.exts, ah, al, sharded=True)
+    want_n = O.remove_censored_exts(k, False, t.key_hi, t.key_lo, t.exts)
+    import copy
+    ts = dbg.remove_censored_exts_sharded(False, copy.copy(t), allk, ctx=ctx)
+    tn = dbg.remove_censored_exts(False, copy.copy(t), ctx=ctx)
+    assert np.array_equal(ts.exts, want_s) and np.array_equal(tn.exts, want_n)
+    assert not np.array_equal(want_n, t.exts)                        # something was actually censored
+    got, _ = compare(ctx, tn, k, False, SPECS[0])
+    og = O.graph_from_arrays(k, False, **{x: got.arrays()[x] for x in ("words", "start", "length", "exts", "data")})
+    assert og.is_compressed(SPECS[0][1]) is None
+
+
+def test_scmap_compress(ctx):
+    rng = np.random.default_rng(8)
+    a = R.random_dna(rng, 200)
+    k = 31
+    t = gpu_table(ctx, [a], k, 1, True)
+    order = {v: i for i, v in enumerate(t.keys())}
+    col = np.zeros(len(t), np.uint32)
+    for j, v in enumerate(R.kmers_of(a, k)):
+        col[order[v]] = j // 50
+    got, _ = compare(ctx, t, k, True, (dbg.ScmapCompress(), O.SPEC_SCMAP_EQ), data=col)
+    assert len(got) == 4
+
+
+def test_c1_shape_end_to_end(ctx):
+    """BASELINE config 1 shape (10k x 150 bp, k=31, stranded, CountFilter(1)) through filter + compress."""
+    hs = dbg.synth_reads_host(n_reads=10000, read_len=150, error_rate=0.001, stranded=True, n_colours=0)
+    t, _ = dbg.filter_kmers(hs, dbg.CountFilter(1), True, False, 4, k=31, ctx=ctx)
+    compare(ctx, t, 31, True, SPECS[0])
