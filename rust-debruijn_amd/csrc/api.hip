@@ -117,6 +117,16 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     uint64_t n_kmers = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_kmers, koff.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {   // fast path: super-k-mer bins + LDS hash tables (fastpath.hip); DBG_PATH=generic|fast|auto overrides
+        const char* force = getenv("DBG_PATH");
+        bool want_fast = !(force && !strcmp(force, "generic"));
+        if (want_fast) {
+            bool used = false;
+            DBG_TRY(filter_kmers_fast(c, s, p, n_kmers, out, &used));
+            if (used) return 0;
+            if (force && !strcmp(force, "fast") && n_kmers) return c->fail(21, "DBG_PATH=fast but the fast path does not support this call shape");
+        }
+    }
     if (n_kmers >= (1ull << 32)) return c->fail(20, "generic path: more than 2^32-1 k-mer instances in one call");
 
     DBuf<uint64_t> a_hi, a_lo, b_hi, b_lo;

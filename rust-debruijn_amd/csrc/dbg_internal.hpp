@@ -53,6 +53,10 @@ struct ReduceOut {
 int reduce_sorted_records(dbg_ctx* ctx, uint64_t n, RecArrays sorted, bool has_hi, int summarizer, uint64_t min_obs,
                           bool report_all, ReduceOut* out);
 
+// ---- fastpath.hip : super-k-mer bins + per-bin LDS hash tables --------------------------------
+int filter_kmers_fast(dbg_ctx* ctx, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
+                      bool* used);
+
 // ---- synth.hip ----------------------------------------------------------------------------
 int synth_reads_dev(dbg_ctx* ctx, const dbg_synth_params* p, uint64_t* words, uint64_t* start, uint32_t* length,
                     uint8_t* data);

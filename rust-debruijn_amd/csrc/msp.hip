@@ -8,78 +8,22 @@
 // k-mer); a first pass counts pieces, an exclusive scan places them, a second pass emits
 // (bucket, Exts::from_slice_bounds, start, len, minimizer_pos [, Lmer words]) in input order.
 #include "dbg_internal.hpp"
+#include "dbg_msp_device.hpp"
 #include <algorithm>
 
 namespace {
 
-struct MspCfg {
-    int k, p;
-    const uint32_t* perm;   // device, [4^p] or null
-    int rc;
-    int lmer_words;
+struct MspScore {
+    MspCfg c;
+    __device__ __forceinline__ uint32_t operator()(uint32_t pm) const { return pmer_score(c, pm); }
 };
-
-__device__ __forceinline__ uint32_t pmer_rc(uint32_t pm, int p) { return (uint32_t)kmer_rc(K128{0, pm}, p).lo; }
-
-__device__ __forceinline__ uint32_t pmer_score(const MspCfg& c, uint32_t pm) {          // msp.rs:305-311
-    uint32_t a = c.perm ? c.perm[pm] : pm;
-    if (c.rc) {
-        uint32_t r = pmer_rc(pm, c.p);
-        uint32_t b = c.perm ? c.perm[r] : r;
-        a = a < b ? a : b;
-    }
-    return a;
-}
-
-struct MinPosD { uint32_t val, pos, pmer; };
-
-// find_min(start, stop) (msp.rs:218-228): rightmost minimal position in [start, stop]
-__device__ __forceinline__ MinPosD find_min(const MspCfg& c, const uint64_t* __restrict__ w, uint64_t st,
-                                            uint32_t start, uint32_t stop, uint32_t pmask) {
-    uint32_t pm = (uint32_t)packed_get_kmer(w, st + start, c.p).lo;
-    MinPosD best{pmer_score(c, pm), start, pm};
-    for (uint32_t pos = start + 1; pos <= stop; pos++) {
-        pm = ((pm << 2) | packed_get(w, st + pos + c.p - 1)) & pmask;
-        uint32_t v = pmer_score(c, pm);
-        if (v <= best.val) best = MinPosD{v, pos, pm};      // equal value: larger pos is "Less" (msp.rs:134-139)
-    }
-    return best;
-}
-
-// Runs Scanner::scan over one sequence and calls emit(start, len, minpos) per interval.
-template <class Emit>
-__device__ __forceinline__ void scan_sequence(const MspCfg& c, const uint64_t* __restrict__ w, uint64_t st, uint32_t m,
-                                              Emit emit) {
-    const int k = c.k, p = c.p;
-    const uint32_t win = (uint32_t)(k - p);
-    const uint32_t pmask = p >= 16 ? 0xffffffffu : ((1u << (2 * p)) - 1);
-    MinPosD minp = find_min(c, w, st, 0, win, pmask);                                  // msp.rs:232
-    uint32_t end_pm = (uint32_t)packed_get_kmer(w, st + win, p).lo;                    // msp.rs:233
-    uint32_t cur_start = 0;
-    const uint32_t nwin = m - (uint32_t)k + 1;
-    for (uint32_t i = 1; i < nwin; i++) {                                              // msp.rs:237
-        end_pm = ((end_pm << 2) | packed_get(w, st + i + win + p - 1)) & pmask;        // incr, msp.rs:239
-        if (i > minp.pos) {                                                            // msp.rs:241
-            MinPosD nm = find_min(c, w, st, i, i + win, pmask);
-            emit(cur_start, i + (uint32_t)k - 1 - cur_start, minp);
-            cur_start = i; minp = nm;
-        } else {
-            uint32_t v = pmer_score(c, end_pm);
-            if (v < minp.val) {                                                        // msp.rs:244
-                emit(cur_start, i + (uint32_t)k - 1 - cur_start, minp);
-                cur_start = i; minp = MinPosD{v, i + win, end_pm};
-            }
-        }
-    }
-    emit(cur_start, m - cur_start, minp);                                              // msp.rs:266-273
-}
 
 __global__ void msp_count_kernel(SeqDev s, MspCfg c, uint32_t* __restrict__ counts) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     uint32_t m = s.length[i];
     uint32_t n = 0;
-    if (m >= (uint32_t)c.k) scan_sequence(c, s.words, s.start[i], m, [&](uint32_t, uint32_t, const MinPosD&) { n++; });
+    if (m >= (uint32_t)c.k) scan_sequence(c.k, c.p, MspScore{c}, s.words, s.start[i], m, [&](uint32_t, uint32_t, const MinPosD&) { n++; });
     counts[i] = n;                                                                     // m < k: empty (msp.rs:294-296)
 }
 
@@ -93,7 +37,7 @@ __global__ void msp_emit_kernel(SeqDev s, MspCfg c, const uint64_t* __restrict__
     const uint64_t st = s.start[i];
     const uint64_t* __restrict__ w = s.words;
     uint64_t o = piece_off[i];
-    scan_sequence(c, w, st, m, [&](uint32_t start, uint32_t len, const MinPosD& mp) {
+    scan_sequence(c.k, c.p, MspScore{c}, w, st, m, [&](uint32_t start, uint32_t len, const MinPosD& mp) {
         uint32_t r = pmer_rc(mp.pmer, c.p);
         bucket[o] = mp.pmer < r ? mp.pmer : r;                                        // min_rc().to_u64() (msp.rs:115-117)
         uint32_t le = start > 0 ? (1u << packed_get(w, st + start - 1)) : 0u;         // lib.rs:645-660

@@ -1,0 +1,124 @@
+"""GPU parity of the fast counting path (super-k-mer bins + per-bin LDS hash tables, fastpath.hip)
+against the CPU oracle, bit-exact, with DBG_PATH=fast so that a silent fall-back to the generic
+radix path cannot make these tests pass.  Also cross-checks fast == generic on the same input."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import refgen as R
+from pkg import dbg
+from test_gpu_filter import assert_tables_equal, random_reads, to_host_seqs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dbg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(autouse=True)
+def force_fast():
+    old = os.environ.get("DBG_PATH")
+    os.environ["DBG_PATH"] = "fast"
+    yield
+    if old is None:
+        os.environ.pop("DBG_PATH", None)
+    else:
+        os.environ["DBG_PATH"] = old
+
+
+def run_fast(ctx, ss, k, summarizer, min_obs, stranded, data_width=0):
+    is_set = summarizer == O.COUNT_FILTER_SET
+    want = O.filter_kmers(ss, k, summarizer, min_obs, stranded=stranded)
+    summ = (dbg.CountFilterSet if is_set else dbg.CountFilter)(min_obs)
+    got, _ = dbg.filter_kmers(to_host_seqs(ss, data_width), summ, stranded, False, 4, k=k, ctx=ctx)
+    assert_tables_equal(got, want, is_set)
+    return got
+
+
+@pytest.mark.parametrize("k,stranded,min_obs", [
+    (47, False, 2), (47, False, 1), (47, True, 1), (31, True, 1), (31, False, 2), (32, False, 1), (33, False, 2),
+    (16, False, 1), (21, True, 2), (51, False, 2), (63, False, 2), (64, False, 1), (64, True, 1),
+])
+def test_fast_count_filter(ctx, k, stranded, min_obs):
+    rng = np.random.default_rng(1000 + k * 3 + stranded)
+    seqs = random_reads(rng, 600, 4000, 150, stranded)
+    run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, min_obs, stranded)
+
+
+@pytest.mark.parametrize("k,ncol", [(47, 4), (31, 32), (63, 7)])
+def test_fast_count_filter_set(ctx, k, ncol):
+    rng = np.random.default_rng(k + ncol)
+    seqs = random_reads(rng, 700, 3000, 150, False)
+    data = rng.integers(0, ncol, size=len(seqs))
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1)
+    run_fast(ctx, ss, k, O.COUNT_FILTER_SET, 2, False, data_width=1)
+
+
+def test_fast_multi_pass_bins(ctx):
+    """Low coverage: far more distinct k-mers per bin than the 2048-entry LDS table holds, so bins are
+    re-streamed in hash-selected passes (and split recursively on overflow)."""
+    rng = np.random.default_rng(4)
+    seqs = random_reads(rng, 1500, 400000, 150, False, err=0.0)
+    got = run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), 47, O.COUNT_FILTER, 1, False)
+    assert len(got) > 100000
+
+
+def test_fast_heavy_repeat_and_saturation(ctx):
+    rng = np.random.default_rng(6)
+    rep = R.random_dna(rng, 60)
+    seqs = [rep] * 70000 + random_reads(rng, 200, 2000, 150, True)
+    ss = O.SeqSet.from_byte_seqs(seqs)
+    got = run_fast(ctx, ss, 47, O.COUNT_FILTER, 2, True)
+    assert int(got.count.max()) == 65535                      # u16 saturation (filter.rs:57)
+    run_fast(ctx, ss, 47, O.COUNT_FILTER, 65536, True)        # min above the saturated count: nothing valid
+
+
+def test_fast_low_complexity(ctx):
+    seqs = [np.zeros(150, np.uint8)] * 30 + [np.tile(np.array([0, 3], np.uint8), 75)] * 20
+    seqs += [np.tile(np.array([0, 1, 2, 3], np.uint8), 40)] * 10 + [R.from_ascii(R.DEGEN)] * 4
+    for k, stranded in ((31, False), (32, False), (47, True), (21, False)):
+        run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, 1, stranded)
+
+
+def test_fast_ragged_and_boundary_exts(ctx):
+    rng = np.random.default_rng(5)
+    seqs = random_reads(rng, 500, 2500, 140, False, ragged=True)
+    seqs += [np.zeros(0, np.uint8), R.random_dna(rng, 47), R.random_dna(rng, 46), R.random_dna(rng, 48)]
+    exts = rng.integers(0, 256, size=len(seqs))
+    ss = O.SeqSet.from_byte_seqs(seqs, exts=exts)
+    for stranded in (False, True):
+        run_fast(ctx, ss, 47, O.COUNT_FILTER, 1, stranded)
+
+
+def test_fast_equals_generic_on_synthetic_stream(ctx):
+    hs = dbg.synth_reads_host(n_reads=30000, read_len=150, error_rate=0.002, stranded=False, n_colours=4)
+    for summ in (dbg.CountFilter(2), dbg.CountFilterSet(2)):
+        os.environ["DBG_PATH"] = "fast"
+        a, _ = dbg.filter_kmers(hs, summ, False, False, 4, k=47, ctx=ctx)
+        os.environ["DBG_PATH"] = "generic"
+        b, _ = dbg.filter_kmers(hs, summ, False, False, 4, k=47, ctx=ctx)
+        assert np.array_equal(a.key_hi, b.key_hi) and np.array_equal(a.key_lo, b.key_lo)
+        assert np.array_equal(a.exts, b.exts)
+        if summ.kind == 0:
+            assert np.array_equal(a.count, b.count)
+        else:
+            assert np.array_equal(a.set_off, b.set_off) and np.array_equal(a.set_val, b.set_val)
+        assert len(a) > 0
+
+
+def test_fast_path_refuses_unsupported_shapes(ctx):
+    rng = np.random.default_rng(1)
+    seqs = random_reads(rng, 50, 1000, 150, False)
+    ss = O.SeqSet.from_byte_seqs(seqs, data=rng.integers(40, 300, size=50), sizeof_d1=2)
+    with pytest.raises(dbg.DbgError):           # labels >= 32 need the generic (sort-based) CountFilterSet
+        dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+    os.environ["DBG_PATH"] = "auto"
+    want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
+    got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+    assert_tables_equal(got, want, True)
