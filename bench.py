@@ -128,6 +128,8 @@ def main():
         u_over_n = n_valid / max(n_inst, 1)
         b_alg = alg_bytes_per_kmer(k, L, is_set, u_over_n)
         # dominant kernel = largest share of measured HIP-event time
+        n_recs = ktimes.pop("sk_records", {}).get("units", 0) / max(args.steps, 1)
+        fast = "bin_count" in ktimes
         dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"]) if ktimes else None
         roof = None
         if dom:
@@ -136,8 +138,15 @@ def main():
             units_per_launch = a["units"] / a["launches"]
             key = 8 if k <= 32 else 16
             rbytes = key + 4                                   # record = key + 4-byte payload in this build
-            per_unit = {"extract_kmers": (L / 4.0) / (L - k + 1) + rbytes, "radix_scatter": 2 * rbytes,
-                        "radix_hist": 8, "reduce_groups": rbytes + u_over_n * (key + 3)}.get(name, 2 * rbytes)
+            nbw = max(2, (2 * k - (15 if k >= 23 else (13 if k >= 21 else max(4, k - 8))) + 31) // 32)
+            rec_b = 8 * (nbw + 1)                              # super-k-mer record bytes
+            b_in = (L / 4.0) / (L - k + 1)
+            sk_b = n_recs * rec_b / max(n_inst, 1)             # super-k-mer bytes per k-mer instance
+            r_alg = key + 1 + (1 if is_set else 0)             # SURVEY 8(d) record R
+            per_unit = {"extract_kmers": b_in + rbytes, "radix_scatter": 2 * rbytes, "radix_hist": 8,
+                        "reduce_groups": rbytes + u_over_n * (key + 3),
+                        "sk_scan": b_in + sk_b + 4.0 * n_recs / max(n_inst, 1), "sk_scatter": 2 * rec_b + 4,
+                        "bin_count": r_alg + u_over_n * (key + 3)}.get(name, 2 * rbytes)
             ach = per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -148,7 +157,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             import oracle_lib as O
-            n_s = 60000                                        # ~6.2M k-mer instances: 10-30 s of single-thread CPU work
+            n_s = 1500000                                      # ~156M k-mer instances: 10-30 s of single-thread CPU work
             hs = dbg.synth_reads_host(n_reads=n_s, read_len=L, genome_len=n_s * L // 30, error_rate=0.001,
                                       stranded=False, n_colours=4)
             so = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if is_set else None, 1 if is_set else 0)
@@ -165,7 +174,9 @@ def main():
             "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=0.001"
                                    % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs),
                        "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid,
-                       "path": "generic (extract -> global LSD radix sort -> segmented reduce)"},
+                       "path": ("fast (super-k-mer bins -> per-bin LDS hash tables -> order-restoring radix sort)" if fast
+                                else "generic (extract -> global LSD radix sort -> segmented reduce)"),
+                       "superkmer_records_per_step": n_recs},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -54,53 +54,182 @@ __device__ __forceinline__ uint32_t bin_of(const FastCfg& c, uint32_t pm) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: count super-k-mers per bin        pass 2: write the records
+// Super-k-mer scan, one wavefront per read.  Lanes own p-mer positions (3 x 64 positions = one tile of
+// 128 window starts + the k-p tail); the sliding-window argmin is a log-step min in LDS over packed
+// (hash << 32 | position) words, so equal hashes resolve to the leftmost position; a window starts a
+// new super-k-mer when its argmin position differs from its predecessor's.  Records are written in
+// read order to a temporary buffer (wave-level allocation, one atomic per tile) together with their
+// bin id; a second, purely bandwidth-bound kernel moves them into bin order.
 // record = NBW base words (bases left-aligned, MSB first) + 1 meta word: len | exts << 8 | D1 << 16
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) sk_count_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n) return;
-    uint32_t m = s.length[i];
-    if (m < (uint32_t)c.k) return;
-    FastScore sc{c.p, c.stranded};
-    scan_sequence(c.k, c.p, sc, s.words, s.start[i], m, [&](uint32_t, uint32_t, const MinPosD& mp) {
-        atomicAdd(&hist[bin_of(c, mp.pmer)], 1u);
-    });
+constexpr int SCAN_TILE_W = 128;                // window starts per tile
+constexpr int SCAN_ARR = 192 + 64;              // positions per tile + padding for the shifted reads
+constexpr uint32_t SCAN_CHUNK = 1024;           // records a wave reserves per global atomic (one hot address otherwise)
+constexpr uint32_t BIN_INVALID = 0xffffffffu;   // unused slot of a reserved chunk
+
+template <int NBW>
+__global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
+                                                      uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
+                                                      unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
+                                                      uint32_t* __restrict__ flags) {
+    constexpr int RW = NBW + 1;
+    __shared__ uint64_t s_arr[4][SCAN_ARR];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* A = s_arr[wave];
+    A[192 + lane] = ~0ull;
+    const int k = c.k, p = c.p;
+    const uint32_t W = (uint32_t)(k - p + 1);
+    const uint64_t* __restrict__ w = s.words;
+    const FastScore sc{c.p, c.stranded};
+    const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t lt = lanemask_lt();
+    uint64_t chunk_base = 0;                        // wave-uniform sub-allocator over reserved chunks
+    uint32_t chunk_used = SCAN_CHUNK;
+
+    // 64 reads per wave iteration: their metadata arrives in three coalesced loads and is broadcast
+    // lane by lane, so the per-read critical path holds a single HBM round trip (the packed words).
+    for (uint64_t rb = gwave * 64; rb < s.n; rb += nwaves * 64) {
+      const uint64_t my = rb + lane;
+      uint32_t v_m = 0, v_ex = 0, v_d1 = 0;
+      uint64_t v_st = 0;
+      if (my < s.n) {
+          v_m = s.length[my]; v_st = s.start[my];
+          if (s.exts) v_ex = s.exts[my];
+          if (s.data) v_d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[my] : (s.data_width == 2 ? ((const uint16_t*)s.data)[my] : ((const uint32_t*)s.data)[my]);
+      }
+      const uint32_t nb_reads = (uint32_t)(s.n - rb < 64 ? s.n - rb : 64);
+      for (uint32_t rj = 0; rj < nb_reads; rj++) {
+        const uint32_t m = __shfl(v_m, rj);
+        if (m < (uint32_t)k) continue;
+        const uint64_t st = __shfl(v_st, rj);
+        const uint32_t sexts = __shfl(v_ex, rj);
+        const uint32_t d1 = __shfl(v_d1, rj);
+        const uint32_t nwin = m - (uint32_t)k + 1, npos = m - (uint32_t)p + 1;
+        uint32_t open_start = 0;            // start window of the piece still open (wave-uniform)
+        uint32_t carry_arg = 0xffffffffu;   // argmin position of the last window of the previous tile
+
+        for (uint32_t t0 = 0; t0 < nwin; t0 += SCAN_TILE_W) {
+            // ---- hashed p-mers of this tile ----
+            uint64_t own[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                uint32_t pos = t0 + ch * 64 + lane;
+                uint64_t v = ~0ull;
+                if (pos < npos) {
+                    uint32_t pm = (uint32_t)packed_get_kmer(w, st + pos, p).lo;
+                    v = ((uint64_t)sc(pm) << 32) | pos;
+                }
+                own[ch] = v;
+                A[ch * 64 + lane] = v;
+            }
+            // ---- log-step sliding minimum: after the loop own[] covers [i, i + span) ----
+            uint32_t span = 1;
+            for (; 2 * span <= W; span <<= 1) {
+                uint64_t x0 = A[lane + span], x1 = A[64 + lane + span], x2 = A[128 + lane + span];
+                own[0] = own[0] < x0 ? own[0] : x0;
+                own[1] = own[1] < x1 ? own[1] : x1;
+                own[2] = own[2] < x2 ? own[2] : x2;
+                A[lane] = own[0]; A[64 + lane] = own[1]; A[128 + lane] = own[2];
+            }
+            const uint32_t rem = W - span;
+            uint32_t arg[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint64_t y = A[ch * 64 + lane + rem];
+                uint64_t mn = own[ch] < y ? own[ch] : y;
+                arg[ch] = (uint32_t)mn;                     // absolute p-mer position of the window minimizer
+            }
+            // ---- piece boundaries ----
+            uint32_t up0 = __shfl_up(arg[0], 1), up1 = __shfl_up(arg[1], 1);
+            uint32_t last0 = __shfl(arg[0], 63);
+            uint32_t prev[2] = {lane ? up0 : carry_arg, lane ? up1 : last0};
+            bool isb[2];
+            uint64_t mask[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                uint32_t i = t0 + ch * 64 + lane;
+                isb[ch] = i < nwin && (i == 0 || arg[ch] != prev[ch]);
+                mask[ch] = __ballot(isb[ch]);
+            }
+            const uint32_t tile_last = (nwin - t0 < (uint32_t)SCAN_TILE_W ? nwin - t0 : (uint32_t)SCAN_TILE_W) - 1;
+            const uint32_t last_arg = tile_last < 64 ? __shfl(arg[0], tile_last) : __shfl(arg[1], tile_last - 64);
+            const bool read_ends = t0 + SCAN_TILE_W >= nwin;
+            uint32_t new_open = open_start;
+            if (mask[1]) new_open = t0 + 64 + (63 - __clzll(mask[1]));
+            else if (mask[0]) new_open = t0 + (63 - __clzll(mask[0]));
+            // ---- emission: the boundary at window i closes the piece that started at the previous
+            //      boundary; lane 0 also closes the last piece when the read ends in this tile ----
+#pragma unroll 1
+            for (int slot = 0; slot < 3; slot++) {
+                bool emit = false;
+                uint32_t ps = 0, pe = 0, pa = 0;
+                if (slot < 2) {
+                    uint32_t i = t0 + slot * 64 + lane;
+                    if (isb[slot] && i > 0) {
+                        emit = true; pe = i; pa = prev[slot];
+                        uint64_t below = mask[slot] & lt;
+                        if (below) ps = t0 + slot * 64 + (63 - __clzll(below));
+                        else if (slot == 1 && mask[0]) ps = t0 + (63 - __clzll(mask[0]));
+                        else ps = open_start;
+                    }
+                } else if (read_ends && lane == 0) {
+                    emit = true; ps = new_open; pe = nwin; pa = last_arg;
+                }
+                uint64_t em = __ballot(emit);
+                if (!em) continue;
+                const uint32_t n_em = __popcll(em);
+                if (chunk_used + n_em > SCAN_CHUNK) {
+                    unsigned long long nb = 0;
+                    if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
+                    chunk_base = __shfl(nb, 0);
+                    chunk_used = 0;
+                }
+                const uint64_t idx = chunk_base + chunk_used + __popcll(em & lt);
+                chunk_used += n_em;
+                if (!emit) continue;
+                if (chunk_base + SCAN_CHUNK > tmp_cap) { atomicOr(&flags[0], 1u); continue; }
+                uint32_t pm = (uint32_t)packed_get_kmer(w, st + pa, p).lo;
+                uint32_t b = bin_of(c, pm);
+                atomicAdd(&hist[b], 1u);
+                uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
+                uint32_t le = ps > 0 ? (1u << packed_get(w, st + ps - 1)) : (sexts & 0xfu);
+                uint32_t re = ps + len < m ? (1u << packed_get(w, st + ps + len)) : (sexts >> 4);
+                uint64_t* o = tmp_recs + idx * RW;
+#pragma unroll
+                for (int q = 0; q < NBW; q++) {
+                    uint32_t b0 = (uint32_t)q * 32;
+                    uint64_t v = 0;
+                    if (b0 < len) {
+                        uint32_t nb = len - b0 < 32 ? len - b0 : 32;
+                        v = packed_get_kmer(w, st + ps + b0, (int)nb).lo << (64 - 2 * nb);
+                    }
+                    o[q] = v;
+                }
+                o[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
+                tmp_bin[idx] = b;
+            }
+            open_start = new_open;
+            carry_arg = last_arg;
+        }
+      }
+    }
 }
 
 template <int NBW>
-__global__ void __launch_bounds__(64) sk_emit_kernel(SeqDev s, FastCfg c, const uint64_t* __restrict__ bin_off,
-                                                     uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs) {
+__global__ void __launch_bounds__(256) sk_scatter_kernel(const uint64_t* __restrict__ tmp_recs, const uint32_t* __restrict__ tmp_bin,
+                                                         uint64_t n_recs, const uint64_t* __restrict__ bin_off,
+                                                         uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs) {
     constexpr int RW = NBW + 1;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n) return;
-    uint32_t m = s.length[i];
-    if (m < (uint32_t)c.k) return;
-    const uint64_t st = s.start[i];
-    const uint64_t* __restrict__ w = s.words;
-    const uint32_t sexts = s.exts ? s.exts[i] : 0u;
-    uint32_t d1 = 0;
-    if (s.data) d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[i] : (s.data_width == 2 ? ((const uint16_t*)s.data)[i] : ((const uint32_t*)s.data)[i]);
-    FastScore sc{c.p, c.stranded};
-    scan_sequence(c.k, c.p, sc, w, st, m, [&](uint32_t start, uint32_t len, const MinPosD& mp) {
-        uint32_t b = bin_of(c, mp.pmer);
-        uint64_t r = bin_off[b] + atomicAdd(&cursor[b], 1u);
-        uint64_t* o = recs + r * RW;
-        // boundary Exts of the piece inside its read: neighbouring base, or the read's own seq_exts at the ends
-        uint32_t le = start > 0 ? (1u << packed_get(w, st + start - 1)) : (sexts & 0xfu);
-        uint32_t re = start + len < m ? (1u << packed_get(w, st + start + len)) : (sexts >> 4);
+    if (i >= n_recs) return;
+    uint32_t b = tmp_bin[i];
+    if (b == BIN_INVALID) return;
+    uint64_t r = bin_off[b] + atomicAdd(&cursor[b], 1u);
+    const uint64_t* src = tmp_recs + i * RW;
+    uint64_t* dst = recs + r * RW;
 #pragma unroll
-        for (int q = 0; q < NBW; q++) {
-            uint32_t b0 = (uint32_t)q * 32;
-            uint64_t v = 0;
-            if (b0 < len) {
-                uint32_t nb = len - b0 < 32 ? len - b0 : 32;
-                v = packed_get_kmer(w, st + start + b0, (int)nb).lo << (64 - 2 * nb);
-            }
-            o[q] = v;
-        }
-        o[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
-    });
+    for (int q = 0; q < RW; q++) dst[q] = src[q];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,26 +274,39 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
     return base + incl;
 }
 
-constexpr int IT_DONE = 0, IT_PROBE = 1, IT_VERIFY = 2, IT_HIT = 3;
+// One workgroup (NT threads = NT/64 waves) owns one bin and one LDS hash table of T entries.
+// Waves stream the bin's records independently -- no block barrier inside a pass:
+//   * a wave loads 64 records (one per lane, 2 KB contiguous), stages them in its private LDS slab and
+//     prefix-sums their k-mer counts with shuffles; lanes then take k-mer instances round-robin;
+//   * insert = linear probing on a 32-bit tag word.  A free slot is claimed with
+//     CAS(tag, 0, tag|BUSY); the claimer writes the 64/128-bit key and then stores the final tag
+//     (LDS operations of one wave retire in order, so the key is visible before the tag flips).
+//     A lane that meets its own tag with BUSY set re-reads it; this never deadlocks: a claimer in
+//     another wave progresses independently, and a claimer in the same wave has executed its key/tag
+//     stores before the loop's next iteration starts;
+//   * count += 1, exts |= e, colour mask |= 1 << d with LDS atomics on the slot.
+// A pass whose distinct keys exceed 7/8 of the table raises a flag that every wave polls; the pass is
+// then re-split by hash (work stack below).
+constexpr uint32_t TAG_BUSY = 0x80000000u;
 
-template <int KW, int NBW, bool IS_SET, int NT, int T, int CH, int ITEMS>
+template <int KW, int NBW, bool IS_SET, int NT, int T>
 __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ bin_off,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
                                                        unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags) {
     constexpr int RW = NBW + 1;
+    constexpr int NWV = NT / 64;
     __shared__ uint32_t s_tag[T];
     __shared__ uint64_t s_lo[T];
     __shared__ uint64_t s_hi[KW == 2 ? T : 1];
     __shared__ uint32_t s_cnt[T];
-    __shared__ uint32_t s_aux[T];
-    __shared__ uint32_t s_msk[IS_SET ? T : 1];
-    __shared__ uint64_t s_rec[CH * RW];
-    __shared__ uint32_t s_off[CH + 1];
-    __shared__ uint32_t s_wsum[NT / 64];
+    __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24)
+    __shared__ uint32_t s_wsum[NWV];
     __shared__ uint32_t s_flag[2];              // [0] table overflow, [1] claimed entries
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_stP[40], s_stR[40];
+    __shared__ int s_sp;
 
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t r0 = bin_off[blockIdx.x], r1 = bin_off[blockIdx.x + 1];
     if (r0 == r1) return;
     const K128 kmask = k128_mask(k);
@@ -172,8 +314,6 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     // Work stack of hash-selected passes (P, r): the pass handles the keys with (hash >> 16) % P == r.
     // A pass whose distinct keys overflow the table emits nothing and is replaced by its two children
     // (2P, r) and (2P, r + P), which partition exactly its key set.
-    __shared__ uint32_t s_stP[40], s_stR[40];
-    __shared__ int s_sp;
     if (tid == 0) { s_stP[0] = 1; s_stR[0] = 0; s_sp = 1; }
     __syncthreads();
     for (uint32_t guard = 0;; guard++) {
@@ -182,136 +322,102 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         if (guard > 20000u) { if (tid == 0) atomicOr(&gflags[3], 2u); break; }                   // watchdog
         const uint32_t P = s_stP[sp - 1], pr = s_stR[sp - 1];
         __syncthreads();
-        if (tid == 0) { s_sp = sp - 1; atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); }
-        bool ovf = false;
-        {
-            for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; if (IS_SET) s_msk[i] = 0; }
-            if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-            __syncthreads();
-            for (uint64_t rb = r0; rb < r1 && !ovf; rb += CH) {
-                const uint32_t nrec = (uint32_t)((r1 - rb) < (uint64_t)CH ? (r1 - rb) : (uint64_t)CH);
-                for (uint32_t w = tid; w < nrec * RW; w += NT) s_rec[w] = recs[rb * RW + w];
-                __syncthreads();
-                uint32_t nk = 0;
-                if (tid < nrec) nk = (uint32_t)(s_rec[tid * RW + NBW] & 0xff) - (uint32_t)k + 1;
-                uint32_t tot;
-                uint32_t incl = block_inclusive_scan<NT>(nk, s_wsum, &tot);
-                if (tid < nrec) s_off[tid + 1] = incl;
-                if (tid == 0) s_off[0] = 0;
-                __syncthreads();
-                for (uint32_t base = 0; base < tot && !ovf; base += NT * ITEMS) {
-                    uint64_t it_lo[ITEMS], it_hi[ITEMS];
-                    uint32_t it_slot[ITEMS], it_tag[ITEMS], it_aux[ITEMS];
-                    int it_state[ITEMS];
-                    // ---- materialise up to ITEMS consecutive k-mer instances ----
-                    const uint32_t i0 = base + tid * ITEMS;
-                    uint32_t rec = 0, j = 0, rlen = 0, rexts = 0, rd = 0;
-                    K128 fw{0, 0};
-                    const uint64_t* rw = s_rec;
-                    if (i0 < tot) {
-                        uint32_t lo_i = 0, hi_i = nrec;                 // largest rec with s_off[rec] <= i0
-                        while (hi_i - lo_i > 1) { uint32_t mid = (lo_i + hi_i) >> 1; if (s_off[mid] <= i0) lo_i = mid; else hi_i = mid; }
-                        rec = lo_i; j = i0 - s_off[rec];
-                    }
+        if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
+        for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        __syncthreads();
+
+        // ---- stream the bin: every wave takes 64-record groups round-robin, one record per lane.
+        //      The record lives in registers; its k-mers are produced by rolling (extend_right on the
+        //      forward strand, extend_left of the complement on the reverse strand) ----
+        for (uint64_t rb = r0 + (uint64_t)wave * 64; rb < r1; rb += (uint64_t)NWV * 64) {
+            if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            const bool have = rb + lane < r1;
+            uint64_t W[4] = {0, 0, 0, 0};
+            uint64_t meta = 0;
+            if (have) {
+                const uint64_t* g = recs + (rb + lane) * RW;
 #pragma unroll
-                    for (int it = 0; it < ITEMS; it++) {
-                        it_state[it] = IT_DONE;
-                        it_lo[it] = it_hi[it] = 0; it_slot[it] = it_tag[it] = it_aux[it] = 0;
-                        if (i0 + it >= tot) continue;
-                        bool fresh = it == 0;
-                        if (it > 0) { j++; if (j + (uint32_t)k > rlen) { rec++; j = 0; fresh = true; } }
-                        if (fresh) {
-                            rw = s_rec + rec * RW;
-                            uint64_t meta = rw[NBW];
-                            rlen = (uint32_t)(meta & 0xff); rexts = (uint32_t)(meta >> 8) & 0xffu; rd = (uint32_t)(meta >> 16);
-                            fw = packed_get_kmer(rw, j, k);
-                        } else {
-                            fw = k128_shl(fw, 2);
-                            fw.hi &= kmask.hi; fw.lo &= kmask.lo;
-                            fw.lo |= packed_get(rw, j + k - 1);
-                        }
-                        // Exts of k-mer j inside the piece (lib.rs:820-832 with seq_exts = the piece's boundary Exts)
-                        uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << packed_get(rw, j - 1));
-                        uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << packed_get(rw, j + k));
-                        uint32_t ex = left | right;
-                        K128 km = fw;
-                        if (!stranded) {
-                            K128 rc = kmer_rc(fw, k);
-                            if (!k128_lt(fw, rc)) { km = rc; ex = exts_rc(ex); }  // ties flip (lib.rs:226-230)
-                        }
-                        uint64_t h = hash_key(km.hi, km.lo);
-                        if (P > 1 && ((uint32_t)(h >> 16) & (P - 1)) != pr) continue;
-                        it_lo[it] = km.lo; it_hi[it] = km.hi;
-                        it_slot[it] = (uint32_t)h & (T - 1);
-                        it_tag[it] = (uint32_t)(h >> 32) | 1u;
-                        it_aux[it] = ex | (rd << 8);
-                        it_state[it] = IT_PROBE;
-                    }
-                    // ---- insert: claim-or-match by 32-bit tag, verify full keys after a barrier ----
-                    // Every item has a total probe budget of T slots over all rounds; claims stop at
-                    // 7/8 occupancy.  Either limit raises the overflow flag and the pass is re-split.
-                    uint32_t it_left[ITEMS];
-#pragma unroll
-                    for (int it = 0; it < ITEMS; it++) it_left[it] = T;
-                    for (uint32_t round = 0;; round++) {
-                        if (round > 2u * T + 8u) { if (tid == 0) atomicOr(&gflags[3], 1u); break; }   // watchdog: cannot happen
-                        bool pending = false;
-#pragma unroll
-                        for (int it = 0; it < ITEMS; it++) {
-                            if (it_state[it] != IT_PROBE) continue;
-                            uint32_t slot = it_slot[it];
-                            uint32_t left = it_left[it];
-                            int st = IT_PROBE;
-                            while (left) {
-                                left--;
-                                uint32_t t = ((volatile uint32_t*)s_tag)[slot];
-                                if (t == 0) {
-                                    if (((volatile uint32_t*)s_flag)[0]) { left = 0; break; }     // pass already overflowed
-                                    t = atomicCAS(&s_tag[slot], 0u, it_tag[it]);
-                                    if (t == 0) {
-                                        s_lo[slot] = it_lo[it];
-                                        if (KW == 2) s_hi[slot] = it_hi[it];
-                                        if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8)) s_flag[0] = 1;
-                                        st = IT_HIT;
-                                        break;
-                                    }
-                                }
-                                if (t == it_tag[it]) { st = IT_VERIFY; break; }
-                                slot = (slot + 1) & (T - 1);
-                            }
-                            if (st == IT_PROBE) { s_flag[0] = 1; st = IT_DONE; }      // budget exhausted / table full
-                            it_slot[it] = slot; it_state[it] = st; it_left[it] = left;
-                        }
-                        __syncthreads();
-                        const uint32_t ovf_now = s_flag[0];          // stable: nobody writes it between the two barriers
-#pragma unroll
-                        for (int it = 0; it < ITEMS; it++) {
-                            if (it_state[it] != IT_VERIFY) continue;
-                            uint32_t slot = it_slot[it];
-                            bool same = s_lo[slot] == it_lo[it];
-                            if (KW == 2) same = same && s_hi[slot] == it_hi[it];
-                            if (same) it_state[it] = IT_HIT;
-                            else { it_slot[it] = (slot + 1) & (T - 1); it_state[it] = IT_PROBE; pending = true; }
-                        }
-                        if (!__syncthreads_or((pending && !ovf_now) ? 1 : 0)) break;
-                    }
-                    ovf = s_flag[0] != 0;
-                    if (!ovf) {
-#pragma unroll
-                        for (int it = 0; it < ITEMS; it++) {
-                            if (it_state[it] != IT_HIT) continue;
-                            uint32_t slot = it_slot[it];
-                            atomicAdd(&s_cnt[slot], 1u);
-                            atomicOr(&s_aux[slot], it_aux[it] & 0xffu);
-                            if (IS_SET) atomicOr(&s_msk[slot], 1u << ((it_aux[it] >> 8) & 31u));
-                        }
-                    }
-                    __syncthreads();        // flags / table settle before the next batch re-reads them
-                }
-                __syncthreads();            // s_rec is overwritten by the next chunk
+                for (int q = 0; q < NBW; q++) W[q] = g[q];
+                meta = g[NBW];
             }
-            // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
-            if (!ovf) {
+            const uint32_t rlen = (uint32_t)(meta & 0xff), rexts = (uint32_t)(meta >> 8) & 0xffu, rd = (uint32_t)(meta >> 16);
+            const uint32_t nk = have ? rlen - (uint32_t)k + 1 : 0u;
+            auto base_at = [&](uint32_t q) -> uint32_t {
+                uint64_t wd = q < 32 ? W[0] : (q < 64 ? W[1] : (NBW > 2 && q < 96 ? W[2] : (NBW > 3 ? W[3] : W[NBW - 1])));
+                return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
+            };
+            K128 fw = k128_shr(K128{W[0], W[1]}, 128 - 2 * k);      // first k-mer (k <= 64 lies in the first two words)
+            K128 rcw = kmer_rc(fw, k);
+            uint32_t lb = 0;                                         // base just left of the current k-mer
+            for (uint32_t j = 0; __any(j < nk); j++) {
+                const bool act = j < nk;
+                const uint32_t nbase = (act && j + (uint32_t)k < rlen) ? base_at(j + k) : 0u;   // base right of the k-mer
+                if (act) {
+                    // Exts of k-mer j inside the piece (lib.rs:820-832 with seq_exts = the piece's boundary Exts)
+                    uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << lb);
+                    uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << nbase);
+                    uint32_t ex = left | right;
+                    K128 km = fw;
+                    if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = exts_rc(ex); }   // ties flip (lib.rs:226-230)
+                    const uint64_t h = hash_key(km.hi, km.lo);
+                    if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
+                        const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
+                        uint32_t slot = (uint32_t)h & (T - 1);
+                        bool hit = false;
+                        for (uint32_t left_probes = T; left_probes;) {
+                            uint32_t t = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (t == 0) {
+                                if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;           // pass already overflowed
+                                t = atomicCAS(&s_tag[slot], 0u, mytag | TAG_BUSY);
+                                if (t == 0) {
+                                    s_lo[slot] = km.lo;
+                                    if (KW == 2) s_hi[slot] = km.hi;
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    __hip_atomic_store(&s_tag[slot], (uint32_t)(mytag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8)) __hip_atomic_store(&s_flag[0], (uint32_t)(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    hit = true;
+                                    break;
+                                }
+                            }
+                            if ((t & ~TAG_BUSY) == mytag) {
+                                if (t & TAG_BUSY) continue;                          // claimer is still writing the key: re-read
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                                bool same = __hip_atomic_load(&s_lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == km.lo;
+                                if (KW == 2) same = same && __hip_atomic_load(&s_hi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == km.hi;
+                                if (same) { hit = true; break; }
+                            }
+                            slot = (slot + 1) & (T - 1);
+                            left_probes--;
+                        }
+                        if (hit) {
+                            atomicAdd(&s_cnt[slot], 1u);
+                            atomicOr(&s_aux[slot], IS_SET ? (ex | (256u << (rd & 31u))) : ex);
+                        } else {
+                            __hip_atomic_store(&s_flag[0], (uint32_t)(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                     // table full / pass overflowed
+                        }
+                    }
+                }
+                // roll to k-mer j+1
+                if (KW == 2) {                                       // 33 <= k <= 64: the first base sits in hi
+                    const int sh = 2 * (k - 1) - 64;
+                    lb = (uint32_t)(fw.hi >> sh) & 3u;
+                    fw.hi = ((fw.hi << 2) | (fw.lo >> 62)) & kmask.hi;
+                    fw.lo = (fw.lo << 2) | nbase;
+                    rcw.lo = (rcw.lo >> 2) | (rcw.hi << 62);
+                    rcw.hi = (rcw.hi >> 2) | ((uint64_t)(3u - nbase) << sh);
+                } else {                                             // k <= 32: everything sits in lo
+                    const int sh = 2 * (k - 1);
+                    lb = (uint32_t)(fw.lo >> sh) & 3u;
+                    fw.lo = ((fw.lo << 2) | nbase) & kmask.lo;
+                    rcw.lo = (rcw.lo >> 2) | ((uint64_t)(3u - nbase) << sh);
+                }
+            }
+        }
+        __syncthreads();
+        const bool ovf = s_flag[0] != 0;
+        // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
+        if (!ovf) {
             uint32_t nvalid = 0;
             for (int i = tid; i < T; i += NT) {
                 if (!s_tag[i]) continue;
@@ -336,14 +442,11 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     if (KW == 2) out.hi[o] = s_hi[i];
                     out.lo[o] = s_lo[i];
                     out.pay[o] = (s_aux[i] & 0xffu) | (c16 << 8);
-                    if (IS_SET) { out.msk[o] = s_msk[i]; }
+                    if (IS_SET) { out.msk[o] = s_aux[i] >> 8; }
                     o++;
                 }
             }
-            }
-            __syncthreads();
-        }
-        if (ovf) {
+        } else {
             if (P >= 4096u || sp + 1 >= 40) { if (tid == 0) atomicOr(&gflags[0], 2u); break; }
             if (tid == 0) { s_stP[sp - 1] = 2 * P; s_stR[sp - 1] = pr; s_stP[sp] = 2 * P; s_stR[sp] = pr + P; s_sp = sp + 1; }
         }
@@ -388,7 +491,7 @@ __global__ void max_label_kernel(const void* data, uint32_t width, uint64_t n, u
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
-int fast_internal_p(int k) { return k >= 21 ? 13 : std::max(4, k - 8); }
+int fast_internal_p(int k) { return k >= 23 ? 15 : (k >= 21 ? 13 : std::max(4, k - 8)); }
 
 // returns 0 and sets *used = true when the fast path produced the table; *used = false means the
 // caller must take the generic path (unsupported shape), nothing was written.
@@ -409,7 +512,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         uint32_t h = 0;
         HIP_TRY(c, hipMemcpyAsync(&h, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (h >= 32) return 0;                          // label domain too wide for the LDS bitmask
+        if (h >= 24) return 0;                          // label domain too wide for the LDS bitmask
     }
     const int p = fast_internal_p(k);
     const int nbw = std::max(2, (2 * k - p + 31) / 32);   // base words per record
@@ -423,33 +526,66 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     SeqDev sd = s;
     if (!is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
 
-    // ---- pass 1: bin histogram ----
-    DBuf<uint32_t> hist, cursor;
-    DBuf<uint64_t> bin_off;
+    // ---- scan: super-k-mer records in read order + bin histogram ----
+    const int rw = nbw + 1;
+    DBuf<uint32_t> hist, cursor, tmp_bin, sflags;
+    DBuf<uint64_t> bin_off, tmp_recs;
+    DBuf<unsigned long long> tmp_cursor;
     ALLOC_OR_FAIL(c, hist, nbins);
     ALLOC_OR_FAIL(c, cursor, nbins);
     ALLOC_OR_FAIL(c, bin_off, (size_t)nbins + 1);
-    HIP_TRY(c, hipMemsetAsync(hist.p, 0, (size_t)nbins * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(cursor.p, 0, (size_t)nbins * 4, c->stream));
-    c->t_begin("sk_count", n_kmers);
-    sk_count_kernel<<<cdiv(s.n, 64), 64, 0, c->stream>>>(sd, cfg, hist.p);
-    c->t_end();
-    LAUNCH_CHECK(c, "sk_count");
+    ALLOC_OR_FAIL(c, tmp_cursor, 1);
+    ALLOC_OR_FAIL(c, sflags, 1);
+    // expected density of minimizer changes is 2/(W+1) per window plus one piece per read
+    uint64_t tmp_cap = (uint64_t)((double)n_kmers * 2.0 / (double)(k - p + 2) * 1.15) + s.n + 1024;
+    if (tmp_cap > n_kmers) tmp_cap = n_kmers;
+    const uint32_t scan_blocks = (uint32_t)std::min<uint64_t>((s.n + 3) / 4, 256ull * 32);
+    const uint64_t chunk_slack = (uint64_t)scan_blocks * 4 * SCAN_CHUNK;      // every wave may strand one partial chunk
+    tmp_cap += chunk_slack;
+    uint64_t n_recs = 0, n_tmp = 0;
+    for (int attempt = 0;; attempt++) {
+        ALLOC_OR_FAIL(c, tmp_recs, tmp_cap * rw);
+        ALLOC_OR_FAIL(c, tmp_bin, tmp_cap);
+        HIP_TRY(c, hipMemsetAsync(hist.p, 0, (size_t)nbins * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(tmp_cursor.p, 0, 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(tmp_bin.p, 0xff, tmp_cap * 4, c->stream));
+        const uint32_t blocks = scan_blocks;
+        c->t_begin("sk_scan", n_kmers);
+        if (nbw == 2) sk_scan_kernel<2><<<blocks, 256, 0, c->stream>>>(sd, cfg, hist.p, tmp_recs.p, tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+        else if (nbw == 3) sk_scan_kernel<3><<<blocks, 256, 0, c->stream>>>(sd, cfg, hist.p, tmp_recs.p, tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+        else sk_scan_kernel<4><<<blocks, 256, 0, c->stream>>>(sd, cfg, hist.p, tmp_recs.p, tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "sk_scan");
+        unsigned long long cur = 0;
+        HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (cur > tmp_cap) {                                  // low-complexity input: more pieces than estimated
+            if (attempt >= 2) return c->fail(133, "fast path: super-k-mer buffer estimate failed");
+            tmp_cap = std::min<uint64_t>(n_kmers, cur) + chunk_slack;
+            continue;
+        }
+        n_tmp = cur;
+        break;
+    }
     DBG_TRY(scan_exclusive_u32_u64(c, hist.p, bin_off.p, nbins));
-    uint64_t n_recs = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_recs, bin_off.p + nbins, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-
-    // ---- pass 2: records ----
-    const int rw = nbw + 1;
+    c->t_begin("sk_records", n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
+    c->t_end();
+    // ---- scatter into bin order ----
     DBuf<uint64_t> recs;
     ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(n_recs * rw, 1));
-    c->t_begin("sk_emit", n_kmers);
-    if (nbw == 2) sk_emit_kernel<2><<<cdiv(s.n, 64), 64, 0, c->stream>>>(sd, cfg, bin_off.p, cursor.p, recs.p);
-    else if (nbw == 3) sk_emit_kernel<3><<<cdiv(s.n, 64), 64, 0, c->stream>>>(sd, cfg, bin_off.p, cursor.p, recs.p);
-    else sk_emit_kernel<4><<<cdiv(s.n, 64), 64, 0, c->stream>>>(sd, cfg, bin_off.p, cursor.p, recs.p);
-    c->t_end();
-    LAUNCH_CHECK(c, "sk_emit");
+    HIP_TRY(c, hipMemsetAsync(cursor.p, 0, (size_t)nbins * 4, c->stream));
+    if (n_tmp) {
+        c->t_begin("sk_scatter", n_recs);
+        if (nbw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(tmp_recs.p, tmp_bin.p, n_tmp, bin_off.p, cursor.p, recs.p);
+        else if (nbw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(tmp_recs.p, tmp_bin.p, n_tmp, bin_off.p, cursor.p, recs.p);
+        else sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(tmp_recs.p, tmp_bin.p, n_tmp, bin_off.p, cursor.p, recs.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "sk_scatter");
+    }
+    tmp_recs.release(); tmp_bin.release();
 
     // ---- per-bin LDS hash tables ----
     DBuf<unsigned long long> out_cursor;
@@ -470,7 +606,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         HIP_TRY(c, hipMemsetAsync(gflags.p, 0, 16, c->stream));
         FastOut fo{u_hi.p, u_lo.p, u_pay.p, u_msk.p, nullptr};
         c->t_begin("bin_count", n_kmers);
-#define GO(KW, NBW, SET) bin_count_kernel<KW, NBW, SET, 512, TABLE, 128, 4><<<nbins, 512, 0, c->stream>>>( \
+#define GO(KW, NBW, SET) bin_count_kernel<KW, NBW, SET, 512, TABLE><<<nbins, 512, 0, c->stream>>>( \
         recs.p, bin_off.p, k, cfg.stranded, prm->min_kmer_obs, fo, cap, out_cursor.p, gflags.p)
         if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
         else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }

@@ -51,7 +51,7 @@ def test_fast_count_filter(ctx, k, stranded, min_obs):
     run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, min_obs, stranded)
 
 
-@pytest.mark.parametrize("k,ncol", [(47, 4), (31, 32), (63, 7)])
+@pytest.mark.parametrize("k,ncol", [(47, 4), (31, 24), (63, 7)])
 def test_fast_count_filter_set(ctx, k, ncol):
     rng = np.random.default_rng(k + ncol)
     seqs = random_reads(rng, 700, 3000, 150, False)
@@ -116,7 +116,7 @@ def test_fast_path_refuses_unsupported_shapes(ctx):
     rng = np.random.default_rng(1)
     seqs = random_reads(rng, 50, 1000, 150, False)
     ss = O.SeqSet.from_byte_seqs(seqs, data=rng.integers(40, 300, size=50), sizeof_d1=2)
-    with pytest.raises(dbg.DbgError):           # labels >= 32 need the generic (sort-based) CountFilterSet
+    with pytest.raises(dbg.DbgError):           # labels >= 24 need the generic (sort-based) CountFilterSet
         dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     os.environ["DBG_PATH"] = "auto"
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
