@@ -82,11 +82,21 @@ def main():
                      colour.data_ptr() if is_set else None, 1 if is_set else 0, reads_per_gpu)
     fp = capi.FilterParams(k, 0, 1 if is_set else 0, args.min_obs, 0, 4)
 
+    D = importlib.import_module("rust-debruijn_amd.distributed")
+    engine = D.HipEngine(ctx, dev)
+
     def step():
-        t = capi.KmerTable()
-        ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
-        res = (t.n, t.n_kmer_instances)
-        lib.dbg_free_table(ctx.h, C.byref(t))
+        if world == 1:
+            # the drop-in entry point: filter_kmers, device-resident in and out
+            t = capi.KmerTable()
+            ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+            res = (t.n, t.n_kmer_instances)
+            lib.dbg_free_table(ctx.h, C.byref(t))
+            return res
+        # N > 1: scan local reads -> all-to-all of minimizer-bin slabs (RCCL over xGMI) -> count owned bins
+        tab, total, n_local, n_recs = D.sharded_filter_kmers(engine, ss, k, False, 1 if is_set else 0, args.min_obs)
+        res = (tab.n, n_local)
+        engine.free_table(tab)
         return res
 
     def barrier():
@@ -176,7 +186,9 @@ def main():
                        "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid,
                        "path": ("fast (super-k-mer bins -> per-bin LDS hash tables -> order-restoring radix sort)" if fast
                                 else "generic (extract -> global LSD radix sort -> segmented reduce)"),
-                       "superkmer_records_per_step": n_recs},
+                       "superkmer_records_per_step": n_recs,
+                       "multi_gpu": ("reads sharded by index; one all-to-all of super-k-mer bin slabs; each rank counts "
+                                     "the bins it owns" if world > 1 else "n/a")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

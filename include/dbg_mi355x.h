@@ -164,6 +164,34 @@ int  dbg_compress_kmers_with_hash(dbg_ctx* ctx, uint32_t k, int stranded, int sp
                                   const uint64_t* seed_order, dbg_graph* out);
 void dbg_free_graph(dbg_ctx* ctx, dbg_graph* g);
 
+/* ---- sharded counting for multi-GPU runs --------------------------------------------------
+ * The reference's own scale-out design is "MSP shard -> independent per-shard filter_kmers"
+ * (src/msp.rs:279-324, src/filter.rs:121-124, src/test.rs:433-456).  Here every rank scans its own
+ * reads into minimizer bins of ONE global bin space, the caller exchanges the bin-ordered slabs (RCCL
+ * all-to-all over xGMI; rank r owns bins [r*n_bins/W, (r+1)*n_bins/W)), and each rank counts the bins
+ * it owns.  All pointers are DEVICE pointers. */
+typedef struct {
+    uint32_t k;
+    int32_t  stranded;
+    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (labels < 24) */
+    uint64_t min_kmer_obs;
+    uint64_t total_kmers;       /* k-mer instances over ALL ranks: fixes the bin count */
+    uint32_t n_bins;            /* in: 0 = derive from total_kmers; out of dbg_shard_plan_make: bins */
+    uint32_t rec_words;         /* out: u64 words per super-k-mer record */
+} dbg_shard_plan;
+
+int  dbg_count_kmer_instances_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t k, uint64_t* n_out);
+int  dbg_shard_plan_make(dbg_ctx* ctx, dbg_shard_plan* plan);
+/* stage 1a: scan local reads; writes bin_off_dev[n_bins+1] (record offsets per bin) and *n_recs */
+int  dbg_shard_scan_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, const dbg_shard_plan* plan, uint64_t* n_recs,
+                        uint64_t* bin_off_dev);
+/* stage 1b: write the records in bin order into recs_out_dev[n_recs * rec_words] */
+int  dbg_shard_scatter_dev(dbg_ctx* ctx, const uint64_t* bin_off_dev, uint64_t* recs_out_dev);
+/* stage 2: count n_bins_local bins whose records are n_src bin-ordered segments of recs_dev:
+ * segment s of local bin b = records [seg_off[s*(n_bins_local+1)+b], seg_off[s*(n_bins_local+1)+b+1]) */
+int  dbg_shard_count_dev(dbg_ctx* ctx, const dbg_shard_plan* plan, const uint64_t* recs_dev, const uint64_t* seg_off_dev,
+                         uint32_t n_src, uint32_t n_bins_local, uint64_t n_kmers_hint, dbg_kmer_table* out_dev);
+
 /* ---- synthetic reads: splitmix64, deterministic ----- */
 typedef struct {
     uint64_t n_reads;

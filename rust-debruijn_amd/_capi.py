@@ -51,6 +51,11 @@ class SynthParams(C.Structure):
                 ("stranded", C.c_int32), ("n_colours", C.c_uint32), ("first_read", C.c_uint64)]
 
 
+class ShardPlan(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("stranded", C.c_int32), ("summarizer", C.c_int32), ("min_kmer_obs", C.c_uint64),
+                ("total_kmers", C.c_uint64), ("n_bins", C.c_uint32), ("rec_words", C.c_uint32)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32), ("units", C.c_uint64)]
 
@@ -62,6 +67,8 @@ EXPORTS = [
     "dbg_remove_censored_exts", "dbg_msp_sequence", "dbg_msp_sequence_dev", "dbg_free_pieces",
     "dbg_compress_kmers_with_hash", "dbg_free_graph", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
+    "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
+    "dbg_shard_count_dev",
 ]
 
 _lib = None
@@ -109,6 +116,12 @@ def load():
     lib.dbg_synth_reads_dev.argtypes = [C.c_void_p, C.POINTER(SynthParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]
     lib.dbg_synth_reads_host.argtypes = [C.POINTER(SynthParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dbg_count_kmer_instances_dev.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.c_uint32, C.POINTER(C.c_uint64)]
+    lib.dbg_shard_plan_make.argtypes = [C.c_void_p, C.POINTER(ShardPlan)]
+    lib.dbg_shard_scan_dev.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(ShardPlan), C.POINTER(C.c_uint64), C.c_void_p]
+    lib.dbg_shard_scatter_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dbg_shard_count_dev.argtypes = [C.c_void_p, C.POINTER(ShardPlan), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_uint64, C.POINTER(KmerTable)]
     lib.dbg_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.dbg_ctx_get_timings.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_uint32, C.POINTER(C.c_uint32)]
     _lib = lib

@@ -27,8 +27,11 @@ extern "C" int dbg_ctx_create(int device, dbg_ctx** out) {
     return 0;
 }
 
+void fast_drop_state(dbg_ctx* c);
+
 extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
     if (!c) return;
+    fast_drop_state(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->t_clear();

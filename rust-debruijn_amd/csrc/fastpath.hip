@@ -290,7 +290,8 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
 constexpr uint32_t TAG_BUSY = 0x80000000u;
 
 template <int KW, int NBW, bool IS_SET, int NT, int T>
-__global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ bin_off,
+__global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ seg_off,
+                                                       uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
                                                        unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags) {
     constexpr int RW = NBW + 1;
@@ -307,8 +308,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ int s_sp;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t r0 = bin_off[blockIdx.x], r1 = bin_off[blockIdx.x + 1];
-    if (r0 == r1) return;
+    // The bin's records arrive as n_src segments (one per source rank after the all-to-all; one in the
+    // single-GPU case): segment s spans records [seg_off[s*stride + bin], seg_off[s*stride + bin + 1]).
+    {
+        uint64_t total = 0;
+        for (uint32_t sg = 0; sg < n_src; sg++) total += seg_off[sg * seg_stride + blockIdx.x + 1] - seg_off[sg * seg_stride + blockIdx.x];
+        if (total == 0) return;
+    }
     const K128 kmask = k128_mask(k);
 
     // Work stack of hash-selected passes (P, r): the pass handles the keys with (hash >> 16) % P == r.
@@ -330,7 +336,11 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         // ---- stream the bin: every wave takes 64-record groups round-robin, one record per lane.
         //      The record lives in registers; its k-mers are produced by rolling (extend_right on the
         //      forward strand, extend_left of the complement on the reverse strand) ----
-        for (uint64_t rb = r0 + (uint64_t)wave * 64; rb < r1; rb += (uint64_t)NWV * 64) {
+        uint32_t grp = 0;                                    // 64-record groups are dealt to the waves round-robin
+        for (uint32_t sg = 0; sg < n_src; sg++) {
+          const uint64_t r0 = seg_off[sg * seg_stride + blockIdx.x], r1 = seg_off[sg * seg_stride + blockIdx.x + 1];
+          for (uint64_t rb = r0; rb < r1; rb += 64, grp++) {
+            if (grp % NWV != wave) continue;
             if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
             const bool have = rb + lane < r1;
             uint64_t W[4] = {0, 0, 0, 0};
@@ -413,6 +423,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     rcw.lo = (rcw.lo >> 2) | ((uint64_t)(3u - nbase) << sh);
                 }
             }
+          }
         }
         __syncthreads();
         const bool ovf = s_flag[0] != 0;
@@ -493,68 +504,79 @@ __global__ void max_label_kernel(const void* data, uint32_t width, uint64_t n, u
 // ------------------------------------------------------------------------------------------------
 int fast_internal_p(int k) { return k >= 23 ? 15 : (k >= 21 ? 13 : std::max(4, k - 8)); }
 
-// returns 0 and sets *used = true when the fast path produced the table; *used = false means the
-// caller must take the generic path (unsupported shape), nothing was written.
-int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
-                      bool* used) {
-    *used = false;
-    const int k = (int)prm->k;
-    const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET;
-    const bool has_hi = k > 32;
-    if (k < 16 || prm->report_all_kmers || n_kmers == 0) return 0;
-    if (is_set) {
-        if (!s.data) return 0;
-        DBuf<uint32_t> mx;
-        ALLOC_OR_FAIL(c, mx, 1);
-        HIP_TRY(c, hipMemsetAsync(mx.p, 0, 4, c->stream));
-        max_label_kernel<<<cdiv(s.n, 256), 256, 0, c->stream>>>(s.data, s.data_width, s.n, mx.p);
-        LAUNCH_CHECK(c, "max_label");
-        uint32_t h = 0;
-        HIP_TRY(c, hipMemcpyAsync(&h, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (h >= 24) return 0;                          // label domain too wide for the LDS bitmask
-    }
-    const int p = fast_internal_p(k);
-    const int nbw = std::max(2, (2 * k - p + 31) / 32);   // base words per record
-    if (nbw < 2 || nbw > 4) return 0;
-    constexpr uint32_t TABLE = 2048;
-    const uint64_t target = 9000;                        // k-mer instances per bin (about 0.15 distinct per instance)
-    uint64_t nb64 = std::max<uint64_t>(1, n_kmers / target);
-    if (nb64 > (1u << 24)) nb64 = 1u << 24;
-    FastCfg cfg{k, p, prm->stranded != 0, (uint32_t)nb64};
-    const uint32_t nbins = cfg.nbins;
-    SeqDev sd = s;
-    if (!is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
+struct FastPlan {
+    int k, p, nbw, rw;
+    bool stranded, is_set, has_hi;
+    uint32_t nbins;
+};
 
-    // ---- scan: super-k-mer records in read order + bin histogram ----
-    const int rw = nbw + 1;
-    DBuf<uint32_t> hist, cursor, tmp_bin, sflags;
-    DBuf<uint64_t> bin_off, tmp_recs;
+static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
+    if (k < 16 || k > 64) return false;
+    pl->k = k; pl->p = fast_internal_p(k);
+    pl->nbw = std::max(2, (2 * k - pl->p + 31) / 32);           // base words per record
+    if (pl->nbw > 4) return false;
+    pl->rw = pl->nbw + 1;
+    pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
+    const uint64_t target = 9000;                               // k-mer instances per bin (about 0.15 distinct per instance)
+    uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
+    if (nb64 > (1u << 24)) nb64 = 1u << 24;
+    pl->nbins = (uint32_t)nb64;
+    return true;
+}
+
+// scan state carried from fast_scan to fast_scatter
+struct FastScan {
+    FastPlan pl;
+    DBuf<uint32_t> hist, tmp_bin;
+    DBuf<uint64_t> tmp_recs;
+    uint64_t n_tmp = 0, n_recs = 0, n_kmers = 0;
+};
+
+// labels must be < 24 for the LDS colour bitmask
+static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
+    *ok = false;
+    if (!s.data) return 0;
+    DBuf<uint32_t> mx;
+    ALLOC_OR_FAIL(c, mx, 1);
+    HIP_TRY(c, hipMemsetAsync(mx.p, 0, 4, c->stream));
+    if (s.n) { max_label_kernel<<<cdiv(s.n, 256), 256, 0, c->stream>>>(s.data, s.data_width, s.n, mx.p); LAUNCH_CHECK(c, "max_label"); }
+    uint32_t h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *ok = h < 24;
+    return 0;
+}
+
+// scan: super-k-mer records in read order + bin histogram
+static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n_kmers, FastScan* st) {
+    st->pl = pl; st->n_kmers = n_kmers;
+    const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
+    const uint32_t nbins = pl.nbins;
+    FastCfg cfg{k, p, pl.stranded, nbins};
+    SeqDev sd = s;
+    if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
+    DBuf<uint32_t> sflags;
     DBuf<unsigned long long> tmp_cursor;
-    ALLOC_OR_FAIL(c, hist, nbins);
-    ALLOC_OR_FAIL(c, cursor, nbins);
-    ALLOC_OR_FAIL(c, bin_off, (size_t)nbins + 1);
+    ALLOC_OR_FAIL(c, st->hist, nbins);
     ALLOC_OR_FAIL(c, tmp_cursor, 1);
     ALLOC_OR_FAIL(c, sflags, 1);
     // expected density of minimizer changes is 2/(W+1) per window plus one piece per read
     uint64_t tmp_cap = (uint64_t)((double)n_kmers * 2.0 / (double)(k - p + 2) * 1.15) + s.n + 1024;
     if (tmp_cap > n_kmers) tmp_cap = n_kmers;
-    const uint32_t scan_blocks = (uint32_t)std::min<uint64_t>((s.n + 3) / 4, 256ull * 32);
+    const uint32_t scan_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 255) / 256, 256ull * 32));
     const uint64_t chunk_slack = (uint64_t)scan_blocks * 4 * SCAN_CHUNK;      // every wave may strand one partial chunk
     tmp_cap += chunk_slack;
-    uint64_t n_recs = 0, n_tmp = 0;
     for (int attempt = 0;; attempt++) {
-        ALLOC_OR_FAIL(c, tmp_recs, tmp_cap * rw);
-        ALLOC_OR_FAIL(c, tmp_bin, tmp_cap);
-        HIP_TRY(c, hipMemsetAsync(hist.p, 0, (size_t)nbins * 4, c->stream));
+        ALLOC_OR_FAIL(c, st->tmp_recs, tmp_cap * rw);
+        ALLOC_OR_FAIL(c, st->tmp_bin, tmp_cap);
+        HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)nbins * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(tmp_cursor.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 4, c->stream));
-        HIP_TRY(c, hipMemsetAsync(tmp_bin.p, 0xff, tmp_cap * 4, c->stream));
-        const uint32_t blocks = scan_blocks;
+        HIP_TRY(c, hipMemsetAsync(st->tmp_bin.p, 0xff, tmp_cap * 4, c->stream));
         c->t_begin("sk_scan", n_kmers);
-        if (nbw == 2) sk_scan_kernel<2><<<blocks, 256, 0, c->stream>>>(sd, cfg, hist.p, tmp_recs.p, tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
-        else if (nbw == 3) sk_scan_kernel<3><<<blocks, 256, 0, c->stream>>>(sd, cfg, hist.p, tmp_recs.p, tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
-        else sk_scan_kernel<4><<<blocks, 256, 0, c->stream>>>(sd, cfg, hist.p, tmp_recs.p, tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+        if (nbw == 2) sk_scan_kernel<2><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+        else if (nbw == 3) sk_scan_kernel<3><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+        else sk_scan_kernel<4><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
         c->t_end();
         LAUNCH_CHECK(c, "sk_scan");
         unsigned long long cur = 0;
@@ -565,34 +587,53 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
             tmp_cap = std::min<uint64_t>(n_kmers, cur) + chunk_slack;
             continue;
         }
-        n_tmp = cur;
+        st->n_tmp = cur;
         break;
     }
-    DBG_TRY(scan_exclusive_u32_u64(c, hist.p, bin_off.p, nbins));
-    HIP_TRY(c, hipMemcpyAsync(&n_recs, bin_off.p + nbins, 8, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+// scatter into bin order: recs_out [n_recs * rw] and bin_off_out [nbins + 1] are caller-provided device buffers.
+// n_recs must first be obtained with fast_bin_offsets.
+static int fast_bin_offsets(dbg_ctx* c, FastScan* st, uint64_t* bin_off_out) {
+    DBG_TRY(scan_exclusive_u32_u64(c, st->hist.p, bin_off_out, st->pl.nbins));
+    HIP_TRY(c, hipMemcpyAsync(&st->n_recs, bin_off_out + st->pl.nbins, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->t_begin("sk_records", n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
+    c->t_begin("sk_records", st->n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
     c->t_end();
-    // ---- scatter into bin order ----
-    DBuf<uint64_t> recs;
-    ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(n_recs * rw, 1));
+    return 0;
+}
+static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out) {
+    const uint32_t nbins = st->pl.nbins;
+    DBuf<uint32_t> cursor;
+    ALLOC_OR_FAIL(c, cursor, nbins);
     HIP_TRY(c, hipMemsetAsync(cursor.p, 0, (size_t)nbins * 4, c->stream));
-    if (n_tmp) {
-        c->t_begin("sk_scatter", n_recs);
-        if (nbw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(tmp_recs.p, tmp_bin.p, n_tmp, bin_off.p, cursor.p, recs.p);
-        else if (nbw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(tmp_recs.p, tmp_bin.p, n_tmp, bin_off.p, cursor.p, recs.p);
-        else sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(tmp_recs.p, tmp_bin.p, n_tmp, bin_off.p, cursor.p, recs.p);
+    if (st->n_tmp) {
+        const uint64_t n_tmp = st->n_tmp;
+        c->t_begin("sk_scatter", st->n_recs);
+        if (st->pl.nbw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
+        else if (st->pl.nbw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
+        else sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
         c->t_end();
         LAUNCH_CHECK(c, "sk_scatter");
     }
-    tmp_recs.release(); tmp_bin.release();
+    st->tmp_recs.release(); st->tmp_bin.release(); st->hist.release();
+    return 0;
+}
 
-    // ---- per-bin LDS hash tables ----
+// per-bin LDS hash tables over `nbins_local` bins whose records arrive as n_src segments, then the
+// order-restoring sort and the output table
+static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* seg_off,
+                      uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local, uint64_t n_kmers_hint, uint64_t n_recs_hint,
+                      dbg_kmer_table* out) {
+    const int k = pl.k, nbw = pl.nbw;
+    const bool is_set = pl.is_set, has_hi = pl.has_hi;
+    constexpr uint32_t TABLE = 2048;
     DBuf<unsigned long long> out_cursor;
     DBuf<uint32_t> gflags;
     ALLOC_OR_FAIL(c, out_cursor, 1);
     ALLOC_OR_FAIL(c, gflags, 4);
-    uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(n_kmers, std::max<uint64_t>(n_kmers / 8, 1u << 20)), 1);
+    uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1);
     DBuf<uint64_t> u_hi, u_lo;
     DBuf<uint32_t> u_pay, u_msk;
     uint64_t n_out = 0;
@@ -605,24 +646,26 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         HIP_TRY(c, hipMemsetAsync(out_cursor.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(gflags.p, 0, 16, c->stream));
         FastOut fo{u_hi.p, u_lo.p, u_pay.p, u_msk.p, nullptr};
-        c->t_begin("bin_count", n_kmers);
-#define GO(KW, NBW, SET) bin_count_kernel<KW, NBW, SET, 512, TABLE><<<nbins, 512, 0, c->stream>>>( \
-        recs.p, bin_off.p, k, cfg.stranded, prm->min_kmer_obs, fo, cap, out_cursor.p, gflags.p)
-        if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
-        else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
-        else if (nbw == 3) { if (is_set) GO(2, 3, true); else GO(2, 3, false); }
-        else { if (is_set) GO(2, 4, true); else GO(2, 4, false); }
+        if (nbins_local) {
+            c->t_begin("bin_count", n_kmers_hint);
+#define GO(KW, NBW, SET) bin_count_kernel<KW, NBW, SET, 512, TABLE><<<nbins_local, 512, 0, c->stream>>>( \
+            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p)
+            if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
+            else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
+            else if (nbw == 3) { if (is_set) GO(2, 3, true); else GO(2, 3, false); }
+            else { if (is_set) GO(2, 4, true); else GO(2, 4, false); }
 #undef GO
-        c->t_end();
-        LAUNCH_CHECK(c, "bin_count");
+            c->t_end();
+            LAUNCH_CHECK(c, "bin_count");
+        }
         unsigned long long cur = 0;
         uint32_t flv[4] = {0, 0, 0, 0};
         HIP_TRY(c, hipMemcpyAsync(&cur, out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(flv, gflags.p, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint32_t fl = flv[0];
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u recs=%llu valid=%llu flags=%u maxP=%u passes=%u wd=%u\n",
-                                         nbins, (unsigned long long)n_recs, cur, fl, flv[1], flv[2], flv[3]);
+        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u wd=%u\n",
+                                         nbins_local, n_src, (unsigned long long)n_recs_hint, cur, fl, flv[1], flv[2], flv[3]);
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (fl & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
         if (fl & 1u) {
@@ -633,7 +676,6 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         n_out = cur;
         break;
     }
-    recs.release();
 
     // ---- order-restoring sort: ascending key (filter.rs:205-206 bucket order + stable sort = global order) ----
     DBuf<uint32_t> idx, t_pay;
@@ -680,7 +722,126 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     out->n = n_out;
     out->key_hi = o_hi.take(); out->key_lo = o_lo.take(); out->exts = o_exts.take(); out->count = o_count.take();
     out->set_off = o_set_off.take(); out->set_val = o_set_val.take(); out->n_set_val = n_setval;
-    out->n_kmer_instances = n_kmers; out->n_passes = 1; out->on_device = 1;
+    out->n_kmer_instances = n_kmers_hint; out->n_passes = 1; out->on_device = 1;
+    return 0;
+}
+
+// returns 0 and sets *used = true when the fast path produced the table; *used = false means the
+// caller must take the generic path (unsupported shape), nothing was written.
+int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
+                      bool* used) {
+    *used = false;
+    const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET;
+    if (prm->report_all_kmers || n_kmers == 0) return 0;
+    FastPlan pl;
+    if (!fast_make_plan((int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
+    if (is_set) { bool ok; DBG_TRY(fast_labels_ok(c, s, &ok)); if (!ok) return 0; }
+    FastScan st;
+    DBG_TRY(fast_scan(c, s, pl, n_kmers, &st));
+    DBuf<uint64_t> bin_off, recs;
+    ALLOC_OR_FAIL(c, bin_off, (size_t)pl.nbins + 1);
+    DBG_TRY(fast_bin_offsets(c, &st, bin_off.p));
+    ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(st.n_recs * pl.rw, 1));
+    DBG_TRY(fast_scatter(c, &st, bin_off.p, recs.p));
+    DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, recs.p, bin_off.p, 1, (uint64_t)pl.nbins + 1, pl.nbins, n_kmers, st.n_recs, out));
     *used = true;
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Sharded counting for multi-GPU runs.  The bin space is global (every rank uses the same plan);
+// rank r owns a contiguous range of bins.  Stage 1 (scan + scatter) runs on every rank over its own
+// reads and leaves its super-k-mer records in bin order, so the slab for each destination rank is
+// contiguous.  The caller exchanges the slabs (RCCL all-to-all over xGMI) and hands stage 2 the
+// received records as n_src bin-ordered segments.
+// ------------------------------------------------------------------------------------------------
+#include <map>
+#include <memory>
+#include <mutex>
+static std::mutex g_shard_mu;
+static std::map<dbg_ctx*, std::unique_ptr<FastScan>> g_shard_state;
+
+void fast_drop_state(dbg_ctx* c) {
+    std::lock_guard<std::mutex> g(g_shard_mu);
+    g_shard_state.erase(c);
+}
+
+extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t k, uint64_t* n_out) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+    DBuf<uint32_t> kcount;
+    DBuf<uint64_t> koff;
+    ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
+    ALLOC_OR_FAIL(c, koff, s.n + 1);
+    DBG_TRY(kmer_counts(c, s, (int)k, kcount.p));
+    DBG_TRY(scan_exclusive_u32_u64(c, kcount.p, koff.p, s.n));
+    HIP_TRY(c, hipMemcpyAsync(n_out, koff.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
+    if (!fast_make_plan((int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins, pl))
+        return c->fail(140, "sharded counting supports 16 <= k <= 64");
+    return 0;
+}
+
+extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
+    FastPlan pl;
+    sp->n_bins = 0;
+    DBG_TRY(plan_from(c, sp, &pl));
+    sp->n_bins = pl.nbins;
+    sp->rec_words = (uint32_t)pl.rw;
+    return 0;
+}
+
+extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_shard_plan* sp, uint64_t* n_recs,
+                                  uint64_t* bin_off_dev) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    FastPlan pl;
+    DBG_TRY(plan_from(c, sp, &pl));
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+    if (pl.is_set) {
+        bool ok;
+        DBG_TRY(fast_labels_ok(c, s, &ok));
+        if (!ok) return c->fail(141, "sharded CountFilterSet needs u8/u16/u32 labels < 24");
+    }
+    uint64_t n_kmers = 0;
+    DBG_TRY(dbg_count_kmer_instances_dev(c, ds, sp->k, &n_kmers));
+    std::unique_ptr<FastScan> st(new FastScan());
+    if (n_kmers) DBG_TRY(fast_scan(c, s, pl, n_kmers, st.get()));
+    else { st->pl = pl; ALLOC_OR_FAIL(c, st->hist, pl.nbins); HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)pl.nbins * 4, c->stream)); }
+    DBG_TRY(fast_bin_offsets(c, st.get(), bin_off_dev));
+    *n_recs = st->n_recs;
+    std::lock_guard<std::mutex> g(g_shard_mu);
+    g_shard_state[c] = std::move(st);
+    return 0;
+}
+
+extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, uint64_t* recs_out_dev) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::unique_ptr<FastScan> st;
+    {
+        std::lock_guard<std::mutex> g(g_shard_mu);
+        auto it = g_shard_state.find(c);
+        if (it == g_shard_state.end()) return c->fail(142, "dbg_shard_scatter_dev without a preceding dbg_shard_scan_dev");
+        st = std::move(it->second);
+        g_shard_state.erase(it);
+    }
+    DBG_TRY(fast_scatter(c, st.get(), bin_off_dev, recs_out_dev));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int dbg_shard_count_dev(dbg_ctx* c, const dbg_shard_plan* sp, const uint64_t* recs_dev, const uint64_t* seg_off_dev,
+                                   uint32_t n_src, uint32_t n_bins_local, uint64_t n_kmers_hint, dbg_kmer_table* out) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    FastPlan pl;
+    DBG_TRY(plan_from(c, sp, &pl));
+    if (n_src == 0) return c->fail(143, "n_src must be >= 1");
+    DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, seg_off_dev, n_src, (uint64_t)n_bins_local + 1, n_bins_local,
+                       std::max<uint64_t>(n_kmers_hint, 1), 0, out));
     return 0;
 }

@@ -1,0 +1,76 @@
+"""CPU checker engine for rust-debruijn_amd.distributed (TEST INFRASTRUCTURE ONLY): the same stage
+interface as HipEngine, implemented with the oracle, so that the torch.distributed orchestration
+(bin ownership, split sizes, the two all-to-alls, the segment table) runs on CPU with gloo."""
+import numpy as np
+import torch
+
+import oracle_lib as O
+
+RW = 4            # 3 base words + 1 meta word, like the product's k=47 record
+P = 8
+
+
+class Plan:
+    def __init__(self, k, stranded, kind, min_obs, total):
+        self.k, self.stranded, self.summarizer, self.min_kmer_obs = k, stranded, kind, min_obs
+        self.n_bins = max(4, total // 400)
+        self.rec_words = RW
+
+
+class OracleEngine:
+    device = torch.device("cpu")
+
+    def count_instances(self, ss, k):
+        return int(sum(max(0, int(l) - k + 1) for l in ss.length))
+
+    def plan(self, k, stranded, kind, min_obs, total):
+        return Plan(k, stranded, kind, min_obs, total)
+
+    def scan(self, ss, plan):
+        rows, bins = [], []
+        for i in range(ss.n):
+            seq = ss.bases(i)
+            if len(seq) < plan.k:
+                continue
+            d = int(ss.data[i]) if ss.data is not None else 0
+            bu, ex, st, ln = O.msp_sequence(seq, plan.k, P, None, rc=not plan.stranded)
+            for b, e, s, l in zip(bu, ex, st, ln):
+                s, l = int(s), int(l)
+                e = int(e)
+                if s == 0:
+                    e |= int(ss.exts[i]) & 0x0F
+                if s + l == len(seq):
+                    e |= int(ss.exts[i]) & 0xF0
+                w = list(O.pack_bases(seq[s:s + l])) + [0, 0, 0]
+                rows.append([int(w[0]), int(w[1]), int(w[2]), l | (e << 8) | (d << 16)])
+                bins.append(((int(b) * 2654435761) % (1 << 32)) * plan.n_bins >> 32)
+        self._rows = np.array(rows, dtype=np.uint64).reshape(-1, RW)
+        self._bins = np.array(bins, dtype=np.int64)
+        hist = np.bincount(self._bins, minlength=plan.n_bins)
+        bin_off = np.concatenate([[0], np.cumsum(hist)]).astype(np.int64)
+        return torch.from_numpy(bin_off), len(rows)
+
+    def scatter(self, plan, bin_off, n_recs):
+        order = np.argsort(self._bins, kind="stable")
+        return torch.from_numpy(self._rows[order].astype(np.int64).reshape(-1))
+
+    def count(self, plan, recs, seg_off, n_src, nb_local, hint):
+        r = recs.numpy().astype(np.uint64).reshape(-1, RW)
+        seg = seg_off.numpy()
+        assert seg.shape == (n_src, nb_local + 1)
+        used = np.zeros(len(r), dtype=bool)
+        seqs, exts, data = [], [], []
+        for s in range(n_src):
+            for b in range(nb_local):
+                for j in range(int(seg[s, b]), int(seg[s, b + 1])):
+                    assert not used[j]
+                    used[j] = True
+                    meta = int(r[j, 3])
+                    l = meta & 0xFF
+                    seqs.append(O.unpack_bases(r[j, :3], 0, l))
+                    exts.append((meta >> 8) & 0xFF)
+                    data.append(meta >> 16)
+        assert used.all()                       # every received record belongs to exactly one owned bin segment
+        ss = O.SeqSet.from_byte_seqs(seqs, exts=exts, data=data if plan.summarizer == O.COUNT_FILTER_SET else None,
+                                     sizeof_d1=1)
+        return O.filter_kmers(ss, plan.k, plan.summarizer, plan.min_kmer_obs, stranded=plan.stranded)
