@@ -178,6 +178,7 @@ typedef struct {
     uint64_t total_kmers;       /* k-mer instances over ALL ranks: fixes the bin count */
     uint32_t n_bins;            /* in: 0 = derive from total_kmers; out of dbg_shard_plan_make: bins */
     uint32_t rec_words;         /* out: u64 words per super-k-mer record */
+    uint32_t bin_group;         /* out: ownership boundaries must be multiples of this many bins */
 } dbg_shard_plan;
 
 int  dbg_count_kmer_instances_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t k, uint64_t* n_out);

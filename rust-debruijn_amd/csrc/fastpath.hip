@@ -66,6 +66,8 @@ constexpr int SCAN_TILE_W = 128;                // window starts per tile
 constexpr int SCAN_ARR = 192 + 64;              // positions per tile + padding for the shifted reads
 constexpr uint32_t SCAN_CHUNK = 1024;           // records a wave reserves per global atomic (one hot address otherwise)
 constexpr uint32_t BIN_INVALID = 0xffffffffu;   // unused slot of a reserved chunk
+constexpr uint32_t NCLS = 4;                    // length classes per bin: records of similar k-mer count sit together
+                                                // so that the 64 records a wave processes finish at about the same time
 
 template <int NBW>
 __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
@@ -190,9 +192,10 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                 if (!emit) continue;
                 if (chunk_base + SCAN_CHUNK > tmp_cap) { atomicOr(&flags[0], 1u); continue; }
                 uint32_t pm = (uint32_t)packed_get_kmer(w, st + pa, p).lo;
-                uint32_t b = bin_of(c, pm);
-                atomicAdd(&hist[b], 1u);
                 uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
+                uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
+                uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
+                atomicAdd(&hist[b], 1u);
                 uint32_t le = ps > 0 ? (1u << packed_get(w, st + ps - 1)) : (sexts & 0xfu);
                 uint32_t re = ps + len < m ? (1u << packed_get(w, st + ps + len)) : (sexts >> 4);
                 uint64_t* o = tmp_recs + idx * RW;
@@ -310,11 +313,20 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // The bin's records arrive as n_src segments (one per source rank after the all-to-all; one in the
     // single-GPU case): segment s spans records [seg_off[s*stride + bin], seg_off[s*stride + bin + 1]).
-    {
-        uint64_t total = 0;
-        for (uint32_t sg = 0; sg < n_src; sg++) total += seg_off[sg * seg_stride + blockIdx.x + 1] - seg_off[sg * seg_stride + blockIdx.x];
-        if (total == 0) return;
+    __shared__ uint64_t s_segbase[65];          // first record of segment s in `recs`
+    __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
+    __shared__ uint32_t s_next;                 // next flat record index to hand out
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t sg = 0; sg < n_src; sg++) {
+            uint64_t a = seg_off[sg * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_off[sg * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS];
+            s_segbase[sg] = a; s_segpre[sg] = acc; acc += (uint32_t)(b - a);
+        }
+        s_segpre[n_src] = acc;
     }
+    __syncthreads();
+    const uint32_t total_recs = s_segpre[n_src];
+    if (total_recs == 0) return;
     const K128 kmask = k128_mask(k);
 
     // Work stack of hash-selected passes (P, r): the pass handles the keys with (hash >> 16) % P == r.
@@ -330,40 +342,52 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         __syncthreads();
         if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_next = 0; }
         __syncthreads();
 
-        // ---- stream the bin: every wave takes 64-record groups round-robin, one record per lane.
-        //      The record lives in registers; its k-mers are produced by rolling (extend_right on the
-        //      forward strand, extend_left of the complement on the reverse strand) ----
-        uint32_t grp = 0;                                    // 64-record groups are dealt to the waves round-robin
-        for (uint32_t sg = 0; sg < n_src; sg++) {
-          const uint64_t r0 = seg_off[sg * seg_stride + blockIdx.x], r1 = seg_off[sg * seg_stride + blockIdx.x + 1];
-          for (uint64_t rb = r0; rb < r1; rb += 64, grp++) {
-            if (grp % NWV != wave) continue;
-            if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-            const bool have = rb + lane < r1;
-            uint64_t W[4] = {0, 0, 0, 0};
-            uint64_t meta = 0;
-            if (have) {
-                const uint64_t* g = recs + (rb + lane) * RW;
+        // ---- stream the bin: every LANE pulls records from a shared LDS cursor, one record at a time,
+        //      with the next record already in flight (its HBM latency hides behind the current
+        //      record's k-mers).  The record lives in registers; its k-mers are produced by rolling
+        //      (extend_right on the forward strand, extend_left of the complement on the reverse) ----
+        auto fetch = [&](uint64_t* Wd, uint64_t& md) -> bool {
+            uint32_t idx = atomicAdd(&s_next, 1u);
+            if (idx >= total_recs) { md = 0; return false; }
+            uint32_t sg = 0;
+            while (sg + 1 < n_src && idx >= s_segpre[sg + 1]) sg++;
+            const uint64_t* g = recs + (s_segbase[sg] + (idx - s_segpre[sg])) * RW;
 #pragma unroll
-                for (int q = 0; q < NBW; q++) W[q] = g[q];
-                meta = g[NBW];
+            for (int q = 0; q < NBW; q++) Wd[q] = g[q];
+            md = g[NBW];
+            return true;
+        };
+        uint64_t W[4] = {0, 0, 0, 0}, Wn[4] = {0, 0, 0, 0};
+        uint64_t meta = 0, metan = 0;
+        bool have_next = fetch(Wn, metan);
+        uint32_t nk = 0, j = 0, rlen = 0, rexts = 0, rd = 0, lb = 0;
+        K128 fw{0, 0}, rcw{0, 0};
+        bool alive = true;                                      // lane still has (or may get) a record
+        auto base_at = [&](uint32_t q) -> uint32_t {
+            uint64_t wd = q < 32 ? W[0] : (q < 64 ? W[1] : (NBW > 2 && q < 96 ? W[2] : (NBW > 3 ? W[3] : W[NBW - 1])));
+            return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
+        };
+        while (__any(alive)) {
+            if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            if (alive && j >= nk) {                             // refill this lane
+                if (!have_next) { alive = false; }
+                else {
+#pragma unroll
+                    for (int q = 0; q < NBW; q++) W[q] = Wn[q];
+                    meta = metan;
+                    have_next = fetch(Wn, metan);
+                    rlen = (uint32_t)(meta & 0xff); rexts = (uint32_t)(meta >> 8) & 0xffu; rd = (uint32_t)(meta >> 16);
+                    nk = rlen - (uint32_t)k + 1; j = 0; lb = 0;
+                    fw = k128_shr(K128{W[0], W[1]}, 128 - 2 * k);   // first k-mer (k <= 64 lies in the first two words)
+                    rcw = kmer_rc(fw, k);
+                }
             }
-            const uint32_t rlen = (uint32_t)(meta & 0xff), rexts = (uint32_t)(meta >> 8) & 0xffu, rd = (uint32_t)(meta >> 16);
-            const uint32_t nk = have ? rlen - (uint32_t)k + 1 : 0u;
-            auto base_at = [&](uint32_t q) -> uint32_t {
-                uint64_t wd = q < 32 ? W[0] : (q < 64 ? W[1] : (NBW > 2 && q < 96 ? W[2] : (NBW > 3 ? W[3] : W[NBW - 1])));
-                return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
-            };
-            K128 fw = k128_shr(K128{W[0], W[1]}, 128 - 2 * k);      // first k-mer (k <= 64 lies in the first two words)
-            K128 rcw = kmer_rc(fw, k);
-            uint32_t lb = 0;                                         // base just left of the current k-mer
-            for (uint32_t j = 0; __any(j < nk); j++) {
-                const bool act = j < nk;
-                const uint32_t nbase = (act && j + (uint32_t)k < rlen) ? base_at(j + k) : 0u;   // base right of the k-mer
-                if (act) {
+            if (alive) {
+                const uint32_t nbase = (j + (uint32_t)k < rlen) ? base_at(j + k) : 0u;   // base right of the k-mer
+                {
                     // Exts of k-mer j inside the piece (lib.rs:820-832 with seq_exts = the piece's boundary Exts)
                     uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << lb);
                     uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << nbase);
@@ -378,14 +402,15 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                         for (uint32_t left_probes = T; left_probes;) {
                             uint32_t t = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (t == 0) {
-                                if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;           // pass already overflowed
+                                if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // pass already overflowed
                                 t = atomicCAS(&s_tag[slot], 0u, mytag | TAG_BUSY);
                                 if (t == 0) {
                                     s_lo[slot] = km.lo;
                                     if (KW == 2) s_hi[slot] = km.hi;
                                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                    __hip_atomic_store(&s_tag[slot], (uint32_t)(mytag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8)) __hip_atomic_store(&s_flag[0], (uint32_t)(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_store(&s_tag[slot], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8))
+                                        __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                     hit = true;
                                     break;
                                 }
@@ -404,7 +429,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                             atomicAdd(&s_cnt[slot], 1u);
                             atomicOr(&s_aux[slot], IS_SET ? (ex | (256u << (rd & 31u))) : ex);
                         } else {
-                            __hip_atomic_store(&s_flag[0], (uint32_t)(1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                     // table full / pass overflowed
+                            __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full / pass overflowed
                         }
                     }
                 }
@@ -422,8 +447,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     fw.lo = ((fw.lo << 2) | nbase) & kmask.lo;
                     rcw.lo = (rcw.lo >> 2) | ((uint64_t)(3u - nbase) << sh);
                 }
+                j++;
             }
-          }
         }
         __syncthreads();
         const bool ovf = s_flag[0] != 0;
@@ -517,7 +542,8 @@ static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kme
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw + 1;
     pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
-    const uint64_t target = 9000;                               // k-mer instances per bin (about 0.15 distinct per instance)
+    uint64_t target = 9000;                                     // k-mer instances per bin (about 0.15 distinct per instance)
+    if (const char* e = getenv("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
     pl->nbins = (uint32_t)nb64;
@@ -551,8 +577,8 @@ static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
 static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n_kmers, FastScan* st) {
     st->pl = pl; st->n_kmers = n_kmers;
     const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
-    const uint32_t nbins = pl.nbins;
-    FastCfg cfg{k, p, pl.stranded, nbins};
+    const uint32_t nbins = pl.nbins * NCLS;                      // sub-bins (bin, length class)
+    FastCfg cfg{k, p, pl.stranded, pl.nbins};
     SeqDev sd = s;
     if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
     DBuf<uint32_t> sflags;
@@ -596,15 +622,15 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
 // scatter into bin order: recs_out [n_recs * rw] and bin_off_out [nbins + 1] are caller-provided device buffers.
 // n_recs must first be obtained with fast_bin_offsets.
 static int fast_bin_offsets(dbg_ctx* c, FastScan* st, uint64_t* bin_off_out) {
-    DBG_TRY(scan_exclusive_u32_u64(c, st->hist.p, bin_off_out, st->pl.nbins));
-    HIP_TRY(c, hipMemcpyAsync(&st->n_recs, bin_off_out + st->pl.nbins, 8, hipMemcpyDeviceToHost, c->stream));
+    DBG_TRY(scan_exclusive_u32_u64(c, st->hist.p, bin_off_out, (uint64_t)st->pl.nbins * NCLS));
+    HIP_TRY(c, hipMemcpyAsync(&st->n_recs, bin_off_out + (uint64_t)st->pl.nbins * NCLS, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->t_begin("sk_records", st->n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
     c->t_end();
     return 0;
 }
 static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out) {
-    const uint32_t nbins = st->pl.nbins;
+    const uint32_t nbins = st->pl.nbins * NCLS;
     DBuf<uint32_t> cursor;
     ALLOC_OR_FAIL(c, cursor, nbins);
     HIP_TRY(c, hipMemsetAsync(cursor.p, 0, (size_t)nbins * 4, c->stream));
@@ -648,8 +674,13 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
         FastOut fo{u_hi.p, u_lo.p, u_pay.p, u_msk.p, nullptr};
         if (nbins_local) {
             c->t_begin("bin_count", n_kmers_hint);
-#define GO(KW, NBW, SET) bin_count_kernel<KW, NBW, SET, 512, TABLE><<<nbins_local, 512, 0, c->stream>>>( \
-            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p)
+            static const int nt_env = getenv("DBG_FAST_NT") ? atoi(getenv("DBG_FAST_NT")) : 512;
+#define GO(KW, NBW, SET) do { if (nt_env == 1024) bin_count_kernel<KW, NBW, SET, 1024, TABLE><<<nbins_local, 1024, 0, c->stream>>>( \
+            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p); \
+            else if (nt_env == 256) bin_count_kernel<KW, NBW, SET, 256, TABLE><<<nbins_local, 256, 0, c->stream>>>( \
+            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p); \
+            else bin_count_kernel<KW, NBW, SET, 512, TABLE><<<nbins_local, 512, 0, c->stream>>>( \
+            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p); } while (0)
             if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
             else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
             else if (nbw == 3) { if (is_set) GO(2, 3, true); else GO(2, 3, false); }
@@ -739,11 +770,11 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     FastScan st;
     DBG_TRY(fast_scan(c, s, pl, n_kmers, &st));
     DBuf<uint64_t> bin_off, recs;
-    ALLOC_OR_FAIL(c, bin_off, (size_t)pl.nbins + 1);
+    ALLOC_OR_FAIL(c, bin_off, (size_t)pl.nbins * NCLS + 1);
     DBG_TRY(fast_bin_offsets(c, &st, bin_off.p));
     ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(st.n_recs * pl.rw, 1));
     DBG_TRY(fast_scatter(c, &st, bin_off.p, recs.p));
-    DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, recs.p, bin_off.p, 1, (uint64_t)pl.nbins + 1, pl.nbins, n_kmers, st.n_recs, out));
+    DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, recs.p, bin_off.p, 1, (uint64_t)pl.nbins * NCLS + 1, pl.nbins, n_kmers, st.n_recs, out));
     *used = true;
     return 0;
 }
@@ -782,7 +813,8 @@ extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, ui
 }
 
 static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
-    if (!fast_make_plan((int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins, pl))
+    if (sp->n_bins % NCLS) return c->fail(144, "n_bins must be a multiple of bin_group");
+    if (!fast_make_plan((int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
         return c->fail(140, "sharded counting supports 16 <= k <= 64");
     return 0;
 }
@@ -791,8 +823,9 @@ extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
     FastPlan pl;
     sp->n_bins = 0;
     DBG_TRY(plan_from(c, sp, &pl));
-    sp->n_bins = pl.nbins;
+    sp->n_bins = pl.nbins * NCLS;
     sp->rec_words = (uint32_t)pl.rw;
+    sp->bin_group = NCLS;
     return 0;
 }
 
@@ -812,7 +845,7 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     DBG_TRY(dbg_count_kmer_instances_dev(c, ds, sp->k, &n_kmers));
     std::unique_ptr<FastScan> st(new FastScan());
     if (n_kmers) DBG_TRY(fast_scan(c, s, pl, n_kmers, st.get()));
-    else { st->pl = pl; ALLOC_OR_FAIL(c, st->hist, pl.nbins); HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)pl.nbins * 4, c->stream)); }
+    else { st->pl = pl; ALLOC_OR_FAIL(c, st->hist, (size_t)pl.nbins * NCLS); HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)pl.nbins * NCLS * 4, c->stream)); }
     DBG_TRY(fast_bin_offsets(c, st.get(), bin_off_dev));
     *n_recs = st->n_recs;
     std::lock_guard<std::mutex> g(g_shard_mu);
@@ -841,7 +874,8 @@ extern "C" int dbg_shard_count_dev(dbg_ctx* c, const dbg_shard_plan* sp, const u
     FastPlan pl;
     DBG_TRY(plan_from(c, sp, &pl));
     if (n_src == 0) return c->fail(143, "n_src must be >= 1");
-    DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, seg_off_dev, n_src, (uint64_t)n_bins_local + 1, n_bins_local,
+    if (n_bins_local % NCLS) return c->fail(144, "n_bins_local must be a multiple of bin_group");
+    DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, seg_off_dev, n_src, (uint64_t)n_bins_local + 1, n_bins_local / NCLS,
                        std::max<uint64_t>(n_kmers_hint, 1), 0, out));
     return 0;
 }

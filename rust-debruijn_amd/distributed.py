@@ -40,7 +40,7 @@ class HipEngine:
         return n.value
 
     def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers):
-        p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0)
+        p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0, 0)
         self.ctx.check(self.lib.dbg_shard_plan_make(self.ctx.h, C.byref(p)))
         return p
 
@@ -71,9 +71,10 @@ class HipEngine:
         self.lib.dbg_free_table(self.ctx.h, C.byref(tab))
 
 
-def owner_bounds(n_bins, world):
-    """rank r owns bins [bounds[r], bounds[r+1])."""
-    return [r * n_bins // world for r in range(world + 1)]
+def owner_bounds(n_bins, world, group=1):
+    """rank r owns bins [bounds[r], bounds[r+1]); boundaries are multiples of `group` (a bin's length
+    classes stay together)."""
+    return [(r * (n_bins // group) // world) * group for r in range(world + 1)]
 
 
 def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None):
@@ -84,7 +85,7 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     rw = plan.rec_words
-    bounds = owner_bounds(plan.n_bins, world)
+    bounds = owner_bounds(plan.n_bins, world, getattr(plan, "bin_group", 1) or 1)
     nb_local = bounds[rank + 1] - bounds[rank]
     hist = (bin_off[1:] - bin_off[:-1]).contiguous()                         # records per bin (local reads)
     edge = bin_off[torch.tensor(bounds, device=bin_off.device)].tolist()     # record offset at each owner boundary

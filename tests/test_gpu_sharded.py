@@ -55,7 +55,7 @@ def test_virtual_ranks_multi_segment(ctx, kind, k, world):
     total = sum(eng.count_instances(s, k) for s in shards)
     plan = eng.plan(k, False, kind, 2, total)
     rw, nb = plan.rec_words, plan.n_bins
-    bounds = D.owner_bounds(nb, world)
+    bounds = D.owner_bounds(nb, world, plan.bin_group)
     scanned = []
     for s in shards:
         bin_off, n = eng.scan(s, plan)
