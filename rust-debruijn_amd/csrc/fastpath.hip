@@ -542,7 +542,7 @@ static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kme
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw + 1;
     pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
-    uint64_t target = 9000;                                     // k-mer instances per bin (about 0.15 distinct per instance)
+    uint64_t target = 7000;                                     // k-mer instances per bin (about 0.15 distinct per instance)
     if (const char* e = getenv("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
@@ -716,10 +716,6 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     if (has_hi) ALLOC_OR_FAIL(c, t_hi, na);
     if (n_out) { iota_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>(idx.p, (uint32_t)n_out); LAUNCH_CHECK(c, "iota"); }
     RecArrays A{has_hi ? u_hi.p : nullptr, u_lo.p, idx.p}, B{has_hi ? t_hi.p : nullptr, t_lo.p, t_pay.p};
-    bool in_b = false;
-    DBG_TRY(radix_sort_records(c, n_out, A, B, 2 * k, 0, 0, &in_b));
-    RecArrays S = in_b ? B : A;
-
     DBuf<uint64_t> o_hi, o_lo, o_set_off;
     DBuf<uint8_t> o_exts;
     DBuf<uint16_t> o_count;
@@ -728,7 +724,17 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     if (is_set) { ALLOC_OR_FAIL(c, setn, na); ALLOC_OR_FAIL(c, msk_sorted, na); ALLOC_OR_FAIL(c, o_set_off, na + 1); }
     else ALLOC_OR_FAIL(c, o_count, na);
     uint64_t n_setval = 0;
-    if (n_out) {
+    bool hybrid_ok = false, data_in_b = false;
+    if (!getenv("DBG_NO_HYBRID_SORT"))
+        DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, u_pay.p, u_msk.p, o_hi.p, o_lo.p, o_exts.p, o_count.p,
+                                  setn.p, msk_sorted.p, &hybrid_ok, &data_in_b));
+    if (!hybrid_ok && n_out) {
+        // plain LSD sort over every key bit (the fallback when a key-prefix group is too large for the
+        // LDS finisher); the (key, idx) pairs are intact in whichever buffer the top-bit passes ended in
+        bool in_b = false;
+        RecArrays X = data_in_b ? B : A, Y = data_in_b ? A : B;
+        DBG_TRY(radix_sort_records(c, n_out, X, Y, 2 * k, 0, 0, &in_b));
+        RecArrays S = in_b ? Y : X;
         if (has_hi) HIP_TRY(c, hipMemcpyAsync(o_hi.p, S.hi, n_out * 8, hipMemcpyDeviceToDevice, c->stream));
         else HIP_TRY(c, hipMemsetAsync(o_hi.p, 0, n_out * 8, c->stream));
         HIP_TRY(c, hipMemcpyAsync(o_lo.p, S.lo, n_out * 8, hipMemcpyDeviceToDevice, c->stream));
