@@ -30,6 +30,21 @@ struct FastCfg {
     uint32_t nbins;
 };
 
+// p-mer (p <= 16) at absolute base offset o: two funnel-shifted words, right-aligned
+__device__ __forceinline__ uint32_t packed_get_pmer(const uint64_t* __restrict__ w, uint64_t o, int p) {
+    const uint64_t wi = o >> 5;
+    const int s = (int)(o & 31) * 2;
+    uint64_t v = w[wi] << s;
+    if (s + 2 * p > 64) v |= w[wi + 1] >> (64 - s);
+    return (uint32_t)(v >> (64 - 2 * p));
+}
+// reverse complement of a right-aligned p-mer held in 32 bits
+__device__ __forceinline__ uint32_t pmer_rc32(uint32_t pm, int p) {
+    uint32_t r = __brev(pm);
+    r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    return (~r) >> (32 - 2 * p);
+}
+
 // bijection on 2p-bit integers (odd multiply and xorshift are both invertible mod 2^(2p))
 __device__ __forceinline__ uint32_t mix_pmer(uint32_t x, int p) {
     const uint32_t mask = p >= 16 ? 0xffffffffu : ((1u << (2 * p)) - 1);
@@ -42,12 +57,12 @@ __device__ __forceinline__ uint32_t mix_pmer(uint32_t x, int p) {
 struct FastScore {
     int p, stranded;
     __device__ __forceinline__ uint32_t operator()(uint32_t pm) const {
-        if (!stranded) { uint32_t r = pmer_rc(pm, p); pm = pm < r ? pm : r; }
+        if (!stranded) { uint32_t r = pmer_rc32(pm, p); pm = pm < r ? pm : r; }
         return mix_pmer(pm, p);
     }
 };
 __device__ __forceinline__ uint32_t bin_of(const FastCfg& c, uint32_t pm) {
-    if (!c.stranded) { uint32_t r = pmer_rc(pm, c.p); pm = pm < r ? pm : r; }
+    if (!c.stranded) { uint32_t r = pmer_rc32(pm, c.p); pm = pm < r ? pm : r; }
     uint32_t h = pm * 0xC2B2AE35u + 0x27D4EB2Fu;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (uint32_t)(((uint64_t)h * c.nbins) >> 32);
@@ -76,8 +91,10 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                                                       uint32_t* __restrict__ flags) {
     constexpr int RW = NBW + 1;
     __shared__ uint64_t s_arr[4][SCAN_ARR];
+    __shared__ uint32_t s_pl[4][3 * 132];        // per-wave piece list: start window, end window, minimizer position
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t* A = s_arr[wave];
+    uint32_t* PL = s_pl[wave];
     A[192 + lane] = ~0ull;
     const int k = c.k, p = c.p;
     const uint32_t W = (uint32_t)(k - p + 1);
@@ -119,7 +136,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                 uint32_t pos = t0 + ch * 64 + lane;
                 uint64_t v = ~0ull;
                 if (pos < npos) {
-                    uint32_t pm = (uint32_t)packed_get_kmer(w, st + pos, p).lo;
+                    uint32_t pm = packed_get_pmer(w, st + pos, p);
                     v = ((uint64_t)sc(pm) << 32) | pos;
                 }
                 own[ch] = v;
@@ -160,57 +177,65 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
             uint32_t new_open = open_start;
             if (mask[1]) new_open = t0 + 64 + (63 - __clzll(mask[1]));
             else if (mask[0]) new_open = t0 + (63 - __clzll(mask[0]));
-            // ---- emission: the boundary at window i closes the piece that started at the previous
-            //      boundary; lane 0 also closes the last piece when the read ends in this tile ----
-#pragma unroll 1
-            for (int slot = 0; slot < 3; slot++) {
-                bool emit = false;
-                uint32_t ps = 0, pe = 0, pa = 0;
-                if (slot < 2) {
-                    uint32_t i = t0 + slot * 64 + lane;
-                    if (isb[slot] && i > 0) {
-                        emit = true; pe = i; pa = prev[slot];
-                        uint64_t below = mask[slot] & lt;
-                        if (below) ps = t0 + slot * 64 + (63 - __clzll(below));
-                        else if (slot == 1 && mask[0]) ps = t0 + (63 - __clzll(mask[0]));
-                        else ps = open_start;
-                    }
-                } else if (read_ends && lane == 0) {
-                    emit = true; ps = new_open; pe = nwin; pa = last_arg;
+            // ---- collect the pieces this tile closes: the boundary at window i closes the piece that
+            //      started at the previous boundary; lane 0 also closes the last piece when the read ends
+            //      here.  They are compacted into a wave-private list so that the (long) record-building
+            //      code below runs once per tile with one piece per lane ----
+            uint32_t npieces = 0;
+#pragma unroll
+            for (int slot = 0; slot < 2; slot++) {
+                const uint32_t i = t0 + slot * 64 + lane;
+                const bool emit = isb[slot] && i > 0;
+                const uint64_t em = __ballot(emit);
+                if (emit) {
+                    uint32_t ps;
+                    const uint64_t below = mask[slot] & lt;
+                    if (below) ps = t0 + slot * 64 + (63 - __clzll(below));
+                    else if (slot == 1 && mask[0]) ps = t0 + (63 - __clzll(mask[0]));
+                    else ps = open_start;
+                    const uint32_t q = npieces + __popcll(em & lt);
+                    PL[q] = ps; PL[132 + q] = i; PL[264 + q] = prev[slot];
                 }
-                uint64_t em = __ballot(emit);
-                if (!em) continue;
-                const uint32_t n_em = __popcll(em);
-                if (chunk_used + n_em > SCAN_CHUNK) {
+                npieces += __popcll(em);
+            }
+            if (read_ends) {
+                if (lane == 0) { PL[npieces] = new_open; PL[132 + npieces] = nwin; PL[264 + npieces] = last_arg; }
+                npieces++;
+            }
+            if (npieces) {
+                if (chunk_used + npieces > SCAN_CHUNK) {
                     unsigned long long nb = 0;
                     if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
                     chunk_base = __shfl(nb, 0);
                     chunk_used = 0;
                 }
-                const uint64_t idx = chunk_base + chunk_used + __popcll(em & lt);
-                chunk_used += n_em;
-                if (!emit) continue;
-                if (chunk_base + SCAN_CHUNK > tmp_cap) { atomicOr(&flags[0], 1u); continue; }
-                uint32_t pm = (uint32_t)packed_get_kmer(w, st + pa, p).lo;
-                uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
-                uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
-                uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
-                atomicAdd(&hist[b], 1u);
-                uint32_t le = ps > 0 ? (1u << packed_get(w, st + ps - 1)) : (sexts & 0xfu);
-                uint32_t re = ps + len < m ? (1u << packed_get(w, st + ps + len)) : (sexts >> 4);
-                uint64_t* o = tmp_recs + idx * RW;
+                const uint64_t idx0 = chunk_base + chunk_used;
+                chunk_used += npieces;
+                if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); }
+                else for (uint32_t t = lane; t < npieces; t += 64) {
+                    const uint32_t ps = PL[t], pe = PL[132 + t], pa = PL[264 + t];
+                    const uint64_t idx = idx0 + t;
+                    uint32_t pm = packed_get_pmer(w, st + pa, p);
+                    uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
+                    uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
+                    uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
+                    atomicAdd(&hist[b], 1u);
+                    uint32_t le = ps > 0 ? (1u << packed_get(w, st + ps - 1)) : (sexts & 0xfu);
+                    uint32_t re = ps + len < m ? (1u << packed_get(w, st + ps + len)) : (sexts >> 4);
+                    uint64_t* o = tmp_recs + idx * RW;
 #pragma unroll
-                for (int q = 0; q < NBW; q++) {
-                    uint32_t b0 = (uint32_t)q * 32;
-                    uint64_t v = 0;
-                    if (b0 < len) {
-                        uint32_t nb = len - b0 < 32 ? len - b0 : 32;
-                        v = packed_get_kmer(w, st + ps + b0, (int)nb).lo << (64 - 2 * nb);
+                    for (int q = 0; q < NBW; q++) {
+                        uint32_t b0 = (uint32_t)q * 32;
+                        uint64_t v = 0;
+                        if (b0 < len) {
+                            uint32_t nb = len - b0 < 32 ? len - b0 : 32;
+                            v = packed_get_kmer(w, st + ps + b0, (int)nb).lo << (64 - 2 * nb);
+                        }
+                        o[q] = v;
                     }
-                    o[q] = v;
+                    o[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
+                    tmp_bin[idx] = b;
                 }
-                o[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
-                tmp_bin[idx] = b;
             }
             open_start = new_open;
             carry_arg = last_arg;
