@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                                                        unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags) {
     constexpr int RW = NBW + 1;
     constexpr int NWV = NT / 64;
-    __shared__ uint32_t s_tag[T];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tag[T];
     __shared__ uint64_t s_lo[T];
     __shared__ uint64_t s_hi[KW == 2 ? T : 1];
     __shared__ uint32_t s_cnt[T];
@@ -370,46 +370,40 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_next = 0; }
         __syncthreads();
 
-        // ---- stream the bin: every LANE pulls records from a shared LDS cursor, one record at a time,
-        //      with the next record already in flight (its HBM latency hides behind the current
-        //      record's k-mers).  The record lives in registers; its k-mers are produced by rolling
-        //      (extend_right on the forward strand, extend_left of the complement on the reverse) ----
-        auto fetch = [&](uint64_t* Wd, uint64_t& md) -> bool {
-            uint32_t idx = atomicAdd(&s_next, 1u);
-            if (idx >= total_recs) { md = 0; return false; }
-            uint32_t sg = 0;
-            while (sg + 1 < n_src && idx >= s_segpre[sg + 1]) sg++;
-            const uint64_t* g = recs + (s_segbase[sg] + (idx - s_segpre[sg])) * RW;
-#pragma unroll
-            for (int q = 0; q < NBW; q++) Wd[q] = g[q];
-            md = g[NBW];
-            return true;
-        };
-        uint64_t W[4] = {0, 0, 0, 0}, Wn[4] = {0, 0, 0, 0};
-        uint64_t meta = 0, metan = 0;
-        bool have_next = fetch(Wn, metan);
-        uint32_t nk = 0, j = 0, rlen = 0, rexts = 0, rd = 0, lb = 0;
-        K128 fw{0, 0}, rcw{0, 0};
-        bool alive = true;                                      // lane still has (or may get) a record
-        auto base_at = [&](uint32_t q) -> uint32_t {
-            uint64_t wd = q < 32 ? W[0] : (q < 64 ? W[1] : (NBW > 2 && q < 96 ? W[2] : (NBW > 3 ? W[3] : W[NBW - 1])));
-            return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
-        };
-        while (__any(alive)) {
+        // ---- stream the bin: waves pull groups of 64 consecutive records (flat index over the bin's
+        //      segments) from a shared LDS cursor, one record per lane.  Records of one length class are
+        //      adjacent (sk_scan sub-bins), so the lanes of a group finish at about the same time.  The
+        //      record lives in registers; its k-mers are produced by rolling (extend_right on the forward
+        //      strand, extend_left of the complement on the reverse strand) ----
+        for (;;) {
+            uint32_t g0 = 0;
+            if (lane == 0) g0 = atomicAdd(&s_next, 64u);
+            g0 = __shfl(g0, 0);
+            if (g0 >= total_recs) break;
             if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-            if (alive && j >= nk) {                             // refill this lane
-                if (!have_next) { alive = false; }
-                else {
+            const uint32_t ridx = g0 + lane;
+            bool alive = ridx < total_recs;
+            uint64_t W[4] = {0, 0, 0, 0};
+            uint64_t meta = 0;
+            if (alive) {
+                uint32_t sg = 0;
+                while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
+                const uint64_t* g = recs + (s_segbase[sg] + (ridx - s_segpre[sg])) * RW;
 #pragma unroll
-                    for (int q = 0; q < NBW; q++) W[q] = Wn[q];
-                    meta = metan;
-                    have_next = fetch(Wn, metan);
-                    rlen = (uint32_t)(meta & 0xff); rexts = (uint32_t)(meta >> 8) & 0xffu; rd = (uint32_t)(meta >> 16);
-                    nk = rlen - (uint32_t)k + 1; j = 0; lb = 0;
-                    fw = k128_shr(K128{W[0], W[1]}, 128 - 2 * k);   // first k-mer (k <= 64 lies in the first two words)
-                    rcw = kmer_rc(fw, k);
-                }
+                for (int q = 0; q < NBW; q++) W[q] = g[q];
+                meta = g[NBW];
             }
+            const uint32_t rlen = (uint32_t)(meta & 0xff), rexts = (uint32_t)(meta >> 8) & 0xffu, rd = (uint32_t)(meta >> 16);
+            const uint32_t nk = alive ? rlen - (uint32_t)k + 1 : 0u;
+            auto base_at = [&](uint32_t q) -> uint32_t {
+                uint64_t wd = q < 32 ? W[0] : (q < 64 ? W[1] : (NBW > 2 && q < 96 ? W[2] : (NBW > 3 ? W[3] : W[NBW - 1])));
+                return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
+            };
+            K128 fw = k128_shr(K128{W[0], W[1]}, 128 - 2 * k);      // first k-mer (k <= 64 lies in the first two words)
+            K128 rcw = kmer_rc(fw, k);
+            uint32_t lb = 0, j = 0;
+          while (__any(j < nk)) {
+            alive = j < nk;
             if (alive) {
                 const uint32_t nbase = (j + (uint32_t)k < rlen) ? base_at(j + k) : 0u;   // base right of the k-mer
                 {
@@ -421,33 +415,50 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = exts_rc(ex); }   // ties flip (lib.rs:226-230)
                     const uint64_t h = hash_key(km.hi, km.lo);
                     if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
+                        // Bucketised linear probing: 4 tags per 16-byte bucket, one ds_read_b128 per bucket.
+                        // A key lives in the first bucket (in probe order) that had a free slot when it was
+                        // inserted; a failed CAS re-reads the bucket, so two lanes can never claim two slots
+                        // for one key.
                         const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
-                        uint32_t slot = (uint32_t)h & (T - 1);
+                        uint32_t bkt = (uint32_t)h & (T / 4 - 1);
+                        uint32_t slot = 0;
                         bool hit = false;
-                        for (uint32_t left_probes = T; left_probes;) {
-                            uint32_t t = __hip_atomic_load(&s_tag[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (t == 0) {
-                                if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // pass already overflowed
-                                t = atomicCAS(&s_tag[slot], 0u, mytag | TAG_BUSY);
-                                if (t == 0) {
-                                    s_lo[slot] = km.lo;
-                                    if (KW == 2) s_hi[slot] = km.hi;
-                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                                    __hip_atomic_store(&s_tag[slot], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8))
-                                        __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    hit = true;
-                                    break;
+                        for (uint32_t left_probes = T / 4; left_probes && !hit;) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            const uint4 t4 = *reinterpret_cast<const uint4*>(&s_tag[bkt * 4]);
+                            const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
+                            bool busy = false;
+                            int empty = -1;
+#pragma unroll
+                            for (int i = 3; i >= 0; i--) {
+                                if (tt[i] == 0) empty = i;
+                                if ((tt[i] & ~TAG_BUSY) == mytag) { if (tt[i] & TAG_BUSY) busy = true; }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                if (!hit && tt[i] == mytag) {                        // ready entry with my tag: verify the key
+                                    bool same = s_lo[bkt * 4 + i] == km.lo;
+                                    if (KW == 2) same = same && s_hi[bkt * 4 + i] == km.hi;
+                                    if (same) { hit = true; slot = bkt * 4 + i; }
                                 }
                             }
-                            if ((t & ~TAG_BUSY) == mytag) {
-                                if (t & TAG_BUSY) continue;                          // claimer is still writing the key: re-read
-                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                                bool same = __hip_atomic_load(&s_lo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == km.lo;
-                                if (KW == 2) same = same && __hip_atomic_load(&s_hi[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == km.hi;
-                                if (same) { hit = true; break; }
+                            if (hit) break;
+                            if (busy) continue;                                      // a claimer is still writing its key: re-read
+                            if (empty >= 0) {
+                                if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // pass already overflowed
+                                const uint32_t sl = bkt * 4 + (uint32_t)empty;
+                                if (atomicCAS(&s_tag[sl], 0u, mytag | TAG_BUSY) == 0u) {
+                                    s_lo[sl] = km.lo;
+                                    if (KW == 2) s_hi[sl] = km.hi;
+                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                                    __hip_atomic_store(&s_tag[sl], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8))
+                                        __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    hit = true; slot = sl;
+                                }
+                                continue;                                            // lost the race: re-read this bucket
                             }
-                            slot = (slot + 1) & (T - 1);
+                            bkt = (bkt + 1) & (T / 4 - 1);
                             left_probes--;
                         }
                         if (hit) {
@@ -474,6 +485,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 }
                 j++;
             }
+          }
         }
         __syncthreads();
         const bool ovf = s_flag[0] != 0;
