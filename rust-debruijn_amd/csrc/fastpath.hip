@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                     uint32_t le = ps > 0 ? (1u << packed_get(w, st + ps - 1)) : (sexts & 0xfu);
                     uint32_t re = ps + len < m ? (1u << packed_get(w, st + ps + len)) : (sexts >> 4);
                     uint64_t* o = tmp_recs + idx * RW;
+                    uint64_t rv[RW];
 #pragma unroll
                     for (int q = 0; q < NBW; q++) {
                         uint32_t b0 = (uint32_t)q * 32;
@@ -231,9 +232,16 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                             uint32_t nb = len - b0 < 32 ? len - b0 : 32;
                             v = packed_get_kmer(w, st + ps + b0, (int)nb).lo << (64 - 2 * nb);
                         }
-                        o[q] = v;
+                        rv[q] = v;
                     }
-                    o[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
+                    rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
+                    if (RW % 2 == 0) {
+#pragma unroll
+                        for (int q = 0; q < RW / 2; q++) ((ulonglong2*)o)[q] = make_ulonglong2(rv[2 * q], rv[2 * q + 1]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < RW; q++) o[q] = rv[q];
+                    }
                     tmp_bin[idx] = b;
                 }
             }
@@ -256,8 +264,13 @@ __global__ void __launch_bounds__(256) sk_scatter_kernel(const uint64_t* __restr
     uint64_t r = bin_off[b] + atomicAdd(&cursor[b], 1u);
     const uint64_t* src = tmp_recs + i * RW;
     uint64_t* dst = recs + r * RW;
+    if (RW % 2 == 0) {                                   // 32-byte records: two 16-byte moves
 #pragma unroll
-    for (int q = 0; q < RW; q++) dst[q] = src[q];
+        for (int q = 0; q < RW / 2; q++) ((ulonglong2*)dst)[q] = ((const ulonglong2*)src)[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < RW; q++) dst[q] = src[q];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,7 +348,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ uint32_t s_stP[40], s_stR[40];
     __shared__ int s_sp;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     // The bin's records arrive as n_src segments (one per source rank after the all-to-all; one in the
     // single-GPU case): segment s spans records [seg_off[s*stride + bin], seg_off[s*stride + bin + 1]).
     __shared__ uint64_t s_segbase[65];          // first record of segment s in `recs`
@@ -552,12 +565,33 @@ __global__ void set_values_kernel(uint32_t n, const uint32_t* __restrict__ msk_s
     uint64_t o = set_off[i];
     while (m) { uint32_t b = __ffs(m) - 1; set_val[o++] = b; m &= m - 1; }   // ascending = sort(); dedup() (filter.rs:97-98)
 }
-__global__ void max_label_kernel(const void* data, uint32_t width, uint64_t n, uint32_t* out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) max_label_kernel(const void* data, uint32_t width, uint64_t n, uint32_t* out) {
+    // grid-stride maximum of the D1 labels; one atomic per workgroup
+    __shared__ uint32_t s_m[4];
     uint32_t v = 0;
-    if (i < n) v = width == 1 ? ((const uint8_t*)data)[i] : (width == 2 ? ((const uint16_t*)data)[i] : ((const uint32_t*)data)[i]);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (width == 1) {
+        const uint64_t n16 = n / 16;
+        const uint4* d16 = (const uint4*)data;
+        for (uint64_t q = i; q < n16; q += stride) {
+            uint4 x = d16[q];
+            uint32_t w4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                uint32_t y = w4[t];
+                uint32_t mx = max(max(y & 0xffu, (y >> 8) & 0xffu), max((y >> 16) & 0xffu, y >> 24));
+                v = max(v, mx);
+            }
+        }
+        for (uint64_t q = n16 * 16 + i; q < n; q += stride) v = max(v, (uint32_t)((const uint8_t*)data)[q]);
+    } else {
+        for (uint64_t q = i; q < n; q += stride) v = max(v, width == 2 ? (uint32_t)((const uint16_t*)data)[q] : ((const uint32_t*)data)[q]);
+    }
     for (int d = 32; d; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])); if (m) atomicMax(out, m); }
 }
 }  // namespace
 
@@ -579,7 +613,7 @@ static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kme
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw + 1;
     pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
-    uint64_t target = 7000;                                     // k-mer instances per bin (about 0.15 distinct per instance)
+    uint64_t target = 9500;                                     // k-mer instances per bin (about 0.15 distinct per instance)
     if (const char* e = getenv("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
@@ -602,7 +636,7 @@ static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
     DBuf<uint32_t> mx;
     ALLOC_OR_FAIL(c, mx, 1);
     HIP_TRY(c, hipMemsetAsync(mx.p, 0, 4, c->stream));
-    if (s.n) { max_label_kernel<<<cdiv(s.n, 256), 256, 0, c->stream>>>(s.data, s.data_width, s.n, mx.p); LAUNCH_CHECK(c, "max_label"); }
+    if (s.n) { max_label_kernel<<<(uint32_t)std::min<uint64_t>(cdiv(s.n, 256), 2048), 256, 0, c->stream>>>(s.data, s.data_width, s.n, mx.p); LAUNCH_CHECK(c, "max_label"); }
     uint32_t h = 0;
     HIP_TRY(c, hipMemcpyAsync(&h, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
