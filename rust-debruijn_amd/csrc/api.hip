@@ -109,7 +109,7 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     const int k = (int)p->k;
     const bool has_hi = k > 32;
     const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
-    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
 
     DBuf<uint32_t> kcount;
     DBuf<uint64_t> koff;

@@ -12,6 +12,7 @@ struct SeqDev {
     const void* data;           // may be null
     uint32_t data_width;        // 0,1,2,4
     uint64_t n;
+    uint64_t n_words;           // words in `words` (loads are clamped to it where they are issued unconditionally)
 };
 
 // k-mer records in HBM: struct-of-arrays, key (hi, lo) + payload (Exts | D1 << 8)

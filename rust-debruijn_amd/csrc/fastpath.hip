@@ -38,6 +38,37 @@ __device__ __forceinline__ uint32_t packed_get_pmer(const uint64_t* __restrict__
     if (s + 2 * p > 64) v |= w[wi + 1] >> (64 - s);
     return (uint32_t)(v >> (64 - 2 * p));
 }
+// p-mer from the two words that hold it (w1 is ignored when the p-mer ends inside w0): no branches
+__device__ __forceinline__ uint32_t pmer_from_words(uint64_t w0, uint64_t w1, uint32_t s /* bit offset 0..62 */, int p) {
+    const uint64_t v = (w0 << s) | ((w1 >> 1) >> (63 - s));
+    return (uint32_t)(v >> (64 - 2 * p));
+}
+// The scan kernel addresses a read through a wave-uniform word pointer `wr` (word of the read's first
+// base) and 32-bit base offsets `rel` from that word's first base: address arithmetic stays 32-bit and
+// the base pointer lives in scalar registers.  Word indices are clamped to last_rel (unconditional loads).
+__device__ __forceinline__ uint32_t rel_pmer(const uint64_t* __restrict__ wr, uint32_t rel, uint32_t last_rel, int p) {
+    const uint32_t wi = rel >> 5, s = (rel & 31u) * 2u;
+    const uint64_t w0 = wr[wi < last_rel ? wi : last_rel], w1 = wr[wi + 1 < last_rel ? wi + 1 : last_rel];
+    return pmer_from_words(w0, w1, s, p);
+}
+__device__ __forceinline__ uint32_t rel_base(const uint64_t* __restrict__ wr, uint32_t rel) {
+    return (uint32_t)(wr[rel >> 5] >> (62 - 2 * (rel & 31u))) & 3u;
+}
+// nb (1..32) bases starting at rel, left-aligned in a u64 (rest zero)
+__device__ __forceinline__ uint64_t rel_word(const uint64_t* __restrict__ wr, uint32_t rel, uint32_t last_rel, uint32_t nb) {
+    const uint32_t wi = rel >> 5, s = (rel & 31u) * 2u;
+    const uint64_t w0 = wr[wi < last_rel ? wi : last_rel], w1 = wr[wi + 1 < last_rel ? wi + 1 : last_rel];
+    const uint64_t v = (w0 << s) | ((w1 >> 1) >> (63 - s));
+    return v & (~0ull << (64 - 2 * nb));
+}
+// nb (1..32) bases starting at absolute base offset o, left-aligned in a u64 (rest zero)
+__device__ __forceinline__ uint64_t packed_get_word(const uint64_t* __restrict__ w, uint64_t o, uint32_t nb) {
+    const uint64_t wi = o >> 5;
+    const int s = (int)(o & 31) * 2;
+    uint64_t v = w[wi] << s;
+    if (s + 2 * (int)nb > 64) v |= w[wi + 1] >> (64 - s);
+    return v & (~0ull << (64 - 2 * nb));
+}
 // reverse complement of a right-aligned p-mer held in 32 bits
 __device__ __forceinline__ uint32_t pmer_rc32(uint32_t pm, int p) {
     uint32_t r = __brev(pm);
@@ -99,6 +130,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
     const int k = c.k, p = c.p;
     const uint32_t W = (uint32_t)(k - p + 1);
     const uint64_t* __restrict__ w = s.words;
+    const uint64_t last_word = s.n_words ? s.n_words - 1 : 0;
     const FastScore sc{c.p, c.stranded};
     const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -125,39 +157,56 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
         const uint32_t sexts = __shfl(v_ex, rj);
         const uint32_t d1 = __shfl(v_d1, rj);
         const uint32_t nwin = m - (uint32_t)k + 1, npos = m - (uint32_t)p + 1;
+        const uint64_t w_first = st >> 5;                                      // word holding the read's first base
+        const uint64_t* __restrict__ wr = w + w_first;
+        const uint32_t sb = (uint32_t)(st & 31);                               // its position inside that word
+        const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
         uint32_t open_start = 0;            // start window of the piece still open (wave-uniform)
         uint32_t carry_arg = 0xffffffffu;   // argmin position of the last window of the previous tile
 
         for (uint32_t t0 = 0; t0 < nwin; t0 += SCAN_TILE_W) {
-            // ---- hashed p-mers of this tile ----
-            uint64_t own[3];
+            // ---- hashed p-mers of this tile: all six word loads are issued before any is consumed
+            //      (indices clamped to the buffer, results of out-of-range lanes are discarded) ----
+            uint32_t oh[3], op[3];                  // hash and position of the running window minimum
+            {
+                uint64_t l0[3], l1[3];
+                uint32_t sh[3];
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                uint32_t pos = t0 + ch * 64 + lane;
-                uint64_t v = ~0ull;
-                if (pos < npos) {
-                    uint32_t pm = packed_get_pmer(w, st + pos, p);
-                    v = ((uint64_t)sc(pm) << 32) | pos;
+                for (int ch = 0; ch < 3; ch++) {
+                    const uint32_t rel = sb + t0 + ch * 64 + lane;
+                    const uint32_t wi = rel >> 5;
+                    sh[ch] = (rel & 31u) * 2u;
+                    l0[ch] = wr[wi < last_rel ? wi : last_rel];
+                    l1[ch] = wr[wi + 1 < last_rel ? wi + 1 : last_rel];
                 }
-                own[ch] = v;
-                A[ch * 64 + lane] = v;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const uint32_t pos = t0 + ch * 64 + lane;
+                    const uint32_t pm = pmer_from_words(l0[ch], l1[ch], sh[ch], p);
+                    oh[ch] = pos < npos ? sc(pm) : 0xffffffffu;
+                    op[ch] = pos;
+                    A[ch * 64 + lane] = ((uint64_t)oh[ch] << 32) | pos;
+                }
             }
-            // ---- log-step sliding minimum: after the loop own[] covers [i, i + span) ----
+            // ---- log-step sliding minimum: after the loop (oh, op) covers [i, i + span).  The right operand
+            //      holds positions further right, so a strict 32-bit compare keeps the leftmost on ties ----
             uint32_t span = 1;
             for (; 2 * span <= W; span <<= 1) {
-                uint64_t x0 = A[lane + span], x1 = A[64 + lane + span], x2 = A[128 + lane + span];
-                own[0] = own[0] < x0 ? own[0] : x0;
-                own[1] = own[1] < x1 ? own[1] : x1;
-                own[2] = own[2] < x2 ? own[2] : x2;
-                A[lane] = own[0]; A[64 + lane] = own[1]; A[128 + lane] = own[2];
+                const uint64_t x0 = A[lane + span], x1 = A[64 + lane + span], x2 = A[128 + lane + span];
+                const uint32_t xh0 = (uint32_t)(x0 >> 32), xh1 = (uint32_t)(x1 >> 32), xh2 = (uint32_t)(x2 >> 32);
+                if (xh0 < oh[0]) { oh[0] = xh0; op[0] = (uint32_t)x0; }
+                if (xh1 < oh[1]) { oh[1] = xh1; op[1] = (uint32_t)x1; }
+                if (xh2 < oh[2]) { oh[2] = xh2; op[2] = (uint32_t)x2; }
+                A[lane] = ((uint64_t)oh[0] << 32) | op[0];
+                A[64 + lane] = ((uint64_t)oh[1] << 32) | op[1];
+                A[128 + lane] = ((uint64_t)oh[2] << 32) | op[2];
             }
             const uint32_t rem = W - span;
             uint32_t arg[2];
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                uint64_t y = A[ch * 64 + lane + rem];
-                uint64_t mn = own[ch] < y ? own[ch] : y;
-                arg[ch] = (uint32_t)mn;                     // absolute p-mer position of the window minimizer
+                const uint64_t y = A[ch * 64 + lane + rem];
+                arg[ch] = (uint32_t)(y >> 32) < oh[ch] ? (uint32_t)y : op[ch];   // position of the window minimizer
             }
             // ---- piece boundaries ----
             uint32_t up0 = __shfl_up(arg[0], 1), up1 = __shfl_up(arg[1], 1);
@@ -215,24 +264,21 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                 else for (uint32_t t = lane; t < npieces; t += 64) {
                     const uint32_t ps = PL[t], pe = PL[132 + t], pa = PL[264 + t];
                     const uint64_t idx = idx0 + t;
-                    uint32_t pm = packed_get_pmer(w, st + pa, p);
+                    uint32_t pm = rel_pmer(wr, sb + pa, last_rel, p);
                     uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
                     uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
                     uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
                     atomicAdd(&hist[b], 1u);
-                    uint32_t le = ps > 0 ? (1u << packed_get(w, st + ps - 1)) : (sexts & 0xfu);
-                    uint32_t re = ps + len < m ? (1u << packed_get(w, st + ps + len)) : (sexts >> 4);
+                    uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
+                    uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
                     uint64_t* o = tmp_recs + idx * RW;
                     uint64_t rv[RW];
 #pragma unroll
                     for (int q = 0; q < NBW; q++) {
-                        uint32_t b0 = (uint32_t)q * 32;
-                        uint64_t v = 0;
-                        if (b0 < len) {
-                            uint32_t nb = len - b0 < 32 ? len - b0 : 32;
-                            v = packed_get_kmer(w, st + ps + b0, (int)nb).lo << (64 - 2 * nb);
-                        }
-                        rv[q] = v;
+                        const uint32_t b0 = (uint32_t)q * 32;
+                        const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
+                        const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
+                        rv[q] = nb ? v : 0ull;
                     }
                     rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
                     if (RW % 2 == 0) {
@@ -284,6 +330,12 @@ struct FastOut {
     uint32_t* nobs;     // CountFilterSet: raw observation count (validity uses nobs, filter.rs:99); else null
 };
 
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+// 64-bit hash of a key: low bits -> bucket, bits 16.. -> pass selection, high word -> tag
 __device__ __forceinline__ uint64_t hash_key(uint64_t hi, uint64_t lo) {
     uint64_t h = lo ^ (hi * 0x9E3779B97F4A7C15ull);
     h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
@@ -877,7 +929,7 @@ void fast_drop_state(dbg_ctx* c) {
 
 extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t k, uint64_t* n_out) {
     HIP_TRY(c, hipSetDevice(c->device));
-    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     DBuf<uint32_t> kcount;
     DBuf<uint64_t> koff;
     ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
@@ -912,7 +964,7 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     c->t_clear();
     FastPlan pl;
     DBG_TRY(plan_from(c, sp, &pl));
-    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     if (pl.is_set) {
         bool ok;
         DBG_TRY(fast_labels_ok(c, s, &ok));

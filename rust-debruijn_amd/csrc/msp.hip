@@ -83,7 +83,7 @@ extern "C" int dbg_msp_sequence_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     HIP_TRY(c, hipSetDevice(c->device));
     c->t_clear();
     memset(out, 0, sizeof(*out));
-    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs};
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     MspCfg cfg{(int)p->k, (int)p->p, p->permutation, p->rc, (int)p->lmer_words};
     DBuf<uint32_t> counts;
     DBuf<uint64_t> off;
