@@ -158,8 +158,17 @@ def main():
                         "sk_scan": b_in + sk_b + 4.0 * n_recs / max(n_inst, 1), "sk_scatter": 2 * rec_b + 4,
                         "bin_count": r_alg + u_over_n * (key + 3)}.get(name, 2 * rbytes)
             ach = per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
+            # HBM traffic from the PMC passes (tools/pmc.sh: separate --pmc runs of this same bench at 10M
+            # reads; FETCH_SIZE doubled per the gfx950 correction), scaled per k-mer instance
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic_10Mreads.json")
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                ent = tj.get(name + "_kernel") or tj.get(name)
+                if ent:
+                    traffic = round(ent["bytes_per_instance"] * n_inst / (a["launches"] / args.steps), 0)
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "alg_bytes_per_unit": round(per_unit, 2), "units_per_launch": units_per_launch,
                     "avg_launch_ms": round(avg_ms, 4), "launches_per_step": a["launches"] / args.steps,
                     "whole_path_alg_frac": round(value * b_alg / HBM_PEAK_GBS, 4),

@@ -182,7 +182,6 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_kernel(RecArrays in, uin
     __shared__ uint64_t s_hi[HAS_HI ? SS_CAP : 1];
     __shared__ uint32_t s_idx[SS_CAP];
     __shared__ uint32_t wc[SS_WAVES][256];
-    __shared__ uint32_t s_dig[256];
     __shared__ uint32_t s_ws[SS_WAVES];
     __shared__ uint32_t s_start, s_end;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
