@@ -164,6 +164,12 @@ int  dbg_compress_kmers_with_hash(dbg_ctx* ctx, uint32_t k, int stranded, int sp
                                   const uint64_t* seed_order, dbg_graph* out);
 void dbg_free_graph(dbg_ctx* ctx, dbg_graph* g);
 
+/* ---- sharded second stage: BaseGraph::combine (src/graph.rs:71-100) and compress_graph
+ *      (src/compression.rs:338-349, which implies finish (graph.rs:116-142) + fix_exts (:337-377)) ---- */
+int  dbg_graph_combine(dbg_ctx* ctx, const dbg_graph* graphs, uint32_t n_graphs, dbg_graph* out);
+int  dbg_compress_graph(dbg_ctx* ctx, uint32_t k, int stranded, int spec, const dbg_graph* old_graph,
+                        const uint64_t* censor_nodes, uint64_t n_censor, dbg_graph* out);
+
 /* ---- sharded counting for multi-GPU runs --------------------------------------------------
  * The reference's own scale-out design is "MSP shard -> independent per-shard filter_kmers"
  * (src/msp.rs:279-324, src/filter.rs:121-124, src/test.rs:433-456).  Here every rank scans its own

@@ -20,7 +20,7 @@ from ._capi import SeqSet as _SeqSet
 
 __all__ = ["Context", "Exts", "CountFilter", "CountFilterSet", "SimpleCompress", "ScmapCompress",
            "PackedDnaStringSet", "KmerTable", "BaseGraph", "filter_kmers", "msp_sequence",
-           "compress_kmers_with_hash", "remove_censored_exts", "remove_censored_exts_sharded",
+           "compress_kmers_with_hash", "compress_graph", "combine_graphs", "remove_censored_exts", "remove_censored_exts_sharded",
            "synth_reads_host", "pack_bases", "unpack_bases", "DbgError", "LEFT", "RIGHT"]
 
 LEFT, RIGHT = 0, 1
@@ -408,6 +408,50 @@ def compress_kmers_with_hash(stranded, spec, index, k=None, seed_order=None, dat
     finally:
         ctx.lib.dbg_free_graph(ctx.h, C.byref(g))
     return out
+
+
+def _graph_to_c(g):
+    """BaseGraph -> dbg_graph over the graph's own numpy arrays (kept alive by the returned tuple)."""
+    words = np.ascontiguousarray(np.concatenate([g.sequences.words, np.zeros(2, np.uint64)]), np.uint64)
+    start = np.ascontiguousarray(g.sequences.start, np.uint64)
+    length = np.ascontiguousarray(g.sequences.length, np.uint32)
+    exts = np.ascontiguousarray(g.exts, np.uint8)
+    data = np.ascontiguousarray(g.data, np.uint32)
+    cg = _capi.Graph(len(start), _np_ptr(words), len(g.sequences.words), g.sequences.n_bases, _np_ptr(start), _np_ptr(length),
+                     _np_ptr(exts), _np_ptr(data), int(bool(g.stranded)))
+    return cg, (words, start, length, exts, data)
+
+
+def _graph_from_c(ctx, g, k):
+    try:
+        seqs = PackedDnaStringSet(_copy(g.seq_words, g.n_seq_words, np.uint64), _copy(g.start, g.n_nodes, np.uint64),
+                                  _copy(g.length, g.n_nodes, np.uint32), g.seq_len_bases)
+        return BaseGraph(k, seqs, _copy(g.exts, g.n_nodes, np.uint8), _copy(g.data, g.n_nodes, np.uint32), bool(g.stranded))
+    finally:
+        ctx.lib.dbg_free_graph(ctx.h, C.byref(g))
+
+
+def combine_graphs(graphs, ctx=None):
+    """BaseGraph::combine (src/graph.rs:71-100)."""
+    ctx = ctx or default_context()
+    graphs = list(graphs)
+    cs = [_graph_to_c(g) for g in graphs]
+    arr = (_capi.Graph * len(cs))(*[c[0] for c in cs])
+    out = _capi.Graph()
+    ctx.check(ctx.lib.dbg_graph_combine(ctx.h, arr, len(cs), C.byref(out)))
+    return _graph_from_c(ctx, out, graphs[0].k if graphs else 0)
+
+
+def compress_graph(stranded, spec, old_graph, censor_nodes=None, ctx=None):
+    """compress_graph (src/compression.rs:338-349): second-stage compaction of a (partly compressed) graph;
+    `old_graph.finish()` and both fix_exts passes are part of the call."""
+    ctx = ctx or default_context()
+    cg, keep = _graph_to_c(old_graph)
+    cn = None if censor_nodes is None else np.ascontiguousarray(censor_nodes, np.uint64)
+    out = _capi.Graph()
+    ctx.check(ctx.lib.dbg_compress_graph(ctx.h, old_graph.k, int(bool(stranded)), spec.kind, C.byref(cg), _np_ptr(cn),
+                                         0 if cn is None else len(cn), C.byref(out)))
+    return _graph_from_c(ctx, out, old_graph.k)
 
 
 def _censor(stranded, table, all_kmers, sharded, ctx):

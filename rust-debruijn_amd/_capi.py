@@ -68,7 +68,7 @@ EXPORTS = [
     "dbg_compress_kmers_with_hash", "dbg_free_graph", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
-    "dbg_shard_count_dev",
+    "dbg_shard_count_dev", "dbg_graph_combine", "dbg_compress_graph",
 ]
 
 _lib = None
@@ -111,6 +111,9 @@ def load():
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Graph)]
     lib.dbg_free_graph.argtypes = [C.c_void_p, C.POINTER(Graph)]
     lib.dbg_free_graph.restype = None
+    lib.dbg_graph_combine.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_uint32, C.POINTER(Graph)]
+    lib.dbg_compress_graph.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Graph), C.c_void_p, C.c_uint64,
+                                       C.POINTER(Graph)]
     lib.dbg_synth_words.argtypes = [C.POINTER(SynthParams)]
     lib.dbg_synth_words.restype = C.c_uint64
     lib.dbg_synth_reads_dev.argtypes = [C.c_void_p, C.POINTER(SynthParams), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1,0 +1,374 @@
+// Second-stage compaction of the sharded flow: BaseGraph::combine (src/graph.rs:71-100),
+// BaseGraph::finish (graph.rs:116-142), DebruijnGraph::{find_link, get_valid_exts, fix_exts}
+// (graph.rs:252-291, :337-377) and compress_graph / CompressFromGraph (src/compression.rs:100-349).
+//
+// The reference indexes node ends with two MPHF maps (first k-mer -> node, last k-mer -> node).  Lookups
+// are exact, so any exact index gives the same answers: here the device extracts the terminal k-mers of
+// every node, radix-sorts them with the node id as payload, and `find_link` is two binary searches.
+// fix_exts and the availability-independent part of try_extend_node (compression.rs:115-205) are batched
+// device kernels; the greedy walk over nodes (build_node, compression.rs:240-287) and the assembly of the
+// path sequences (sequence_of_path, graph.rs:471-491) stay on the host.  Nodes are visited in index order
+// (compression.rs:322), so the result does not depend on any MPHF internals.
+#include "dbg_internal.hpp"
+#include <algorithm>
+#include <deque>
+
+namespace {
+
+struct EndIndex {            // sorted terminal k-mers of one side + owning node
+    const uint64_t* hi;      // null when k <= 32
+    const uint64_t* lo;
+    const uint32_t* node;
+    uint32_t n;
+};
+
+__device__ __forceinline__ K128 ekey(const EndIndex& t, uint32_t i) { return K128{t.hi ? t.hi[i] : 0ull, t.lo[i]}; }
+__device__ __forceinline__ int64_t search_kmer(const EndIndex& t, K128 q) {          // graph.rs:243-249
+    uint32_t lo = 0, hi = t.n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (k128_lt(ekey(t, mid), q)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < t.n && k128_eq(ekey(t, lo), q)) return (int64_t)t.node[lo];
+    return -1;
+}
+
+struct Link { int64_t node; int side; int flip; };
+// find_link (graph.rs:252-291): dir Left looks for the k-mer at a node's RIGHT end, then (unstranded) for
+// its reverse complement at a LEFT end; dir Right the mirror image.
+__device__ __forceinline__ Link find_link(const EndIndex& left, const EndIndex& right, K128 kmer, int dir, int stranded, int k) {
+    K128 rc = kmer_rc(kmer, k);
+    int64_t idx;
+    if (dir == 0) {
+        if ((idx = search_kmer(right, kmer)) >= 0) return Link{idx, 1, 0};
+        if (!stranded && (idx = search_kmer(left, rc)) >= 0) return Link{idx, 0, 1};
+    } else {
+        if ((idx = search_kmer(left, kmer)) >= 0) return Link{idx, 0, 0};
+        if (!stranded && (idx = search_kmer(right, rc)) >= 0) return Link{idx, 1, 1};
+    }
+    return Link{-1, 0, 0};
+}
+
+__global__ void term_kmers_kernel(const uint64_t* __restrict__ words, const uint64_t* __restrict__ start,
+                                  const uint32_t* __restrict__ length, uint32_t n, int k,
+                                  uint64_t* f_hi, uint64_t* f_lo, uint64_t* l_hi, uint64_t* l_lo, uint32_t* ids_a, uint32_t* ids_b) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    K128 f = packed_get_kmer(words, start[i], k);                                   // first_kmer (lib.rs:369-371)
+    K128 l = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);         // last_kmer (lib.rs:374-376)
+    if (f_hi) { f_hi[i] = f.hi; l_hi[i] = l.hi; }
+    f_lo[i] = f.lo; l_lo[i] = l.lo;
+    ids_a[i] = i; ids_b[i] = i;
+}
+
+// get_valid_exts (graph.rs:344-377): keep an extension iff it links to a node (that is valid)
+__global__ void fix_exts_kernel(EndIndex left, EndIndex right, const uint64_t* __restrict__ words,
+                                const uint64_t* __restrict__ start, const uint32_t* __restrict__ length, uint32_t n, int k,
+                                int stranded, const uint8_t* __restrict__ valid, const uint8_t* __restrict__ exts_in,
+                                uint8_t* __restrict__ exts_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    K128 lk = packed_get_kmer(words, start[i], k);
+    K128 rk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);
+    uint32_t e = exts_in[i], ne = 0;
+    for (uint32_t b = 0; b < 4; b++) {
+        if (e & (1u << b)) {
+            Link L = find_link(left, right, kmer_extend_left(lk, k, b), 0, stranded, k);
+            if (L.node >= 0 && (!valid || valid[L.node])) ne |= 1u << b;
+        }
+        if (e & (16u << b)) {
+            Link L = find_link(left, right, kmer_extend_right(rk, k, b), 1, stranded, k);
+            if (L.node >= 0 && (!valid || valid[L.node])) ne |= 16u << b;
+        }
+    }
+    exts_out[i] = (uint8_t)ne;
+}
+
+// link word per (node, dir): the availability-independent part of try_extend_node (compression.rs:115-205)
+constexpr uint32_t NL_TERM = 0xFFFFFFFFu;        // Terminal whatever the availability
+constexpr uint32_t NL_NOKMER = 0xFFFFFFFEu;      // reference panics "No kmer" (compression.rs:138)
+constexpr uint32_t NL_INCONSISTENT = 0xFFFFFFFDu;// assert!(consistent) fails (compression.rs:165)
+constexpr uint32_t NL_PANIC_BIT = 1u;            // incoming_count == 0 -> panic "unreachable" if the node is available (:190-195)
+// otherwise (next_node << 2) | (next_side_outgoing << 1) | panic_bit
+
+__device__ __forceinline__ bool join_ok(int spec, uint32_t a, uint32_t b) { return spec == DBG_SPEC_SCMAP_EQ ? a == b : true; }
+
+__global__ void node_link_kernel(EndIndex left, EndIndex right, const uint64_t* __restrict__ words,
+                                 const uint64_t* __restrict__ start, const uint32_t* __restrict__ length, uint32_t n, int k,
+                                 int stranded /* the walk's */, int g_stranded /* the graph's: drives find_link */, int spec,
+                                 const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data,
+                                 uint32_t* __restrict__ link /* [2][n] */) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t e = exts[i];
+    K128 fk = packed_get_kmer(words, start[i], k);
+    K128 lk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);
+    const bool self_pal = !stranded && length[i] == (uint32_t)k && (k % 2 == 0) && k128_eq(fk, kmer_rc(fk, k));   // :121
+    for (int dir = 0; dir < 2; dir++) {
+        uint32_t out = NL_TERM;
+        uint32_t bits = (e >> (4 * dir)) & 0xfu;
+        if (__popc(bits) == 1 && !self_pal) {                                          // :120-123
+            uint32_t base = 31 - __clz(bits);
+            K128 end_kmer = dir == 0 ? fk : lk;                                        // term_kmer(dir) :127
+            K128 next_kmer = dir == 0 ? kmer_extend_left(end_kmer, k, base) : kmer_extend_right(end_kmer, k, base);
+            Link L = find_link(left, right, next_kmer, dir, g_stranded, k);           // :130 (self.graph.find_link)
+            if (L.node < 0) out = NL_NOKMER;
+            else {
+                const uint32_t nn = (uint32_t)L.node;
+                bool consistent = length[nn] == (uint32_t)k ||                         // :145-165
+                                  (dir == 0 && L.side == 1 && !L.flip) || (dir == 0 && L.side == 0 && L.flip) ||
+                                  (dir == 1 && L.side == 0 && !L.flip) || (dir == 1 && L.side == 1 && L.flip);
+                bool next_pal = !stranded && (k % 2 == 0) && k128_eq(next_kmer, kmer_rc(next_kmer, k));          // :174
+                if (!consistent) out = NL_INCONSISTENT;
+                else if (next_pal || !join_ok(spec, data ? data[i] : 0u, data ? data[nn] : 0u)) out = NL_TERM;   // :173-182
+                else {
+                    uint32_t incoming = __popc((exts[nn] >> (4 * L.side)) & 0xfu);     // num_ext_dir(next_side_incoming) :187
+                    int outgoing = 1 - L.side;                                         // next_side_incoming.flip() :185
+                    if (incoming == 0) out = (nn << 2) | ((uint32_t)outgoing << 1) | NL_PANIC_BIT;
+                    else if (incoming == 1) out = (nn << 2) | ((uint32_t)outgoing << 1);
+                    else out = NL_TERM;                                                // :199-203
+                }
+            }
+        }
+        link[(uint64_t)dir * n + i] = out;
+    }
+}
+
+// ---- host helpers --------------------------------------------------------------------------
+struct HostBits {           // growing packed base stream (DnaString::push, dna_string.rs:303-310)
+    std::vector<uint64_t> words;
+    uint64_t len = 0;
+    inline void push(uint32_t b) {
+        if ((len & 31) == 0) words.push_back(0);
+        words.back() |= (uint64_t)(b & 3u) << (62 - 2 * (len & 31));
+        len++;
+    }
+};
+inline uint32_t hget(const uint64_t* w, uint64_t o) { return (uint32_t)((w[o >> 5] >> (62 - 2 * (o & 31))) & 3ull); }
+
+inline uint32_t spec_reduce_h(int spec, uint32_t a, uint32_t b, bool* panic) {
+    switch (spec) {
+        case DBG_SPEC_SIMPLE_SAT_ADD_U16: { uint32_t s = a + b; return s > 65535u ? 65535u : s; }
+        case DBG_SPEC_SIMPLE_ADD_MOD_U16: return (a + b) % 65535u;
+        case DBG_SPEC_SIMPLE_MAX_U16: return std::max(a, b);
+        case DBG_SPEC_SCMAP_EQ: if (a != b) *panic = true; return a;
+        case DBG_SPEC_SIMPLE_WRAP_ADD_U16: return (a + b) & 0xFFFFu;
+    }
+    return a;
+}
+
+void* dup_bytes(const void* p, size_t bytes) { void* q = malloc(bytes ? bytes : 1); if (bytes) memcpy(q, p, bytes); return q; }
+
+void graph_out(const HostBits& seq, const std::vector<uint64_t>& st, const std::vector<uint32_t>& ln,
+               const std::vector<uint8_t>& ex, const std::vector<uint32_t>& da, int stranded, dbg_graph* out) {
+    out->n_nodes = st.size(); out->n_seq_words = seq.words.size(); out->seq_len_bases = seq.len;
+    out->seq_words = (uint64_t*)dup_bytes(seq.words.data(), seq.words.size() * 8);
+    out->start = (uint64_t*)dup_bytes(st.data(), st.size() * 8);
+    out->length = (uint32_t*)dup_bytes(ln.data(), ln.size() * 4);
+    out->exts = (uint8_t*)dup_bytes(ex.data(), ex.size());
+    out->data = (uint32_t*)dup_bytes(da.data(), da.size() * 4);
+    out->stranded = stranded;
+}
+
+// Device-resident DebruijnGraph index (finish, graph.rs:116-142) + fix_exts / links on it.
+struct DevGraph {
+    DBuf<uint64_t> words, start, f_hi, f_lo, l_hi, l_lo, t_hi, t_lo;
+    DBuf<uint32_t> length, f_id, l_id, t_id, data;
+    DBuf<uint8_t> exts;
+    EndIndex left{nullptr, nullptr, nullptr, 0}, right{nullptr, nullptr, nullptr, 0};
+    uint32_t n = 0;
+};
+
+int dev_graph_build(dbg_ctx* c, int k, const dbg_graph* g, DevGraph* d) {
+    const uint32_t n = (uint32_t)g->n_nodes;
+    const bool has_hi = k > 32;
+    d->n = n;
+    const size_t na = std::max<uint32_t>(n, 1), nw = std::max<uint64_t>(g->n_seq_words, 1);
+    ALLOC_OR_FAIL(c, d->words, nw + 2); ALLOC_OR_FAIL(c, d->start, na); ALLOC_OR_FAIL(c, d->length, na);
+    ALLOC_OR_FAIL(c, d->exts, na); ALLOC_OR_FAIL(c, d->data, na);
+    HIP_TRY(c, hipMemsetAsync(d->words.p, 0, (nw + 2) * 8, c->stream));
+    if (g->n_seq_words) HIP_TRY(c, hipMemcpyAsync(d->words.p, g->seq_words, g->n_seq_words * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(d->start.p, g->start, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d->length.p, g->length, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d->exts.p, g->exts, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        if (g->data) HIP_TRY(c, hipMemcpyAsync(d->data.p, g->data, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(c, hipMemsetAsync(d->data.p, 0, (size_t)n * 4, c->stream));
+    }
+    if (has_hi) { ALLOC_OR_FAIL(c, d->f_hi, na); ALLOC_OR_FAIL(c, d->l_hi, na); ALLOC_OR_FAIL(c, d->t_hi, na); }
+    ALLOC_OR_FAIL(c, d->f_lo, na); ALLOC_OR_FAIL(c, d->l_lo, na); ALLOC_OR_FAIL(c, d->t_lo, na);
+    ALLOC_OR_FAIL(c, d->f_id, na); ALLOC_OR_FAIL(c, d->l_id, na); ALLOC_OR_FAIL(c, d->t_id, na);
+    if (n) {
+        term_kmers_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(d->words.p, d->start.p, d->length.p, n, k, d->f_hi.p, d->f_lo.p,
+                                                                d->l_hi.p, d->l_lo.p, d->f_id.p, d->l_id.p);
+        LAUNCH_CHECK(c, "term_kmers");
+    }
+    // sort (first k-mer, node) and (last k-mer, node); a copy of the unsorted keys is not needed afterwards
+    bool in_b = false;
+    RecArrays F{has_hi ? d->f_hi.p : nullptr, d->f_lo.p, d->f_id.p}, T{has_hi ? d->t_hi.p : nullptr, d->t_lo.p, d->t_id.p};
+    DBG_TRY(radix_sort_records(c, n, F, T, 2 * k, 0, 0, &in_b));
+    if (in_b) { std::swap(d->f_hi, d->t_hi); std::swap(d->f_lo, d->t_lo); std::swap(d->f_id, d->t_id); }
+    RecArrays L{has_hi ? d->l_hi.p : nullptr, d->l_lo.p, d->l_id.p}, T2{has_hi ? d->t_hi.p : nullptr, d->t_lo.p, d->t_id.p};
+    DBG_TRY(radix_sort_records(c, n, L, T2, 2 * k, 0, 0, &in_b));
+    if (in_b) { std::swap(d->l_hi, d->t_hi); std::swap(d->l_lo, d->t_lo); std::swap(d->l_id, d->t_id); }
+    d->left = EndIndex{has_hi ? d->f_hi.p : nullptr, d->f_lo.p, d->f_id.p, n};
+    d->right = EndIndex{has_hi ? d->l_hi.p : nullptr, d->l_lo.p, d->l_id.p, n};
+    return 0;
+}
+
+// fix_exts (graph.rs:337-342) in place on the device exts; valid may be null
+int dev_fix_exts(dbg_ctx* c, int k, int stranded, DevGraph* d, const uint8_t* valid_dev) {
+    if (!d->n) return 0;
+    DBuf<uint8_t> out;
+    ALLOC_OR_FAIL(c, out, d->n);
+    c->t_begin("graph_fix_exts", d->n);
+    fix_exts_kernel<<<cdiv(d->n, 256), 256, 0, c->stream>>>(d->left, d->right, d->words.p, d->start.p, d->length.p, d->n, k, stranded,
+                                                             valid_dev, d->exts.p, out.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "fix_exts");
+    std::swap(d->exts, out);
+    return 0;
+}
+}  // namespace
+
+// BaseGraph::combine (graph.rs:71-100): sequences re-added back-to-back, exts/data concatenated
+extern "C" int dbg_graph_combine(dbg_ctx* c, const dbg_graph* graphs, uint32_t n_graphs, dbg_graph* out) {
+    memset(out, 0, sizeof(*out));
+    bool all_s = true, none_s = true;
+    HostBits seq;
+    std::vector<uint64_t> st; std::vector<uint32_t> ln, da; std::vector<uint8_t> ex;
+    for (uint32_t gi = 0; gi < n_graphs; gi++) {
+        const dbg_graph& g = graphs[gi];
+        for (uint64_t i = 0; i < g.n_nodes; i++) {
+            st.push_back(seq.len);
+            for (uint32_t p = 0; p < g.length[i]; p++) seq.push(hget(g.seq_words, g.start[i] + p));
+            ln.push_back(g.length[i]);
+            ex.push_back(g.exts[i]);
+            da.push_back(g.data ? g.data[i] : 0u);
+        }
+        all_s = all_s && g.stranded; none_s = none_s && !g.stranded;
+    }
+    if (!all_s && !none_s) return c->fail(50, "attempted to combine stranded and unstranded graphs (graph.rs:90)");
+    graph_out(seq, st, ln, ex, da, all_s ? 1 : 0, out);
+    return 0;
+}
+
+// compress_graph (compression.rs:338-349): old_graph is an (unfinished or finished) BaseGraph on the host
+extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spec, const dbg_graph* old_graph,
+                                  const uint64_t* censor_nodes, uint64_t n_censor, dbg_graph* out) {
+    const int k = (int)k_;
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (spec < 0 || spec > 4) return c->fail(41, "unknown CompressionSpec");
+    if (old_graph->n_nodes >= (1ull << 30)) return c->fail(51, "compress_graph: at most 2^30-1 nodes per call in this build");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    memset(out, 0, sizeof(*out));
+    const uint32_t n = (uint32_t)old_graph->n_nodes;
+    for (uint32_t i = 0; i < n; i++) if (old_graph->length[i] < (uint32_t)k) return c->fail(52, "node shorter than k");
+    // old_graph.finish() is implied by the DebruijnGraph argument of the reference; the graph's own
+    // strandedness drives find_link (graph.rs:270,282), the `stranded` argument drives the walk
+    const int g_stranded = old_graph->stranded;
+    std::vector<uint8_t> available(n, 1);                                              // :297-307
+    for (uint64_t i = 0; i < n_censor; i++) { if (censor_nodes[i] >= n) return c->fail(53, "censor node out of range"); available[censor_nodes[i]] = 0; }
+
+    DevGraph d;
+    DBG_TRY(dev_graph_build(c, k, old_graph, &d));
+    DBuf<uint8_t> d_avail;
+    ALLOC_OR_FAIL(c, d_avail, std::max<uint32_t>(n, 1));
+    if (n) HIP_TRY(c, hipMemcpyAsync(d_avail.p, available.data(), n, hipMemcpyHostToDevice, c->stream));
+    DBG_TRY(dev_fix_exts(c, k, g_stranded, &d, d_avail.p));                            // old_graph.fix_exts(Some(&available)) :309
+    std::vector<uint32_t> link(2 * (size_t)n);
+    std::vector<uint8_t> exts(n);
+    if (n) {
+        DBuf<uint32_t> d_link;
+        ALLOC_OR_FAIL(c, d_link, 2 * (size_t)n);
+        c->t_begin("graph_node_links", n);
+        node_link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(d.left, d.right, d.words.p, d.start.p, d.length.p, n, k, stranded, g_stranded, spec,
+                                                               d.exts.p, d.data.p, d_link.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "node_links");
+        HIP_TRY(c, hipMemcpyAsync(link.data(), d_link.p, 2 * (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(exts.data(), d.exts.p, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    // ---- host: greedy walk in node order (compression.rs:322-327) ----
+    const uint64_t* W = old_graph->seq_words;
+    HostBits seq;
+    std::vector<uint64_t> g_start; std::vector<uint32_t> g_len, g_data; std::vector<uint8_t> g_exts;
+    std::vector<std::pair<uint32_t, int>> l_path, r_path;
+    bool spec_panic = false;
+    auto single_dir = [&](uint32_t id, int dir) -> uint32_t { return dir ? (exts[id] >> 4) : (exts[id] & 0xfu); };
+    // extend_node (compression.rs:208-235): path of (node, incoming dir) + terminal exts nibble
+    auto extend = [&](uint32_t start_node, int start_dir, std::vector<std::pair<uint32_t, int>>& path, int* err) -> uint32_t {
+        path.clear();
+        uint32_t cur = start_node; int dir = start_dir;
+        available[start_node] = 0;                                                     // :214
+        for (;;) {
+            uint32_t L = link[(uint64_t)dir * n + cur];
+            if (L == NL_TERM) return single_dir(cur, dir);
+            if (L == NL_NOKMER) { *err = 1; return 0; }
+            if (L == NL_INCONSISTENT) { *err = 2; return 0; }
+            uint32_t nn = L >> 2; int outgoing = (int)((L >> 1) & 1u);
+            if (!available[nn]) return single_dir(cur, dir);                           // :173-182
+            if (L & NL_PANIC_BIT) { *err = 3; return 0; }                              // :190-195
+            path.push_back({nn, 1 - outgoing});                                        // (next_node, next_dir_incoming) :221-222
+            available[nn] = 0;
+            cur = nn; dir = outgoing;
+        }
+    };
+    for (uint32_t nc = 0; nc < n; nc++) {
+        if (!available[nc]) continue;                                                  // :323
+        int err = 0;
+        uint32_t l_ext = extend(nc, 0, l_path, &err);                                  // :241
+        uint32_t r_ext = err ? 0 : extend(nc, 1, r_path, &err);                        // :242
+        if (err == 1) return c->fail(55, "No kmer (compression.rs:138)");
+        if (err == 2) return c->fail(56, "assertion failed: consistent (compression.rs:165)");
+        if (err == 3) return c->fail(57, "unreachable (compression.rs:195)");
+        std::deque<std::pair<uint32_t, int>> node_path;                                // (node, Dir) with Left = as stored
+        uint32_t node_data = old_graph->data ? old_graph->data[nc] : 0u;               // :247
+        node_path.push_back({nc, 0});
+        for (auto& pr : l_path) {                                                      // :251-256
+            node_path.push_front({pr.first, 1 - pr.second});
+            node_data = spec_reduce_h(spec, node_data, old_graph->data ? old_graph->data[pr.first] : 0u, &spec_panic);
+        }
+        for (auto& pr : r_path) {                                                      // :259-264
+            node_path.push_back({pr.first, pr.second});
+            node_data = spec_reduce_h(spec, node_data, old_graph->data ? old_graph->data[pr.first] : 0u, &spec_panic);
+        }
+        if (spec_panic) return c->fail(46, "ScmapCompress::reduce on unequal data: Should not happen (compression.rs:90)");
+        uint32_t left_extend = (!l_path.empty() && l_path.back().second == 0) ? (exts_complement(l_ext) & 0xfu) : l_ext;   // :266-270
+        uint32_t right_extend = (!r_path.empty() && r_path.back().second == 1) ? (exts_complement(r_ext) & 0xfu) : r_ext;  // :272-276
+        // sequence_of_path (graph.rs:471-491)
+        g_start.push_back(seq.len);
+        uint32_t total = 0, idx = 0;
+        for (auto& pr : node_path) {
+            const uint64_t s0 = old_graph->start[pr.first];
+            const uint32_t len = old_graph->length[pr.first];
+            for (uint32_t p = idx == 0 ? 0 : (uint32_t)k - 1; p < len; p++) {
+                uint32_t b = pr.second == 0 ? hget(W, s0 + p) : 3u - hget(W, s0 + len - 1 - p);   // DnaStringSlice::rc get (dna_string.rs:572-578)
+                seq.push(b);
+                total++;
+            }
+            idx++;
+        }
+        g_len.push_back(total);
+        g_exts.push_back((uint8_t)(((right_extend & 0xfu) << 4) | (left_extend & 0xfu)));
+        g_data.push_back(node_data);
+    }
+    // ---- graph.finish(); dbg.fix_exts(None) (compression.rs:330-331) ----
+    dbg_graph ng;
+    memset(&ng, 0, sizeof(ng));
+    graph_out(seq, g_start, g_len, g_exts, g_data, stranded, &ng);
+    {
+        DevGraph d2;
+        int r = dev_graph_build(c, k, &ng, &d2);
+        if (!r) r = dev_fix_exts(c, k, stranded, &d2, nullptr);
+        if (!r && ng.n_nodes) {
+            if (hipMemcpyAsync(ng.exts, d2.exts.p, ng.n_nodes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) r = c->fail(100, "copy of fixed exts failed");
+        }
+        if (r) { free(ng.seq_words); free(ng.start); free(ng.length); free(ng.exts); free(ng.data); return r; }
+    }
+    *out = ng;
+    return 0;
+}
