@@ -1,0 +1,131 @@
+// C++ rendition of the reference's own end-to-end checks (src/test.rs:299-414 `reassemble_contigs`,
+// src/test.rs:418-504 `reassemble_sharded`, kmer.rs:10-34 doctest) written against the C++ host mirror
+// include/debruijn_mi355x.hpp -- i.e. what the crate's tests look like after switching to the MI355X path.
+// No oracle is involved: the assertions are the reference's invariants, computed natively.
+#include <algorithm>
+#include <cstdio>
+#include <map>
+#include <random>
+#include <set>
+#include "debruijn_mi355x.hpp"
+
+using namespace debruijn;
+typedef unsigned __int128 u128;
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+template <class K> static K rc(K a) { K r; for (int i = 0; i < K::k(); i++) r.storage = (r.storage << 2) | (3 - ((a.storage >> (2 * i)) & 3)); return r; }
+template <class K> static K min_rc(K a) { K r = rc(a); return a < r ? a : r; }
+template <class K> static std::vector<K> kmers_from_bytes(const std::vector<uint8_t>& s) {      // lib.rs:288-306
+    std::vector<K> out;
+    if ((int)s.size() < K::k()) return out;
+    u128 mask = K::k() == 64 ? ~(u128)0 : (((u128)1 << (2 * K::k())) - 1);
+    K cur;
+    for (size_t i = 0; i < s.size(); i++) {
+        cur.storage = ((cur.storage << 2) | s[i]) & mask;
+        if ((int)i + 1 >= K::k()) out.push_back(cur);
+    }
+    return out;
+}
+template <class K> static K extend(K a, uint8_t b, Dir d) {                                       // kmer.rs:469-487
+    u128 mask = K::k() == 64 ? ~(u128)0 : (((u128)1 << (2 * K::k())) - 1);
+    K r;
+    if (d == Dir::Right) r.storage = ((a.storage << 2) | b) & mask;
+    else r.storage = (a.storage >> 2) | ((u128)b << (2 * (K::k() - 1)));
+    return r;
+}
+static std::vector<uint8_t> random_dna(std::mt19937_64& r, size_t n) { std::vector<uint8_t> v(n); for (auto& x : v) x = r() % 4; return v; }
+static std::vector<std::vector<uint8_t>> simple_random_contigs(std::mt19937_64& r) {              // test.rs:58-95
+    auto p1 = random_dna(r, 40), p2 = random_dna(r, 30), pc = random_dna(r, 100), p3 = random_dna(r, 30), p4 = random_dna(r, 40);
+    std::vector<uint8_t> c1 = p1, c2 = p2, c3 = random_dna(r, 30);
+    c1.insert(c1.end(), pc.begin(), pc.end()); c1.insert(c1.end(), p3.begin(), p3.end());
+    c2.insert(c2.end(), pc.begin(), pc.end()); c2.insert(c2.end(), p4.begin(), p4.end());
+    auto pal = random_dna(r, 33);
+    c3.insert(c3.end(), pal.begin(), pal.end());
+    for (auto it = pal.rbegin(); it != pal.rend(); ++it) c3.push_back(3 - *it);
+    auto tail = random_dna(r, 50); c3.insert(c3.end(), tail.begin(), tail.end());
+    return {c1, c2, c3};
+}
+
+template <class K> static int check_graph(const BaseGraph<K, uint16_t>& graph, const std::set<u128>& truth) {   // test.rs:386-413
+    std::set<u128> all;
+    for (size_t i = 0; i < graph.len(); i++) {
+        DnaString s = graph.sequences.get(i);
+        std::vector<uint8_t> b; for (size_t j = 0; j < s.len; j++) b.push_back(s.get(j));
+        auto ks = kmers_from_bytes<K>(b);
+        CHECK(!ks.empty());
+        for (auto& km : ks) { u128 c = min_rc(km).storage; CHECK(truth.count(c)); all.insert(c); }
+        for (uint8_t x = 0; x < 4; x++) {
+            if (graph.exts[i].has_ext(Dir::Left, x)) CHECK(truth.count(min_rc(extend(ks.front(), x, Dir::Left)).storage));
+            if (graph.exts[i].has_ext(Dir::Right, x)) CHECK(truth.count(min_rc(extend(ks.back(), x, Dir::Right)).storage));
+        }
+    }
+    CHECK(all == truth);
+    return 0;
+}
+
+template <class K> static int reassemble(Context& ctx, const std::vector<std::vector<uint8_t>>& contigs) {
+    const bool stranded = false;
+    std::set<u128> truth;
+    for (auto& c : contigs) for (auto& km : kmers_from_bytes<K>(c)) truth.insert(min_rc(km).storage);
+    // msp pieces, each fed twice (test.rs:318-324)
+    std::vector<std::tuple<DnaString, Exts, uint8_t>> seqs;
+    std::map<uint32_t, std::vector<std::tuple<DnaString, Exts, uint8_t>>> shards;
+    for (auto& c : contigs) {
+        auto msps = msp_sequence<6>(ctx, K::k(), c, nullptr, true);
+        for (uint8_t d = 0; d < 2; d++)
+            for (auto& m : msps) { seqs.emplace_back(std::get<2>(m), std::get<1>(m), d); shards[std::get<0>(m)].emplace_back(std::get<2>(m), std::get<1>(m), d); }
+    }
+    // un-sharded: filter_kmers + compress_kmers_with_hash (test.rs:344-413)
+    auto res = filter_kmers<K>(ctx, seqs, CountFilter(2), stranded, false, 4);
+    std::set<u128> got; for (auto& k : res.first.keys) got.insert(k.storage);
+    CHECK(got == truth);
+    CHECK(std::is_sorted(res.first.keys.begin(), res.first.keys.end()));
+    auto graph = compress_kmers_with_hash<K>(ctx, stranded, SimpleCompress(Reduce::SaturatingAdd), res.first);
+    if (check_graph<K>(graph, truth)) return 1;
+    // sharded: per-shard filter + compress, combine, compress_graph (test.rs:446-503)
+    std::vector<BaseGraph<K, uint16_t>> shard_asms;
+    for (auto& kv : shards) {
+        auto r = filter_kmers<K>(ctx, kv.second, CountFilter(2), stranded, false, 4);
+        shard_asms.push_back(compress_kmers_with_hash<K>(ctx, stranded, SimpleCompress(Reduce::SaturatingAdd), r.first));
+    }
+    auto combined = combine<K, uint16_t>(ctx, shard_asms);
+    auto dbg = compress_graph<K, uint16_t>(ctx, false, SimpleCompress(Reduce::Max), combined);
+    if (check_graph<K>(dbg, truth)) return 1;
+    size_t nk = 0; for (auto l : dbg.sequences.length) nk += l - K::k() + 1;
+    CHECK(nk == truth.size());                               // each k-mer in exactly one node
+    return 0;
+}
+
+int main() {
+    // kmer.rs:10-34 doctest (ordering + formatting of the key type that crosses the boundary)
+    typedef Kmer<16> Kmer16;
+    std::vector<Kmer16> ks;
+    std::string s = "TACGTACGTACGTACGTT";
+    for (int i = 0; i < 3; i++) ks.push_back(Kmer16::from_ascii(s.substr(i, 16)));
+    std::sort(ks.begin(), ks.end());
+    if (!(ks[0].to_string() == "ACGTACGTACGTACGT" && ks[1].to_string() == "CGTACGTACGTACGTT" && ks[2].to_string() == "TACGTACGTACGTACG")) return 2;
+    try {
+        Context ctx(0);
+        std::mt19937_64 rng(12345);
+        for (int it = 0; it < 3; it++) {
+            auto contigs = simple_random_contigs(rng);
+            if (reassemble<Kmer<32>>(ctx, contigs)) return 1;
+            if (reassemble<Kmer<31>>(ctx, contigs)) return 1;
+            if (reassemble<Kmer<47>>(ctx, contigs)) return 1;
+        }
+        // CountFilterSet through the mirror
+        std::vector<std::tuple<DnaString, Exts, uint8_t>> seqs;
+        auto g = random_dna(rng, 200);
+        for (int i = 0; i < 30; i++) seqs.emplace_back(DnaString::from_bytes(g), Exts::empty(), (uint8_t)(i % 3));
+        auto rs = filter_kmers<Kmer<47>>(ctx, seqs, CountFilterSet(2), true, false, 4);
+        if (rs.first.len() != 200 - 47 + 1) return 3;
+        for (auto& v : rs.first.data) if (v != std::vector<uint8_t>({0, 1, 2})) return 4;
+        // the reference would panic on memory_size = 0 (filter.rs:158)
+        bool threw = false;
+        try { filter_kmers<Kmer<31>>(ctx, seqs, CountFilter(1), false, false, 0); } catch (const Panic&) { threw = true; }
+        if (!threw) return 5;
+    } catch (const Panic& e) { fprintf(stderr, "panic: %s\n", e.what()); return 9; }
+    printf("cpp mirror ok\n");
+    return 0;
+}

@@ -1,0 +1,35 @@
+"""Runs the C++ host-mirror test program (tests/cpp/test_mirror.cpp over include/debruijn_mi355x.hpp):
+the reference's reassemble_contigs / reassemble_sharded checks written against the C++ interface."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "_build", "test_mirror")
+
+
+def build_cpp_mirror():
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "cpp", "test_mirror.cpp")
+    deps = [src, os.path.join(ROOT, "include", "debruijn_mi355x.hpp"), os.path.join(ROOT, "include", "dbg_mi355x.h")]
+    if os.path.exists(BIN) and all(os.path.getmtime(d) <= os.path.getmtime(BIN) for d in deps):
+        return BIN
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), src, "-o", BIN,
+                           "-L" + os.path.join(ROOT, "rust-debruijn_amd"), "-ldbg_mi355x",
+                           "-Wl,-rpath,$ORIGIN/../../../rust-debruijn_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    return BIN
+
+
+def test_cpp_mirror_compiles():
+    """CPU check: the C++ mirror header and its test program compile and link against the C ABI library."""
+    build_cpp_mirror()
+    assert os.path.exists(BIN)
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_runs():
+    build_cpp_mirror()
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cpp mirror ok" in r.stdout
