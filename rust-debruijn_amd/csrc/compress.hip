@@ -118,6 +118,10 @@ struct BitPusher {          // DnaString::push (dna_string.rs:303-310) into a gr
 };
 }  // namespace
 
+int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
+                          const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
+                          dbg_graph* out, bool* done);
+
 extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int stranded, int spec, uint64_t n,
                                             const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                                             const uint32_t* data, const uint64_t* seed_order, dbg_graph* out) {
@@ -153,10 +157,10 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
         key_hi = s_hi.data(); key_lo = s_lo.data(); exts = s_exts.data(); if (data) data = s_data.data();
     }
 
-    // ---- device: neighbour links ----
+    // ---- device: neighbour links, then (when the links are mutual) the whole unitig construction ----
     std::vector<uint32_t> link(2 * n);
     if (n) {
-        DBuf<uint64_t> d_hi, d_lo; DBuf<uint8_t> d_exts; DBuf<uint32_t> d_data, d_link;
+        DBuf<uint64_t> d_hi, d_lo; DBuf<uint8_t> d_exts; DBuf<uint32_t> d_data, d_link, d_rank;
         if (has_hi) { ALLOC_OR_FAIL(c, d_hi, n); HIP_TRY(c, hipMemcpyAsync(d_hi.p, key_hi, n * 8, hipMemcpyHostToDevice, c->stream)); }
         ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n); ALLOC_OR_FAIL(c, d_link, 2 * n);
         HIP_TRY(c, hipMemcpyAsync(d_lo.p, key_lo, n * 8, hipMemcpyHostToDevice, c->stream));
@@ -167,6 +171,30 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
         link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p);
         c->t_end();
         LAUNCH_CHECK(c, "link_kernel");
+        const char* mode = getenv("DBG_COMPRESS");                 // device | host | (default) auto
+        const bool want_device = !(mode && !strcmp(mode, "host"));
+        if (want_device) {
+            // seed rank of every sorted id: position at which the reference's loop (compression.rs:574) visits it
+            std::vector<uint32_t> rank_h;
+            if (seed_order || !sorted) {
+                rank_h.assign(n, 0xFFFFFFFFu);
+                for (uint64_t cidx = 0; cidx < n; cidx++) {
+                    uint64_t sid = seed_order ? seed_order[cidx] : cidx;
+                    if (sid >= n) return c->fail(44, "seed_order entry out of range");
+                    uint32_t id = sorted ? (uint32_t)sid : rank[sid];
+                    if (rank_h[id] != 0xFFFFFFFFu) return c->fail(47, "seed_order is not a permutation");
+                    rank_h[id] = (uint32_t)cidx;
+                }
+                ALLOC_OR_FAIL(c, d_rank, n);
+                HIP_TRY(c, hipMemcpyAsync(d_rank.p, rank_h.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+            }
+            bool done = false;
+            DBG_TRY(compress_links_device(c, k, (uint32_t)n, has_hi ? d_hi.p : nullptr, d_lo.p, d_exts.p, d_data.p, d_link.p,
+                                          rank_h.empty() ? nullptr : d_rank.p, spec, stranded, out, &done));
+            if (done) return 0;
+            if (mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the neighbour links are not mutual");
+            // links were only modified if cycles were cut, which happens after the mutuality check passed
+        }
         HIP_TRY(c, hipMemcpyAsync(link.data(), d_link.p, 2 * n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }

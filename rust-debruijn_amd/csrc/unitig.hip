@@ -1,0 +1,306 @@
+// Device-side unitig construction for compress_kmers_with_hash (src/compression.rs:355-583).
+//
+// The reference grows each unitig greedily from a seed (compression.rs:450-541) in seed order
+// (compression.rs:574).  Because the "Unique" relation of try_extend_kmer (compression.rs:382-444) is
+// mutual -- A extends to B through side d exactly when B extends back to A through its facing side -- the
+// k-mers form disjoint simple chains (and rare simple cycles), and the greedy result is a function of the
+// chains and the seed ranks alone:
+//   * a chain becomes one node; its seed is the member with the smallest seed rank; the node's sequence is
+//     read in the seed's stored orientation; nodes are emitted in increasing seed rank;
+//   * an isolated cycle is cut at the right side of its seed (the left walk consumes the whole cycle first).
+// That makes the construction data-parallel: pointer jumping over the 2n directed states "(k-mer, side I
+// leave through)" gives every k-mer its distance to both chain ends, the end states and the minimum rank on
+// either side; everything else is per-k-mer arithmetic, two prefix sums and atomic ORs into the packed
+// output.  If the links are not mutual (inconsistent Exts, which also makes the reference panic or depend
+// on visiting order) the caller falls back to the literal host walk.
+#include "dbg_internal.hpp"
+#include <algorithm>
+
+namespace {
+constexpr uint32_t U_TERM = 0xFFFFFFFFu;
+constexpr uint32_t U_PANIC = 0x80000000u;
+constexpr uint32_t ST_NONE = 0xFFFFFFFFu;
+constexpr uint32_t R_INF = 0xFFFFFFFFu;
+
+struct __attribute__((aligned(16))) Jump {
+    uint32_t nxt;       // state reached after `dist` steps, ST_NONE once the walk has hit a terminal side
+    uint32_t dist;      // k-mers passed so far (excluding the start)
+    uint32_t minr;      // minimum seed rank among them
+    uint32_t endst;     // valid when nxt == ST_NONE: the terminal state (k-mer, side) the walk stopped at
+};
+
+__device__ __forceinline__ bool link_valid(uint32_t L, uint32_t self) {
+    return L != U_TERM && !(L & U_PANIC) && ((L & 0x7FFFFFFFu) >> 1) != self;     // self links are terminal (compression.rs:410-415)
+}
+
+// flags: bit0 = a PANIC link exists, bit1 = a non-mutual link exists
+__global__ void check_links_kernel(const uint32_t* __restrict__ link, uint32_t n, uint32_t* __restrict__ flags) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 2 * n) return;
+    uint32_t i = s >> 1, p = s & 1;
+    uint32_t L = link[(uint64_t)p * n + i];
+    if (L == U_TERM) return;
+    if (L & U_PANIC) { atomicOr(flags, 1u); return; }
+    uint32_t j = L >> 1, nd = L & 1;
+    if (j == i) return;
+    uint32_t q = 1 - nd;                                           // side of j that faces i
+    uint32_t back = link[(uint64_t)q * n + j];
+    if (back != ((i << 1) | (1 - p))) atomicOr(flags, 2u);
+}
+
+__global__ void init_states_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, uint32_t n, Jump* __restrict__ J) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 2 * n) return;
+    uint32_t i = s >> 1, p = s & 1;
+    uint32_t L = link[(uint64_t)p * n + i];
+    Jump o;
+    if (link_valid(L, i)) { uint32_t j = L >> 1, nd = L & 1; o.nxt = 2 * j + nd; o.dist = 1; o.minr = rank ? rank[j] : j; o.endst = ST_NONE; }
+    else { o.nxt = ST_NONE; o.dist = 0; o.minr = R_INF; o.endst = s; }
+    J[s] = o;
+}
+
+__global__ void jump_kernel(const Jump* __restrict__ in, Jump* __restrict__ out, uint32_t n2, uint32_t* __restrict__ any) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (s < n2) {
+        Jump a = in[s];
+        if (a.nxt != ST_NONE) {
+            Jump b = in[a.nxt];
+            a.dist += b.dist;
+            a.minr = a.minr < b.minr ? a.minr : b.minr;
+            a.nxt = b.nxt;
+            if (b.nxt == ST_NONE) a.endst = b.endst;
+            live = a.nxt != ST_NONE;
+        }
+        out[s] = a;
+    }
+    if (__any(live) && (threadIdx.x & 63) == 0) atomicOr(any, 1u);
+}
+
+// after the doubling has covered 2n steps, any state still walking sits on a cycle; cut it at its seed's right side
+__global__ void cut_cycles_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t* __restrict__ link, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jump a = J[2 * i];
+    if (a.nxt == ST_NONE) return;
+    uint32_t r = rank ? rank[i] : i;
+    if (r <= a.minr) {                                             // I hold the smallest rank of my cycle
+        uint32_t L = link[(uint64_t)n + i];                        // my right link
+        uint32_t j = L >> 1, nd = L & 1;
+        link[(uint64_t)n + i] = U_TERM;
+        link[(uint64_t)(1 - nd) * n + j] = U_TERM;
+    }
+}
+
+struct NodeInfo { uint32_t seedrank, pos, m; bool toA_is_left; };
+__device__ __forceinline__ NodeInfo node_info(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t i) {
+    Jump a = J[2 * i], b = J[2 * i + 1];
+    NodeInfo o;
+    uint32_t r = rank ? rank[i] : i;
+    uint32_t mr = a.minr < b.minr ? a.minr : b.minr;
+    o.seedrank = r < mr ? r : mr;
+    o.m = a.dist + b.dist + 1;
+    o.toA_is_left = a.endst < b.endst;                             // chain end A = the smaller terminal state
+    o.pos = o.toA_is_left ? a.dist : b.dist;                       // distance from end A
+    return o;
+}
+
+__global__ void mark_seeds_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t n, int k,
+                                  uint32_t* __restrict__ flag_by_rank, uint32_t* __restrict__ len_by_rank, uint8_t* __restrict__ rev_by_rank) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    NodeInfo f = node_info(J, rank, i);
+    uint32_t r = rank ? rank[i] : i;
+    if (r == f.seedrank) {
+        flag_by_rank[r] = 1;
+        len_by_rank[r] = f.m + (uint32_t)k - 1;
+        rev_by_rank[r] = f.toA_is_left ? 0 : 1;                    // seed's left side must face the unitig's left end
+    }
+}
+
+__global__ void gather_lens_kernel(const uint32_t* __restrict__ flag_by_rank, const uint32_t* __restrict__ uidx_by_rank,
+                                   const uint32_t* __restrict__ len_by_rank, uint32_t n, uint32_t* __restrict__ ulen) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && flag_by_rank[r]) ulen[uidx_by_rank[r]] = len_by_rank[r];
+}
+
+__device__ __forceinline__ void or_bits(uint64_t* __restrict__ words, uint64_t base_off, K128 v, int nbases) {
+    // OR `nbases` bases (right-aligned in v, base 0 most significant) into the packed stream at base offset base_off
+    K128 top = k128_shl(v, 128 - 2 * nbases);                      // left-align
+    uint64_t w = base_off >> 5;
+    int s = (int)(base_off & 31) * 2;
+    uint64_t p0 = s ? top.hi >> s : top.hi;
+    uint64_t p1 = s ? (top.hi << (64 - s)) | (top.lo >> s) : top.lo;
+    uint64_t p2 = s ? top.lo << (64 - s) : 0;
+    if (p0) atomicOr((unsigned long long*)&words[w], (unsigned long long)p0);
+    if (p1) atomicOr((unsigned long long*)&words[w + 1], (unsigned long long)p1);
+    if (p2) atomicOr((unsigned long long*)&words[w + 2], (unsigned long long)p2);
+}
+
+__global__ void emit_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t n, int k,
+                            const uint64_t* __restrict__ key_hi, const uint64_t* __restrict__ key_lo, const uint8_t* __restrict__ exts,
+                            const uint32_t* __restrict__ data, int spec, const uint32_t* __restrict__ uidx_by_rank,
+                            const uint8_t* __restrict__ rev_by_rank, const uint64_t* __restrict__ ustart,
+                            uint64_t* __restrict__ words, uint32_t* __restrict__ uexts, unsigned long long* __restrict__ uacc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    NodeInfo f = node_info(J, rank, i);
+    const uint32_t ui = uidx_by_rank[f.seedrank];
+    const bool rev = rev_by_rank[f.seedrank] != 0;
+    const uint32_t u = rev ? f.m - 1 - f.pos : f.pos;              // position in the unitig
+    const bool fwd = f.toA_is_left != rev;                         // stored orientation == unitig orientation?
+    K128 km{key_hi ? key_hi[i] : 0ull, key_lo[i]};
+    uint32_t e = exts[i];
+    if (!fwd) { km = kmer_rc(km, k); e = exts_rc(e); }
+    const uint64_t st = ustart[ui];
+    if (u == 0) or_bits(words, st, km, k);                         // the first k-mer contributes all k bases
+    else or_bits(words, st + u + (uint32_t)k - 1, K128{0, km.lo & 3ull}, 1);   // every other one its last base
+    uint32_t eo = 0;
+    if (u == 0) eo |= e & 0x0fu;                                   // left end keeps its outward (hanging) exts
+    if (u == f.m - 1) eo |= e & 0xf0u;
+    if (eo) atomicOr(&uexts[ui], eo);
+    const uint32_t d = data ? data[i] : 0u;
+    if (spec == DBG_SPEC_SIMPLE_MAX_U16) __hip_atomic_fetch_max((uint32_t*)&uacc[ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // low word of the zeroed accumulator
+    else if (spec == DBG_SPEC_SCMAP_EQ) { if ((rank ? rank[i] : i) == f.seedrank) uacc[ui] = d; }
+    else atomicAdd(&uacc[ui], (unsigned long long)d);
+}
+
+__global__ void finish_nodes_kernel(uint32_t n_nodes, int spec, int k, const uint32_t* __restrict__ ulen, const uint32_t* __restrict__ uexts,
+                                    const unsigned long long* __restrict__ uacc, uint8_t* __restrict__ o_exts, uint32_t* __restrict__ o_data) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_nodes) return;
+    o_exts[u] = (uint8_t)uexts[u];
+    unsigned long long a = uacc[u];
+    uint32_t m = ulen[u] - (uint32_t)k + 1;
+    // (an if-chain: a switch with a `default` arm was miscompiled by hipcc 7.2 for gfx950 here)
+    uint32_t d = (uint32_t)a;                                                              // max / ScmapCompress: the value itself
+    if (spec == DBG_SPEC_SIMPLE_SAT_ADD_U16) d = a > 65535ull ? 65535u : (uint32_t)a;
+    else if (spec == DBG_SPEC_SIMPLE_ADD_MOD_U16) { if (m != 1) d = (uint32_t)(a % 65535ull); }   // a lone k-mer is never reduced
+    else if (spec == DBG_SPEC_SIMPLE_WRAP_ADD_U16) { if (m != 1) d = (uint32_t)(a & 0xFFFFull); }
+    o_data[u] = d;
+}
+
+// ScmapCompress::reduce panics on unequal data (compression.rs:88-93); with join_test = equality a chain can
+// only hold equal data, so nothing to check.  For SimpleCompress specs join_test is always true.
+}  // namespace
+
+// Builds the BaseGraph on the device from the neighbour links.  rank_dev: seed rank of every (sorted) k-mer id,
+// or null for the identity.  link_dev is modified when cycles are cut.  *done = false (nothing produced)
+// when the links are not mutual or contain a panic marker: the caller then runs the literal host walk.
+int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
+                          const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
+                          dbg_graph* out, bool* done) {
+    *done = false;
+    if (n == 0 || n >= (1u << 30)) return 0;
+    const uint32_t n2 = 2 * n;
+    DBuf<uint32_t> flags;
+    ALLOC_OR_FAIL(c, flags, 2);
+    HIP_TRY(c, hipMemsetAsync(flags.p, 0, 8, c->stream));
+    check_links_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, n, flags.p);
+    LAUNCH_CHECK(c, "check_links");
+    uint32_t fl[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(fl, flags.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (fl[0]) return 0;
+
+    DBuf<Jump> JA, JB;
+    ALLOC_OR_FAIL(c, JA, n2);
+    ALLOC_OR_FAIL(c, JB, n2);
+    Jump* cur = nullptr;
+    for (int phase = 0; phase < 2; phase++) {
+        init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, n, JA.p);
+        LAUNCH_CHECK(c, "init_states");
+        Jump *a = JA.p, *b = JB.p;
+        bool live = true;
+        int rounds = 0;
+        const int max_rounds = 33;                                 // 2^33 steps > any chain
+        c->t_begin("unitig_pointer_jump", n);
+        while (live && rounds < max_rounds) {
+            HIP_TRY(c, hipMemsetAsync(flags.p + 1, 0, 4, c->stream));
+            jump_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(a, b, n2, flags.p + 1);
+            LAUNCH_CHECK(c, "jump");
+            uint32_t any = 0;
+            HIP_TRY(c, hipMemcpyAsync(&any, flags.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            std::swap(a, b);
+            live = any != 0;
+            rounds++;
+        }
+        c->t_end();
+        cur = a;
+        if (!live) break;
+        if (phase == 1) return c->fail(150, "unitig construction: cycle cutting did not terminate");
+        // cycles: cut each at its seed's right side and redo the doubling
+        cut_cycles_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, link_dev, n);
+        LAUNCH_CHECK(c, "cut_cycles");
+    }
+    // ---- seeds -> node order -> offsets ----
+    DBuf<uint32_t> flag_by_rank, len_by_rank, uidx_by_rank, ulen, uexts;
+    DBuf<uint8_t> rev_by_rank;
+    DBuf<uint64_t> ustart;
+    ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
+    ALLOC_OR_FAIL(c, rev_by_rank, n);
+    HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
+    mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
+    LAUNCH_CHECK(c, "mark_seeds");
+    DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
+    uint32_t n_nodes = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_nodes, uidx_by_rank.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ALLOC_OR_FAIL(c, ulen, std::max<uint32_t>(n_nodes, 1));
+    ALLOC_OR_FAIL(c, ustart, (size_t)n_nodes + 1);
+    ALLOC_OR_FAIL(c, uexts, std::max<uint32_t>(n_nodes, 1));
+    gather_lens_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(flag_by_rank.p, uidx_by_rank.p, len_by_rank.p, n, ulen.p);
+    LAUNCH_CHECK(c, "gather_lens");
+    DBG_TRY(scan_exclusive_u32_u64(c, ulen.p, ustart.p, n_nodes));
+    uint64_t total_bases = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total_bases, ustart.p + n_nodes, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_words = (total_bases + 31) / 32;
+    DBuf<uint64_t> words;
+    DBuf<unsigned long long> uacc;
+    DBuf<uint8_t> o_exts;
+    DBuf<uint32_t> o_data;
+    ALLOC_OR_FAIL(c, words, n_words + 3);
+    ALLOC_OR_FAIL(c, uacc, std::max<uint32_t>(n_nodes, 1));
+    ALLOC_OR_FAIL(c, o_exts, std::max<uint32_t>(n_nodes, 1));
+    ALLOC_OR_FAIL(c, o_data, std::max<uint32_t>(n_nodes, 1));
+    HIP_TRY(c, hipMemsetAsync(words.p, 0, (n_words + 3) * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(uacc.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(uexts.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 4, c->stream));
+    c->t_begin("unitig_emit", n);
+    emit_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, n, k, key_hi, key_lo, exts, data, spec, uidx_by_rank.p, rev_by_rank.p,
+                                                     ustart.p, words.p, uexts.p, uacc.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "emit");
+    if (n_nodes) {
+        finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, o_exts.p, o_data.p);
+        LAUNCH_CHECK(c, "finish_nodes");
+    }
+    if (getenv("DBG_DEBUG") && n_nodes) {
+        unsigned long long a0 = 0; uint32_t d0 = 0, e0 = 0;
+        (void)hipMemcpy(&a0, uacc.p, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&d0, o_data.p, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&e0, uexts.p, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[unitig] nodes=%u spec=%d uacc[0]=%llx o_data[0]=%x uexts[0]=%x uacc.p=%p o_data.p=%p uexts.p=%p\n", n_nodes, spec, a0, d0, e0,
+                (void*)uacc.p, (void*)o_data.p, (void*)uexts.p);
+    }
+    // ---- to the host BaseGraph ----
+    memset(out, 0, sizeof(*out));
+    out->stranded = stranded ? 1 : 0;
+    out->n_nodes = n_nodes; out->n_seq_words = n_words; out->seq_len_bases = total_bases;
+    out->seq_words = (uint64_t*)malloc(std::max<uint64_t>(n_words, 1) * 8);
+    out->start = (uint64_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
+    out->length = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    out->exts = (uint8_t*)malloc(std::max<uint32_t>(n_nodes, 1));
+    out->data = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    if (n_words) HIP_TRY(c, hipMemcpyAsync(out->seq_words, words.p, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_nodes) {
+        HIP_TRY(c, hipMemcpyAsync(out->start, ustart.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->length, ulen.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->exts, o_exts.p, (size_t)n_nodes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(out->data, o_data.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *done = true;
+    return 0;
+}

@@ -24,6 +24,20 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True, params=["device", "host"])
+def compress_mode(request):
+    """Every test runs twice: DBG_COMPRESS=device (pointer-jumping unitig construction on the GPU; fails loudly
+    instead of falling back) and DBG_COMPRESS=host (device links + literal greedy walk on the host)."""
+    import os
+    old = os.environ.get("DBG_COMPRESS")
+    os.environ["DBG_COMPRESS"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("DBG_COMPRESS", None)
+    else:
+        os.environ["DBG_COMPRESS"] = old
+
+
 def gpu_table(ctx, contigs, k, min_obs, stranded, dup=1):
     seqs = []
     for c in contigs:
