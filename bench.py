@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--summarizer", default="set", choices=["set", "count"])
     ap.add_argument("--min-obs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compress-reads", type=int, default=10_000_000,
+                    help="reads of the stream used for the secondary unitigs/s measurement (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -185,6 +187,32 @@ def main():
                    "sample": "first %d reads of an equally-parameterised stream (%.1fM k-mer instances), "
                              "oracle filter_kmers single thread, %.1f s" % (n_s, n_s * (L - k + 1) / 1e6, sec),
                    "host_cores_available": os.cpu_count()}
+        comp = None
+        if args.compress_reads and world == 1:
+            # second half of the metric ("+ unitigs/s compressed"): CountFilter(2) table of a prefix of the same
+            # stream -> host (the Rust caller holds a BoomHashMap2 in host memory) -> compress_kmers_with_hash.
+            # Timed end to end at the host boundary: H2D of the index, device links + unitig construction, D2H.
+            m = min(args.compress_reads, reads_per_gpu)
+            ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, None, 0, m)
+            fp2 = capi.FilterParams(k, 0, 0, 2, 0, 4)
+            t2 = capi.KmerTable()
+            ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss2), C.byref(fp2), C.byref(t2)))
+            h2 = capi.KmerTable()
+            ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t2), C.byref(h2)))
+            lib.dbg_free_table(ctx.h, C.byref(t2))
+            nk = h2.n
+            d32 = np.ctypeslib.as_array(C.cast(h2.count, C.POINTER(C.c_uint16)), shape=(max(nk, 1),))[:nk].astype(np.uint32)
+            g = capi.Graph()
+            c0 = time.perf_counter()
+            ctx.check(lib.dbg_compress_kmers_with_hash(ctx.h, k, 0, 0, nk, h2.key_hi, h2.key_lo, h2.exts,
+                                                       d32.ctypes.data_as(C.c_void_p), None, C.byref(g)))
+            cdt = time.perf_counter() - c0
+            comp = {"reads": m, "valid_kmers": nk, "unitigs": g.n_nodes, "seconds": round(cdt, 4),
+                    "unitigs_per_s": round(g.n_nodes / cdt, 1), "kmers_per_s": round(nk / cdt, 1),
+                    "spec": "SimpleCompress(saturating_add)", "seed_order": "ascending key (policy B)",
+                    "boundary": "host arrays in, host BaseGraph out (PCIe included)"}
+            lib.dbg_free_graph(ctx.h, C.byref(g))
+            lib.dbg_free_table(None, C.byref(h2))
         out = {
             "metric": "Gkmer/s extracted+counted (k=%d, 150 bp synthetic reads)" % k, "value": round(value, 4),
             "unit": "Gkmer/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,7 +226,7 @@ def main():
                        "superkmer_records_per_step": n_recs,
                        "multi_gpu": ("reads sharded by index; one all-to-all of super-k-mer bin slabs; each rank counts "
                                      "the bins it owns" if world > 1 else "n/a")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "compress": comp,
         }
         print(json.dumps(out))
     ctx.close()
