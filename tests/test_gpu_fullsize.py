@@ -1,0 +1,196 @@
+"""GPU, BASELINE.json full size (configs[1]: 10^8 reads x 150 bp, k = 47, non-stranded): size-independent
+properties of filter_kmers that hold for the reference by construction (src/filter.rs:139-231):
+
+  * the output keys are strictly ascending (the order handed to BoomHashMap2::new, filter.rs:227-230) and canonical
+    (key <= rc(key), lib.rs:224-231);
+  * with CountFilter(1) every k-mer instance is counted exactly once: sum(count) == N == sum(len - k + 1)
+    (no key reaches the u16 saturation point at 30x coverage of a random genome, checked);
+  * linearity over a partition of the reads ("checksum of checksums"): the multiset checksum
+    sum(count * h(key)) mod 2^64 of the whole input equals the sum of the checksums of its two halves, and
+    the number of distinct keys is sub-additive;
+  * CountFilterSet(2) and CountFilter(2) select the same key set, and the colour sets are non-empty subsets of
+    the C = 4 colours;
+  * a 10^5-read prefix of the same stream is bit-exact against the CPU oracle (SURVEY.md section 8d, C3 note).
+
+Everything is computed on the device (torch views over the library's device arrays); nothing reads the
+reference tree."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from pkg import dbg
+
+pytestmark = pytest.mark.gpu
+
+K, L = 47, 150
+N_READS = int(os.environ.get("DBG_FULLSIZE_READS", 100_000_000))
+
+
+class _DevArr:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def dev_view(ptr, n, typestr="<i8"):
+    import torch
+    if not ptr or n == 0:
+        return torch.zeros(0, dtype=torch.int64, device="cuda")
+    return torch.as_tensor(_DevArr(C.cast(ptr, C.c_void_p).value, n, typestr), device="cuda")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import importlib
+    import torch
+    capi = importlib.import_module("rust-debruijn_amd._capi")
+    ctx = dbg.Context(0)
+    lib = ctx.lib
+    dev = torch.device("cuda", 0)
+    p = dbg.synth_params(n_reads=N_READS, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001,
+                         stranded=False, n_colours=4, first_read=0)
+    nw = lib.dbg_synth_words(C.byref(p))
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    start = torch.empty(N_READS, dtype=torch.int64, device=dev)
+    length = torch.empty(N_READS, dtype=torch.int32, device=dev)
+    colour = torch.empty(N_READS, dtype=torch.uint8, device=dev)
+    ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), words.data_ptr(), start.data_ptr(), length.data_ptr(), colour.data_ptr()))
+    e = dict(capi=capi, ctx=ctx, lib=lib, torch=torch, p=p, nw=nw, words=words, start=start, length=length, colour=colour)
+    yield e
+    ctx.close()
+
+
+def run_filter(e, first, n, summarizer, min_obs):
+    capi, ctx, lib = e["capi"], e["ctx"], e["lib"]
+    is_set = summarizer == 1
+    ss = capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"][first:].data_ptr(), e["length"][first:].data_ptr(), None,
+                     e["colour"][first:].data_ptr() if is_set else None, 1 if is_set else 0, n)
+    fp = capi.FilterParams(K, 0, summarizer, min_obs, 0, 4)
+    t = capi.KmerTable()
+    ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+    return t
+
+
+def mix64(torch, hi, lo):
+    """64-bit multiplicative checksum term of a key; int64 arithmetic wraps mod 2^64 on the device."""
+    a = lo * -7046029254386353131 + hi * -4417276706812531889          # 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F
+    a = a ^ ((a >> 29) & 0x7FFFFFFFF)
+    return a * -4658895280553007687                                     # 0xBF58476D1CE4E5B9
+
+
+def table_stats(e, t):
+    torch = e["torch"]
+    hi, lo = dev_view(t.key_hi, t.n), dev_view(t.key_lo, t.n)
+    cnt = dev_view(t.count, t.n, "<u2").to(torch.int64) if t.count else None
+    out = dict(n=int(t.n), n_inst=int(t.n_kmer_instances))
+    # strictly ascending as unsigned (hi, lo): flip the sign bit of lo for an unsigned compare
+    if t.n > 1:
+        ulo = lo ^ (-9223372036854775808)
+        ok = (hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (ulo[1:] > ulo[:-1]))
+        out["ascending"] = bool(ok.all().item())
+        del ulo, ok
+    else:
+        out["ascending"] = True
+    if cnt is not None:
+        out["sum_count"] = int(cnt.sum().item())
+        out["max_count"] = int(cnt.max().item())
+        out["checksum"] = int((mix64(torch, hi, lo) * cnt).sum().item())
+    out["keysum"] = int(mix64(torch, hi, lo).sum().item())
+    return out
+
+
+def host_sample(e, t, n_sample, seed):
+    """random sample of table rows copied to the host: (hi, lo) as Python ints"""
+    torch = e["torch"]
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    idx = torch.randint(0, int(t.n), (n_sample,), device="cuda", generator=g)
+    hi = dev_view(t.key_hi, t.n)[idx].cpu().numpy().astype(np.uint64)
+    lo = dev_view(t.key_lo, t.n)[idx].cpu().numpy().astype(np.uint64)
+    return hi, lo
+
+
+def test_fullsize_count_properties(env):
+    e = env
+    lib, ctx = e["lib"], e["ctx"]
+    n_expected = N_READS * (L - K + 1)
+    half = N_READS // 2
+
+    whole = run_filter(e, 0, N_READS, 0, 1)
+    sw = table_stats(e, whole)
+    hi, lo = host_sample(e, whole, 200_000, 1)
+    lib.dbg_free_table(ctx.h, C.byref(whole))
+    assert sw["n_inst"] == n_expected
+    assert sw["ascending"]
+    assert sw["max_count"] < 65535                       # no saturation, so counts are exactly additive
+    assert sw["sum_count"] == n_expected                 # every instance counted once
+    # canonical keys (lib.rs:224-231) and k-mer width (kmer.rs:429-437) on a random sample
+    for h, l in zip(hi[:20000].tolist(), lo[:20000].tolist()):
+        v = (h << 64) | l
+        assert v >> (2 * K) == 0
+        assert v <= O.kmer_rc(K, v)
+
+    a = run_filter(e, 0, half, 0, 1)
+    sa = table_stats(e, a)
+    lib.dbg_free_table(ctx.h, C.byref(a))
+    b = run_filter(e, half, N_READS - half, 0, 1)
+    sb = table_stats(e, b)
+    lib.dbg_free_table(ctx.h, C.byref(b))
+    assert sa["ascending"] and sb["ascending"]
+    assert sa["sum_count"] + sb["sum_count"] == n_expected
+    M = (1 << 64) - 1
+    assert (sa["checksum"] + sb["checksum"]) & M == sw["checksum"] & M      # linearity over a partition of the reads
+    assert max(sa["n"], sb["n"]) <= sw["n"] <= sa["n"] + sb["n"]
+
+
+def test_fullsize_filter_set_vs_count(env):
+    """configs[1] proper: CountFilterSet<u8>(2) -- same valid key set as CountFilter(2); colour sets are sorted,
+    deduplicated, non-empty subsets of {0..3} (filter.rs:90-99)."""
+    e = env
+    torch, lib, ctx = e["torch"], e["lib"], e["ctx"]
+    tc = run_filter(e, 0, N_READS, 0, 2)
+    sc = table_stats(e, tc)
+    cmin = int(dev_view(tc.count, tc.n, "<u2").to(torch.int64).min().item())
+    lib.dbg_free_table(ctx.h, C.byref(tc))
+    ts = run_filter(e, 0, N_READS, 1, 2)
+    ss = table_stats(e, ts)
+    off = dev_view(ts.set_off, ts.n + 1)
+    val = dev_view(ts.set_val, ts.n_set_val, "<u4").to(torch.int64) if ts.n_set_val else None
+    sizes = off[1:] - off[:-1]
+    assert int(off[0].item()) == 0 and int(off[-1].item()) == int(ts.n_set_val)
+    assert int(sizes.min().item()) >= 1 and int(sizes.max().item()) <= 4
+    assert int(val.min().item()) >= 0 and int(val.max().item()) <= 3
+    # inside one set the labels are strictly ascending: a non-ascending step may only happen at a set boundary
+    nonasc = (val[1:] <= val[:-1]).nonzero().flatten() + 1
+    is_boundary = torch.zeros(int(ts.n_set_val) + 1, dtype=torch.bool, device="cuda")
+    is_boundary[off] = True
+    assert bool(is_boundary[nonasc].all().item())
+    lib.dbg_free_table(ctx.h, C.byref(ts))
+    assert cmin >= 2
+    assert sc["ascending"] and ss["ascending"]
+    assert sc["n"] == ss["n"] and sc["keysum"] == ss["keysum"]
+    assert sc["n_inst"] == ss["n_inst"] == N_READS * (L - K + 1)
+
+
+def test_fullsize_prefix_bit_exact(env):
+    """A prefix of the full-size stream (sparse coverage: almost every k-mer is a singleton) against the oracle."""
+    e = env
+    capi, lib, ctx = e["capi"], e["lib"], e["ctx"]
+    m = 100_000
+    t = run_filter(e, 0, m, 1, 1)
+    h = capi.KmerTable()
+    ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))
+    lib.dbg_free_table(ctx.h, C.byref(t))
+    n = h.n
+    as_np = lambda p, ct, cnt: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(max(cnt, 1),))[:cnt].copy()
+    g_hi, g_lo = as_np(h.key_hi, C.c_uint64, n), as_np(h.key_lo, C.c_uint64, n)
+    g_ex = as_np(h.exts, C.c_uint8, n)
+    g_off, g_val = as_np(h.set_off, C.c_uint64, n + 1), as_np(h.set_val, C.c_uint32, h.n_set_val)
+    lib.dbg_free_table(None, C.byref(h))
+    # the same reads from the bit-identical host generator
+    hs = dbg.synth_reads_host(n_reads=m, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001, stranded=False, n_colours=4)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1), K, O.COUNT_FILTER_SET, 1, stranded=False)
+    assert n == want.n
+    assert np.array_equal(g_hi, want.key_hi) and np.array_equal(g_lo, want.key_lo) and np.array_equal(g_ex, want.exts)
+    assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)
