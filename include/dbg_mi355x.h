@@ -170,6 +170,36 @@ int  dbg_graph_combine(dbg_ctx* ctx, const dbg_graph* graphs, uint32_t n_graphs,
 int  dbg_compress_graph(dbg_ctx* ctx, uint32_t k, int stranded, int spec, const dbg_graph* old_graph,
                         const uint64_t* censor_nodes, uint64_t n_censor, dbg_graph* out);
 
+/* ---- far side of the path: edges and GFA text of a graph ------------------------------------
+ * dbg_graph_edges = Node::l_edges / r_edges (src/graph.rs:1041-1049 -> find_edges :223-241 -> find_link
+ * :252-291) for every node, resolved on the device against sorted node-end indices (finish, :116-142).
+ * target[8*i + b] (b < 4: left edge through base b; b >= 4: right edge through base b-4) = target node or
+ * 0xFFFFFFFF; info bit0 = incoming side of the target is Right, bit1 = target flipped.  Host arrays. */
+typedef struct {
+    uint64_t  n_nodes;
+    uint32_t* target;           /* [8 * n_nodes] */
+    uint8_t*  info;             /* [8 * n_nodes] */
+} dbg_edges;
+int  dbg_graph_edges(dbg_ctx* ctx, uint32_t k, const dbg_graph* g, dbg_edges* out);
+void dbg_free_edges(dbg_edges* e);
+/* DebruijnGraph::write_gfa / to_gfa (src/graph.rs:537-611): byte-identical text for the same BaseGraph */
+int  dbg_graph_to_gfa(dbg_ctx* ctx, uint32_t k, const dbg_graph* g, char** text, uint64_t* len);
+int  dbg_graph_write_gfa(dbg_ctx* ctx, uint32_t k, const dbg_graph* g, const char* path);
+void dbg_free_text(char* text);
+
+/* ---- near side of the path: ASCII <-> 2-bit packing -----------------------------------------
+ * dbg_pack_acgt = DnaString::from_acgt_bytes (src/dna_string.rs:222-250; AVX2 helpers convert_bases /
+ * pack_32_bases, src/bitops_avx2.rs:9-132): n ASCII characters -> ceil(n/32) words, first base in the top
+ * two bits, anything outside [aAcCgGtT] -> A (base_to_bits, src/lib.rs:65-73).  *n_invalid (host, may be
+ * NULL) = how many characters were not ACGT.  A batch of reads concatenated without separators packs
+ * straight into PackedDnaStringSet layout with start[i] = byte offset of read i (dna_string.rs:811-821).
+ * dbg_unpack_acgt = DnaString::to_ascii_vec (bits_to_ascii, src/lib.rs:53-61) of bases
+ * [first_base, first_base + n).  _dev: device pointers in and out. */
+int  dbg_pack_acgt(dbg_ctx* ctx, const uint8_t* ascii, uint64_t n, uint64_t* words, uint64_t* n_invalid);
+int  dbg_pack_acgt_dev(dbg_ctx* ctx, const uint8_t* ascii_dev, uint64_t n, uint64_t* words_dev, uint64_t* n_invalid);
+int  dbg_unpack_acgt(dbg_ctx* ctx, const uint64_t* words, uint64_t first_base, uint64_t n, uint8_t* ascii);
+int  dbg_unpack_acgt_dev(dbg_ctx* ctx, const uint64_t* words_dev, uint64_t first_base, uint64_t n, uint8_t* ascii_dev);
+
 /* ---- sharded counting for multi-GPU runs --------------------------------------------------
  * The reference's own scale-out design is "MSP shard -> independent per-shard filter_kmers"
  * (src/msp.rs:279-324, src/filter.rs:121-124, src/test.rs:433-456).  Here every rank scans its own

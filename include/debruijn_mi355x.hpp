@@ -252,6 +252,50 @@ BaseGraph<K, D> combine(Context& ctx, const std::vector<BaseGraph<K, D>>& graphs
     return r;
 }
 
+// DebruijnGraph::write_gfa (graph.rs:603-616) as a string, and to_gfa (graph.rs:598-601)
+template <class K, class D>
+std::string write_gfa(Context& ctx, const BaseGraph<K, D>& graph) {
+    detail::CGraph cg(graph);
+    char* t = nullptr; uint64_t n = 0;
+    ctx.check(dbg_graph_to_gfa(ctx.raw(), (uint32_t)K::k(), &cg.g, &t, &n));
+    std::string s(t, n);
+    dbg_free_text(t);
+    return s;
+}
+template <class K, class D>
+void to_gfa(Context& ctx, const BaseGraph<K, D>& graph, const std::string& path) {
+    detail::CGraph cg(graph);
+    ctx.check(dbg_graph_write_gfa(ctx.raw(), (uint32_t)K::k(), &cg.g, path.c_str()));
+}
+
+// Node::l_edges / r_edges (graph.rs:1041-1049): (target node, incoming side of the target: 0 = Left, 1 = Right, flipped)
+struct Edge { size_t node; int dir; bool flip; };
+template <class K, class D>
+std::vector<std::pair<std::vector<Edge>, std::vector<Edge>>> edges(Context& ctx, const BaseGraph<K, D>& graph) {
+    detail::CGraph cg(graph);
+    dbg_edges e{};
+    ctx.check(dbg_graph_edges(ctx.raw(), (uint32_t)K::k(), &cg.g, &e));
+    std::vector<std::pair<std::vector<Edge>, std::vector<Edge>>> out(e.n_nodes);
+    for (uint64_t i = 0; i < e.n_nodes; i++)
+        for (int b = 0; b < 8; b++) {
+            uint32_t t = e.target[i * 8 + b];
+            if (t == 0xFFFFFFFFu) continue;
+            Edge ed{t, e.info[i * 8 + b] & 1, (e.info[i * 8 + b] & 2) != 0};
+            (b < 4 ? out[i].first : out[i].second).push_back(ed);
+        }
+    dbg_free_edges(&e);
+    return out;
+}
+
+// DnaString::from_acgt_bytes (dna_string.rs:222-250), packed on the device
+inline DnaString from_acgt_bytes(Context& ctx, const std::string& ascii) {
+    DnaString d;
+    d.storage.assign((ascii.size() + 31) / 32, 0);
+    d.len = ascii.size();
+    ctx.check(dbg_pack_acgt(ctx.raw(), (const uint8_t*)ascii.data(), ascii.size(), d.storage.data(), nullptr));
+    return d;
+}
+
 // compress_graph (compression.rs:338-349)
 template <class K, class D, class S>
 BaseGraph<K, D> compress_graph(Context& ctx, bool stranded, const S& spec, const BaseGraph<K, D>& old_graph,

@@ -183,6 +183,19 @@ void DnaString::extend(const uint8_t* b, size_t n) {  // :312-343
 DnaString DnaString::from_bytes(const uint8_t* b, size_t n) {
     DnaString d; d.extend(b, n); return d;
 }
+DnaString DnaString::from_acgt_bytes(const uint8_t* b, size_t n) {     // dna_string.rs:222-250
+    // the AVX2 branch (:229-244; bitops_avx2.rs:9-132) produces the same words as the scalar one (:247-249):
+    // convert_bases maps [aAcCgGtT] like base_to_bits and everything else to 0, pack_32_bases puts the first
+    // byte in the top two bits.  Restated here in the scalar form.
+    DnaString d;
+    for (size_t i = 0; i < n; i++) d.push(base_to_bits(b[i]));
+    return d;
+}
+std::vector<uint8_t> DnaString::to_ascii_vec() const {                  // dna_string.rs:297-299, bits_to_ascii lib.rs:53-61
+    std::vector<uint8_t> v(len);
+    for (size_t i = 0; i < len; i++) v[i] = (uint8_t)"ACGT"[get(i)];
+    return v;
+}
 DnaString DnaString::from_dna_string(const char* s) { // :187-195
     DnaString d;
     std::vector<uint8_t> b;
@@ -724,6 +737,28 @@ static std::vector<Edge> find_edges(const DebruijnGraph& g, size_t node_id, Dir 
         }
     }
     return edges;
+}
+
+// node_to_gfa + write_gfa (graph.rs:537-611) without tags
+std::string graph_write_gfa(const DebruijnGraph& g) {
+    std::string out = "H\tVN:Z:debruijn-rs\n";                                          // :604
+    for (size_t i = 0; i < g.base.len(); i++) {                                         // :609-612
+        SeqView v = g.base.sequences.get(i);
+        out += "S\t" + std::to_string(i) + "\t";                                        // :557-562
+        for (size_t p = 0; p < v.length; p++) out += "ACGT"[v.get(p)];                  // Display, dna_string.rs:466-473
+        out += "\n";
+        for (auto& e : find_edges(g, i, Left)) {                                        // :565-579
+            if (e.node >= i)
+                out += "L\t" + std::to_string(i) + "\t-\t" + std::to_string(e.node) + "\t" + (e.dir == Left ? "+" : "-") + "\t" +
+                       std::to_string(g.k - 1) + "M\n";
+        }
+        for (auto& e : find_edges(g, i, Right)) {                                       // :581-595
+            if (e.node > i)
+                out += "L\t" + std::to_string(i) + "\t+\t" + std::to_string(e.node) + "\t" + (e.dir == Left ? "+" : "-") + "\t" +
+                       std::to_string(g.k - 1) + "M\n";
+        }
+    }
+    return out;
 }
 
 bool graph_is_compressed(const DebruijnGraph& g, Spec spec, size_t& a, size_t& b) {   // graph.rs:296-334

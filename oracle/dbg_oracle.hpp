@@ -157,6 +157,8 @@ struct DnaString {
     void extend(const uint8_t* b, size_t n);          // dna_string.rs:312-343
     static DnaString from_bytes(const uint8_t* b, size_t n);       // dna_string.rs (extend over bytes)
     static DnaString from_dna_string(const char* s);               // dna_string.rs:187-195
+    static DnaString from_acgt_bytes(const uint8_t* b, size_t n);  // dna_string.rs:222-250 (scalar branch :247-249)
+    std::vector<uint8_t> to_ascii_vec() const;                     // dna_string.rs:297-299
     std::string to_string() const;
 };
 
@@ -296,6 +298,8 @@ int  graph_combine(const std::vector<BaseGraph>& graphs, BaseGraph& out, std::st
 void graph_finish(int k, BaseGraph&& base, DebruijnGraph& out);
 // find_link: returns true + (node, dir, flip) (graph.rs:252-291)
 bool graph_find_link(const DebruijnGraph& g, Kmer kmer, Dir dir, size_t& node, Dir& ndir, bool& flip);
+// write_gfa (graph.rs:537-611, no tag function): the text the reference writes for this graph
+std::string graph_write_gfa(const DebruijnGraph& g);
 // is_compressed: returns -1 for None else encodes first offending pair in (a,b)
 bool graph_is_compressed(const DebruijnGraph& g, Spec spec, size_t& a, size_t& b);
 int  compress_graph(bool stranded, Spec spec, DebruijnGraph&& old_graph,

@@ -215,6 +215,23 @@ void* orc_compress_graph(void* h, int stranded, int spec, const uint64_t* censor
     return out;
 }
 
+// write_gfa -> copies min(cap, len) bytes, returns len
+uint64_t orc_graph_gfa(void* h, char* buf, uint64_t cap) {
+    orc_graph_finish(h);
+    std::string t = graph_write_gfa(((OrcGraph*)h)->dbg);
+    if (buf) memcpy(buf, t.data(), std::min<uint64_t>(cap, t.size()));
+    return t.size();
+}
+// from_acgt_bytes -> storage words (ceil(n/32)); to_ascii_vec of a packed range
+void orc_pack_acgt(const uint8_t* ascii, uint64_t n, uint64_t* words) {
+    DnaString d = DnaString::from_acgt_bytes(ascii, n);
+    for (size_t i = 0; i < d.storage.size(); i++) words[i] = d.storage[i];
+}
+void orc_unpack_acgt(const uint64_t* words, uint64_t first_base, uint64_t n, uint8_t* ascii) {
+    SeqView v{words, (size_t)first_base, (size_t)n};
+    for (uint64_t i = 0; i < n; i++) ascii[i] = (uint8_t)"ACGT"[v.get(i)];
+}
+
 // ---- timing helper for bench.py's cpu_baseline leg: runs filter_kmers and returns seconds ----
 double orc_time_filter_kmers(const uint64_t* words, const uint64_t* start, const uint32_t* length,
                              const uint8_t* exts, const uint32_t* data, uint64_t n_seqs, uint32_t sizeof_d1,

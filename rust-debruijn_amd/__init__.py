@@ -200,6 +200,21 @@ class BaseGraph:
         return dict(words=self.sequences.words, start=self.sequences.start, length=self.sequences.length,
                     exts=self.exts, data=self.data, n_bases=self.sequences.n_bases)
 
+    def edges(self, ctx=None):
+        """Node::l_edges / r_edges (src/graph.rs:1041-1049) of every node: ([l_edges], [r_edges]) per node, each
+        edge (target_node, incoming_dir 'L'|'R', flipped) in the reference's order."""
+        return graph_edges(self, ctx)
+
+    def write_gfa(self, ctx=None):
+        """DebruijnGraph::write_gfa (src/graph.rs:603-616) -> bytes."""
+        return graph_to_gfa(self, ctx)
+
+    def to_gfa(self, path, ctx=None):
+        """DebruijnGraph::to_gfa (src/graph.rs:598-601)."""
+        ctx = ctx or default_context()
+        cg, keep = _graph_to_c(self)
+        ctx.check(ctx.lib.dbg_graph_write_gfa(ctx.h, self.k, C.byref(cg), str(path).encode()))
+
 
 # ------------------------------------------------------------------------------------------------
 # context
@@ -452,6 +467,67 @@ def compress_graph(stranded, spec, old_graph, censor_nodes=None, ctx=None):
     ctx.check(ctx.lib.dbg_compress_graph(ctx.h, old_graph.k, int(bool(stranded)), spec.kind, C.byref(cg), _np_ptr(cn),
                                          0 if cn is None else len(cn), C.byref(out)))
     return _graph_from_c(ctx, out, old_graph.k)
+
+
+def graph_edges(graph, ctx=None):
+    ctx = ctx or default_context()
+    cg, keep = _graph_to_c(graph)
+    e = _capi.Edges()
+    ctx.check(ctx.lib.dbg_graph_edges(ctx.h, graph.k, C.byref(cg), C.byref(e)))
+    n = int(e.n_nodes)
+    tgt = np.ctypeslib.as_array(C.cast(e.target, C.POINTER(C.c_uint32)), shape=(max(n * 8, 1),))[:n * 8].copy().reshape(n, 8)
+    info = np.ctypeslib.as_array(C.cast(e.info, C.POINTER(C.c_uint8)), shape=(max(n * 8, 1),))[:n * 8].copy().reshape(n, 8)
+    ctx.lib.dbg_free_edges(C.byref(e))
+    out = []
+    for i in range(n):
+        sides = []
+        for s in range(2):
+            sides.append([(int(tgt[i, 4 * s + b]), "R" if info[i, 4 * s + b] & 1 else "L", bool(info[i, 4 * s + b] & 2))
+                          for b in range(4) if tgt[i, 4 * s + b] != 0xFFFFFFFF])
+        out.append(tuple(sides))
+    return out
+
+
+def graph_to_gfa(graph, ctx=None):
+    ctx = ctx or default_context()
+    cg, keep = _graph_to_c(graph)
+    txt, ln = C.c_void_p(), C.c_uint64()
+    ctx.check(ctx.lib.dbg_graph_to_gfa(ctx.h, graph.k, C.byref(cg), C.byref(txt), C.byref(ln)))
+    b = C.string_at(txt, ln.value)
+    ctx.lib.dbg_free_text(txt)
+    return b
+
+
+def pack_acgt(ascii_bytes, ctx=None):
+    """DnaString::from_acgt_bytes (src/dna_string.rs:222-250): -> (packed u64 words, number of non-ACGT characters)."""
+    ctx = ctx or default_context()
+    a = np.frombuffer(bytes(ascii_bytes), np.uint8) if not isinstance(ascii_bytes, np.ndarray) else np.ascontiguousarray(ascii_bytes, np.uint8)
+    words = np.zeros((len(a) + 31) // 32, np.uint64)
+    bad = C.c_uint64()
+    ctx.check(ctx.lib.dbg_pack_acgt(ctx.h, _np_ptr(a) if len(a) else None, len(a), _np_ptr(words) if len(words) else None, C.byref(bad)))
+    return words, int(bad.value)
+
+
+def unpack_acgt(words, first_base, n, ctx=None):
+    """DnaString::to_ascii_vec (src/dna_string.rs:297-299) of bases [first_base, first_base + n) -> bytes."""
+    ctx = ctx or default_context()
+    w = np.ascontiguousarray(words, np.uint64)
+    out = np.zeros(n, np.uint8)
+    if n:
+        ctx.check(ctx.lib.dbg_unpack_acgt(ctx.h, _np_ptr(w), first_base, n, _np_ptr(out)))
+    return out.tobytes()
+
+
+def seqs_from_acgt(reads, exts=None, data=None, ctx=None):
+    """A batch of ASCII reads -> HostSeqs in PackedDnaStringSet layout (dna_string.rs:811-821), packed on the GPU."""
+    lens = np.array([len(r) for r in reads], np.uint32)
+    start = np.zeros(len(reads), np.uint64)
+    if len(reads):
+        start[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    words, _ = pack_acgt(b"".join(bytes(r) for r in reads), ctx)
+    d = None if data is None else np.ascontiguousarray(data, np.uint8)
+    e = None if exts is None else np.ascontiguousarray(exts, np.uint8)
+    return HostSeqs(words, start, lens, e, d, 0 if d is None else 1)
 
 
 def _censor(stranded, table, all_kmers, sharded, ctx):

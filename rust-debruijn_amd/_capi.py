@@ -45,6 +45,10 @@ class Graph(C.Structure):
                 ("data", C.c_void_p), ("stranded", C.c_int32)]
 
 
+class Edges(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("target", C.c_void_p), ("info", C.c_void_p)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("read_len", C.c_uint32), ("genome_len", C.c_uint64),
                 ("genome_seed", C.c_uint64), ("read_seed", C.c_uint64), ("error_rate", C.c_double),
@@ -69,6 +73,8 @@ EXPORTS = [
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
     "dbg_shard_count_dev", "dbg_graph_combine", "dbg_compress_graph",
+    "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
+    "dbg_pack_acgt", "dbg_pack_acgt_dev", "dbg_unpack_acgt", "dbg_unpack_acgt_dev",
 ]
 
 _lib = None
@@ -114,6 +120,17 @@ def load():
     lib.dbg_graph_combine.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_uint32, C.POINTER(Graph)]
     lib.dbg_compress_graph.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Graph), C.c_void_p, C.c_uint64,
                                        C.POINTER(Graph)]
+    lib.dbg_graph_edges.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Graph), C.POINTER(Edges)]
+    lib.dbg_free_edges.argtypes = [C.POINTER(Edges)]
+    lib.dbg_free_edges.restype = None
+    lib.dbg_graph_to_gfa.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Graph), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.dbg_graph_write_gfa.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Graph), C.c_char_p]
+    lib.dbg_free_text.argtypes = [C.c_void_p]
+    lib.dbg_free_text.restype = None
+    lib.dbg_pack_acgt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.dbg_pack_acgt_dev.argtypes = lib.dbg_pack_acgt.argtypes
+    lib.dbg_unpack_acgt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.dbg_unpack_acgt_dev.argtypes = lib.dbg_unpack_acgt.argtypes
     lib.dbg_synth_words.argtypes = [C.POINTER(SynthParams)]
     lib.dbg_synth_words.restype = C.c_uint64
     lib.dbg_synth_reads_dev.argtypes = [C.c_void_p, C.POINTER(SynthParams), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -134,6 +134,35 @@ __global__ void node_link_kernel(EndIndex left, EndIndex right, const uint64_t* 
     }
 }
 
+// find_edges (graph.rs:223-241) for both sides of every node: slot b (left) / 4 + b (right) of node i holds the
+// link reached through extension base b, or EDGE_NONE when the ext bit is clear or no node end matches
+// ("this edge doesn't exist within this shard").  info: bit0 = incoming side of the target is Right,
+// bit1 = the target is flipped.
+constexpr uint32_t EDGE_NONE = 0xFFFFFFFFu;
+__global__ void edges_kernel(EndIndex left, EndIndex right, const uint64_t* __restrict__ words,
+                             const uint64_t* __restrict__ start, const uint32_t* __restrict__ length, uint32_t n, int k,
+                             int stranded, const uint8_t* __restrict__ exts, uint32_t* __restrict__ target, uint8_t* __restrict__ info) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    K128 lk = packed_get_kmer(words, start[i], k);                                  // term_kmer(Dir::Left)
+    K128 rk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);        // term_kmer(Dir::Right)
+    const uint32_t e = exts[i];
+    for (uint32_t b = 0; b < 4; b++) {
+        uint32_t t = EDGE_NONE, f = 0;
+        if (e & (1u << b)) {
+            Link L = find_link(left, right, kmer_extend_left(lk, k, b), 0, stranded, k);
+            if (L.node >= 0) { t = (uint32_t)L.node; f = (uint32_t)L.side | ((uint32_t)L.flip << 1); }
+        }
+        target[(uint64_t)i * 8 + b] = t; info[(uint64_t)i * 8 + b] = (uint8_t)f;
+        t = EDGE_NONE; f = 0;
+        if (e & (16u << b)) {
+            Link L = find_link(left, right, kmer_extend_right(rk, k, b), 1, stranded, k);
+            if (L.node >= 0) { t = (uint32_t)L.node; f = (uint32_t)L.side | ((uint32_t)L.flip << 1); }
+        }
+        target[(uint64_t)i * 8 + 4 + b] = t; info[(uint64_t)i * 8 + 4 + b] = (uint8_t)f;
+    }
+}
+
 // ---- host helpers --------------------------------------------------------------------------
 struct HostBits {           // growing packed base stream (DnaString::push, dna_string.rs:303-310)
     std::vector<uint64_t> words;
@@ -370,5 +399,96 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
         if (r) { free(ng.seq_words); free(ng.start); free(ng.length); free(ng.exts); free(ng.data); return r; }
     }
     *out = ng;
+    return 0;
+}
+
+// Node::l_edges / r_edges (graph.rs:1041-1049) of every node of a (finished) graph, computed on the device.
+extern "C" int dbg_graph_edges(dbg_ctx* c, uint32_t k_, const dbg_graph* g, dbg_edges* out) {
+    const int k = (int)k_;
+    memset(out, 0, sizeof(*out));
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (g->n_nodes >= (1ull << 30)) return c->fail(51, "graph_edges: at most 2^30-1 nodes per call in this build");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)g->n_nodes;
+    for (uint32_t i = 0; i < n; i++) if (g->length[i] < (uint32_t)k) return c->fail(52, "node shorter than k");
+    out->n_nodes = n;
+    out->target = (uint32_t*)malloc(std::max<size_t>((size_t)n * 8 * 4, 1));
+    out->info = (uint8_t*)malloc(std::max<size_t>((size_t)n * 8, 1));
+    if (!n) return 0;
+    DevGraph d;
+    DBG_TRY(dev_graph_build(c, k, g, &d));
+    DBuf<uint32_t> d_t;
+    DBuf<uint8_t> d_i;
+    ALLOC_OR_FAIL(c, d_t, (size_t)n * 8);
+    ALLOC_OR_FAIL(c, d_i, (size_t)n * 8);
+    c->t_begin("graph_edges", n);
+    edges_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(d.left, d.right, d.words.p, d.start.p, d.length.p, n, k, g->stranded, d.exts.p, d_t.p, d_i.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "graph_edges");
+    HIP_TRY(c, hipMemcpyAsync(out->target, d_t.p, (size_t)n * 8 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out->info, d_i.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" void dbg_free_edges(dbg_edges* e) {
+    if (!e) return;
+    free(e->target); free(e->info);
+    memset(e, 0, sizeof(*e));
+}
+
+// DebruijnGraph::write_gfa (graph.rs:537-611): header, then per node its S line, the L lines of its left
+// edges with target >= node (":563"), then of its right edges with target > node (":579").  Node sequences
+// are unpacked to ASCII and edges resolved on the device; the host only formats lines.
+extern "C" int dbg_graph_to_gfa(dbg_ctx* c, uint32_t k_, const dbg_graph* g, char** text, uint64_t* len) {
+    *text = nullptr; *len = 0;
+    dbg_edges E;
+    DBG_TRY(dbg_graph_edges(c, k_, g, &E));
+    const uint32_t n = (uint32_t)g->n_nodes;
+    std::vector<uint8_t> ascii(std::max<uint64_t>(g->seq_len_bases, 1));
+    if (g->seq_len_bases) {
+        int r = dbg_unpack_acgt(c, g->seq_words, 0, g->seq_len_bases, ascii.data());
+        if (r) { dbg_free_edges(&E); return r; }
+    }
+    std::string s;
+    s.reserve((size_t)g->seq_len_bases + (size_t)n * 48 + 64);
+    s += "H\tVN:Z:debruijn-rs\n";
+    char buf[96];
+    const unsigned ov = k_ - 1;
+    for (uint32_t i = 0; i < n; i++) {
+        int m = snprintf(buf, sizeof(buf), "S\t%u\t", i);
+        s.append(buf, m);
+        s.append((const char*)ascii.data() + g->start[i], g->length[i]);
+        s += '\n';
+        for (int side = 0; side < 2; side++) {
+            for (int b = 0; b < 4; b++) {
+                const uint32_t t = E.target[(size_t)i * 8 + side * 4 + b];
+                if (t == EDGE_NONE) continue;
+                if (side == 0 ? t < i : t <= i) continue;
+                const char to_dir = (E.info[(size_t)i * 8 + side * 4 + b] & 1) ? '-' : '+';     // Dir::Left => "+", Dir::Right => "-"
+                m = snprintf(buf, sizeof(buf), "L\t%u\t%c\t%u\t%c\t%uM\n", i, side == 0 ? '-' : '+', t, to_dir, ov);
+                s.append(buf, m);
+            }
+        }
+    }
+    dbg_free_edges(&E);
+    char* o = (char*)malloc(s.size() + 1);
+    if (!o) return c->fail(101, "out of host memory");
+    memcpy(o, s.data(), s.size());
+    o[s.size()] = 0;
+    *text = o; *len = s.size();
+    return 0;
+}
+extern "C" void dbg_free_text(char* t) { free(t); }
+
+// DebruijnGraph::to_gfa (graph.rs:598-601)
+extern "C" int dbg_graph_write_gfa(dbg_ctx* c, uint32_t k, const dbg_graph* g, const char* path) {
+    char* t = nullptr; uint64_t len = 0;
+    DBG_TRY(dbg_graph_to_gfa(c, k, g, &t, &len));
+    FILE* f = fopen(path, "wb");
+    if (!f) { free(t); return c->fail(102, std::string("cannot create ") + path); }
+    size_t w = fwrite(t, 1, len, f);
+    int r = fclose(f);
+    free(t);
+    if (w != len || r) return c->fail(103, std::string("short write to ") + path);
     return 0;
 }

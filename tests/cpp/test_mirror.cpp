@@ -121,6 +121,35 @@ int main() {
         auto rs = filter_kmers<Kmer<47>>(ctx, seqs, CountFilterSet(2), true, false, 4);
         if (rs.first.len() != 200 - 47 + 1) return 3;
         for (auto& v : rs.first.data) if (v != std::vector<uint8_t>({0, 1, 2})) return 4;
+        // from_acgt_bytes on the device == from_dna_string (dna_string.rs:968-971), incl. non-ACGT -> A
+        {
+            std::string a = "ACGTAAAAAAAAAATTATATAACGTacgtNNACGTACGTACGTACGTACGTACGTACGTACGTACGTAC";
+            DnaString x = from_acgt_bytes(ctx, a), y = DnaString::from_dna_string(a);
+            if (x.len != y.len || x.storage != y.storage) return 6;
+        }
+        // GFA text of a compressed graph: header, one S line per node, every L line overlaps by k-1 (graph.rs:537-611)
+        {
+            auto contigs = simple_random_contigs(rng);
+            std::vector<std::tuple<DnaString, Exts, uint8_t>> cs;
+            for (auto& c : contigs) cs.emplace_back(DnaString::from_bytes(c), Exts::empty(), (uint8_t)0);
+            auto fk = filter_kmers<Kmer<31>>(ctx, cs, CountFilter(1), false, false, 4);
+            auto gr = compress_kmers_with_hash<Kmer<31>>(ctx, false, SimpleCompress(), fk.first);
+            std::string gfa = write_gfa(ctx, gr);
+            if (gfa.rfind("H\tVN:Z:debruijn-rs\n", 0) != 0) return 7;
+            size_t n_s = 0, n_l = 0;
+            for (size_t p = 0; (p = gfa.find('\n', p)) != std::string::npos; p++) {
+                if (p + 1 < gfa.size() && gfa[p + 1] == 'S') n_s++;
+                if (p + 1 < gfa.size() && gfa[p + 1] == 'L') n_l++;
+            }
+            if (n_s != gr.len()) return 7;
+            auto ed = edges(ctx, gr);
+            size_t want_l = 0;
+            for (size_t i = 0; i < ed.size(); i++) {
+                for (auto& e : ed[i].first) if (e.node >= i) want_l++;
+                for (auto& e : ed[i].second) if (e.node > i) want_l++;
+            }
+            if (n_l != want_l) return 8;
+        }
         // the reference would panic on memory_size = 0 (filter.rs:158)
         bool threw = false;
         try { filter_kmers<Kmer<31>>(ctx, seqs, CountFilter(1), false, false, 0); } catch (const Panic&) { threw = true; }

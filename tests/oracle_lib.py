@@ -40,7 +40,7 @@ def lib():
                   "orc_compress_graph"):
             getattr(_lib, f).restype = C.c_void_p
         for f in ("orc_table_len", "orc_table_all_len", "orc_table_setval_len", "orc_graph_len",
-                  "orc_graph_n_words", "orc_graph_n_bases", "orc_dnastring_pack", "orc_dnastring_push"):
+                  "orc_graph_n_words", "orc_graph_n_bases", "orc_dnastring_pack", "orc_dnastring_push", "orc_graph_gfa"):
             getattr(_lib, f).restype = C.c_uint64
         _lib.orc_table_passes.restype = C.c_uint32
         _lib.orc_msp_scan.restype = C.c_int64
@@ -304,6 +304,14 @@ class Graph:
         lib().orc_graph_finish(self.h)
         return self
 
+    def write_gfa(self):
+        """DebruijnGraph::write_gfa (graph.rs:603-616) -> bytes"""
+        L = lib()
+        n = L.orc_graph_gfa(self.h, None, C.c_uint64(0))
+        buf = C.create_string_buffer(max(n, 1))
+        L.orc_graph_gfa(self.h, buf, C.c_uint64(n))
+        return buf.raw[:n]
+
     def compress_graph(self, stranded, spec, censor=None):
         c = None if censor is None else np.ascontiguousarray(censor, dtype=np.uint64)
         h = lib().orc_compress_graph(self.h, int(stranded), spec, _p(c), C.c_uint64(0 if c is None else len(c)))
@@ -334,6 +342,23 @@ def graph_from_arrays(k, stranded, words, start, length, exts, data=None):
     h = lib().orc_graph_from_arrays(k, int(stranded), C.c_uint64(len(start)), _p(words), _p(start), _p(length),
                                     _p(exts), _p(d))
     return Graph(h, k)
+
+
+def pack_acgt(ascii_bytes):
+    """DnaString::from_acgt_bytes (dna_string.rs:222-250) -> storage words"""
+    a = np.frombuffer(bytes(ascii_bytes), np.uint8)
+    words = np.zeros((len(a) + 31) // 32, np.uint64)
+    if len(a):
+        lib().orc_pack_acgt(_p(a), C.c_uint64(len(a)), _p(words))
+    return words
+
+
+def unpack_acgt(words, first_base, n):
+    w = np.ascontiguousarray(words, np.uint64)
+    out = np.zeros(n, np.uint8)
+    if n:
+        lib().orc_unpack_acgt(_p(w), C.c_uint64(first_base), C.c_uint64(n), _p(out))
+    return out.tobytes()
 
 
 def graph_combine(graphs):

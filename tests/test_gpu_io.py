@@ -1,0 +1,97 @@
+"""GPU parity for the data formats either side of the path: dbg_pack_acgt / dbg_unpack_acgt vs the oracle's
+from_acgt_bytes / to_ascii_vec (dna_string.rs:222-250, :297-299; bitops_avx2.rs:138-216), and dbg_graph_edges /
+dbg_graph_to_gfa vs the oracle's write_gfa (graph.rs:223-291, :537-611): byte-identical text."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import refgen as R
+from pkg import dbg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dbg.Context(0)
+    yield c
+    c.close()
+
+
+def test_pack_known_and_edge_lengths(ctx):
+    for s in [b"", b"A", b"ACGTACGT", b"C" * 32, b"ACGT" * 8, b"AAAAAAAACCCCCCCCGGGGGGGGTTTTTTTT", b"ACGTAAAAAAAAAATTATATAACGT",
+              b"acgtnNxX" * 9, b"T" * 31, b"G" * 33, b"T" * 64, b"T" * 65]:
+        w, bad = dbg.pack_acgt(s, ctx)
+        assert np.array_equal(w, O.pack_acgt(s))
+        assert bad == sum(1 for c in s if c not in b"ACGTacgt")
+        up = dbg.unpack_acgt(w, 0, len(s), ctx)
+        assert up == O.unpack_acgt(w, 0, len(s))
+        assert up == bytes(b"ACGT"[{65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3}.get(c, 0)] for c in s)
+
+
+def test_pack_random_bytes(ctx):
+    rng = np.random.default_rng(11)
+    for n in [1, 31, 32, 33, 1000, 4096, 100_003, 1_000_000]:
+        # mostly ACGT, some lowercase, some arbitrary bytes (every byte value appears)
+        a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        lower = rng.random(n) < 0.1
+        a[lower] |= 0x20
+        junk = rng.random(n) < 0.05
+        a[junk] = rng.integers(0, 256, int(junk.sum())).astype(np.uint8)
+        w, bad = dbg.pack_acgt(a, ctx)
+        assert np.array_equal(w, O.pack_acgt(a.tobytes()))
+        valid = np.isin(a, np.frombuffer(b"ACGTacgt", np.uint8))
+        assert bad == int((~valid).sum())
+        first = int(rng.integers(0, n))
+        m = int(rng.integers(0, n - first + 1))
+        assert dbg.unpack_acgt(w, first, m, ctx) == O.unpack_acgt(w, first, m)
+
+
+def test_ascii_reads_through_filter(ctx):
+    """ASCII reads -> GPU packer -> filter_kmers equals the same reads given as 0-3 bytes."""
+    rng = np.random.default_rng(5)
+    contigs = R.random_contigs(rng)
+    ascii_reads = [R.to_ascii(c).encode() for c in contigs]
+    hs = dbg.seqs_from_acgt(ascii_reads, ctx=ctx)
+    t1, _ = dbg.filter_kmers(hs, dbg.CountFilter(1), False, False, 4, k=31, ctx=ctx)
+    t2, _ = dbg.filter_kmers([(c, 0, None) for c in contigs], dbg.CountFilter(1), False, False, 4, k=31, ctx=ctx)
+    assert np.array_equal(t1.key_lo, t2.key_lo) and np.array_equal(t1.exts, t2.exts) and np.array_equal(t1.count, t2.count)
+
+
+@pytest.mark.parametrize("k,stranded", [(31, False), (31, True), (47, False), (64, False), (16, False)])
+def test_gfa_matches_oracle(ctx, k, stranded, tmp_path):
+    rng = np.random.default_rng(100 + k + stranded)
+    for trial in range(2):
+        contigs = R.random_contigs(rng) if trial else R.simple_random_contigs(rng)
+        t, _ = dbg.filter_kmers([(c, 0, None) for c in contigs], dbg.CountFilter(1), stranded, False, 4, k=k, ctx=ctx)
+        g = dbg.compress_kmers_with_hash(stranded, dbg.SimpleCompress("saturating_add"), t, k=k, ctx=ctx)
+        ga = g.arrays()
+        og = O.graph_from_arrays(k, stranded, ga["words"], ga["start"], ga["length"], ga["exts"], ga["data"])
+        want = og.write_gfa()
+        got = g.write_gfa(ctx)
+        assert got == want
+        assert got.count(b"\nS\t") == len(g) and got.startswith(b"H\tVN:Z:debruijn-rs\n")
+        # to_gfa writes the same bytes to a file (graph.rs:598-601)
+        p = tmp_path / ("g%d.gfa" % trial)
+        g.to_gfa(p, ctx)
+        assert p.read_bytes() == want
+        # edges(): consistent with the L lines
+        ed = g.edges(ctx)
+        n_l = sum(1 for i, (l, r) in enumerate(ed) for e in l if e[0] >= i) + sum(1 for i, (l, r) in enumerate(ed) for e in r if e[0] > i)
+        assert n_l == got.count(b"\nL\t")
+
+
+def test_gfa_uncompressed_and_empty(ctx):
+    """One node per k-mer (test.rs:257-264 shape): many short nodes, every overlap is an edge; and the empty graph."""
+    k = 21
+    rng = np.random.default_rng(9)
+    contigs = R.simple_random_contigs(rng)
+    t, _ = dbg.filter_kmers([(c, 0, None) for c in contigs], dbg.CountFilter(1), False, False, 4, k=k, ctx=ctx)
+    n = len(t)
+    ps = dbg.PackedDnaStringSet.from_seqs([np.array([(v >> (2 * (k - 1 - i))) & 3 for i in range(k)], np.uint8) for v in t.keys()])
+    g = dbg.BaseGraph(k, ps, t.exts.copy(), t.count.astype(np.uint32), False)
+    og = O.graph_from_arrays(k, False, ps.words, ps.start, ps.length, g.exts, g.data)
+    assert g.write_gfa(ctx) == og.write_gfa()
+    empty = dbg.BaseGraph(k, dbg.PackedDnaStringSet(np.zeros(2, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32), 0),
+                          np.zeros(0, np.uint8), np.zeros(0, np.uint32), False)
+    assert empty.write_gfa(ctx) == b"H\tVN:Z:debruijn-rs\n"
