@@ -41,10 +41,10 @@ int extract_kmers(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uint64_t 
 int radix_sort_records(dbg_ctx* ctx, uint64_t n, RecArrays a, RecArrays b, int key_bits, int pay_shift,
                        int pay_bits, bool* result_in_b);
 
-// hybrid sort of the output table: LSD passes over the top key bits + LDS finisher with payload gather
-int sort_table_hybrid(dbg_ctx* ctx, uint64_t n, RecArrays a, RecArrays b, int key_bits, bool is_set,
-                      const uint32_t* u_pay, const uint32_t* u_msk, uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts,
-                      uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk, bool* ok, bool* data_in_b);
+// hybrid sort of the output table: LSD passes over the top key bits + LDS finisher that also decodes the payload
+// (Exts | count << 8, or Exts | colour mask << 8) into the table columns
+int sort_table_hybrid(dbg_ctx* ctx, uint64_t n, RecArrays a, RecArrays b, int key_bits, bool is_set, bool allow_hybrid,
+                      uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts, uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk);
 
 // ---- reduce.hip : group_by key + KmerSummarizer::summarize (filter.rs:53-62, :85-100) -------
 struct ReduceOut {

@@ -325,9 +325,7 @@ __global__ void __launch_bounds__(256) sk_scatter_kernel(const uint64_t* __restr
 struct FastOut {
     uint64_t* hi;       // null when k <= 32
     uint64_t* lo;
-    uint32_t* pay;      // exts | min(count, 65535) << 8
-    uint32_t* msk;      // CountFilterSet: bit d set iff label d observed (labels < 32); else null
-    uint32_t* nobs;     // CountFilterSet: raw observation count (validity uses nobs, filter.rs:99); else null
+    uint32_t* pay;      // CountFilter: exts | min(count, 65535) << 8;  CountFilterSet: exts | colour mask << 8 (labels < 24)
 };
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -581,8 +579,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     if (!valid) continue;
                     if (KW == 2) out.hi[o] = s_hi[i];
                     out.lo[o] = s_lo[i];
-                    out.pay[o] = (s_aux[i] & 0xffu) | (c16 << 8);
-                    if (IS_SET) { out.msk[o] = s_aux[i] >> 8; }
+                    out.pay[o] = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
                     o++;
                 }
             }
@@ -594,23 +591,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     }
 }
 
-// iota, gather and CSR helpers for the order-restoring stage
-__global__ void iota_kernel(uint32_t* p, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
-}
-template <bool IS_SET>
-__global__ void finalize_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ pay,
-                                const uint32_t* __restrict__ msk, uint8_t* __restrict__ exts, uint16_t* __restrict__ count,
-                                uint32_t* __restrict__ setn, uint32_t* __restrict__ msk_sorted) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t j = idx[i];
-    uint32_t p = pay[j];
-    exts[i] = (uint8_t)(p & 0xffu);
-    if (IS_SET) { uint32_t m = msk[j]; msk_sorted[i] = m; setn[i] = __popc(m); }
-    else count[i] = (uint16_t)(p >> 8);
-}
+// CSR helper for the order-restoring stage
 __global__ void set_values_kernel(uint32_t n, const uint32_t* __restrict__ msk_sorted, const uint64_t* __restrict__ set_off,
                                   uint32_t* __restrict__ set_val) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -786,17 +767,16 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     ALLOC_OR_FAIL(c, gflags, 4);
     uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1);
     DBuf<uint64_t> u_hi, u_lo;
-    DBuf<uint32_t> u_pay, u_msk;
+    DBuf<uint32_t> u_pay;
     uint64_t n_out = 0;
     for (int attempt = 0;; attempt++) {
         if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
         if (has_hi) ALLOC_OR_FAIL(c, u_hi, cap);
         ALLOC_OR_FAIL(c, u_lo, cap);
         ALLOC_OR_FAIL(c, u_pay, cap);
-        if (is_set) ALLOC_OR_FAIL(c, u_msk, cap);
         HIP_TRY(c, hipMemsetAsync(out_cursor.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(gflags.p, 0, 16, c->stream));
-        FastOut fo{u_hi.p, u_lo.p, u_pay.p, u_msk.p, nullptr};
+        FastOut fo{u_hi.p, u_lo.p, u_pay.p};
         if (nbins_local) {
             c->t_begin("bin_count", n_kmers_hint);
             static const int nt_env = getenv("DBG_FAST_NT") ? atoi(getenv("DBG_FAST_NT")) : 512;
@@ -834,13 +814,12 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     }
 
     // ---- order-restoring sort: ascending key (filter.rs:205-206 bucket order + stable sort = global order) ----
-    DBuf<uint32_t> idx, t_pay;
+    DBuf<uint32_t> t_pay;
     DBuf<uint64_t> t_hi, t_lo;
     size_t na = std::max<uint64_t>(n_out, 1);
-    ALLOC_OR_FAIL(c, idx, na); ALLOC_OR_FAIL(c, t_pay, na); ALLOC_OR_FAIL(c, t_lo, na);
+    ALLOC_OR_FAIL(c, t_pay, na); ALLOC_OR_FAIL(c, t_lo, na);
     if (has_hi) ALLOC_OR_FAIL(c, t_hi, na);
-    if (n_out) { iota_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>(idx.p, (uint32_t)n_out); LAUNCH_CHECK(c, "iota"); }
-    RecArrays A{has_hi ? u_hi.p : nullptr, u_lo.p, idx.p}, B{has_hi ? t_hi.p : nullptr, t_lo.p, t_pay.p};
+    RecArrays A{has_hi ? u_hi.p : nullptr, u_lo.p, u_pay.p}, B{has_hi ? t_hi.p : nullptr, t_lo.p, t_pay.p};
     DBuf<uint64_t> o_hi, o_lo, o_set_off;
     DBuf<uint8_t> o_exts;
     DBuf<uint16_t> o_count;
@@ -849,26 +828,8 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     if (is_set) { ALLOC_OR_FAIL(c, setn, na); ALLOC_OR_FAIL(c, msk_sorted, na); ALLOC_OR_FAIL(c, o_set_off, na + 1); }
     else ALLOC_OR_FAIL(c, o_count, na);
     uint64_t n_setval = 0;
-    bool hybrid_ok = false, data_in_b = false;
-    if (!getenv("DBG_NO_HYBRID_SORT"))
-        DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, u_pay.p, u_msk.p, o_hi.p, o_lo.p, o_exts.p, o_count.p,
-                                  setn.p, msk_sorted.p, &hybrid_ok, &data_in_b));
-    if (!hybrid_ok && n_out) {
-        // plain LSD sort over every key bit (the fallback when a key-prefix group is too large for the
-        // LDS finisher); the (key, idx) pairs are intact in whichever buffer the top-bit passes ended in
-        bool in_b = false;
-        RecArrays X = data_in_b ? B : A, Y = data_in_b ? A : B;
-        DBG_TRY(radix_sort_records(c, n_out, X, Y, 2 * k, 0, 0, &in_b));
-        RecArrays S = in_b ? Y : X;
-        if (has_hi) HIP_TRY(c, hipMemcpyAsync(o_hi.p, S.hi, n_out * 8, hipMemcpyDeviceToDevice, c->stream));
-        else HIP_TRY(c, hipMemsetAsync(o_hi.p, 0, n_out * 8, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(o_lo.p, S.lo, n_out * 8, hipMemcpyDeviceToDevice, c->stream));
-        c->t_begin("finalize", n_out);
-        if (is_set) finalize_kernel<true><<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, S.pay, u_pay.p, u_msk.p, o_exts.p, nullptr, setn.p, msk_sorted.p);
-        else finalize_kernel<false><<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, S.pay, u_pay.p, nullptr, o_exts.p, o_count.p, nullptr, nullptr);
-        c->t_end();
-        LAUNCH_CHECK(c, "finalize");
-    }
+    DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
+                              setn.p, msk_sorted.p));
     if (is_set) {
         DBG_TRY(scan_exclusive_u32_u64(c, setn.p, o_set_off.p, n_out));
         HIP_TRY(c, hipMemcpyAsync(&n_setval, o_set_off.p + n_out, 8, hipMemcpyDeviceToHost, c->stream));

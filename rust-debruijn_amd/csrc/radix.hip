@@ -8,11 +8,11 @@
 #include <algorithm>
 
 namespace {
-constexpr int RS_THREADS = 256;
+constexpr int RS_THREADS = 512;
 constexpr int RS_WAVES = RS_THREADS / DBG_WAVE;
 constexpr int RS_ITEMS = 16;                        // rounds of 64 consecutive elements per wave
 constexpr int RS_WAVE_CHUNK = RS_ITEMS * DBG_WAVE;  // 1024
-constexpr int RS_TILE = RS_WAVES * RS_WAVE_CHUNK;   // 4096
+constexpr int RS_TILE = RS_WAVES * RS_WAVE_CHUNK;   // 8192: ~32 elements per digit, 256-byte runs in the output
 
 // digit source: 0 = payload (u32), 1 = key lo, 2 = key hi
 struct DigitSel {
@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t digit_of(const DigitSel& ds, uint64_t hi, ui
 __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(RecArrays in, uint32_t n, DigitSel ds,
                                                                 uint32_t* __restrict__ hist, uint32_t nblocks) {
     __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t base = blockIdx.x * RS_TILE + wave * RS_WAVE_CHUNK + lane;
@@ -42,22 +42,31 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(RecArrays in, ui
         }
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < 256) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// One tile: rank every element inside the tile (wave-level ballot multisplit + per-wave digit counters), bring
+// the tile into digit order in LDS one array at a time, and write it out linearly: consecutive lanes then hit
+// consecutive addresses of a digit's run (8192/256 = 32 elements on average) instead of 64 scattered slots.
 template <bool HAS_HI>
 __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in, RecArrays out, uint32_t n, DigitSel ds,
                                                                    const uint32_t* __restrict__ hist_scanned,
                                                                    uint32_t nblocks) {
-    __shared__ uint32_t wc[RS_WAVES][256];
+    __shared__ uint64_t stage[RS_TILE];                 // 64 KB; the per-wave counters alias its first 8 KB
+    __shared__ uint8_t s_dig[RS_TILE];                  // digit of the element at each tile-sorted position
+    __shared__ uint32_t s_gbase[256];                   // global position of tile-sorted position 0 of digit d, minus its tile offset
+    __shared__ uint32_t s_ws[4];
+    uint32_t (*wc)[256] = reinterpret_cast<uint32_t (*)[256]>(stage);
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&wc[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t base = blockIdx.x * RS_TILE + wave * RS_WAVE_CHUNK + lane;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile0 = blockIdx.x * RS_TILE;
+    const uint32_t base = tile0 + wave * RS_WAVE_CHUNK + lane;
+    const uint32_t tile_n = n - tile0 < (uint32_t)RS_TILE ? n - tile0 : (uint32_t)RS_TILE;
     const uint64_t lt = lanemask_lt();
     uint64_t hi[RS_ITEMS], lo[RS_ITEMS];
     uint32_t pay[RS_ITEMS];
-    uint32_t rank[RS_ITEMS];            // digit in the top byte, wave-local rank in the low 24 bits
+    uint32_t rank[RS_ITEMS];            // digit in the top byte, wave-local rank in the low 24 bits; then the tile position
     volatile uint32_t* mywc = &wc[wave][0];
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
@@ -68,6 +77,10 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in,
             lo[r] = in.lo[e];
             pay[r] = in.pay[e];
         } else { hi[r] = 0; lo[r] = 0; pay[r] = 0; }
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        bool valid = base + r * 64 < n;
         uint32_t d = digit_of(ds, hi[r], lo[r], pay[r]);
         // lanes holding the same digit (multisplit by ballot, 8 digit bits)
         uint64_t same = __ballot(valid);
@@ -84,28 +97,55 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in,
         rank[r] = (d << 24) | (wbase + before);
     }
     __syncthreads();
-    {   // per digit: turn per-wave totals into global bases (block base + waves before)
-        uint32_t d = threadIdx.x;
-        uint32_t run = hist_scanned[(size_t)d * nblocks + blockIdx.x];
+    {   // digit totals of the tile -> exclusive scan over the 256 digits -> per-wave bases inside the tile
+        uint32_t tot = 0;
+        if (tid < 256) {
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) {
-            uint32_t t = wc[w][d];
-            wc[w][d] = run;
-            run += t;
+            for (int w = 0; w < RS_WAVES; w++) tot += wc[w][tid];
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { uint32_t o = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += o; }
+        if (tid < 256 && lane == 63) s_ws[wave] = incl;
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < wave; w++) off += s_ws[w];
+            uint32_t run = off + incl - tot;                      // tile position of the first element with digit tid
+            s_gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - run;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; w++) { uint32_t t = wc[w][tid]; wc[w][tid] = run; run += t; }
         }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
-        uint32_t e = base + r * 64;
-        if (e < n) {
-            uint32_t d = rank[r] >> 24;
-            uint32_t pos = wc[wave][d] + (rank[r] & 0xffffffu);
-            if (HAS_HI) out.hi[pos] = hi[r];
-            out.lo[pos] = lo[r];
-            out.pay[pos] = pay[r];
+        uint32_t d = rank[r] >> 24;
+        rank[r] = wc[wave][d] + (rank[r] & 0xffffffu);            // position inside the digit-ordered tile
+    }
+    __syncthreads();                                              // counters are dead: the stage buffer may be overwritten
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        if (base + r * 64 < n) {
+            stage[rank[r]] = lo[r];
+            s_dig[rank[r]] = (uint8_t)digit_of(ds, hi[r], lo[r], pay[r]);
         }
     }
+    __syncthreads();
+    for (uint32_t i = tid; i < tile_n; i += RS_THREADS) out.lo[s_gbase[s_dig[i]] + i] = stage[i];
+    if (HAS_HI) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_ITEMS; r++) if (base + r * 64 < n) stage[rank[r]] = hi[r];
+        __syncthreads();
+        for (uint32_t i = tid; i < tile_n; i += RS_THREADS) out.hi[s_gbase[s_dig[i]] + i] = stage[i];
+    }
+    __syncthreads();
+    uint32_t* stage32 = reinterpret_cast<uint32_t*>(stage);
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) if (base + r * 64 < n) stage32[rank[r]] = pay[r];
+    __syncthreads();
+    for (uint32_t i = tid; i < tile_n; i += RS_THREADS) out.pay[s_gbase[s_dig[i]] + i] = stage32[i];
 }
 }  // namespace
 
@@ -151,15 +191,14 @@ int radix_sort_records(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int
 
 // ------------------------------------------------------------------------------------------------
 // Hybrid sort for the output table: a few stable LSD passes over the TOP key bits leave the array
-// grouped by key prefix; `span_sort_kernel` then finishes the order inside LDS.  Workgroup w owns
-// the prefix groups that START inside the record window [w*C, (w+1)*C); it loads them (at most CAP
-// records), radix-sorts the full key in LDS (stable, 8 bits per pass, same ballot multisplit as
-// above) and writes the sorted keys plus the gathered payload.  HBM sees the records 3-4 times
-// instead of once per 8 key bits.
+// grouped by key prefix (about 32 records per group); `span_sort_kernel` then finishes the order inside
+// LDS.  Workgroup w owns the prefix groups that START inside the record window [w*C, (w+1)*C); it loads
+// them (at most CAP records), ranks every record inside its own group by direct key comparison (keys of
+// the output table are distinct), permutes through LDS and writes the sorted keys together with the
+// decoded payload.  HBM sees the records once per top-bit pass plus once here, instead of once per 8 key bits.
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int SS_THREADS = 512;
-constexpr int SS_WAVES = SS_THREADS / 64;
 constexpr int SS_ITEMS = 6;
 constexpr int SS_CAP = SS_THREADS * SS_ITEMS;       // 3072 records per workgroup
 constexpr int SS_WINDOW = 2560;                      // C: a prefix group must be <= CAP - C = 512 records
@@ -171,34 +210,50 @@ __device__ __forceinline__ uint32_t key_prefix(uint64_t hi, uint64_t lo, int key
     return (uint32_t)((lo >> sh) | (hi << (64 - sh)));
 }
 
+// pay = Exts | count << 8 (CountFilter) or Exts | colour mask << 8 (CountFilterSet)
 template <bool HAS_HI, bool IS_SET>
 __global__ void __launch_bounds__(SS_THREADS) span_sort_kernel(RecArrays in, uint32_t n, int key_bits, int top_bits,
-                                                               const uint32_t* __restrict__ u_pay, const uint32_t* __restrict__ u_msk,
                                                                uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
                                                                uint8_t* __restrict__ o_exts, uint16_t* __restrict__ o_count,
                                                                uint32_t* __restrict__ o_setn, uint32_t* __restrict__ o_msk,
                                                                uint32_t* __restrict__ flags) {
     __shared__ uint64_t s_lo[SS_CAP];
     __shared__ uint64_t s_hi[HAS_HI ? SS_CAP : 1];
-    __shared__ uint32_t s_idx[SS_CAP];
-    __shared__ uint32_t wc[SS_WAVES][256];
-    __shared__ uint32_t s_ws[SS_WAVES];
+    __shared__ uint32_t s_pay[SS_CAP];
+    __shared__ uint32_t s_pre[SS_CAP];
     __shared__ uint32_t s_start, s_end;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t lt = lanemask_lt();
+    const uint32_t tid = threadIdx.x;
     const uint32_t base = blockIdx.x * SS_WINDOW;
     const uint32_t avail = n - base < (uint32_t)SS_CAP ? n - base : (uint32_t)SS_CAP;
     if (tid == 0) { s_start = 0xffffffffu; s_end = 0xffffffffu; }
     __syncthreads();
-    // ---- which prefix groups start in this window? ----
-    for (uint32_t i = tid; i < avail; i += SS_THREADS) {
-        uint32_t g = base + i;
-        uint32_t pc = key_prefix(HAS_HI ? in.hi[g] : 0, in.lo[g], key_bits, top_bits);
-        bool boundary = g == 0;
-        if (!boundary) boundary = pc != key_prefix(HAS_HI ? in.hi[g - 1] : 0, in.lo[g - 1], key_bits, top_bits);
-        if (boundary) {
-            if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i);
-            else atomicMin(&s_end, i);
+    // ---- load the window (+ overhang) and find which prefix groups start in it ----
+    uint64_t hi[SS_ITEMS], lo[SS_ITEMS];
+    uint32_t pay[SS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i < avail) {
+            const uint32_t g = base + i;
+            hi[r] = HAS_HI ? in.hi[g] : 0; lo[r] = in.lo[g]; pay[r] = in.pay[g];
+            const uint32_t pc = key_prefix(hi[r], lo[r], key_bits, top_bits);
+            s_pre[i] = pc;
+            s_lo[i] = lo[r];
+            if (HAS_HI) s_hi[i] = hi[r];
+        }
+    }
+    uint32_t prev0 = 0;                                          // prefix of the record just before the window
+    if (base > 0 && tid == 0) prev0 = key_prefix(HAS_HI ? in.hi[base - 1] : 0, in.lo[base - 1], key_bits, top_bits);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i < avail) {
+            bool boundary = i == 0 ? (base == 0 || s_pre[0] != prev0) : s_pre[i] != s_pre[i - 1];
+            if (boundary) {
+                if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i);
+                else atomicMin(&s_end, i);
+            }
         }
     }
     __syncthreads();
@@ -212,152 +267,134 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_kernel(RecArrays in, uin
         }
         end = avail;
     }
-    const uint32_t m = end - start;
-    // ---- load (positions: wave-chunked, round-major) ----
-    uint64_t hi[SS_ITEMS], lo[SS_ITEMS];
-    uint32_t idx[SS_ITEMS];
+    // ---- rank inside the group: position = group start + number of smaller keys in the group ----
+    uint32_t pos[SS_ITEMS];
 #pragma unroll
     for (int r = 0; r < SS_ITEMS; r++) {
-        uint32_t p = wave * (64 * SS_ITEMS) + r * 64 + lane;
-        if (p < m) {
-            uint32_t g = base + start + p;
-            hi[r] = HAS_HI ? in.hi[g] : 0; lo[r] = in.lo[g]; idx[r] = in.pay[g];
-        } else { hi[r] = ~0ull; lo[r] = ~0ull; idx[r] = 0xffffffffu; }   // padding: sorts last (stable)
-    }
-    // ---- stable LSD radix sort in LDS over the full key ----
-    for (int shift = 0; shift < key_bits; shift += 8) {
-        for (int i = tid; i < SS_WAVES * 256; i += SS_THREADS) (&wc[0][0])[i] = 0;
-        __syncthreads();
-        uint32_t rank[SS_ITEMS];
-        volatile uint32_t* mywc = &wc[wave][0];
-#pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) {
-            uint64_t v = shift < 64 ? lo[r] : hi[r];
-            uint32_t d = (uint32_t)(v >> (shift & 63)) & 0xffu;
-            uint64_t same = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                uint64_t bal = __ballot((d >> b) & 1u);
-                same &= ((d >> b) & 1u) ? bal : ~bal;
+        const uint32_t i = tid + r * SS_THREADS;
+        pos[r] = 0xffffffffu;
+        if (i >= start && i < end) {
+            const uint32_t pc = s_pre[i];
+            uint32_t less = 0, gs = i;
+            for (uint32_t j = i; j > start && s_pre[j - 1] == pc; j--) {
+                const uint64_t jl = s_lo[j - 1];
+                const bool lt = HAS_HI ? (s_hi[j - 1] < hi[r] || (s_hi[j - 1] == hi[r] && jl <= lo[r])) : jl <= lo[r];   // equal keys keep input order
+                less += lt ? 1u : 0u;
+                gs = j - 1;
             }
-            uint32_t before = __popcll(same & lt);
-            uint32_t cnt = __popcll(same);
-            uint32_t wbase = mywc[d];
-            if (before == 0) mywc[d] = wbase + cnt;
-            rank[r] = (d << 24) | (wbase + before);
+            for (uint32_t j = i + 1; j < end && s_pre[j] == pc; j++) {
+                const uint64_t jl = s_lo[j];
+                const bool lt = HAS_HI ? (s_hi[j] < hi[r] || (s_hi[j] == hi[r] && jl < lo[r])) : jl < lo[r];
+                less += lt ? 1u : 0u;
+            }
+            pos[r] = gs + less;
         }
-        __syncthreads();
-        // digit totals -> exclusive scan over the 256 digits -> per-wave bases
-        uint32_t tot = 0;
-        if (tid < 256) {
-#pragma unroll
-            for (int w = 0; w < SS_WAVES; w++) tot += wc[w][tid];
-        }
-        uint32_t incl = tot;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) { uint32_t o = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += o; }
-        if (lane == 63) s_ws[wave] = incl;
-        __syncthreads();
-        if (tid < 256) {
-            uint32_t off = 0;
-            for (uint32_t w = 0; w < wave; w++) off += s_ws[w];
-            uint32_t run = off + incl - tot;                      // exclusive prefix of digit tid
-#pragma unroll
-            for (int w = 0; w < SS_WAVES; w++) { uint32_t t = wc[w][tid]; wc[w][tid] = run; run += t; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) {
-            uint32_t d = rank[r] >> 24;
-            uint32_t pos = wc[wave][d] + (rank[r] & 0xffffffu);
-            s_lo[pos] = lo[r];
-            if (HAS_HI) s_hi[pos] = hi[r];
-            s_idx[pos] = idx[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) {
-            uint32_t p = wave * (64 * SS_ITEMS) + r * 64 + lane;
-            lo[r] = s_lo[p];
-            if (HAS_HI) hi[r] = s_hi[p];
-            idx[r] = s_idx[p];
-        }
-        __syncthreads();
     }
-    // ---- write sorted keys + gathered payload ----
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < SS_ITEMS; r++) {
-        uint32_t p = wave * (64 * SS_ITEMS) + r * 64 + lane;
-        if (p < m) {
-            uint32_t g = base + start + p;
-            o_hi[g] = HAS_HI ? hi[r] : 0;
-            o_lo[g] = lo[r];
-            uint32_t pay = u_pay[idx[r]];
-            o_exts[g] = (uint8_t)(pay & 0xffu);
-            if (IS_SET) { uint32_t mk = u_msk[idx[r]]; o_msk[g] = mk; o_setn[g] = __popc(mk); }
-            else o_count[g] = (uint16_t)(pay >> 8);
+        if (pos[r] != 0xffffffffu) {
+            s_lo[pos[r]] = lo[r];
+            if (HAS_HI) s_hi[pos[r]] = hi[r];
+            s_pay[pos[r]] = pay[r];
+        }
+    }
+    __syncthreads();
+    // ---- write sorted keys + decoded payload, linearly ----
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i >= start && i < end) {
+            const uint32_t g = base + i;
+            o_hi[g] = HAS_HI ? s_hi[i] : 0;
+            o_lo[g] = s_lo[i];
+            const uint32_t p = s_pay[i];
+            o_exts[g] = (uint8_t)(p & 0xffu);
+            if (IS_SET) { o_msk[g] = p >> 8; o_setn[g] = __popc(p >> 8); }
+            else o_count[g] = (uint16_t)(p >> 8);
         }
     }
 }
+
+template <bool IS_SET>
+__global__ void decode_payload_kernel(uint32_t n, const uint32_t* __restrict__ pay, uint8_t* __restrict__ exts,
+                                      uint16_t* __restrict__ count, uint32_t* __restrict__ setn, uint32_t* __restrict__ msk) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pay[i];
+    exts[i] = (uint8_t)(p & 0xffu);
+    if (IS_SET) { msk[i] = p >> 8; setn[i] = __popc(p >> 8); }
+    else count[i] = (uint16_t)(p >> 8);
+}
 }  // namespace
 
-// Sorts (key, idx) records ascending by key and gathers the payload; returns *ok = false (nothing
-// written) when a key-prefix group is too large for the LDS finisher -- the caller then uses the
-// plain LSD sort.  a = input (clobbered), b = scratch.
-int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int key_bits, bool is_set,
-                      const uint32_t* u_pay, const uint32_t* u_msk, uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts,
-                      uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk, bool* ok, bool* data_in_b) {
-    *ok = false;
-    *data_in_b = false;
-    if (n64 == 0) { *ok = true; return 0; }
-    if (n64 >= (1ull << 32) - SS_CAP) return 0;
+// Sorts (key, payload) records ascending by key and writes the output table columns.  a = input (clobbered),
+// b = scratch.  Falls back to the plain LSD sort over every key bit when a key-prefix group is too large for
+// the LDS finisher (the records are intact in whichever buffer the top-bit passes ended in).
+int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int key_bits, bool is_set, bool allow_hybrid,
+                      uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts, uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk) {
+    if (n64 == 0) return 0;
+    if (n64 >= (1ull << 32) - SS_CAP) return ctx->fail(110, "sort_table: more than 2^32-1 records in one call");
     const uint32_t n = (uint32_t)n64;
     const bool has_hi = a.hi != nullptr;
-    // enough top bits that an average prefix group holds ~32 records
-    int top_bits = 0;
-    while (top_bits < key_bits && top_bits < 24 && (n64 >> top_bits) > 32) top_bits += 8;
-    if (top_bits > key_bits) top_bits = key_bits;
-    // digit boundaries sit at multiples of 8 from bit 0 so that no digit straddles the two key words
-    const int s0 = top_bits ? ((key_bits - top_bits) / 8) * 8 : key_bits;
-    top_bits = key_bits - s0;
     RecArrays src = a, dst = b;
-    if (top_bits > 0) {
-        const uint32_t nblocks = cdiv(n, RS_TILE);
-        DBuf<uint32_t> hist, hist_scanned;
-        ALLOC_OR_FAIL(ctx, hist, (size_t)256 * nblocks);
-        ALLOC_OR_FAIL(ctx, hist_scanned, (size_t)256 * nblocks + 1);
-        for (int s = s0; s < key_bits; s += 8) {
-            DigitSel ds = s < 64 ? DigitSel{1, s, (uint32_t)((1u << std::min(8, std::min(64, key_bits) - s)) - 1)}
-                                 : DigitSel{2, s - 64, (uint32_t)((1u << std::min(8, key_bits - s)) - 1)};
-            ctx->t_begin("radix_hist", n);
-            radix_hist_kernel<<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, n, ds, hist.p, nblocks);
-            ctx->t_end();
-            LAUNCH_CHECK(ctx, "radix_hist");
-            DBG_TRY(scan_exclusive_u32(ctx, hist.p, hist_scanned.p, (uint64_t)256 * nblocks));
-            ctx->t_begin("radix_scatter", n);
-            if (has_hi) radix_scatter_kernel<true><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
-            else        radix_scatter_kernel<false><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
-            ctx->t_end();
-            LAUNCH_CHECK(ctx, "radix_scatter");
-            std::swap(src, dst);
-            *data_in_b = !*data_in_b;
+    if (allow_hybrid) {
+        // enough top bits that an average prefix group holds ~32 records
+        int top_bits = 0;
+        while (top_bits < key_bits && top_bits < 32 && (n64 >> top_bits) > 32) top_bits += 8;
+        if (top_bits > key_bits) top_bits = key_bits;
+        // digit boundaries sit at multiples of 8 from bit 0 so that no digit straddles the two key words
+        const int s0 = top_bits ? ((key_bits - top_bits) / 8) * 8 : key_bits;
+        top_bits = key_bits - s0;
+        if (top_bits > 0) {
+            const uint32_t nblocks = cdiv(n, RS_TILE);
+            DBuf<uint32_t> hist, hist_scanned;
+            ALLOC_OR_FAIL(ctx, hist, (size_t)256 * nblocks);
+            ALLOC_OR_FAIL(ctx, hist_scanned, (size_t)256 * nblocks + 1);
+            for (int s = s0; s < key_bits; s += 8) {
+                DigitSel ds = s < 64 ? DigitSel{1, s, (uint32_t)((1u << std::min(8, std::min(64, key_bits) - s)) - 1)}
+                                     : DigitSel{2, s - 64, (uint32_t)((1u << std::min(8, key_bits - s)) - 1)};
+                ctx->t_begin("radix_hist", n);
+                radix_hist_kernel<<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, n, ds, hist.p, nblocks);
+                ctx->t_end();
+                LAUNCH_CHECK(ctx, "radix_hist");
+                DBG_TRY(scan_exclusive_u32(ctx, hist.p, hist_scanned.p, (uint64_t)256 * nblocks));
+                ctx->t_begin("radix_scatter", n);
+                if (has_hi) radix_scatter_kernel<true><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
+                else        radix_scatter_kernel<false><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
+                ctx->t_end();
+                LAUNCH_CHECK(ctx, "radix_scatter");
+                std::swap(src, dst);
+            }
         }
-    }
-    DBuf<uint32_t> flags;
-    ALLOC_OR_FAIL(ctx, flags, 1);
-    HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
-    const uint32_t nwg = cdiv(n, SS_WINDOW);
-    ctx->t_begin("span_sort", n);
-#define GO(HH, SS) span_sort_kernel<HH, SS><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, u_pay, u_msk, \
-        o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p)
-    if (has_hi) { if (is_set) GO(true, true); else GO(true, false); }
-    else        { if (is_set) GO(false, true); else GO(false, false); }
+        DBuf<uint32_t> flags;
+        ALLOC_OR_FAIL(ctx, flags, 1);
+        HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
+        const uint32_t nwg = cdiv(n, SS_WINDOW);
+        ctx->t_begin("span_sort", n);
+#define GO(HH, SS) span_sort_kernel<HH, SS><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, \
+            o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p)
+        if (has_hi) { if (is_set) GO(true, true); else GO(true, false); }
+        else        { if (is_set) GO(false, true); else GO(false, false); }
 #undef GO
+        ctx->t_end();
+        LAUNCH_CHECK(ctx, "span_sort");
+        uint32_t fl = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (fl == 0) return 0;
+    }
+    // plain LSD sort over every key bit
+    bool in_b = false;
+    DBG_TRY(radix_sort_records(ctx, n64, src, dst, key_bits, 0, 0, &in_b));
+    RecArrays S = in_b ? dst : src;
+    if (has_hi) HIP_TRY(ctx, hipMemcpyAsync(o_hi, S.hi, n64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemsetAsync(o_hi, 0, n64 * 8, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(o_lo, S.lo, n64 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->t_begin("finalize", n64);
+    if (is_set) decode_payload_kernel<true><<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, S.pay, o_exts, nullptr, o_setn, o_msk);
+    else decode_payload_kernel<false><<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, S.pay, o_exts, o_count, nullptr, nullptr);
     ctx->t_end();
-    LAUNCH_CHECK(ctx, "span_sort");
-    uint32_t fl = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *ok = fl == 0;
+    LAUNCH_CHECK(ctx, "finalize");
     return 0;
 }
