@@ -337,11 +337,17 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 // (A chain of 32-bit multiplies was measured: cheaper in VALU but no faster -- the kernel is bound by LDS
 // round-trip latency at 4 waves/SIMD, and weaker mixing costs extra probes.)
 __device__ __forceinline__ uint64_t hash_key(uint64_t hi, uint64_t lo) {
+#ifdef DBG_HASH_CHEAP
+    uint64_t h = (lo ^ ((hi << 23) | (hi >> 41))) * 0xD6E8FEB86659FD93ull;
+    h ^= h >> 29;
+    return h;
+#else
     uint64_t h = lo ^ (hi * 0x9E3779B97F4A7C15ull);
     h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32;
     return h;
+#endif
 }
 
 template <int NT>
@@ -368,20 +374,33 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
 }
 
 // One workgroup (NT threads = NT/64 waves) owns one bin and one LDS hash table of T entries.
-// Waves stream the bin's records independently -- no block barrier inside a pass:
-//   * a wave loads 64 records (one per lane, 2 KB contiguous), stages them in its private LDS slab and
-//     prefix-sums their k-mer counts with shuffles; lanes then take k-mer instances round-robin;
-//   * insert = linear probing on a 32-bit tag word.  A free slot is claimed with
+// The workgroup streams the bin in batches of NT records, cut into chunks of <= 8 k-mers that are dealt to
+// all lanes (see "stream the bin" below):
+//   * insert = bucketised linear probing on 32-bit tags (4 per bucket).  A free slot is claimed with
 //     CAS(tag, 0, tag|BUSY); the claimer writes the 64/128-bit key and then stores the final tag
-//     (LDS operations of one wave retire in order, so the key is visible before the tag flips).
+//     (LDS operations of one wave are performed in order, so the key is visible before the tag flips).
 //     A lane that meets its own tag with BUSY set re-reads it; this never deadlocks: a claimer in
 //     another wave progresses independently, and a claimer in the same wave has executed its key/tag
 //     stores before the loop's next iteration starts;
 //   * count += 1, exts |= e, colour mask |= 1 << d with LDS atomics on the slot.
-// A pass whose distinct keys exceed 7/8 of the table raises a flag that every wave polls; the pass is
-// then re-split by hash (work stack below).
+// A pass that runs out of slots (or is more than 7/8 full with batches still to come) is re-split by hash
+// (work stack below).
+// Measured on MI355X (profiles/): per-lane rounds 1.08 per k-mer (5.9 % lost CAS races, 1.4 % next bucket,
+// 1 % BUSY re-reads); the kernel is VALU-bound (~65 % of SIMD cycles) once the probe is kept to one
+// dependent LDS access per branch.
 constexpr uint32_t TAG_BUSY = 0x80000000u;
 
+#ifdef DBG_COUNT_STATS
+#define STAT(i, v) atomicAdd(&s_stat[i], (uint32_t)(v))
+#else
+#define STAT(i, v) do {} while (0)
+#endif
+#ifdef DBG_PHASE_TIMES
+__device__ unsigned long long g_phase_cycles[8];
+#define PH(i) do { if (tid == 0) { unsigned long long now_ = wall_clock64(); atomicAdd(&g_phase_cycles[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
 template <int KW, int NBW, bool IS_SET, int NT, int T>
 __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ seg_off,
                                                        uint32_t n_src, uint64_t seg_stride,
@@ -390,10 +409,17 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     constexpr int RW = NBW + 1;
     constexpr int NWV = NT / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_tag[T];
-    __shared__ uint64_t s_lo[T];
-    __shared__ uint64_t s_hi[KW == 2 ? T : 1];
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[KW * T];   // KW == 2: {lo, hi} pairs, one ds_read_b128 per entry
     __shared__ uint32_t s_cnt[T];
     __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24)
+    constexpr uint32_t CAPC = (NBW == 4 ? 2 : 4) * NT;      // chunk-map capacity per batch
+    __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
+    __shared__ uint16_t s_cmap[CAPC];           // chunk -> record slot | chunk index << 10
+    __shared__ uint32_t s_m, s_cproc;
+#ifdef DBG_COUNT_STATS
+    __shared__ uint32_t s_stat[16];
+    if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
+#endif
     __shared__ uint32_t s_wsum[NWV];
     __shared__ uint32_t s_flag[2];              // [0] table overflow, [1] claimed entries
     __shared__ unsigned long long s_base;
@@ -401,11 +427,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ int s_sp;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
+#ifdef DBG_PHASE_TIMES
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     // The bin's records arrive as n_src segments (one per source rank after the all-to-all; one in the
     // single-GPU case): segment s spans records [seg_off[s*stride + bin], seg_off[s*stride + bin + 1]).
     __shared__ uint64_t s_segbase[65];          // first record of segment s in `recs`
     __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
-    __shared__ uint32_t s_next;                 // next flat record index to hand out
     if (tid == 0) {
         uint32_t acc = 0;
         for (uint32_t sg = 0; sg < n_src; sg++) {
@@ -416,6 +444,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     }
     __syncthreads();
     const uint32_t total_recs = s_segpre[n_src];
+    PH(0);
     if (total_recs == 0) return;
     const K128 kmask = k128_mask(k);
 
@@ -432,43 +461,94 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         __syncthreads();
         if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_next = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
         __syncthreads();
+        PH(1);
 
-        // ---- stream the bin: waves pull groups of 64 consecutive records (flat index over the bin's
-        //      segments) from a shared LDS cursor, one record per lane.  Records of one length class are
-        //      adjacent (sk_scan sub-bins), so the lanes of a group finish at about the same time.  The
-        //      record lives in registers; its k-mers are produced by rolling (extend_right on the forward
-        //      strand, extend_left of the complement on the reverse strand) ----
-        for (;;) {
-            uint32_t g0 = 0;
-            if (lane == 0) g0 = atomicAdd(&s_next, 64u);
-            g0 = __shfl(g0, 0);
-            if (g0 >= total_recs) break;
-            if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-            const uint32_t ridx = g0 + lane;
-            bool alive = ridx < total_recs;
-            uint64_t W[4] = {0, 0, 0, 0};
-            uint64_t meta = 0;
-            if (alive) {
+        // ---- stream the bin, chunk-parallel.  A super-k-mer record holds 1..W k-mers; handing whole records to
+        //      lanes leaves the waves of the workgroup badly balanced (a bin is only ~1.3 records per lane).  So
+        //      the workgroup stages a batch of NT records in LDS, cuts every record into ceil(nk/CH) nearly equal
+        //      chunks (block prefix sum -> chunk map), and deals the chunks round-robin to all NT lanes.  A lane
+        //      re-creates the chunk's first k-mer from the staged record (one funnel shift + one reverse
+        //      complement per chunk) and then rolls (extend_right on the forward strand, extend_left of the
+        //      complement on the reverse strand).  The next batch is prefetched into registers meanwhile. ----
+        constexpr uint32_t CH = 8;
+        // (scalars, not arrays: an indexed private array is placed in scratch memory by the compiler)
+        uint64_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, P0 = 0, P1 = 0, P2 = 0, P3 = 0;
+        uint64_t meta = 0, pmeta = 0;
+        auto base_at = [&](uint32_t q) -> uint32_t {
+            uint64_t wd = q < 32 ? W0 : (q < 64 ? W1 : (NBW > 2 && q < 96 ? W2 : (NBW > 3 ? W3 : (NBW > 2 ? W2 : W1))));
+            return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
+        };
+        auto load_rec = [&](uint32_t ridx) {                         // -> P0..P3, pmeta (zero when past the end)
+            P0 = P1 = P2 = P3 = 0;
+            pmeta = 0;
+            if (ridx < total_recs) {
                 uint32_t sg = 0;
                 while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
                 const uint64_t* g = recs + (s_segbase[sg] + (ridx - s_segpre[sg])) * RW;
-#pragma unroll
-                for (int q = 0; q < NBW; q++) W[q] = g[q];
-                meta = g[NBW];
+                P0 = g[0]; P1 = g[1];
+                if (NBW > 2) P2 = g[2];
+                if (NBW > 3) P3 = g[3];
+                pmeta = g[NBW];
             }
-            const uint32_t rlen = (uint32_t)(meta & 0xff), rexts = (uint32_t)(meta >> 8) & 0xffu, rd = (uint32_t)(meta >> 16);
-            const uint32_t nk = alive ? rlen - (uint32_t)k + 1 : 0u;
-            auto base_at = [&](uint32_t q) -> uint32_t {
-                uint64_t wd = q < 32 ? W[0] : (q < 64 ? W[1] : (NBW > 2 && q < 96 ? W[2] : (NBW > 3 ? W[3] : W[NBW - 1])));
-                return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
-            };
-            K128 fw = k128_shr(K128{W[0], W[1]}, 128 - 2 * k);      // first k-mer (k <= 64 lies in the first two words)
-            K128 rcw = kmer_rc(fw, k);
-            uint32_t lb = 0, j = 0;
-          while (__any(j < nk)) {
-            alive = j < nk;
+        };
+        load_rec(tid);
+        bool pass_ovf = false;
+
+        for (uint32_t bstart = 0; bstart < total_recs && !pass_ovf;) {
+            // A. stage this batch's records (prefetched) + per-record chunking
+            const bool have = bstart + tid < total_recs;
+            uint32_t nkr = have ? (uint32_t)(pmeta & 0xff) - (uint32_t)k + 1u : 0u;
+            const uint32_t nch = (nkr + CH - 1) / CH;
+            const uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;     // chunk c: cb + (c < cr) k-mers
+            s_slab[tid] = P0; s_slab[NT + tid] = P1;
+            if (NBW > 2) s_slab[2 * NT + tid] = P2;
+            if (NBW > 3) s_slab[3 * NT + tid] = P3;
+            s_slab[NBW * NT + tid] = (pmeta & 0xffffffffffffull) | ((uint64_t)cb << 48) | ((uint64_t)cr << 52);
+            if (tid == 0) { s_m = NT; s_cproc = 0; }
+            uint32_t totc;
+            const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &totc);   // barriers inside
+            if (incl <= CAPC) {
+                if (nch) atomicMax(&s_cproc, incl);
+                for (uint32_t c = 0; c < nch; c++) s_cmap[incl - nch + c] = (uint16_t)(tid | (c << 10));
+            } else if (have) atomicMin(&s_m, tid);
+            __syncthreads();
+            const uint32_t nrec = total_recs - bstart < (uint32_t)NT ? total_recs - bstart : (uint32_t)NT;
+            const uint32_t m = s_m < nrec ? s_m : nrec;             // records of this batch whose chunks fit the map (>= 1)
+            const uint32_t cproc = s_cproc;
+            // B. prefetch the next batch while this one is processed
+            load_rec(bstart + m + tid);
+            // C. chunks, round-robin over the whole workgroup
+            for (uint32_t q0 = tid - lane; q0 < cproc; q0 += NT) {
+                const uint32_t q = q0 + lane;
+                const bool act = q < cproc;
+                const uint32_t e = act ? (uint32_t)s_cmap[q] : 0u;
+                const uint32_t r = e & 1023u, c = e >> 10;
+                W0 = s_slab[r]; W1 = s_slab[NT + r];
+                if (NBW > 2) W2 = s_slab[2 * NT + r];
+                if (NBW > 3) W3 = s_slab[3 * NT + r];
+                meta = s_slab[NBW * NT + r];
+                const uint32_t rlen = (uint32_t)(meta & 0xff), rexts = (uint32_t)(meta >> 8) & 0xffu, rd = (uint32_t)(meta >> 16);
+                const uint32_t cbase = (uint32_t)(meta >> 48) & 15u, crem = (uint32_t)(meta >> 52) & 7u;
+                uint32_t j = c * cbase + (c < crem ? c : crem);
+                const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
+                // k-mer j of the record: bases [j, j + k) of the 2-bit stream W[0..NBW)
+                K128 fw;
+                {
+                    const uint32_t sft = 2 * j, ws = sft >> 6, bs = sft & 63;
+                    const uint64_t A = ws == 0 ? W0 : W1, B = ws == 0 ? W1 : (NBW > 2 ? W2 : 0ull),
+                                   C = ws == 0 ? (NBW > 2 ? W2 : 0ull) : (NBW > 3 ? W3 : 0ull);
+                    const uint64_t h = bs ? (A << bs) | (B >> (64 - bs)) : A, l = bs ? (B << bs) | (C >> (64 - bs)) : B;
+                    fw = k128_shr(K128{h, l}, 128 - 2 * k);
+                }
+                K128 rcw = kmer_rc(fw, k);
+                uint32_t lb = j ? base_at(j - 1) : 0u;
+                while (__any(j < jend)) {
+                    const bool alive = j < jend;
+#ifdef DBG_COUNT_STATS
+            { uint64_t bal = __ballot(alive); if (lane == 0) { atomicAdd(&s_stat[4], 1u); atomicAdd(&s_stat[5], (uint32_t)__popcll(bal)); } }
+#endif
             if (alive) {
                 const uint32_t nbase = (j + (uint32_t)k < rlen) ? base_at(j + k) : 0u;   // base right of the k-mer
                 {
@@ -480,57 +560,64 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = exts_rc(ex); }   // ties flip (lib.rs:226-230)
                     const uint64_t h = hash_key(km.hi, km.lo);
                     if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
-                        // Bucketised linear probing: 4 tags per 16-byte bucket, one ds_read_b128 per bucket.
-                        // A key lives in the first bucket (in probe order) that had a free slot when it was
-                        // inserted; a failed CAS re-reads the bucket, so two lanes can never claim two slots
-                        // for one key.
+                        // Bucketised linear probing: 4 tags per 16-byte bucket.  One round = one ds_read_b128 of the
+                        // bucket's tags, then at most one dependent LDS operation per lane: the 16-byte key of the one
+                        // candidate slot whose tag matches, or a CAS on the first free slot.  (Divergent branches run
+                        // one after the other, so every extra dependent LDS access inside a branch costs the whole
+                        // wave a round trip; the candidate is therefore chosen with compares and selects only.)
+                        // A key lives in the first bucket (in probe order) that had a free slot when it was inserted;
+                        // a failed CAS re-reads the bucket, so two lanes can never claim two slots for one key.
                         const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
                         uint32_t bkt = (uint32_t)h & (T / 4 - 1);
-                        uint32_t slot = 0;
+                        uint32_t slot = 0, tried = 0, nprobe = 0;
                         bool hit = false;
-                        for (uint32_t left_probes = T / 4; left_probes && !hit;) {
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        for (;;) {
+                            asm volatile("" ::: "memory");                           // re-read the tags every round
                             const uint4 t4 = *reinterpret_cast<const uint4*>(&s_tag[bkt * 4]);
-                            const uint32_t tt[4] = {t4.x, t4.y, t4.z, t4.w};
-                            bool busy = false;
-                            int empty = -1;
-#pragma unroll
-                            for (int i = 3; i >= 0; i--) {
-                                if (tt[i] == 0) empty = i;
-                                if ((tt[i] & ~TAG_BUSY) == mytag) { if (tt[i] & TAG_BUSY) busy = true; }
+                            const uint32_t mm = ((t4.x == mytag ? 1u : 0u) | (t4.y == mytag ? 2u : 0u) | (t4.z == mytag ? 4u : 0u) |
+                                                 (t4.w == mytag ? 8u : 0u)) & ~tried;
+                            const uint32_t bz = mytag | TAG_BUSY;
+                            const bool busy = t4.x == bz || t4.y == bz || t4.z == bz || t4.w == bz;
+                            const uint32_t em = (t4.x == 0u ? 1u : 0u) | (t4.y == 0u ? 2u : 0u) | (t4.z == 0u ? 4u : 0u) | (t4.w == 0u ? 8u : 0u);
+                            STAT(6, 1);
+                            if (mm) {                                                // ready entry with my tag: verify the key
+                                const uint32_t i = (uint32_t)__ffs((int)mm) - 1u, sl = bkt * 4 + i;
+                                bool same;
+                                if (KW == 2) {
+                                    const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s_key[2 * sl]);
+                                    same = kk.x == km.lo && kk.y == km.hi;
+                                } else same = s_key[sl] == km.lo;
+                                if (same) { hit = true; slot = sl; break; }
+                                tried |= 1u << i;                                    // a different key with the same 31-bit tag
+                                STAT(8, 1);
+                                continue;
                             }
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                if (!hit && tt[i] == mytag) {                        // ready entry with my tag: verify the key
-                                    bool same = s_lo[bkt * 4 + i] == km.lo;
-                                    if (KW == 2) same = same && s_hi[bkt * 4 + i] == km.hi;
-                                    if (same) { hit = true; slot = bkt * 4 + i; }
-                                }
-                            }
-                            if (hit) break;
-                            if (busy) continue;                                      // a claimer is still writing its key: re-read
-                            if (empty >= 0) {
-                                if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // pass already overflowed
-                                const uint32_t sl = bkt * 4 + (uint32_t)empty;
-                                if (atomicCAS(&s_tag[sl], 0u, mytag | TAG_BUSY) == 0u) {
-                                    s_lo[sl] = km.lo;
-                                    if (KW == 2) s_hi[sl] = km.hi;
-                                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            if (busy) { STAT(9, 1); continue; }                      // a claimer is still writing its key: re-read
+                            if (em) {
+                                const uint32_t sl = bkt * 4 + (uint32_t)__ffs((int)em) - 1u;
+                                if (atomicCAS(&s_tag[sl], 0u, bz) == 0u) {
+                                    if (KW == 2) *reinterpret_cast<ulonglong2*>(&s_key[2 * sl]) = make_ulonglong2(km.lo, km.hi);
+                                    else s_key[sl] = km.lo;
+                                    asm volatile("" ::: "memory");                   // the key store is issued before the tag store
                                     __hip_atomic_store(&s_tag[sl], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (atomicAdd(&s_flag[1], 1u) + 1u > (uint32_t)(T - T / 8))
-                                        __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    atomicAdd(&s_flag[1], 1u);                       // occupancy, polled between batches
                                     hit = true; slot = sl;
+                                    STAT(11, 1);
+                                    break;
                                 }
+                                STAT(10, 1);
                                 continue;                                            // lost the race: re-read this bucket
                             }
                             bkt = (bkt + 1) & (T / 4 - 1);
-                            left_probes--;
+                            tried = 0;
+                            STAT(7, 1);
+                            if (++nprobe >= (uint32_t)(T / 4)) break;                // table full
                         }
                         if (hit) {
                             atomicAdd(&s_cnt[slot], 1u);
                             atomicOr(&s_aux[slot], IS_SET ? (ex | (256u << (rd & 31u))) : ex);
                         } else {
-                            __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full / pass overflowed
+                            __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full: the pass is re-split
                         }
                     }
                 }
@@ -550,9 +637,20 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 }
                 j++;
             }
-          }
+                }   // rolling loop
+            }       // chunk loop
+            PH(2);
+            __syncthreads();
+            PH(3);
+            bstart += m;
+            // a table more than 7/8 full makes the remaining batches probe long chains: give up early and re-split the pass
+            if (bstart < total_recs && tid == 0 && s_flag[1] > (uint32_t)(T - T / 8)) s_flag[0] = 1;
+            if (bstart < total_recs) __syncthreads();
+            pass_ovf = __hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
         }
+                 // wave 0's own streaming time
         __syncthreads();
+        PH(3);                 // waiting for the slowest wave
         const bool ovf = s_flag[0] != 0;
         // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
         if (!ovf) {
@@ -565,8 +663,10 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             }
             uint32_t tot_valid;
             uint32_t incl = block_inclusive_scan<NT>(nvalid, s_wsum, &tot_valid);
+            PH(4);
             if (tid == 0) s_base = tot_valid ? atomicAdd(out_cursor, (unsigned long long)tot_valid) : 0ull;
             __syncthreads();
+            PH(5);
             uint64_t o = s_base + (incl - nvalid);
             if (tot_valid && s_base + tot_valid > out_cap) {
                 if (tid == 0) atomicOr(&gflags[0], 1u);                    // output buffer too small: host retries
@@ -577,8 +677,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     uint32_t c16 = c > 65535u ? 65535u : c;
                     bool valid = IS_SET ? (uint64_t)c >= min_obs : (uint64_t)c16 >= min_obs;
                     if (!valid) continue;
-                    if (KW == 2) out.hi[o] = s_hi[i];
-                    out.lo[o] = s_lo[i];
+                    if (KW == 2) { out.hi[o] = s_key[2 * i + 1]; out.lo[o] = s_key[2 * i]; }
+                    else out.lo[o] = s_key[i];
                     out.pay[o] = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
                     o++;
                 }
@@ -588,7 +688,12 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (tid == 0) { s_stP[sp - 1] = 2 * P; s_stR[sp - 1] = pr; s_stP[sp] = 2 * P; s_stR[sp] = pr + P; s_sp = sp + 1; }
         }
         __syncthreads();
+        PH(6);
     }
+#ifdef DBG_COUNT_STATS
+    __syncthreads();
+    if (threadIdx.x >= 4 && threadIdx.x < 16 && s_stat[threadIdx.x]) atomicAdd(&gflags[threadIdx.x], s_stat[threadIdx.x]);
+#endif
 }
 
 // CSR helper for the order-restoring stage
@@ -764,7 +869,7 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     DBuf<unsigned long long> out_cursor;
     DBuf<uint32_t> gflags;
     ALLOC_OR_FAIL(c, out_cursor, 1);
-    ALLOC_OR_FAIL(c, gflags, 4);
+    ALLOC_OR_FAIL(c, gflags, 16);
     uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1);
     DBuf<uint64_t> u_hi, u_lo;
     DBuf<uint32_t> u_pay;
@@ -775,33 +880,54 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
         ALLOC_OR_FAIL(c, u_lo, cap);
         ALLOC_OR_FAIL(c, u_pay, cap);
         HIP_TRY(c, hipMemsetAsync(out_cursor.p, 0, 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(gflags.p, 0, 16, c->stream));
+        HIP_TRY(c, hipMemsetAsync(gflags.p, 0, 64, c->stream));
         FastOut fo{u_hi.p, u_lo.p, u_pay.p};
         if (nbins_local) {
             c->t_begin("bin_count", n_kmers_hint);
             static const int nt_env = getenv("DBG_FAST_NT") ? atoi(getenv("DBG_FAST_NT")) : 512;
-#define GO(KW, NBW, SET) do { if (nt_env == 1024) bin_count_kernel<KW, NBW, SET, 1024, TABLE><<<nbins_local, 1024, 0, c->stream>>>( \
-            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p); \
-            else if (nt_env == 256) bin_count_kernel<KW, NBW, SET, 256, TABLE><<<nbins_local, 256, 0, c->stream>>>( \
-            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p); \
-            else bin_count_kernel<KW, NBW, SET, 512, TABLE><<<nbins_local, 512, 0, c->stream>>>( \
-            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p); } while (0)
+            static const int tb_env = getenv("DBG_FAST_TABLE") ? atoi(getenv("DBG_FAST_TABLE")) : 2048;
+#define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, 0, c->stream>>>( \
+            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p)
+#define GO(KW, NBW, SET) do { \
+            if (tb_env == 512 && nt_env == 128) L(KW, NBW, SET, 128, 512); \
+            else if (tb_env == 512) L(KW, NBW, SET, 256, 512); \
+            else if (tb_env == 1024 && nt_env == 128) L(KW, NBW, SET, 128, 1024); \
+            else if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
+            else if (tb_env == 1024) L(KW, NBW, SET, 512, 1024); \
+            else if (nt_env == 1024) L(KW, NBW, SET, 1024, TABLE); \
+            else if (nt_env == 256) L(KW, NBW, SET, 256, TABLE); \
+            else L(KW, NBW, SET, 512, TABLE); } while (0)
             if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
             else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
             else if (nbw == 3) { if (is_set) GO(2, 3, true); else GO(2, 3, false); }
             else { if (is_set) GO(2, 4, true); else GO(2, 4, false); }
 #undef GO
+#undef L
             c->t_end();
             LAUNCH_CHECK(c, "bin_count");
         }
         unsigned long long cur = 0;
-        uint32_t flv[4] = {0, 0, 0, 0};
+        uint32_t flv[16] = {0};
         HIP_TRY(c, hipMemcpyAsync(&cur, out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(flv, gflags.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(flv, gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint32_t fl = flv[0];
         if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u wd=%u\n",
                                          nbins_local, n_src, (unsigned long long)n_recs_hint, cur, fl, flv[1], flv[2], flv[3]);
+#ifdef DBG_PHASE_TIMES
+        if (getenv("DBG_DEBUG")) {
+            unsigned long long ph[8];
+            (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_cycles), sizeof(ph));
+            fprintf(stderr, "[fastpath-phases] (100MHz ticks, summed over bins) prologue=%llu clear=%llu stream(w0)=%llu wait=%llu scan=%llu cursor=%llu write=%llu\n",
+                    ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+            unsigned long long z[8] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z));
+        }
+#endif
+#ifdef DBG_COUNT_STATS
+        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath-stats] wave-iterations=%u active lanes=%u (%.1f/64); lane-rounds=%u next-bucket=%u tag-collision=%u busy=%u cas-lost=%u inserts=%u\n",
+                                         flv[4], flv[5], flv[4] ? (double)flv[5] / flv[4] : 0.0, flv[6], flv[7], flv[8], flv[9], flv[10], flv[11]);
+#endif
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (fl & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
         if (fl & 1u) {

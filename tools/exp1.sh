@@ -1,0 +1,3 @@
+#!/bin/bash
+B="timeout 120 python bench.py --reads 2000000 --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0"
+DBG_DEBUG=1 $B 2>&1 | grep "fastpath\|bin_count" | cut -c1-400
