@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                                                       uint32_t* __restrict__ flags) {
     constexpr int RW = NBW + 1;
     __shared__ uint64_t s_arr[4][SCAN_ARR];
-    __shared__ uint32_t s_pl[4][3 * 132];        // per-wave piece list: start window, end window, minimizer position
+    constexpr uint32_t PLC = 256;                // per-wave ring of pending pieces (start window, end window, minimizer position, read)
+    __shared__ uint32_t s_pl[4][4 * PLC];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t* A = s_arr[wave];
     uint32_t* PL = s_pl[wave];
@@ -137,6 +138,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
     const uint64_t lt = lanemask_lt();
     uint64_t chunk_base = 0;                        // wave-uniform sub-allocator over reserved chunks
     uint32_t chunk_used = SCAN_CHUNK;
+    uint32_t pl_head = 0, pl_n = 0;                 // pending pieces (wave-uniform)
 
     // 64 reads per wave iteration: their metadata arrives in three coalesced loads and is broadcast
     // lane by lane, so the per-read critical path holds a single HBM round trip (the packed words).
@@ -150,12 +152,62 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
           if (s.data) v_d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[my] : (s.data_width == 2 ? ((const uint16_t*)s.data)[my] : ((const uint32_t*)s.data)[my]);
       }
       const uint32_t nb_reads = (uint32_t)(s.n - rb < 64 ? s.n - rb : 64);
+      // Record building is long; it runs on full wavefronts: pieces of successive reads wait in the ring and
+      // are turned into records 64 at a time (the read's metadata is fetched back from the owning lane).
+      auto flush = [&](uint32_t cnt) {
+          if (chunk_used + cnt > SCAN_CHUNK) {
+              unsigned long long nb = 0;
+              if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
+              chunk_base = __shfl(nb, 0);
+              chunk_used = 0;
+          }
+          const uint64_t idx = chunk_base + chunk_used + lane;
+          chunk_used += cnt;
+          const uint32_t q = (pl_head + lane) & (PLC - 1);
+          const bool act = lane < cnt;
+          const uint32_t ps = PL[q], pe = PL[PLC + q], pa = PL[2 * PLC + q], pr = act ? PL[3 * PLC + q] : 0u;
+          const uint32_t m = __shfl(v_m, pr);
+          const uint64_t st = __shfl(v_st, pr);
+          const uint32_t sexts = __shfl(v_ex, pr), d1 = __shfl(v_d1, pr);
+          pl_head = (pl_head + cnt) & (PLC - 1);
+          pl_n -= cnt;
+          if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); return; }
+          if (!act) return;
+          const uint32_t nwin = m - (uint32_t)k + 1;
+          const uint64_t w_first = st >> 5;
+          const uint64_t* __restrict__ wr = w + w_first;
+          const uint32_t sb = (uint32_t)(st & 31);
+          const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
+          uint32_t pm = rel_pmer(wr, sb + pa, last_rel, p);
+          uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
+          uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
+          uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
+          atomicAdd(&hist[b], 1u);
+          uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
+          uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
+          uint64_t* o = tmp_recs + idx * RW;
+          uint64_t rv[RW];
+#pragma unroll
+          for (int qq = 0; qq < NBW; qq++) {
+              const uint32_t b0 = (uint32_t)qq * 32;
+              const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
+              const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
+              rv[qq] = nb ? v : 0ull;
+          }
+          rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
+          if (RW % 2 == 0) {
+#pragma unroll
+              for (int qq = 0; qq < RW / 2; qq++) ((ulonglong2*)o)[qq] = make_ulonglong2(rv[2 * qq], rv[2 * qq + 1]);
+          } else {
+#pragma unroll
+              for (int qq = 0; qq < RW; qq++) o[qq] = rv[qq];
+          }
+          tmp_bin[idx] = b;
+      };
       for (uint32_t rj = 0; rj < nb_reads; rj++) {
         const uint32_t m = __shfl(v_m, rj);
         if (m < (uint32_t)k) continue;
         const uint64_t st = __shfl(v_st, rj);
-        const uint32_t sexts = __shfl(v_ex, rj);
-        const uint32_t d1 = __shfl(v_d1, rj);
         const uint32_t nwin = m - (uint32_t)k + 1, npos = m - (uint32_t)p + 1;
         const uint64_t w_first = st >> 5;                                      // word holding the read's first base
         const uint64_t* __restrict__ wr = w + w_first;
@@ -242,59 +294,23 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                     if (below) ps = t0 + slot * 64 + (63 - __clzll(below));
                     else if (slot == 1 && mask[0]) ps = t0 + (63 - __clzll(mask[0]));
                     else ps = open_start;
-                    const uint32_t q = npieces + __popcll(em & lt);
-                    PL[q] = ps; PL[132 + q] = i; PL[264 + q] = prev[slot];
+                    const uint32_t q = (pl_head + pl_n + npieces + __popcll(em & lt)) & (PLC - 1);
+                    PL[q] = ps; PL[PLC + q] = i; PL[2 * PLC + q] = prev[slot]; PL[3 * PLC + q] = rj;
                 }
                 npieces += __popcll(em);
             }
             if (read_ends) {
-                if (lane == 0) { PL[npieces] = new_open; PL[132 + npieces] = nwin; PL[264 + npieces] = last_arg; }
+                const uint32_t q = (pl_head + pl_n + npieces) & (PLC - 1);
+                if (lane == 0) { PL[q] = new_open; PL[PLC + q] = nwin; PL[2 * PLC + q] = last_arg; PL[3 * PLC + q] = rj; }
                 npieces++;
             }
-            if (npieces) {
-                if (chunk_used + npieces > SCAN_CHUNK) {
-                    unsigned long long nb = 0;
-                    if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
-                    chunk_base = __shfl(nb, 0);
-                    chunk_used = 0;
-                }
-                const uint64_t idx0 = chunk_base + chunk_used;
-                chunk_used += npieces;
-                if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); }
-                else for (uint32_t t = lane; t < npieces; t += 64) {
-                    const uint32_t ps = PL[t], pe = PL[132 + t], pa = PL[264 + t];
-                    const uint64_t idx = idx0 + t;
-                    uint32_t pm = rel_pmer(wr, sb + pa, last_rel, p);
-                    uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
-                    uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
-                    uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
-                    atomicAdd(&hist[b], 1u);
-                    uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
-                    uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
-                    uint64_t* o = tmp_recs + idx * RW;
-                    uint64_t rv[RW];
-#pragma unroll
-                    for (int q = 0; q < NBW; q++) {
-                        const uint32_t b0 = (uint32_t)q * 32;
-                        const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
-                        const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
-                        rv[q] = nb ? v : 0ull;
-                    }
-                    rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
-                    if (RW % 2 == 0) {
-#pragma unroll
-                        for (int q = 0; q < RW / 2; q++) ((ulonglong2*)o)[q] = make_ulonglong2(rv[2 * q], rv[2 * q + 1]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < RW; q++) o[q] = rv[q];
-                    }
-                    tmp_bin[idx] = b;
-                }
-            }
+            pl_n += npieces;
+            while (pl_n >= 64) { flush(64u); }
             open_start = new_open;
             carry_arg = last_arg;
         }
       }
+      if (pl_n) flush(pl_n);                        // the lanes' read metadata changes with the next batch
     }
 }
 
