@@ -121,13 +121,13 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                                                       unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
                                                       uint32_t* __restrict__ flags) {
     constexpr int RW = NBW + 1;
-    __shared__ uint64_t s_arr[4][SCAN_ARR];
+    __shared__ uint32_t s_arr[4][SCAN_ARR];      // (hash's top 24 bits << 8) | tile-local position: min() is the leftmost argmin
     constexpr uint32_t PLC = 256;                // per-wave ring of pending pieces (start window, end window, minimizer position, read)
     __shared__ uint32_t s_pl[4][4 * PLC];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t* A = s_arr[wave];
+    uint32_t* A = s_arr[wave];
     uint32_t* PL = s_pl[wave];
-    A[192 + lane] = ~0ull;
+    A[192 + lane] = ~0u;
     const int k = c.k, p = c.p;
     const uint32_t W = (uint32_t)(k - p + 1);
     const uint64_t* __restrict__ w = s.words;
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
         for (uint32_t t0 = 0; t0 < nwin; t0 += SCAN_TILE_W) {
             // ---- hashed p-mers of this tile: all six word loads are issued before any is consumed
             //      (indices clamped to the buffer, results of out-of-range lanes are discarded) ----
-            uint32_t oh[3], op[3];                  // hash and position of the running window minimum
+            uint32_t ov[3];                         // running window minimum, packed
             {
                 uint64_t l0[3], l1[3];
                 uint32_t sh[3];
@@ -235,30 +235,29 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                 for (int ch = 0; ch < 3; ch++) {
                     const uint32_t pos = t0 + ch * 64 + lane;
                     const uint32_t pm = pmer_from_words(l0[ch], l1[ch], sh[ch], p);
-                    oh[ch] = pos < npos ? sc(pm) : 0xffffffffu;
-                    op[ch] = pos;
-                    A[ch * 64 + lane] = ((uint64_t)oh[ch] << 32) | pos;
+                    // ordering key: top 24 bits of the bijective hash, then the position (leftmost wins ties --
+                    // also ties between different p-mers, which is still a function of the window alone)
+                    ov[ch] = pos < npos ? (((sc(pm) << (32 - 2 * p)) & 0xffffff00u) | (uint32_t)(ch * 64 + lane)) : 0xffffffffu;
+                    A[ch * 64 + lane] = ov[ch];
                 }
             }
-            // ---- log-step sliding minimum: after the loop (oh, op) covers [i, i + span).  The right operand
-            //      holds positions further right, so a strict 32-bit compare keeps the leftmost on ties ----
+            // ---- log-step sliding minimum: after the loop ov covers [i, i + span) ----
             uint32_t span = 1;
             for (; 2 * span <= W; span <<= 1) {
-                const uint64_t x0 = A[lane + span], x1 = A[64 + lane + span], x2 = A[128 + lane + span];
-                const uint32_t xh0 = (uint32_t)(x0 >> 32), xh1 = (uint32_t)(x1 >> 32), xh2 = (uint32_t)(x2 >> 32);
-                if (xh0 < oh[0]) { oh[0] = xh0; op[0] = (uint32_t)x0; }
-                if (xh1 < oh[1]) { oh[1] = xh1; op[1] = (uint32_t)x1; }
-                if (xh2 < oh[2]) { oh[2] = xh2; op[2] = (uint32_t)x2; }
-                A[lane] = ((uint64_t)oh[0] << 32) | op[0];
-                A[64 + lane] = ((uint64_t)oh[1] << 32) | op[1];
-                A[128 + lane] = ((uint64_t)oh[2] << 32) | op[2];
+                const uint32_t x0 = A[lane + span], x1 = A[64 + lane + span], x2 = A[128 + lane + span];
+                ov[0] = x0 < ov[0] ? x0 : ov[0];
+                ov[1] = x1 < ov[1] ? x1 : ov[1];
+                ov[2] = x2 < ov[2] ? x2 : ov[2];
+                A[lane] = ov[0];
+                A[64 + lane] = ov[1];
+                A[128 + lane] = ov[2];
             }
             const uint32_t rem = W - span;
             uint32_t arg[2];
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
-                const uint64_t y = A[ch * 64 + lane + rem];
-                arg[ch] = (uint32_t)(y >> 32) < oh[ch] ? (uint32_t)y : op[ch];   // position of the window minimizer
+                const uint32_t y = A[ch * 64 + lane + rem];
+                arg[ch] = t0 + ((y < ov[ch] ? y : ov[ch]) & 0xffu);              // position of the window minimizer
             }
             // ---- piece boundaries ----
             uint32_t up0 = __shfl_up(arg[0], 1), up1 = __shfl_up(arg[1], 1);
