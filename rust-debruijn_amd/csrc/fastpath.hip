@@ -92,9 +92,10 @@ struct FastScore {
         return mix_pmer(pm, p);
     }
 };
-__device__ __forceinline__ uint32_t bin_of(const FastCfg& c, uint32_t pm) {
-    if (!c.stranded) { uint32_t r = pmer_rc32(pm, c.p); pm = pm < r ? pm : r; }
-    uint32_t h = pm * 0xC2B2AE35u + 0x27D4EB2Fu;
+// bin of a super-k-mer from its minimizer's ordering hash (a bijection of the canonical p-mer).  Minimizer hashes
+// crowd towards small values, so the bin index comes from a second, unrelated mix of that value.
+__device__ __forceinline__ uint32_t bin_of_hash(const FastCfg& c, uint32_t mh) {
+    uint32_t h = mh * 0xC2B2AE35u + 0x27D4EB2Fu;
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
     return (uint32_t)(((uint64_t)h * c.nbins) >> 32);
 }
@@ -112,14 +113,17 @@ constexpr int SCAN_TILE_W = 128;                // window starts per tile
 constexpr int SCAN_ARR = 192 + 64;              // positions per tile + padding for the shifted reads
 constexpr uint32_t SCAN_CHUNK = 1024;           // records a wave reserves per global atomic (one hot address otherwise)
 constexpr uint32_t BIN_INVALID = 0xffffffffu;   // unused slot of a reserved chunk
-constexpr uint32_t NCLS = 4;                    // length classes per bin: records of similar k-mer count sit together
+constexpr uint32_t NCLS = 1;                    // length classes per bin: records of similar k-mer count sit together
                                                 // so that the 64 records a wave processes finish at about the same time
 
-template <int NBW>
+// DIRECT: a record goes straight to slot atomicAdd(cursor[bin]) of its bin's fixed-capacity slab (slab_cap records per
+// bin); only the records of bins that outgrow their slab take the read-order temporary buffer and the scatter kernel.
+template <int NBW, bool DIRECT>
 __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
                                                       uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
                                                       unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
-                                                      uint32_t* __restrict__ flags) {
+                                                      uint32_t* __restrict__ flags, uint64_t* __restrict__ slab,
+                                                      uint32_t slab_cap, uint32_t* __restrict__ cursor) {
     constexpr int RW = NBW + 1;
     __shared__ uint32_t s_arr[4][SCAN_ARR];      // (hash's top 24 bits << 8) | tile-local position: min() is the leftmost argmin
     constexpr uint32_t PLC = 256;                // per-wave ring of pending pieces (start window, end window, minimizer position, read)
@@ -155,14 +159,6 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
       // Record building is long; it runs on full wavefronts: pieces of successive reads wait in the ring and
       // are turned into records 64 at a time (the read's metadata is fetched back from the owning lane).
       auto flush = [&](uint32_t cnt) {
-          if (chunk_used + cnt > SCAN_CHUNK) {
-              unsigned long long nb = 0;
-              if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
-              chunk_base = __shfl(nb, 0);
-              chunk_used = 0;
-          }
-          const uint64_t idx = chunk_base + chunk_used + lane;
-          chunk_used += cnt;
           const uint32_t q = (pl_head + lane) & (PLC - 1);
           const bool act = lane < cnt;
           const uint32_t ps = PL[q], pe = PL[PLC + q], pa = PL[2 * PLC + q], pr = act ? PL[3 * PLC + q] : 0u;
@@ -171,38 +167,63 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
           const uint32_t sexts = __shfl(v_ex, pr), d1 = __shfl(v_d1, pr);
           pl_head = (pl_head + cnt) & (PLC - 1);
           pl_n -= cnt;
-          if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); return; }
-          if (!act) return;
-          const uint32_t nwin = m - (uint32_t)k + 1;
-          const uint64_t w_first = st >> 5;
-          const uint64_t* __restrict__ wr = w + w_first;
-          const uint32_t sb = (uint32_t)(st & 31);
-          const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
-          uint32_t pm = rel_pmer(wr, sb + pa, last_rel, p);
-          uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
-          uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
-          uint32_t b = bin_of(c, pm) * NCLS + (cls < NCLS ? cls : NCLS - 1);
-          atomicAdd(&hist[b], 1u);
-          uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
-          uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
-          uint64_t* o = tmp_recs + idx * RW;
+          uint32_t b = 0;
           uint64_t rv[RW];
 #pragma unroll
-          for (int qq = 0; qq < NBW; qq++) {
-              const uint32_t b0 = (uint32_t)qq * 32;
-              const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
-              const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
-              rv[qq] = nb ? v : 0ull;
-          }
-          rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
-          if (RW % 2 == 0) {
+          for (int qq = 0; qq < RW; qq++) rv[qq] = 0;
+          if (act) {
+              const uint32_t nwin = m - (uint32_t)k + 1;
+              const uint64_t w_first = st >> 5;
+              const uint64_t* __restrict__ wr = w + w_first;
+              const uint32_t sb = (uint32_t)(st & 31);
+              const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
+              const uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
+              const uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
+              b = bin_of_hash(c, pa) * NCLS + (cls < NCLS ? cls : NCLS - 1);
+              const uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
+              const uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
 #pragma unroll
-              for (int qq = 0; qq < RW / 2; qq++) ((ulonglong2*)o)[qq] = make_ulonglong2(rv[2 * qq], rv[2 * qq + 1]);
-          } else {
-#pragma unroll
-              for (int qq = 0; qq < RW; qq++) o[qq] = rv[qq];
+              for (int qq = 0; qq < NBW; qq++) {
+                  const uint32_t b0 = (uint32_t)qq * 32;
+                  const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
+                  const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
+                  rv[qq] = nb ? v : 0ull;
+              }
+              rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
           }
-          tmp_bin[idx] = b;
+          auto store_rec = [&](uint64_t* o) {
+              if (RW % 2 == 0) {
+#pragma unroll
+                  for (int qq = 0; qq < RW / 2; qq++) ((ulonglong2*)o)[qq] = make_ulonglong2(rv[2 * qq], rv[2 * qq + 1]);
+              } else {
+#pragma unroll
+                  for (int qq = 0; qq < RW; qq++) o[qq] = rv[qq];
+              }
+          };
+          bool to_tmp = act;                        // lanes whose record goes to the read-order buffer
+          if (DIRECT) {
+              uint32_t r = 0;
+              if (act) r = atomicAdd(&cursor[b], 1u);
+              to_tmp = act && r >= slab_cap;
+              if (act && !to_tmp) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
+          }
+          const uint64_t tm = __ballot(to_tmp);
+          if (!tm) return;
+          const uint32_t nt = (uint32_t)__popcll(tm);
+          if (chunk_used + nt > SCAN_CHUNK) {
+              unsigned long long nb = 0;
+              if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
+              chunk_base = __shfl(nb, 0);
+              chunk_used = 0;
+          }
+          const uint64_t idx = chunk_base + chunk_used + (uint32_t)__popcll(tm & lt);
+          chunk_used += nt;
+          if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); return; }
+          if (to_tmp) {
+              atomicAdd(&hist[b], 1u);
+              store_rec(tmp_recs + idx * RW);
+              tmp_bin[idx] = b;
+          }
       };
       for (uint32_t rj = 0; rj < nb_reads; rj++) {
         const uint32_t m = __shfl(v_m, rj);
@@ -214,7 +235,8 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
         const uint32_t sb = (uint32_t)(st & 31);                               // its position inside that word
         const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
         uint32_t open_start = 0;            // start window of the piece still open (wave-uniform)
-        uint32_t carry_arg = 0xffffffffu;   // argmin position of the last window of the previous tile
+        uint32_t open_vstart = 0;           // start window of the run of equal minimizer values still open
+        uint32_t carry_arg = 0xffffffffu;   // minimizer hash of the last window of the previous tile
 
         for (uint32_t t0 = 0; t0 < nwin; t0 += SCAN_TILE_W) {
             // ---- hashed p-mers of this tile: all six word loads are issued before any is consumed
@@ -235,9 +257,9 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                 for (int ch = 0; ch < 3; ch++) {
                     const uint32_t pos = t0 + ch * 64 + lane;
                     const uint32_t pm = pmer_from_words(l0[ch], l1[ch], sh[ch], p);
-                    // ordering key: top 24 bits of the bijective hash, then the position (leftmost wins ties --
-                    // also ties between different p-mers, which is still a function of the window alone)
-                    ov[ch] = pos < npos ? (((sc(pm) << (32 - 2 * p)) & 0xffffff00u) | (uint32_t)(ch * 64 + lane)) : 0xffffffffu;
+                    // ordering key = bijective hash of the canonical p-mer (< 2^30): equal keys are equal p-mers, so the
+                    // window minimum VALUE -- all that is kept -- is the same on both strands and in every read
+                    ov[ch] = pos < npos ? sc(pm) : 0xffffffffu;
                     A[ch * 64 + lane] = ov[ch];
                 }
             }
@@ -257,12 +279,14 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 const uint32_t y = A[ch * 64 + lane + rem];
-                arg[ch] = t0 + ((y < ov[ch] ? y : ov[ch]) & 0xffu);              // position of the window minimizer
+                arg[ch] = y < ov[ch] ? y : ov[ch];                               // hash of the window's minimizer
             }
             // ---- piece boundaries ----
             uint32_t up0 = __shfl_up(arg[0], 1), up1 = __shfl_up(arg[1], 1);
             uint32_t last0 = __shfl(arg[0], 63);
             uint32_t prev[2] = {lane ? up0 : carry_arg, lane ? up1 : last0};
+            // A piece = maximal run of windows with the same minimizer value, cut every W windows (a record holds
+            // at most W k-mers; only repeats -- the same p-mer again within a window length -- run longer).
             bool isb[2];
             uint64_t mask[2];
 #pragma unroll
@@ -271,6 +295,25 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                 isb[ch] = i < nwin && (i == 0 || arg[ch] != prev[ch]);
                 mask[ch] = __ballot(isb[ch]);
             }
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                const uint32_t i = t0 + ch * 64 + lane;
+                const uint64_t le = mask[ch] & (lt | (1ull << lane));               // value boundaries at or before this lane
+                uint32_t vs;                                                       // start of the run this window is in
+                if (le) vs = t0 + ch * 64 + (63 - __clzll(le));
+                else if (ch == 1 && mask[0]) vs = t0 + (63 - __clzll(mask[0]));
+                else vs = open_vstart;
+                const uint32_t d = i - vs;
+                if (i < nwin && d >= W && d % W == 0) isb[ch] = true;
+            }
+            {   // the next tile needs the start of the run that is open at the end of this one
+                uint32_t nv = open_vstart;
+                if (mask[1]) nv = t0 + 64 + (63 - __clzll(mask[1]));
+                else if (mask[0]) nv = t0 + (63 - __clzll(mask[0]));
+                open_vstart = nv;
+            }
+            mask[0] = __ballot(isb[0]);
+            mask[1] = __ballot(isb[1]);
             const uint32_t tile_last = (nwin - t0 < (uint32_t)SCAN_TILE_W ? nwin - t0 : (uint32_t)SCAN_TILE_W) - 1;
             const uint32_t last_arg = tile_last < 64 ? __shfl(arg[0], tile_last) : __shfl(arg[1], tile_last - 64);
             const bool read_ends = t0 + SCAN_TILE_W >= nwin;
@@ -353,8 +396,9 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 // round-trip latency at 4 waves/SIMD, and weaker mixing costs extra probes.)
 __device__ __forceinline__ uint64_t hash_key(uint64_t hi, uint64_t lo) {
 #ifdef DBG_HASH_CHEAP
-    uint64_t h = (lo ^ ((hi << 23) | (hi >> 41))) * 0xD6E8FEB86659FD93ull;
-    h ^= h >> 29;
+    uint64_t h = lo ^ (hi * 0x9E3779B97F4A7C15ull);
+    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 32;
     return h;
 #else
     uint64_t h = lo ^ (hi * 0x9E3779B97F4A7C15ull);
@@ -417,7 +461,8 @@ __device__ unsigned long long g_phase_cycles[8];
 #define PH(i) do {} while (0)
 #endif
 template <int KW, int NBW, bool IS_SET, int NT, int T>
-__global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ seg_off,
+__global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
+                                                       const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
                                                        unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags) {
@@ -445,14 +490,15 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
 #ifdef DBG_PHASE_TIMES
     unsigned long long t_prev_ = wall_clock64();
 #endif
-    // The bin's records arrive as n_src segments (one per source rank after the all-to-all; one in the
-    // single-GPU case): segment s spans records [seg_off[s*stride + bin], seg_off[s*stride + bin + 1]).
+    // The bin's records arrive as n_src segments (one per source rank after the all-to-all; the bin's slab plus
+    // its overflow in the single-GPU case): segment s spans records [seg_beg[s*stride + bin], seg_end[s*stride + bin])
+    // of `recs` (of `recs_alt` for s >= alt_from).
     __shared__ uint64_t s_segbase[65];          // first record of segment s in `recs`
     __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
     if (tid == 0) {
         uint32_t acc = 0;
         for (uint32_t sg = 0; sg < n_src; sg++) {
-            uint64_t a = seg_off[sg * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_off[sg * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS];
+            uint64_t a = seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[sg * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
             s_segbase[sg] = a; s_segpre[sg] = acc; acc += (uint32_t)(b - a);
         }
         s_segpre[n_src] = acc;
@@ -501,7 +547,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (ridx < total_recs) {
                 uint32_t sg = 0;
                 while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
-                const uint64_t* g = recs + (s_segbase[sg] + (ridx - s_segpre[sg])) * RW;
+                const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + (s_segbase[sg] + (ridx - s_segpre[sg])) * RW;
                 P0 = g[0]; P1 = g[1];
                 if (NBW > 2) P2 = g[2];
                 if (NBW > 3) P3 = g[3];
@@ -782,6 +828,10 @@ struct FastScan {
     DBuf<uint32_t> hist, tmp_bin;
     DBuf<uint64_t> tmp_recs;
     uint64_t n_tmp = 0, n_recs = 0, n_kmers = 0;
+    // direct mode: per-bin slabs of slab_cap records + fill counts (records beyond the slab are in tmp_*)
+    DBuf<uint64_t> slab;
+    DBuf<uint32_t> cursor;
+    uint32_t slab_cap = 0;
 };
 
 // labels must be < 24 for the LDS colour bitmask
@@ -800,7 +850,7 @@ static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
 }
 
 // scan: super-k-mer records in read order + bin histogram
-static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n_kmers, FastScan* st) {
+static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n_kmers, FastScan* st, bool direct = false) {
     st->pl = pl; st->n_kmers = n_kmers;
     const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
     const uint32_t nbins = pl.nbins * NCLS;                      // sub-bins (bin, length class)
@@ -815,6 +865,15 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     // expected density of minimizer changes is 2/(W+1) per window plus one piece per read
     uint64_t tmp_cap = (uint64_t)((double)n_kmers * 2.0 / (double)(k - p + 2) * 1.15) + s.n + 1024;
     if (tmp_cap > n_kmers) tmp_cap = n_kmers;
+    if (direct) {
+        // bins are hash-distributed, so a slab of 1.3 x the mean bin size (+ slack for small bins) holds almost every
+        // bin; what does not fit (heavy minimizers of low-complexity sequence) goes through the read-order buffer
+        const double mean = (double)tmp_cap / (double)nbins;
+        st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
+        ALLOC_OR_FAIL(c, st->slab, (uint64_t)nbins * st->slab_cap * rw);
+        ALLOC_OR_FAIL(c, st->cursor, nbins);
+        tmp_cap = tmp_cap / 16 + 4096;
+    }
     const uint32_t scan_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 255) / 256, 256ull * 32));
     const uint64_t chunk_slack = (uint64_t)scan_blocks * 4 * SCAN_CHUNK;      // every wave may strand one partial chunk
     tmp_cap += chunk_slack;
@@ -825,10 +884,13 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         HIP_TRY(c, hipMemsetAsync(tmp_cursor.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(st->tmp_bin.p, 0xff, tmp_cap * 4, c->stream));
+        if (direct) HIP_TRY(c, hipMemsetAsync(st->cursor.p, 0, (size_t)nbins * 4, c->stream));
         c->t_begin("sk_scan", n_kmers);
-        if (nbw == 2) sk_scan_kernel<2><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
-        else if (nbw == 3) sk_scan_kernel<3><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
-        else sk_scan_kernel<4><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p);
+#define SCAN(NBW_, D_) sk_scan_kernel<NBW_, D_><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, \
+            tmp_cursor.p, tmp_cap, sflags.p, st->slab.p, st->slab_cap, st->cursor.p)
+        if (direct) { if (nbw == 2) SCAN(2, true); else if (nbw == 3) SCAN(3, true); else SCAN(4, true); }
+        else { if (nbw == 2) SCAN(2, false); else if (nbw == 3) SCAN(3, false); else SCAN(4, false); }
+#undef SCAN
         c->t_end();
         LAUNCH_CHECK(c, "sk_scan");
         unsigned long long cur = 0;
@@ -847,12 +909,14 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
 
 // scatter into bin order: recs_out [n_recs * rw] and bin_off_out [nbins + 1] are caller-provided device buffers.
 // n_recs must first be obtained with fast_bin_offsets.
-static int fast_bin_offsets(dbg_ctx* c, FastScan* st, uint64_t* bin_off_out) {
+static int fast_bin_offsets(dbg_ctx* c, FastScan* st, uint64_t* bin_off_out, bool book = true) {
     DBG_TRY(scan_exclusive_u32_u64(c, st->hist.p, bin_off_out, (uint64_t)st->pl.nbins * NCLS));
     HIP_TRY(c, hipMemcpyAsync(&st->n_recs, bin_off_out + (uint64_t)st->pl.nbins * NCLS, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->t_begin("sk_records", st->n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
-    c->t_end();
+    if (book) {
+        c->t_begin("sk_records", st->n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
+        c->t_end();
+    }
     return 0;
 }
 static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out) {
@@ -875,7 +939,8 @@ static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint6
 
 // per-bin LDS hash tables over `nbins_local` bins whose records arrive as n_src segments, then the
 // order-restoring sort and the output table
-static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* seg_off,
+static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
+                      const uint64_t* seg_beg, const uint64_t* seg_end,
                       uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local, uint64_t n_kmers_hint, uint64_t n_recs_hint,
                       dbg_kmer_table* out) {
     const int k = pl.k, nbw = pl.nbw;
@@ -902,7 +967,7 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
             static const int nt_env = getenv("DBG_FAST_NT") ? atoi(getenv("DBG_FAST_NT")) : 512;
             static const int tb_env = getenv("DBG_FAST_TABLE") ? atoi(getenv("DBG_FAST_TABLE")) : 2048;
 #define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, 0, c->stream>>>( \
-            recs, seg_off, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p)
+            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p)
 #define GO(KW, NBW, SET) do { \
             if (tb_env == 512 && nt_env == 128) L(KW, NBW, SET, 128, 512); \
             else if (tb_env == 512) L(KW, NBW, SET, 256, 512); \
@@ -990,6 +1055,23 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     return 0;
 }
 
+// segment bounds of the direct layout: segment 0 = the bin's slab, segment 1 = its overflow records (bin order, own buffer)
+__global__ void slab_bounds_kernel(const uint32_t* __restrict__ cursor, uint32_t slab_cap, const uint64_t* __restrict__ ovf_off,
+                                   uint32_t nb, uint64_t* __restrict__ beg, uint64_t* __restrict__ end, unsigned long long* __restrict__ total) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = 0;
+    if (b < nb) {
+        cnt = cursor[b];
+        beg[b] = (uint64_t)b * slab_cap;
+        end[b] = (uint64_t)b * slab_cap + (cnt < slab_cap ? cnt : slab_cap);
+        beg[nb + b] = ovf_off[b];
+        end[nb + b] = ovf_off[b + 1];
+    }
+    unsigned long long v = cnt;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+
 // returns 0 and sets *used = true when the fast path produced the table; *used = false means the
 // caller must take the generic path (unsupported shape), nothing was written.
 int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
@@ -1001,13 +1083,32 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     if (!fast_make_plan((int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
     if (is_set) { bool ok; DBG_TRY(fast_labels_ok(c, s, &ok)); if (!ok) return 0; }
     FastScan st;
-    DBG_TRY(fast_scan(c, s, pl, n_kmers, &st));
-    DBuf<uint64_t> bin_off, recs;
-    ALLOC_OR_FAIL(c, bin_off, (size_t)pl.nbins * NCLS + 1);
-    DBG_TRY(fast_bin_offsets(c, &st, bin_off.p));
-    ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(st.n_recs * pl.rw, 1));
-    DBG_TRY(fast_scatter(c, &st, bin_off.p, recs.p));
-    DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, recs.p, bin_off.p, 1, (uint64_t)pl.nbins * NCLS + 1, pl.nbins, n_kmers, st.n_recs, out));
+    DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
+    const uint32_t nb = pl.nbins * NCLS;
+    DBuf<uint64_t> ovf_off, ovf_recs, seg;
+    DBuf<unsigned long long> total;
+    ALLOC_OR_FAIL(c, ovf_off, (size_t)nb + 1);
+    DBG_TRY(fast_bin_offsets(c, &st, ovf_off.p, false));          // st.n_recs = records that did not fit their slab
+    ALLOC_OR_FAIL(c, ovf_recs, std::max<uint64_t>(st.n_recs * pl.rw, 1));
+    DBuf<uint64_t> slab;
+    DBuf<uint32_t> cursor;
+    std::swap(slab, st.slab); std::swap(cursor, st.cursor);
+    const uint32_t slab_cap = st.slab_cap;
+    DBG_TRY(fast_scatter(c, &st, ovf_off.p, ovf_recs.p));
+    ALLOC_OR_FAIL(c, seg, (size_t)nb * 4);
+    ALLOC_OR_FAIL(c, total, 1);
+    HIP_TRY(c, hipMemsetAsync(total.p, 0, 8, c->stream));
+    slab_bounds_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(cursor.p, slab_cap, ovf_off.p, nb, seg.p, seg.p + 2 * (size_t)nb, total.p);
+    LAUNCH_CHECK(c, "slab_bounds");
+    unsigned long long n_recs_total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_recs_total, total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->t_begin("sk_records", n_recs_total);    // bookkeeping entry: units = super-k-mer records (no kernel)
+    c->t_end();
+    if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] direct slabs: cap=%u records/bin, %llu records, %llu took the overflow path\n", slab_cap,
+                                     n_recs_total, (unsigned long long)st.n_recs);
+    DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, st.n_recs ? 2u : 1u, (uint64_t)nb,
+                       pl.nbins, n_kmers, n_recs_total, out));
     *used = true;
     return 0;
 }
@@ -1108,7 +1209,7 @@ extern "C" int dbg_shard_count_dev(dbg_ctx* c, const dbg_shard_plan* sp, const u
     DBG_TRY(plan_from(c, sp, &pl));
     if (n_src == 0) return c->fail(143, "n_src must be >= 1");
     if (n_bins_local % NCLS) return c->fail(144, "n_bins_local must be a multiple of bin_group");
-    DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, seg_off_dev, n_src, (uint64_t)n_bins_local + 1, n_bins_local / NCLS,
+    DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, recs_dev, n_src, seg_off_dev, seg_off_dev + 1, n_src, (uint64_t)n_bins_local + 1, n_bins_local / NCLS,
                        std::max<uint64_t>(n_kmers_hint, 1), 0, out));
     return 0;
 }
