@@ -605,20 +605,30 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 }
                 K128 rcw = kmer_rc(fw, k);
                 uint32_t lb = j ? base_at(j - 1) : 0u;
+                // the (at most CH) bases that follow the chunk's first k-mer, top-aligned; zero beyond the record's end
+                uint32_t nx;
+                {
+                    const uint32_t sft = 2 * (j + (uint32_t)k), ws = sft >> 6, bs = sft & 63;
+                    const uint64_t A = ws == 0 ? W0 : (ws == 1 ? W1 : (NBW > 2 && ws == 2 ? W2 : (NBW > 3 && ws == 3 ? W3 : 0ull)));
+                    const uint64_t B = ws == 0 ? W1 : (NBW > 2 && ws == 1 ? W2 : (NBW > 3 && ws == 2 ? W3 : 0ull));
+                    const uint64_t v = bs ? (A << bs) | (B >> (64 - bs)) : A;
+                    nx = (uint32_t)(v >> 32);
+                }
                 while (__any(j < jend)) {
                     const bool alive = j < jend;
 #ifdef DBG_COUNT_STATS
             { uint64_t bal = __ballot(alive); if (lane == 0) { atomicAdd(&s_stat[4], 1u); atomicAdd(&s_stat[5], (uint32_t)__popcll(bal)); } }
 #endif
             if (alive) {
-                const uint32_t nbase = (j + (uint32_t)k < rlen) ? base_at(j + k) : 0u;   // base right of the k-mer
+                const uint32_t nbase = nx >> 30;                                         // base right of the k-mer (0 past the end)
+                nx <<= 2;
                 {
                     // Exts of k-mer j inside the piece (lib.rs:820-832 with seq_exts = the piece's boundary Exts)
                     uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << lb);
                     uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << nbase);
                     uint32_t ex = left | right;
                     K128 km = fw;
-                    if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = exts_rc(ex); }   // ties flip (lib.rs:226-230)
+                    if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = __brev(ex) >> 24; }   // ties flip (lib.rs:226-230); Exts::rc = byte bit-reversal
                     const uint64_t h = hash_key(km.hi, km.lo);
                     if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
                         // Bucketised linear probing: 4 tags per 16-byte bucket.  One round = one ds_read_b128 of the
