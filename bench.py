@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--summarizer", default="set", choices=["set", "count"])
     ap.add_argument("--min-obs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="time the multi-GPU pipeline (scan -> compaction -> exchange -> count) even on one GPU")
     ap.add_argument("--compress-reads", type=int, default=10_000_000,
                     help="reads of the stream used for the secondary unitigs/s measurement (0 = skip)")
     args = ap.parse_args()
@@ -88,7 +90,7 @@ def main():
     engine = D.HipEngine(ctx, dev)
 
     def step():
-        if world == 1:
+        if world == 1 and not args.force_sharded:
             # the drop-in entry point: filter_kmers, device-resident in and out
             t = capi.KmerTable()
             ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
@@ -157,7 +159,7 @@ def main():
             r_alg = key + 1 + (1 if is_set else 0)             # SURVEY 8(d) record R
             per_unit = {"extract_kmers": b_in + rbytes, "radix_scatter": 2 * rbytes, "radix_hist": 8,
                         "reduce_groups": rbytes + u_over_n * (key + 3),
-                        "sk_scan": b_in + sk_b + 4.0 * n_recs / max(n_inst, 1), "sk_scatter": 2 * rec_b + 4,
+                        "sk_scan": b_in + sk_b, "sk_scatter": 2 * rec_b + 4, "slab_compact": 2 * rec_b,
                         "bin_count": r_alg + u_over_n * (key + 3)}.get(name, 2 * rbytes)
             ach = per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
             # HBM traffic from the PMC passes (tools/pmc.sh: separate --pmc runs of this same bench at 10M
@@ -221,7 +223,7 @@ def main():
             "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=0.001"
                                    % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs),
                        "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid,
-                       "path": ("fast (super-k-mer bins -> per-bin LDS hash tables -> order-restoring radix sort)" if fast
+                       "path": ("fast (minimizer scan -> super-k-mer slabs per bin -> per-bin LDS hash tables -> order-restoring hybrid sort)" if fast
                                 else "generic (extract -> global LSD radix sort -> segmented reduce)"),
                        "superkmer_records_per_step": n_recs,
                        "multi_gpu": ("reads sharded by index; one all-to-all of super-k-mer bin slabs; each rank counts "

@@ -1082,6 +1082,27 @@ __global__ void slab_bounds_kernel(const uint32_t* __restrict__ cursor, uint32_t
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
 }
 
+// Sharded flow: the all-to-all wants every destination's records contiguous and in bin order, so the slabs are
+// compacted (one wave per bin, 16-byte moves: a coalesced copy) and the few overflow records are scattered behind them.
+template <int RW>
+__global__ void __launch_bounds__(256) slab_compact_kernel(const uint64_t* __restrict__ slab, uint32_t slab_cap, const uint32_t* __restrict__ cursor,
+                                                            const uint64_t* __restrict__ bin_off, uint32_t nb, uint64_t* __restrict__ out,
+                                                            uint64_t* __restrict__ ovf_base) {
+    const uint32_t b = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (b >= nb) return;
+    const uint32_t cnt = cursor[b], n = cnt < slab_cap ? cnt : slab_cap;
+    const uint64_t o = bin_off[b];
+    if (lane == 0) ovf_base[b] = o + n;
+    const uint64_t* src = slab + (uint64_t)b * slab_cap * RW;
+    uint64_t* dst = out + o * RW;
+    const uint32_t words = n * RW;
+    if (RW % 2 == 0 && ((o * RW) & 1) == 0) {                       // 16-byte aligned on both sides (slab_cap is a multiple of 4)
+        for (uint32_t i = lane * 2; i < words; i += 128) *(ulonglong2*)(dst + i) = *(const ulonglong2*)(src + i);
+    } else {
+        for (uint32_t i = lane; i < words; i += 64) dst[i] = src[i];
+    }
+}
+
 // returns 0 and sets *used = true when the fast path produced the table; *used = false means the
 // caller must take the generic path (unsupported shape), nothing was written.
 int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
@@ -1188,9 +1209,20 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     uint64_t n_kmers = 0;
     DBG_TRY(dbg_count_kmer_instances_dev(c, ds, sp->k, &n_kmers));
     std::unique_ptr<FastScan> st(new FastScan());
-    if (n_kmers) DBG_TRY(fast_scan(c, s, pl, n_kmers, st.get()));
-    else { st->pl = pl; ALLOC_OR_FAIL(c, st->hist, (size_t)pl.nbins * NCLS); HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)pl.nbins * NCLS * 4, c->stream)); }
-    DBG_TRY(fast_bin_offsets(c, st.get(), bin_off_dev));
+    const uint32_t nb = pl.nbins * NCLS;
+    if (n_kmers) DBG_TRY(fast_scan(c, s, pl, n_kmers, st.get(), true));
+    else {
+        st->pl = pl; st->slab_cap = 4;
+        ALLOC_OR_FAIL(c, st->hist, nb); ALLOC_OR_FAIL(c, st->cursor, nb); ALLOC_OR_FAIL(c, st->slab, 4);
+        HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)nb * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(st->cursor.p, 0, (size_t)nb * 4, c->stream));
+    }
+    // per-bin record counts (slab + overflow) -> exclusive offsets of the bin-ordered layout
+    DBG_TRY(scan_exclusive_u32_u64(c, st->cursor.p, bin_off_dev, nb));
+    HIP_TRY(c, hipMemcpyAsync(&st->n_recs, bin_off_dev + nb, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->t_begin("sk_records", st->n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
+    c->t_end();
     *n_recs = st->n_recs;
     std::lock_guard<std::mutex> g(g_shard_mu);
     g_shard_state[c] = std::move(st);
@@ -1207,7 +1239,18 @@ extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, ui
         st = std::move(it->second);
         g_shard_state.erase(it);
     }
-    DBG_TRY(fast_scatter(c, st.get(), bin_off_dev, recs_out_dev));
+    const uint32_t nb = st->pl.nbins * NCLS;
+    DBuf<uint64_t> ovf_base;
+    ALLOC_OR_FAIL(c, ovf_base, (size_t)nb + 1);
+    c->t_begin("slab_compact", st->n_recs);
+    const uint32_t blocks = cdiv((uint64_t)nb * 64, 256);
+    if (st->pl.rw == 3) slab_compact_kernel<3><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
+    else if (st->pl.rw == 4) slab_compact_kernel<4><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
+    else slab_compact_kernel<5><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "slab_compact");
+    st->slab.release(); st->cursor.release();
+    DBG_TRY(fast_scatter(c, st.get(), ovf_base.p, recs_out_dev));     // records that did not fit their slab go behind it
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }
