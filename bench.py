@@ -199,6 +199,16 @@ def main():
             fp2 = capi.FilterParams(k, 0, 0, 2, 0, 4)
             t2 = capi.KmerTable()
             ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss2), C.byref(fp2), C.byref(t2)))
+            # (a) index kept in HBM between filter_kmers and compress (dbg_compress_kmers_with_hash_dev); graph to the host
+            gd = capi.Graph()
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, 0, 0, t2.n, t2.key_hi, t2.key_lo, t2.exts, None, t2.count, C.byref(gd)))
+            ddt = time.perf_counter() - c0
+            dev_nodes = gd.n_nodes
+            dev_k = {t["name"]: round(t["ms"], 2) for t in ctx.timings()} if False else None
+            lib.dbg_free_graph(ctx.h, C.byref(gd))
+            # (b) the reference's boundary: index in host memory
             h2 = capi.KmerTable()
             ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t2), C.byref(h2)))
             lib.dbg_free_table(ctx.h, C.byref(t2))
@@ -212,7 +222,9 @@ def main():
             comp = {"reads": m, "valid_kmers": nk, "unitigs": g.n_nodes, "seconds": round(cdt, 4),
                     "unitigs_per_s": round(g.n_nodes / cdt, 1), "kmers_per_s": round(nk / cdt, 1),
                     "spec": "SimpleCompress(saturating_add)", "seed_order": "ascending key (policy B)",
-                    "boundary": "host arrays in, host BaseGraph out (PCIe included)"}
+                    "boundary": "host arrays in, host BaseGraph out (PCIe included)",
+                    "device_resident_index": {"seconds": round(ddt, 4), "unitigs": dev_nodes, "unitigs_per_s": round(dev_nodes / ddt, 1),
+                                              "kmers_per_s": round(nk / ddt, 1), "boundary": "index in HBM, host BaseGraph out"}}
             lib.dbg_free_graph(ctx.h, C.byref(g))
             lib.dbg_free_table(None, C.byref(h2))
         out = {

@@ -162,6 +162,12 @@ int  dbg_compress_kmers_with_hash(dbg_ctx* ctx, uint32_t k, int stranded, int sp
                                   uint64_t n, const uint64_t* key_hi, const uint64_t* key_lo,
                                   const uint8_t* exts, const uint32_t* data,
                                   const uint64_t* seed_order, dbg_graph* out);
+/* Same, index resident on the device (e.g. the table of dbg_filter_kmers_dev; keys strictly ascending, which is
+ * checked).  data = data_dev (u32) if non-NULL, else count16_dev (u16, widened) if non-NULL, else zeros.  Seed order =
+ * ascending key.  The graph is returned on the host. */
+int  dbg_compress_kmers_with_hash_dev(dbg_ctx* ctx, uint32_t k, int stranded, int spec, uint64_t n,
+                                      const uint64_t* key_hi_dev, const uint64_t* key_lo_dev, const uint8_t* exts_dev,
+                                      const uint32_t* data_dev, const uint16_t* count16_dev, dbg_graph* out);
 void dbg_free_graph(dbg_ctx* ctx, dbg_graph* g);
 
 /* ---- sharded second stage: BaseGraph::combine (src/graph.rs:71-100) and compress_graph

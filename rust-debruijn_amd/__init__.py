@@ -425,6 +425,31 @@ def compress_kmers_with_hash(stranded, spec, index, k=None, seed_order=None, dat
     return out
 
 
+def filter_and_compress_dev(seqs, summarizer, stranded, spec, k, ctx=None):
+    """filter_kmers (CountFilter) followed by compress_kmers_with_hash with the index kept in HBM between the two calls
+    (dbg_filter_kmers_dev -> dbg_compress_kmers_with_hash_dev); data = the count column.  -> (BaseGraph, n_valid_kmers)"""
+    import torch
+    ctx = ctx or default_context()
+    hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples(seqs)
+    dev = torch.device("cuda", 0)
+    w = torch.from_numpy(np.concatenate([hs.words, np.zeros(2, np.uint64)]).view(np.int64)).to(dev)
+    st = torch.from_numpy(hs.start.view(np.int64)).to(dev)
+    ln = torch.from_numpy(hs.length.view(np.int32)).to(dev)
+    ex = None if hs.exts is None else torch.from_numpy(hs.exts).to(dev)
+    ss = _capi.SeqSet(w.data_ptr(), w.numel(), st.data_ptr(), ln.data_ptr(), None if ex is None else ex.data_ptr(), None, 0, len(hs.start))
+    fp = _capi.FilterParams(k, int(bool(stranded)), 0, summarizer.min_kmer_obs, 0, 4)
+    t = _capi.KmerTable()
+    ctx.check(ctx.lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+    g = _capi.Graph()
+    try:
+        ctx.check(ctx.lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, int(bool(stranded)), spec.kind, t.n, t.key_hi, t.key_lo, t.exts,
+                                                           None, t.count, C.byref(g)))
+        n = int(t.n)
+    finally:
+        ctx.lib.dbg_free_table(ctx.h, C.byref(t))
+    return _graph_from_c(ctx, g, k), n
+
+
 def _graph_to_c(g):
     """BaseGraph -> dbg_graph over the graph's own numpy arrays (kept alive by the returned tuple)."""
     words = np.ascontiguousarray(np.concatenate([g.sequences.words, np.zeros(2, np.uint64)]), np.uint64)

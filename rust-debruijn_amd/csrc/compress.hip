@@ -22,13 +22,21 @@ struct KeysDev {
     const uint64_t* hi;     // null when k <= 32
     const uint64_t* lo;
     uint64_t n;
+    // optional prefix index over the ascending keys: pidx[p] = first position whose top `pbits` key bits are >= p
+    // (2^pbits + 1 entries).  Turns the 27-step binary search over 10^8 keys into a 2-3 step one inside a bucket.
+    const uint32_t* pidx = nullptr;
+    int pbits = 0, key_bits = 0;
 };
 
 __device__ __forceinline__ K128 key_at(const KeysDev& t, uint64_t i) { return K128{t.hi ? t.hi[i] : 0ull, t.lo[i]}; }
 
+__device__ __forceinline__ uint32_t key_prefix_bits(K128 a, int key_bits, int pbits) {
+    return (uint32_t)k128_shr(a, key_bits - pbits).lo;
+}
 // index of `q` in the ascending key array, or -1
 __device__ __forceinline__ int64_t find_key(const KeysDev& t, K128 q) {
     uint64_t lo = 0, hi = t.n;
+    if (t.pidx) { const uint32_t p = key_prefix_bits(q, t.key_bits, t.pbits); lo = t.pidx[p]; hi = t.pidx[p + 1]; }
     while (lo < hi) {
         uint64_t mid = (lo + hi) >> 1;
         K128 m = key_at(t, mid);
@@ -74,6 +82,27 @@ __global__ void link_kernel(KeysDev t, const uint8_t* __restrict__ exts, const u
         }
         link[(uint64_t)dir * t.n + i] = out;
     }
+}
+
+// pidx[p] = lower bound of prefix p: position i fills the entries of every prefix in (prefix(key[i-1]), prefix(key[i])]
+__global__ void prefix_index_kernel(KeysDev t, int pbits, uint32_t* __restrict__ pidx) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > t.n) return;
+    const uint32_t np = 1u << pbits;
+    const uint32_t lo = i == 0 ? 0u : key_prefix_bits(key_at(t, i - 1), t.key_bits, pbits) + 1u;
+    const uint32_t hi = i == t.n ? np : key_prefix_bits(key_at(t, i), t.key_bits, pbits);     // inclusive
+    for (uint64_t p = lo; p <= hi; p++) pidx[p] = (uint32_t)i;
+}
+
+// strictly ascending keys?  (flag |= 1 if not)
+__global__ void sorted_check_kernel(KeysDev t, uint32_t* __restrict__ flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= t.n) return;
+    if (!k128_lt(key_at(t, i - 1), key_at(t, i))) atomicOr(flag, 1u);
+}
+__global__ void widen_u16_kernel(const uint16_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
 }
 
 // remove_censored_exts(_sharded) (filter.rs:238-306)
@@ -122,6 +151,21 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
                           const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
                           dbg_graph* out, bool* done);
 
+// builds the prefix index of an ascending key array (n < 2^32); *t gets the index attached
+static int attach_prefix_index(dbg_ctx* c, KeysDev* t, int k, DBuf<uint32_t>* store) {
+    t->key_bits = 2 * k;
+    int pb = 8;
+    while (pb < 24 && pb < 2 * k && (t->n >> pb) > 4) pb++;          // ~4 keys per bucket, at most 2^24 buckets
+    if (pb > 2 * k) pb = 2 * k;
+    ALLOC_OR_FAIL(c, (*store), ((size_t)1 << pb) + 1);
+    KeysDev plain = *t;
+    plain.pidx = nullptr;
+    prefix_index_kernel<<<cdiv(t->n + 1, 256), 256, 0, c->stream>>>(plain, pb, store->p);
+    LAUNCH_CHECK(c, "prefix_index");
+    t->pidx = store->p; t->pbits = pb;
+    return 0;
+}
+
 extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int stranded, int spec, uint64_t n,
                                             const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                                             const uint32_t* data, const uint64_t* seed_order, dbg_graph* out) {
@@ -136,37 +180,58 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
     out->stranded = stranded ? 1 : 0;
     const bool has_hi = k > 32;
 
-    // ids are positions in ascending key order; map the caller's ids when its arrays are not sorted
+    // ids are positions in ascending key order; the arrays are uploaded as they are and checked on the device; only
+    // an unsorted index (a BoomHashMap2 in slot order) takes the host sort + second upload
     auto key_of = [&](uint64_t i) { return K128{has_hi && key_hi ? key_hi[i] : 0ull, key_lo[i]}; };
     bool sorted = true;
-    for (uint64_t i = 1; i < n && sorted; i++) sorted = k128_lt(key_of(i - 1), key_of(i));
     std::vector<uint64_t> s_hi, s_lo; std::vector<uint8_t> s_exts; std::vector<uint32_t> s_data;
     std::vector<uint32_t> order;        // sorted position -> caller id
     std::vector<uint32_t> rank;         // caller id -> sorted position
-    if (!sorted) {
-        order.resize(n); std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k128_lt(key_of(a), key_of(b)); });
-        for (uint64_t i = 1; i < n; i++)
-            if (k128_eq(key_of(order[i - 1]), key_of(order[i]))) return c->fail(43, "duplicate k-mer in index");
-        rank.resize(n); s_hi.resize(n); s_lo.resize(n); s_exts.resize(n); if (data) s_data.resize(n);
-        for (uint64_t i = 0; i < n; i++) {
-            uint32_t o = order[i]; rank[o] = (uint32_t)i;
-            s_hi[i] = has_hi && key_hi ? key_hi[o] : 0; s_lo[i] = key_lo[o]; s_exts[i] = exts[o];
-            if (data) s_data[i] = data[o];
-        }
-        key_hi = s_hi.data(); key_lo = s_lo.data(); exts = s_exts.data(); if (data) data = s_data.data();
-    }
+    std::vector<uint32_t> link;
 
     // ---- device: neighbour links, then (when the links are mutual) the whole unitig construction ----
-    std::vector<uint32_t> link(2 * n);
     if (n) {
-        DBuf<uint64_t> d_hi, d_lo; DBuf<uint8_t> d_exts; DBuf<uint32_t> d_data, d_link, d_rank;
-        if (has_hi) { ALLOC_OR_FAIL(c, d_hi, n); HIP_TRY(c, hipMemcpyAsync(d_hi.p, key_hi, n * 8, hipMemcpyHostToDevice, c->stream)); }
-        ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n); ALLOC_OR_FAIL(c, d_link, 2 * n);
-        HIP_TRY(c, hipMemcpyAsync(d_lo.p, key_lo, n * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(d_exts.p, exts, n, hipMemcpyHostToDevice, c->stream));
-        if (data) { ALLOC_OR_FAIL(c, d_data, n); HIP_TRY(c, hipMemcpyAsync(d_data.p, data, n * 4, hipMemcpyHostToDevice, c->stream)); }
+        DBuf<uint64_t> d_hi, d_lo; DBuf<uint8_t> d_exts; DBuf<uint32_t> d_data, d_link, d_rank, d_flag;
+        if (has_hi) ALLOC_OR_FAIL(c, d_hi, n);
+        ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n); ALLOC_OR_FAIL(c, d_link, 2 * n); ALLOC_OR_FAIL(c, d_flag, 1);
+        if (data) ALLOC_OR_FAIL(c, d_data, n);
+        auto upload = [&]() -> int {
+            if (has_hi) {
+                if (key_hi) HIP_TRY(c, hipMemcpyAsync(d_hi.p, key_hi, n * 8, hipMemcpyHostToDevice, c->stream));
+                else HIP_TRY(c, hipMemsetAsync(d_hi.p, 0, n * 8, c->stream));
+            }
+            HIP_TRY(c, hipMemcpyAsync(d_lo.p, key_lo, n * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(d_exts.p, exts, n, hipMemcpyHostToDevice, c->stream));
+            if (data) HIP_TRY(c, hipMemcpyAsync(d_data.p, data, n * 4, hipMemcpyHostToDevice, c->stream));
+            return 0;
+        };
+        DBG_TRY(upload());
         KeysDev t{has_hi ? d_hi.p : nullptr, d_lo.p, n};
+        {
+            uint32_t fl = 0;
+            HIP_TRY(c, hipMemsetAsync(d_flag.p, 0, 4, c->stream));
+            sorted_check_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_flag.p);
+            LAUNCH_CHECK(c, "sorted_check");
+            HIP_TRY(c, hipMemcpyAsync(&fl, d_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            sorted = fl == 0;
+        }
+        if (!sorted) {
+            order.resize(n); std::iota(order.begin(), order.end(), 0u);
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k128_lt(key_of(a), key_of(b)); });
+            for (uint64_t i = 1; i < n; i++)
+                if (k128_eq(key_of(order[i - 1]), key_of(order[i]))) return c->fail(43, "duplicate k-mer in index");
+            rank.resize(n); s_hi.resize(n); s_lo.resize(n); s_exts.resize(n); if (data) s_data.resize(n);
+            for (uint64_t i = 0; i < n; i++) {
+                uint32_t o = order[i]; rank[o] = (uint32_t)i;
+                s_hi[i] = has_hi && key_hi ? key_hi[o] : 0; s_lo[i] = key_lo[o]; s_exts[i] = exts[o];
+                if (data) s_data[i] = data[o];
+            }
+            key_hi = s_hi.data(); key_lo = s_lo.data(); exts = s_exts.data(); if (data) data = s_data.data();
+            DBG_TRY(upload());
+        }
+        DBuf<uint32_t> d_pidx;
+        DBG_TRY(attach_prefix_index(c, &t, k, &d_pidx));
         c->t_begin("compress_links", n);
         link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p);
         c->t_end();
@@ -195,6 +260,7 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
             if (mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the neighbour links are not mutual");
             // links were only modified if cycles were cut, which happens after the mutuality check passed
         }
+        link.resize(2 * n);
         HIP_TRY(c, hipMemcpyAsync(link.data(), d_link.p, 2 * n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -269,6 +335,60 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
     out->exts = (uint8_t*)dup(g_exts.data(), g_exts.size());
     out->data = (uint32_t*)dup(g_data.data(), g_data.size() * 4);
     return 0;
+}
+
+// Device-resident index in (the table dbg_filter_kmers_dev returns: ascending keys), host BaseGraph out.  Seed order =
+// ascending key (policy B).  data: data_dev (u32) if given, else count16_dev widened, else zeros.
+extern "C" int dbg_compress_kmers_with_hash_dev(dbg_ctx* c, uint32_t k_, int stranded, int spec, uint64_t n,
+                                                const uint64_t* key_hi_dev, const uint64_t* key_lo_dev, const uint8_t* exts_dev,
+                                                const uint32_t* data_dev, const uint16_t* count16_dev, dbg_graph* out) {
+    const int k = (int)k_;
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (spec < 0 || spec > 4) return c->fail(41, "unknown CompressionSpec");
+    if (n >= (1ull << 30)) return c->fail(42, "compress: at most 2^30-1 k-mers per call in this build");
+    if (n && (!key_lo_dev || !exts_dev)) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    memset(out, 0, sizeof(*out));
+    out->stranded = stranded ? 1 : 0;
+    if (!n) return 0;
+    const bool has_hi = k > 32;
+    DBuf<uint32_t> d_link, d_flag, d_wide;
+    ALLOC_OR_FAIL(c, d_link, 2 * n); ALLOC_OR_FAIL(c, d_flag, 1);
+    const uint32_t* d_data = data_dev;
+    if (!d_data && count16_dev) {
+        ALLOC_OR_FAIL(c, d_wide, n);
+        widen_u16_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(count16_dev, n, d_wide.p);
+        LAUNCH_CHECK(c, "widen_u16");
+        d_data = d_wide.p;
+    }
+    KeysDev t{has_hi ? key_hi_dev : nullptr, key_lo_dev, n};
+    uint32_t fl = 0;
+    HIP_TRY(c, hipMemsetAsync(d_flag.p, 0, 4, c->stream));
+    sorted_check_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_flag.p);
+    LAUNCH_CHECK(c, "sorted_check");
+    HIP_TRY(c, hipMemcpyAsync(&fl, d_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (fl) return c->fail(49, "dbg_compress_kmers_with_hash_dev needs strictly ascending keys");
+    DBuf<uint32_t> d_pidx;
+    DBG_TRY(attach_prefix_index(c, &t, k, &d_pidx));
+    c->t_begin("compress_links", n);
+    link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, d_data, k, stranded, spec, d_link.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "link_kernel");
+    bool done = false;
+    DBG_TRY(compress_links_device(c, k, (uint32_t)n, t.hi, t.lo, exts_dev, d_data, d_link.p, nullptr, spec, stranded, out, &done));
+    if (done) return 0;
+    // inconsistent Exts (non-mutual links): the literal walk needs the index on the host
+    std::vector<uint64_t> h_hi(has_hi ? n : 0), h_lo(n); std::vector<uint8_t> h_ex(n); std::vector<uint32_t> h_da(d_data ? n : 0);
+    if (has_hi) HIP_TRY(c, hipMemcpyAsync(h_hi.data(), key_hi_dev, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_lo.data(), key_lo_dev, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_ex.data(), exts_dev, n, hipMemcpyDeviceToHost, c->stream));
+    if (d_data) HIP_TRY(c, hipMemcpyAsync(h_da.data(), d_data, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    d_link.release(); d_wide.release();
+    return dbg_compress_kmers_with_hash(c, k_, stranded, spec, n, has_hi ? h_hi.data() : nullptr, h_lo.data(), h_ex.data(),
+                                        d_data ? h_da.data() : nullptr, nullptr, out);
 }
 
 extern "C" void dbg_free_graph(dbg_ctx*, dbg_graph* g) {

@@ -59,10 +59,17 @@ __global__ void init_states_kernel(const uint32_t* __restrict__ link, const uint
     J[s] = o;
 }
 
-__global__ void jump_kernel(const Jump* __restrict__ in, Jump* __restrict__ out, uint32_t n2, uint32_t* __restrict__ any) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = false;
-    if (s < n2) {
+// One doubling round over the LIVE states only (most chains are short: after r rounds only the states more than 2^r
+// steps from their chain end are still walking).  A state that reaches its end in this round is kept for one more round,
+// in which it only copies its final value into the other buffer -- so a finished state reads the same from both buffers
+// and no buffer is written while it is being read.
+__global__ void jump_kernel(const Jump* __restrict__ in, Jump* __restrict__ out, const uint32_t* __restrict__ live_in, uint32_t n_live,
+                            uint32_t* __restrict__ live_out, uint32_t* __restrict__ counters /* [0] next live count, [1] still walking */) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false, walking = false;
+    uint32_t s = 0;
+    if (t < n_live) {
+        s = live_in ? live_in[t] : t;
         Jump a = in[s];
         if (a.nxt != ST_NONE) {
             Jump b = in[a.nxt];
@@ -70,11 +77,28 @@ __global__ void jump_kernel(const Jump* __restrict__ in, Jump* __restrict__ out,
             a.minr = a.minr < b.minr ? a.minr : b.minr;
             a.nxt = b.nxt;
             if (b.nxt == ST_NONE) a.endst = b.endst;
-            live = a.nxt != ST_NONE;
+            walking = a.nxt != ST_NONE;
+            keep = true;                                          // walking on, or finalising next round
         }
         out[s] = a;
     }
-    if (__any(live) && (threadIdx.x & 63) == 0) atomicOr(any, 1u);
+    // ordered append: one global atomic per 1024-thread block (a hot single address otherwise), waves in order
+    __shared__ uint32_t s_cnt[16], s_base;
+    __shared__ uint32_t s_walk;
+    const uint64_t km = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_walk = 0;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
+    __syncthreads();
+    if (__any(walking) && lane == 0) s_walk = 1;
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; w++) { uint32_t x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
+        s_base = tot ? atomicAdd(&counters[0], tot) : 0u;
+    }
+    __syncthreads();
+    if (keep) live_out[s_base + s_cnt[wave] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = s;
+    if (threadIdx.x == 0 && s_walk) atomicOr(&counters[1], 1u);
 }
 
 // after the doubling has covered 2n steps, any state still walking sits on a cycle; cut it at its seed's right side
@@ -204,31 +228,41 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     if (fl[0]) return 0;
 
     DBuf<Jump> JA, JB;
+    DBuf<uint32_t> LA, LB, counters;
     ALLOC_OR_FAIL(c, JA, n2);
     ALLOC_OR_FAIL(c, JB, n2);
+    ALLOC_OR_FAIL(c, LA, n2);
+    ALLOC_OR_FAIL(c, LB, n2);
+    ALLOC_OR_FAIL(c, counters, 2);
     Jump* cur = nullptr;
     for (int phase = 0; phase < 2; phase++) {
         init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, n, JA.p);
         LAUNCH_CHECK(c, "init_states");
         Jump *a = JA.p, *b = JB.p;
-        bool live = true;
+        uint32_t *la = nullptr, *lb = LB.p;                         // round 0 visits every state
+        uint32_t n_live = n2;
+        bool walking = true;
         int rounds = 0;
-        const int max_rounds = 33;                                 // 2^33 steps > any chain
+        const int max_rounds = 34;                                 // 2^33 steps > any chain (+ the finalising round)
         c->t_begin("unitig_pointer_jump", n);
-        while (live && rounds < max_rounds) {
-            HIP_TRY(c, hipMemsetAsync(flags.p + 1, 0, 4, c->stream));
-            jump_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(a, b, n2, flags.p + 1);
+        while (n_live && rounds < max_rounds) {
+            HIP_TRY(c, hipMemsetAsync(counters.p, 0, 8, c->stream));
+            jump_kernel<<<cdiv(n_live, 1024), 1024, 0, c->stream>>>(a, b, la, n_live, lb, counters.p);
             LAUNCH_CHECK(c, "jump");
-            uint32_t any = 0;
-            HIP_TRY(c, hipMemcpyAsync(&any, flags.p + 1, 4, hipMemcpyDeviceToHost, c->stream));
+            uint32_t cnt[2] = {0, 0};
+            HIP_TRY(c, hipMemcpyAsync(cnt, counters.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             std::swap(a, b);
-            live = any != 0;
+            la = lb; lb = (lb == LB.p) ? LA.p : LB.p;
+            n_live = cnt[0];
+            walking = cnt[1] != 0;
             rounds++;
         }
         c->t_end();
+        // every state's final value is in the buffer written last; states that finished earlier were copied into both
         cur = a;
-        if (!live) break;
+        if (!n_live) break;
+        (void)walking;
         if (phase == 1) return c->fail(150, "unitig construction: cycle cutting did not terminate");
         // cycles: cut each at its seed's right side and redo the doubling
         cut_cycles_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, link_dev, n);

@@ -168,3 +168,18 @@ def test_c1_shape_end_to_end(ctx):
     hs = dbg.synth_reads_host(n_reads=10000, read_len=150, error_rate=0.001, stranded=True, n_colours=0)
     t, _ = dbg.filter_kmers(hs, dbg.CountFilter(1), True, False, 4, k=31, ctx=ctx)
     compare(ctx, t, 31, True, SPECS[0])
+
+
+def test_device_resident_index(ctx, compress_mode):
+    """dbg_filter_kmers_dev -> dbg_compress_kmers_with_hash_dev (index never leaves HBM) equals the host-boundary calls."""
+    if compress_mode != "device":
+        pytest.skip("device-resident entry point")
+    rng = np.random.default_rng(77)
+    for k, stranded in [(31, False), (47, False), (47, True), (64, False)]:
+        contigs = R.random_contigs(rng)
+        seqs = [(c, 0, None) for c in contigs] * 2
+        got, n = dbg.filter_and_compress_dev(seqs, dbg.CountFilter(2), stranded, SPECS[0][0], k, ctx=ctx)
+        t, _ = dbg.filter_kmers(seqs, dbg.CountFilter(2), stranded, False, 4, k=k, ctx=ctx)
+        assert n == len(t)
+        want = O.compress_kmers(k, stranded, SPECS[0][1], t.key_hi, t.key_lo, t.exts, t.count, None)
+        assert graphs_equal(got.arrays(), want.arrays())

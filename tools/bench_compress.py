@@ -15,6 +15,14 @@ ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), words.data_ptr(), start.dat
 ss = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, None, 0, n_reads)
 fp = capi.FilterParams(k, 0, 0, 2, 0, 4)
 t = capi.KmerTable(); ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+for rep in range(2):                     # device-resident index
+    ctx.enable_timing(True)
+    g = capi.Graph(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, 0, 0, t.n, t.key_hi, t.key_lo, t.exts, None, t.count, C.byref(g)))
+    dt = time.perf_counter() - t0
+    print("dev-index nodes", g.n_nodes, "time %.3f s" % dt, "unitigs/s %.3e" % (g.n_nodes / dt), "kmers/s %.3e" % (t.n / dt),
+          {x["name"]: round(x["ms"], 1) for x in ctx.timings()}, flush=True)
+    lib.dbg_free_graph(ctx.h, C.byref(g))
 h = capi.KmerTable(); ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h))); lib.dbg_free_table(ctx.h, C.byref(t))
 n = h.n
 print("valid kmers", n, flush=True)
