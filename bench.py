@@ -46,8 +46,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="time the multi-GPU pipeline (scan -> compaction -> exchange -> count) even on one GPU")
-    ap.add_argument("--compress-reads", type=int, default=10_000_000,
-                    help="reads of the stream used for the secondary unitigs/s measurement (0 = skip)")
+    ap.add_argument("--compress-reads", type=int, default=-1,
+                    help="reads of the stream used for the secondary unitigs/s measurement (0 = skip, -1 = all: BASELINE config 3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -194,7 +194,7 @@ def main():
             # second half of the metric ("+ unitigs/s compressed"): CountFilter(2) table of a prefix of the same
             # stream -> host (the Rust caller holds a BoomHashMap2 in host memory) -> compress_kmers_with_hash.
             # Timed end to end at the host boundary: H2D of the index, device links + unitig construction, D2H.
-            m = min(args.compress_reads, reads_per_gpu)
+            m = reads_per_gpu if args.compress_reads < 0 else min(args.compress_reads, reads_per_gpu)
             ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, None, 0, m)
             fp2 = capi.FilterParams(k, 0, 0, 2, 0, 4)
             t2 = capi.KmerTable()
@@ -206,7 +206,6 @@ def main():
             ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, 0, 0, t2.n, t2.key_hi, t2.key_lo, t2.exts, None, t2.count, C.byref(gd)))
             ddt = time.perf_counter() - c0
             dev_nodes = gd.n_nodes
-            dev_k = {t["name"]: round(t["ms"], 2) for t in ctx.timings()} if False else None
             lib.dbg_free_graph(ctx.h, C.byref(gd))
             # (b) the reference's boundary: index in host memory
             h2 = capi.KmerTable()

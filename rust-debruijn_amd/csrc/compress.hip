@@ -425,6 +425,9 @@ extern "C" int dbg_remove_censored_exts(dbg_ctx* c, uint32_t k_, int stranded, d
         all.hi = has_hi ? a_hi.p : nullptr; all.lo = a_lo.p;
         ex = d_exts.p;
     }
+    DBuf<uint32_t> pi_valid, pi_all;
+    if (n < (1ull << 32)) DBG_TRY(attach_prefix_index(c, &valid, k, &pi_valid));
+    if (na && na < (1ull << 32)) DBG_TRY(attach_prefix_index(c, &all, k, &pi_all));
     c->t_begin("remove_censored_exts", n);
     censor_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(valid, all, ex, k, stranded, sharded);
     c->t_end();
