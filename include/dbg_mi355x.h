@@ -234,6 +234,13 @@ int  dbg_shard_scatter_dev(dbg_ctx* ctx, const uint64_t* bin_off_dev, uint64_t* 
  * segment s of local bin b = records [seg_off[s*(n_bins_local+1)+b], seg_off[s*(n_bins_local+1)+b+1]) */
 int  dbg_shard_count_dev(dbg_ctx* ctx, const dbg_shard_plan* plan, const uint64_t* recs_dev, const uint64_t* seg_off_dev,
                          uint32_t n_src, uint32_t n_bins_local, uint64_t n_kmers_hint, dbg_kmer_table* out_dev);
+/* The same in pieces, so that the caller can count one range of its bins while the records of the next range are still
+ * in flight: begin; then for each contiguous range of owned bins a record buffer + its [n_src][n_bins_chunk + 1] segment
+ * table (n_kmers_units is only used for the timing record); finish sorts everything counted since begin. */
+int  dbg_shard_count_begin(dbg_ctx* ctx, const dbg_shard_plan* plan, uint64_t n_kmers_hint);
+int  dbg_shard_count_bins_dev(dbg_ctx* ctx, const uint64_t* recs_dev, const uint64_t* seg_off_dev, uint32_t n_src,
+                              uint32_t n_bins_chunk, uint64_t n_kmers_units);
+int  dbg_shard_count_finish(dbg_ctx* ctx, dbg_kmer_table* out);
 
 /* ---- synthetic reads: splitmix64, deterministic ----- */
 typedef struct {

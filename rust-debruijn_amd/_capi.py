@@ -72,7 +72,7 @@ EXPORTS = [
     "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_free_graph", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
-    "dbg_shard_count_dev", "dbg_graph_combine", "dbg_compress_graph",
+    "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
     "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
     "dbg_pack_acgt", "dbg_pack_acgt_dev", "dbg_unpack_acgt", "dbg_unpack_acgt_dev",
 ]
@@ -144,6 +144,9 @@ def load():
     lib.dbg_shard_scatter_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.dbg_shard_count_dev.argtypes = [C.c_void_p, C.POINTER(ShardPlan), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_uint64, C.POINTER(KmerTable)]
+    lib.dbg_shard_count_begin.argtypes = [C.c_void_p, C.POINTER(ShardPlan), C.c_uint64]
+    lib.dbg_shard_count_bins_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    lib.dbg_shard_count_finish.argtypes = [C.c_void_p, C.POINTER(KmerTable)]
     lib.dbg_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.dbg_ctx_get_timings.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_uint32, C.POINTER(C.c_uint32)]
     _lib = lib

@@ -949,35 +949,65 @@ static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint6
 
 // per-bin LDS hash tables over `nbins_local` bins whose records arrive as n_src segments, then the
 // order-restoring sort and the output table
-static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
-                      const uint64_t* seg_beg, const uint64_t* seg_end,
-                      uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local, uint64_t n_kmers_hint, uint64_t n_recs_hint,
-                      dbg_kmer_table* out) {
+// Counting state that outlives one bin_count launch: the unsorted (key, payload) records of the valid k-mers found so
+// far.  The multi-GPU flow counts its bins in several chunks (while the next chunk is still on the wire) and sorts once.
+struct FastCountState {
+    FastPlan pl;
+    uint64_t min_obs = 0, cap = 0, n_out = 0, n_kmers_hint = 0;
+    DBuf<uint64_t> u_hi, u_lo;
+    DBuf<uint32_t> u_pay, gflags;
+    DBuf<unsigned long long> out_cursor;
+};
+
+static int fast_count_alloc(dbg_ctx* c, FastCountState* st, uint64_t cap) {
+    if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+    DBuf<uint64_t> n_hi, n_lo;
+    DBuf<uint32_t> n_pay;
+    if (st->pl.has_hi) ALLOC_OR_FAIL(c, n_hi, cap);
+    ALLOC_OR_FAIL(c, n_lo, cap);
+    ALLOC_OR_FAIL(c, n_pay, cap);
+    if (st->n_out) {                                             // keep what earlier chunks produced
+        if (st->pl.has_hi) HIP_TRY(c, hipMemcpyAsync(n_hi.p, st->u_hi.p, st->n_out * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(n_lo.p, st->u_lo.p, st->n_out * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(n_pay.p, st->u_pay.p, st->n_out * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    std::swap(st->u_hi, n_hi); std::swap(st->u_lo, n_lo); std::swap(st->u_pay, n_pay);
+    st->cap = cap;
+    return 0;
+}
+
+static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, uint64_t n_kmers_hint, FastCountState* st) {
+    st->pl = pl; st->min_obs = min_obs; st->n_out = 0; st->n_kmers_hint = n_kmers_hint;
+    ALLOC_OR_FAIL(c, st->out_cursor, 1);
+    ALLOC_OR_FAIL(c, st->gflags, 16);
+    HIP_TRY(c, hipMemsetAsync(st->out_cursor.p, 0, 8, c->stream));
+    return fast_count_alloc(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1));
+}
+
+// per-bin LDS hash tables over `nbins_local` bins whose records arrive as n_src segments; valid k-mers are appended to the state
+static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
+                           const uint64_t* seg_beg, const uint64_t* seg_end, uint32_t n_src, uint64_t seg_stride,
+                           uint32_t nbins_local, uint64_t n_kmers_units, uint64_t n_recs_hint) {
+    const FastPlan& pl = st->pl;
     const int k = pl.k, nbw = pl.nbw;
     const bool is_set = pl.is_set, has_hi = pl.has_hi;
+    const uint64_t min_obs = st->min_obs;
     constexpr uint32_t TABLE = 2048;
-    DBuf<unsigned long long> out_cursor;
-    DBuf<uint32_t> gflags;
-    ALLOC_OR_FAIL(c, out_cursor, 1);
-    ALLOC_OR_FAIL(c, gflags, 16);
-    uint64_t cap = std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1);
-    DBuf<uint64_t> u_hi, u_lo;
-    DBuf<uint32_t> u_pay;
-    uint64_t n_out = 0;
     for (int attempt = 0;; attempt++) {
-        if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
-        if (has_hi) ALLOC_OR_FAIL(c, u_hi, cap);
-        ALLOC_OR_FAIL(c, u_lo, cap);
-        ALLOC_OR_FAIL(c, u_pay, cap);
-        HIP_TRY(c, hipMemsetAsync(out_cursor.p, 0, 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(gflags.p, 0, 64, c->stream));
-        FastOut fo{u_hi.p, u_lo.p, u_pay.p};
+        const uint64_t cap = st->cap;
+        unsigned long long start = st->n_out;
+        HIP_TRY(c, hipMemcpyAsync(st->out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(st->gflags.p, 0, 64, c->stream));
+        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p};
+        unsigned long long* out_cursor_p = st->out_cursor.p;
+        uint32_t* gflags_p = st->gflags.p;
         if (nbins_local) {
-            c->t_begin("bin_count", n_kmers_hint);
+            c->t_begin("bin_count", n_kmers_units);
             static const int nt_env = getenv("DBG_FAST_NT") ? atoi(getenv("DBG_FAST_NT")) : 512;
             static const int tb_env = getenv("DBG_FAST_TABLE") ? atoi(getenv("DBG_FAST_TABLE")) : 2048;
 #define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, 0, c->stream>>>( \
-            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor.p, gflags.p)
+            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
 #define GO(KW, NBW, SET) do { \
             if (tb_env == 512 && nt_env == 128) L(KW, NBW, SET, 128, 512); \
             else if (tb_env == 512) L(KW, NBW, SET, 256, 512); \
@@ -998,8 +1028,8 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
         }
         unsigned long long cur = 0;
         uint32_t flv[16] = {0};
-        HIP_TRY(c, hipMemcpyAsync(&cur, out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(flv, gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&cur, st->out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(flv, st->gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint32_t fl = flv[0];
         if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u wd=%u\n",
@@ -1020,15 +1050,24 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
 #endif
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (fl & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
-        if (fl & 1u) {
+        if (fl & 1u) {                                            // output buffer too small: grow (earlier chunks are kept) and redo this launch
             if (attempt >= 3 || cur >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 valid k-mers");
-            cap = cur + cur / 16 + 1024;
+            DBG_TRY(fast_count_alloc(c, st, cur + cur / 16 + 1024));
             continue;
         }
-        n_out = cur;
+        st->n_out = cur;
         break;
     }
+    return 0;
+}
 
+// order-restoring sort of everything counted so far -> the output table
+static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out) {
+    const FastPlan& pl = st->pl;
+    const int k = pl.k;
+    const bool is_set = pl.is_set, has_hi = pl.has_hi;
+    const uint64_t n_out = st->n_out, n_kmers_hint = st->n_kmers_hint;
+    DBuf<uint64_t>& u_hi = st->u_hi; DBuf<uint64_t>& u_lo = st->u_lo; DBuf<uint32_t>& u_pay = st->u_pay;
     // ---- order-restoring sort: ascending key (filter.rs:205-206 bucket order + stable sort = global order) ----
     DBuf<uint32_t> t_pay;
     DBuf<uint64_t> t_hi, t_lo;
@@ -1063,6 +1102,16 @@ static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const ui
     out->set_off = o_set_off.take(); out->set_val = o_set_val.take(); out->n_set_val = n_setval;
     out->n_kmer_instances = n_kmers_hint; out->n_passes = 1; out->on_device = 1;
     return 0;
+}
+
+static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
+                      const uint64_t* seg_beg, const uint64_t* seg_end,
+                      uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local, uint64_t n_kmers_hint, uint64_t n_recs_hint,
+                      dbg_kmer_table* out) {
+    FastCountState st;
+    DBG_TRY(fast_count_begin(c, pl, min_obs, n_kmers_hint, &st));
+    DBG_TRY(fast_count_bins(c, &st, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, nbins_local, n_kmers_hint, n_recs_hint));
+    return fast_count_finish(c, &st, out);
 }
 
 // segment bounds of the direct layout: segment 0 = the bin's slab, segment 1 = its overflow records (bin order, own buffer)
@@ -1157,10 +1206,12 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
 #include <mutex>
 static std::mutex g_shard_mu;
 static std::map<dbg_ctx*, std::unique_ptr<FastScan>> g_shard_state;
+static std::map<dbg_ctx*, std::unique_ptr<FastCountState>> g_count_state;
 
 void fast_drop_state(dbg_ctx* c) {
     std::lock_guard<std::mutex> g(g_shard_mu);
     g_shard_state.erase(c);
+    g_count_state.erase(c);
 }
 
 extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t k, uint64_t* n_out) {
@@ -1265,4 +1316,46 @@ extern "C" int dbg_shard_count_dev(dbg_ctx* c, const dbg_shard_plan* sp, const u
     DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, recs_dev, n_src, seg_off_dev, seg_off_dev + 1, n_src, (uint64_t)n_bins_local + 1, n_bins_local / NCLS,
                        std::max<uint64_t>(n_kmers_hint, 1), 0, out));
     return 0;
+}
+
+// Chunked form of dbg_shard_count_dev: begin, then any number of bin ranges (each with its own record buffer and segment
+// table -- e.g. one per all-to-all chunk, counted while the next chunk is on the wire), then one sort in finish.
+extern "C" int dbg_shard_count_begin(dbg_ctx* c, const dbg_shard_plan* sp, uint64_t n_kmers_hint) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    FastPlan pl;
+    DBG_TRY(plan_from(c, sp, &pl));
+    std::unique_ptr<FastCountState> st(new FastCountState());
+    DBG_TRY(fast_count_begin(c, pl, sp->min_kmer_obs, std::max<uint64_t>(n_kmers_hint, 1), st.get()));
+    std::lock_guard<std::mutex> g(g_shard_mu);
+    g_count_state[c] = std::move(st);
+    return 0;
+}
+
+extern "C" int dbg_shard_count_bins_dev(dbg_ctx* c, const uint64_t* recs_dev, const uint64_t* seg_off_dev, uint32_t n_src,
+                                        uint32_t n_bins_chunk, uint64_t n_kmers_units) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    FastCountState* st = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_shard_mu);
+        auto it = g_count_state.find(c);
+        if (it == g_count_state.end()) return c->fail(145, "dbg_shard_count_bins_dev without dbg_shard_count_begin");
+        st = it->second.get();
+    }
+    if (n_src == 0) return c->fail(143, "n_src must be >= 1");
+    if (n_bins_chunk % NCLS) return c->fail(144, "n_bins_chunk must be a multiple of bin_group");
+    return fast_count_bins(c, st, recs_dev, recs_dev, n_src, seg_off_dev, seg_off_dev + 1, n_src, (uint64_t)n_bins_chunk + 1,
+                           n_bins_chunk / NCLS, n_kmers_units, 0);
+}
+
+extern "C" int dbg_shard_count_finish(dbg_ctx* c, dbg_kmer_table* out) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::unique_ptr<FastCountState> st;
+    {
+        std::lock_guard<std::mutex> g(g_shard_mu);
+        auto it = g_count_state.find(c);
+        if (it == g_count_state.end()) return c->fail(145, "dbg_shard_count_finish without dbg_shard_count_begin");
+        st = std::move(it->second);
+        g_count_state.erase(it);
+    }
+    return fast_count_finish(c, st.get(), out);
 }

@@ -67,6 +67,26 @@ class HipEngine:
                                                     n_bins_local, n_kmers_hint, C.byref(tab)))
         return tab
 
+    # chunked counting: count a range of the owned bins while the next range is still on the wire; one sort at the end
+    def count_begin(self, plan, n_kmers_hint):
+        self.ctx.check(self.lib.dbg_shard_count_begin(self.ctx.h, C.byref(plan), n_kmers_hint))
+
+    def count_bins(self, plan, recs, seg_off, n_src, n_bins_chunk, n_kmers_units=0):
+        """recs / seg_off must be complete in device memory (the caller has synchronised the stream that produced them)."""
+        seg_off = seg_off.contiguous()
+        self._keep3 = (recs, seg_off)
+        self.ctx.check(self.lib.dbg_shard_count_bins_dev(self.ctx.h, recs.data_ptr(), seg_off.data_ptr(), n_src, n_bins_chunk,
+                                                         n_kmers_units))
+
+    def count_finish(self, plan):
+        tab = _capi.KmerTable()
+        self.ctx.check(self.lib.dbg_shard_count_finish(self.ctx.h, C.byref(tab)))
+        return tab
+
+    def sync(self):
+        """wait for everything queued on torch's current stream (collectives that were wait()-ed, tensor ops)"""
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def free_table(self, tab):
         self.lib.dbg_free_table(self.ctx.h, C.byref(tab))
 
@@ -77,46 +97,85 @@ def owner_bounds(n_bins, world, group=1):
     return [(r * (n_bins // group) // world) * group for r in range(world + 1)]
 
 
-def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None):
+def chunk_bounds(n_local_bins, n_chunks, group=1):
+    """split a rank's owned bins into n_chunks contiguous ranges (boundaries multiples of `group`)"""
+    return [(c * (n_local_bins // group) // n_chunks) * group for c in range(n_chunks + 1)]
+
+
+def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n_chunks=None):
     """All-to-all of bin-ordered super-k-mer slabs, then count the owned bins.  Works for any
-    world size (including 1) and any torch.distributed backend that implements all_to_all."""
+    world size (including 1) and any torch.distributed backend that implements all_to_all_single.
+
+    The owned bin range of every rank is cut into n_chunks ranges; the records of range c+1 are exchanged
+    (asynchronous all-to-all) while range c is being counted, and the table is sorted once at the end."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     rw = plan.rec_words
-    bounds = owner_bounds(plan.n_bins, world, getattr(plan, "bin_group", 1) or 1)
+    grp = getattr(plan, "bin_group", 1) or 1
+    bounds = owner_bounds(plan.n_bins, world, grp)
     nb_local = bounds[rank + 1] - bounds[rank]
-    hist = (bin_off[1:] - bin_off[:-1]).contiguous()                         # records per bin (local reads)
-    edge = bin_off[torch.tensor(bounds, device=bin_off.device)].tolist()     # record offset at each owner boundary
-    send_counts = [edge[d + 1] - edge[d] for d in range(world)]
-    if world == 1:
-        recv_hist, recv = hist.view(1, nb_local), recs
-        recv_counts = [send_counts[0]]
-    else:
-        # 1) per-bin record counts of my bins from every source rank
-        recv_hist = torch.empty(world * nb_local, dtype=hist.dtype, device=hist.device)
-        dist.all_to_all_single(recv_hist, hist, output_split_sizes=[nb_local] * world,
-                               input_split_sizes=[bounds[d + 1] - bounds[d] for d in range(world)], group=group)
-        recv_hist = recv_hist.view(world, nb_local)
-        recv_counts = recv_hist.sum(dim=1).tolist()
-        # 2) the records themselves: one contiguous slab per (source, destination) pair
-        recv = torch.empty(max(sum(recv_counts) * rw, 1), dtype=recs.dtype, device=recs.device)
-        dist.all_to_all_single(recv[:sum(recv_counts) * rw], recs, output_split_sizes=[c * rw for c in recv_counts],
-                               input_split_sizes=[c * rw for c in send_counts], group=group)
-    # segment table: records of local bin b from source s = [seg_off[s, b], seg_off[s, b+1])
-    base = torch.zeros(world, dtype=torch.int64, device=recv_hist.device)
-    if world > 1:
-        base[1:] = torch.cumsum(torch.tensor(recv_counts[:-1], dtype=torch.int64, device=base.device), 0)
-    seg_off = torch.zeros(world, nb_local + 1, dtype=torch.int64, device=recv_hist.device)
-    seg_off[:, 1:] = torch.cumsum(recv_hist.to(torch.int64), dim=1)
-    seg_off += base[:, None]
-    # hint for the output buffer: this rank's share of the instances
     hint = max(n_local_kmers, 1)
-    return engine.count(plan, recv, seg_off, world, nb_local, hint)
+    hist = (bin_off[1:] - bin_off[:-1]).contiguous()                         # records per bin (local reads)
+    if world == 1:
+        seg_off = torch.zeros(1, nb_local + 1, dtype=torch.int64, device=hist.device)
+        seg_off[0, 1:] = torch.cumsum(hist.to(torch.int64), 0)
+        engine.sync()
+        engine.count_begin(plan, hint)
+        engine.count_bins(plan, recs, seg_off, 1, nb_local, hint)
+        return engine.count_finish(plan)
+    if n_chunks is None:
+        n_chunks = 4
+    n_chunks = max(1, min(n_chunks, max(nb_local // grp, 1)))
+    # 1) per-bin record counts of my bins from every source rank
+    recv_hist = torch.empty(world * nb_local, dtype=hist.dtype, device=hist.device)
+    dist.all_to_all_single(recv_hist, hist, output_split_sizes=[nb_local] * world,
+                           input_split_sizes=[bounds[d + 1] - bounds[d] for d in range(world)], group=group)
+    recv_hist = recv_hist.view(world, nb_local).to(torch.int64)
+    # 2) chunk geometry.  Chunk c of destination d = d's owned bins [cb_d[c], cb_d[c+1]); every rank computes the same cuts.
+    cuts = [chunk_bounds(bounds[d + 1] - bounds[d], n_chunks, grp) for d in range(world)]
+    gidx = torch.tensor([[bounds[d] + cuts[d][c] for c in range(n_chunks + 1)] for d in range(world)], device=bin_off.device)
+    send_edge = bin_off[gidx].tolist()                                       # [d][c] record offset in my bin-ordered `recs`
+    my = cuts[rank]
+    csum = torch.zeros(world, nb_local + 1, dtype=torch.int64, device=recv_hist.device)
+    csum[:, 1:] = torch.cumsum(recv_hist, dim=1)
+    recv_edge = csum[:, torch.tensor(my, device=csum.device)].tolist()       # [s][c] records source s holds before my chunk c
+
+    def launch(c):
+        """start the exchange of chunk c; returns (work, recv tensor, per-source record counts)"""
+        parts = [recs[send_edge[d][c] * rw: send_edge[d][c + 1] * rw] for d in range(world)]
+        send = torch.cat(parts) if sum(p.numel() for p in parts) else torch.zeros(0, dtype=recs.dtype, device=recs.device)
+        in_split = [p.numel() for p in parts]
+        cnt = [recv_edge[s][c + 1] - recv_edge[s][c] for s in range(world)]
+        recv = torch.empty(max(sum(cnt) * rw, 1), dtype=recs.dtype, device=recs.device)
+        work = dist.all_to_all_single(recv[:sum(cnt) * rw], send, output_split_sizes=[x * rw for x in cnt],
+                                      input_split_sizes=in_split, group=group, async_op=True)
+        return work, recv, cnt, send
+
+    engine.sync()
+    engine.count_begin(plan, hint)
+    pending = launch(0)
+    for c in range(n_chunks):
+        work, recv, cnt, send = pending
+        work.wait()
+        engine.sync()                                                        # chunk c is complete in device memory
+        if c + 1 < n_chunks:
+            pending = launch(c + 1)                                          # goes on the wire while chunk c is counted
+        lo, hi = my[c], my[c + 1]
+        # segment table of the chunk: records of its bin b from source s = [seg[s, b], seg[s, b+1])
+        seg = csum[:, lo:hi + 1] - csum[:, lo:lo + 1]
+        base = torch.zeros(world, dtype=torch.int64, device=seg.device)
+        if world > 1:
+            base[1:] = torch.cumsum(torch.tensor(cnt[:-1], dtype=torch.int64, device=seg.device), 0)
+        seg = (seg + base[:, None]).contiguous()
+        engine.sync()
+        engine.count_bins(plan, recv, seg, world, hi - lo, hint // n_chunks)
+        del send
+    return engine.count_finish(plan)
 
 
-def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None):
+def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None, n_chunks=None):
     """Distributed filter_kmers: returns this rank's table (the valid k-mers of the bins it owns,
     ascending by key) and the global k-mer instance count."""
     import torch
@@ -130,5 +189,5 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
     plan = engine.plan(k, stranded, summarizer_kind, min_obs, total)
     bin_off, n_recs = engine.scan(ss, plan)
     recs = engine.scatter(plan, bin_off, n_recs)
-    tab = exchange_and_count(engine, plan, bin_off, recs, n_local, group)
+    tab = exchange_and_count(engine, plan, bin_off, recs, n_local, group, n_chunks)
     return tab, total, n_local, n_recs

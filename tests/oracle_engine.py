@@ -54,6 +54,36 @@ class OracleEngine:
         order = np.argsort(self._bins, kind="stable")
         return torch.from_numpy(self._rows[order].astype(np.int64).reshape(-1))
 
+    # chunked form used by the pipelined exchange
+    def sync(self):
+        pass
+
+    def count_begin(self, plan, hint):
+        self._acc = ([], [], [])
+
+    def count_bins(self, plan, recs, seg_off, n_src, nb_chunk, units=0):
+        r = recs.numpy().astype(np.uint64).reshape(-1, RW)[: int(seg_off.max())] if recs.numel() >= RW else np.zeros((0, RW), np.uint64)
+        seg = seg_off.numpy()
+        assert seg.shape == (n_src, nb_chunk + 1)
+        used = np.zeros(len(r), dtype=bool)
+        for s in range(n_src):
+            for b in range(nb_chunk):
+                for j in range(int(seg[s, b]), int(seg[s, b + 1])):
+                    assert not used[j]
+                    used[j] = True
+                    meta = int(r[j, 3])
+                    l = meta & 0xFF
+                    self._acc[0].append(O.unpack_bases(r[j, :3], 0, l))
+                    self._acc[1].append((meta >> 8) & 0xFF)
+                    self._acc[2].append(meta >> 16)
+        assert used.all()                       # every received record belongs to exactly one bin segment of the chunk
+
+    def count_finish(self, plan):
+        seqs, exts, data = self._acc
+        ss = O.SeqSet.from_byte_seqs(seqs, exts=exts, data=data if plan.summarizer == O.COUNT_FILTER_SET else None,
+                                     sizeof_d1=1)
+        return O.filter_kmers(ss, plan.k, plan.summarizer, plan.min_kmer_obs, stranded=plan.stranded)
+
     def count(self, plan, recs, seg_off, n_src, nb_local, hint):
         r = recs.numpy().astype(np.uint64).reshape(-1, RW)
         seg = seg_off.numpy()

@@ -78,7 +78,25 @@ def test_virtual_ranks_multi_segment(ctx, kind, k, world):
             seg_off[s, 1:] = torch.cumsum(hists[s], 0)
             seg_off[s] += base
             base += counts[s]
-        tab = eng.count(plan, recv, seg_off, world, nb_local, total)
+        if owner % 2 == 0:
+            tab = eng.count(plan, recv, seg_off, world, nb_local, total)
+        else:
+            # chunked form (what the pipelined exchange drives): the owned bins in three ranges, each with its own record
+            # buffer and segment table, one sort at the end
+            cb = D.chunk_bounds(nb_local, 3, plan.bin_group)
+            eng.count_begin(plan, 64)                       # tiny hint: forces the grow-and-keep path of the output buffer
+            for c in range(3):
+                l2, h2 = cb[c], cb[c + 1]
+                parts, seg_c, base_c = [], torch.zeros(world, h2 - l2 + 1, dtype=torch.int64, device=eng.device), 0
+                for s_, (bin_off, recs) in enumerate(scanned):
+                    a, b = int(bin_off[lo + l2]), int(bin_off[lo + h2])
+                    parts.append(recs[a * rw:b * rw])
+                    seg_c[s_] = bin_off[lo + l2:lo + h2 + 1] - bin_off[lo + l2] + base_c
+                    base_c += b - a
+                rc = torch.cat(parts) if base_c else torch.zeros(1, dtype=torch.int64, device=eng.device)
+                eng.sync()
+                eng.count_bins(plan, rc, seg_c, world, h2 - l2, 0)
+            tab = eng.count_finish(plan)
         t = table_to_host(ctx, tab, k)
         eng.free_table(tab)
         assert t.keys() == sorted(t.keys())
