@@ -152,8 +152,8 @@ def main():
             units_per_launch = a["units"] / a["launches"]
             key = 8 if k <= 32 else 16
             rbytes = key + 4                                   # record = key + 4-byte payload in this build
-            nbw = max(2, (2 * k - (15 if k >= 23 else (13 if k >= 21 else max(4, k - 8))) + 31) // 32)
-            rec_b = 8 * (nbw + 1)                              # super-k-mer record bytes
+            pint = 15 if k >= 23 else (13 if k >= 21 else max(4, k - 8))
+            rec_b = 8 * max(2, (2 * (2 * k - pint) + 20 + 63) // 64)   # super-k-mer record bytes (bases + 20 meta bits)
             b_in = (L / 4.0) / (L - k + 1)
             sk_b = n_recs * rec_b / max(n_inst, 1)             # super-k-mer bytes per k-mer instance
             r_alg = key + 1 + (1 if is_set else 0)             # SURVEY 8(d) record R

@@ -107,12 +107,14 @@ __device__ __forceinline__ uint32_t bin_of_hash(const FastCfg& c, uint32_t mh) {
 // new super-k-mer when its argmin position differs from its predecessor's.  Records are written in
 // read order to a temporary buffer (wave-level allocation, one atomic per tile) together with their
 // bin id; a second, purely bandwidth-bound kernel moves them into bin order.
-// record = NBW base words (bases left-aligned, MSB first) + 1 meta word: len | exts << 8 | D1 << 16
+// record = NBW words: bases left-aligned, MSB first; the low META_BITS bits of the last word (always free: NBW is
+// chosen that way) hold len (7) | exts << 7 (8) | D1 << 15 (5: the fast path needs labels < 24).  24 bytes at k = 47.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_TILE_W = 128;                // window starts per tile
 constexpr int SCAN_ARR = 192 + 64;              // positions per tile + padding for the shifted reads
 constexpr uint32_t SCAN_CHUNK = 1024;           // records a wave reserves per global atomic (one hot address otherwise)
 constexpr uint32_t BIN_INVALID = 0xffffffffu;   // unused slot of a reserved chunk
+constexpr int META_BITS = 20;
 constexpr uint32_t NCLS = 1;                    // length classes per bin: records of similar k-mer count sit together
                                                 // so that the 64 records a wave processes finish at about the same time
 
@@ -124,8 +126,8 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                                                       unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
                                                       uint32_t* __restrict__ flags, uint64_t* __restrict__ slab,
                                                       uint32_t slab_cap, uint32_t* __restrict__ cursor) {
-    constexpr int RW = NBW + 1;
-    __shared__ uint32_t s_arr[4][SCAN_ARR];      // (hash's top 24 bits << 8) | tile-local position: min() is the leftmost argmin
+    constexpr int RW = NBW;
+    __shared__ uint32_t s_arr[4][SCAN_ARR];      // ordering hash of the canonical p-mer at each position of the tile
     constexpr uint32_t PLC = 256;                // per-wave ring of pending pieces (start window, end window, minimizer position, read)
     __shared__ uint32_t s_pl[4][4 * PLC];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                   const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
                   rv[qq] = nb ? v : 0ull;
               }
-              rv[NBW] = (uint64_t)len | ((uint64_t)((re << 4) | le) << 8) | ((uint64_t)d1 << 16);
+              rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 31u) << 15);
           }
           auto store_rec = [&](uint64_t* o) {
               if (RW % 2 == 0) {
@@ -360,7 +362,7 @@ template <int NBW>
 __global__ void __launch_bounds__(256) sk_scatter_kernel(const uint64_t* __restrict__ tmp_recs, const uint32_t* __restrict__ tmp_bin,
                                                          uint64_t n_recs, const uint64_t* __restrict__ bin_off,
                                                          uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs) {
-    constexpr int RW = NBW + 1;
+    constexpr int RW = NBW;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_recs) return;
     uint32_t b = tmp_bin[i];
@@ -466,7 +468,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
                                                        unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags) {
-    constexpr int RW = NBW + 1;
+    constexpr int RW = NBW;
     constexpr int NWV = NT / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_tag[T];
     __shared__ __attribute__((aligned(16))) uint64_t s_key[KW * T];   // KW == 2: {lo, hi} pairs, one ds_read_b128 per entry
@@ -474,6 +476,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24)
     constexpr uint32_t CAPC = (NBW == 4 ? 2 : 4) * NT;      // chunk-map capacity per batch
     __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
+    __shared__ uint8_t s_chk[NT];               // per staged record: chunk length cb | remainder cr << 4
     __shared__ uint16_t s_cmap[CAPC];           // chunk -> record slot | chunk index << 10
     __shared__ uint32_t s_m, s_cproc;
 #ifdef DBG_COUNT_STATS
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 P0 = g[0]; P1 = g[1];
                 if (NBW > 2) P2 = g[2];
                 if (NBW > 3) P3 = g[3];
-                pmeta = g[NBW];
+                pmeta = (NBW == 2 ? P1 : (NBW == 3 ? P2 : P3)) & ((1ull << META_BITS) - 1);
             }
         };
         load_rec(tid);
@@ -560,13 +563,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         for (uint32_t bstart = 0; bstart < total_recs && !pass_ovf;) {
             // A. stage this batch's records (prefetched) + per-record chunking
             const bool have = bstart + tid < total_recs;
-            uint32_t nkr = have ? (uint32_t)(pmeta & 0xff) - (uint32_t)k + 1u : 0u;
+            uint32_t nkr = have ? (uint32_t)(pmeta & 0x7f) - (uint32_t)k + 1u : 0u;
             const uint32_t nch = (nkr + CH - 1) / CH;
             const uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;     // chunk c: cb + (c < cr) k-mers
             s_slab[tid] = P0; s_slab[NT + tid] = P1;
             if (NBW > 2) s_slab[2 * NT + tid] = P2;
             if (NBW > 3) s_slab[3 * NT + tid] = P3;
-            s_slab[NBW * NT + tid] = (pmeta & 0xffffffffffffull) | ((uint64_t)cb << 48) | ((uint64_t)cr << 52);
+            s_chk[tid] = (uint8_t)(cb | (cr << 4));
             if (tid == 0) { s_m = NT; s_cproc = 0; }
             uint32_t totc;
             const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &totc);   // barriers inside
@@ -589,9 +592,14 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 W0 = s_slab[r]; W1 = s_slab[NT + r];
                 if (NBW > 2) W2 = s_slab[2 * NT + r];
                 if (NBW > 3) W3 = s_slab[3 * NT + r];
-                meta = s_slab[NBW * NT + r];
-                const uint32_t rlen = (uint32_t)(meta & 0xff), rexts = (uint32_t)(meta >> 8) & 0xffu, rd = (uint32_t)(meta >> 16);
-                const uint32_t cbase = (uint32_t)(meta >> 48) & 15u, crem = (uint32_t)(meta >> 52) & 7u;
+                {   // the record's meta bits sit below its bases in the last word
+                    uint64_t& WL = NBW == 2 ? W1 : (NBW == 3 ? W2 : W3);
+                    meta = WL & ((1ull << META_BITS) - 1);
+                    WL &= ~((1ull << META_BITS) - 1);
+                }
+                const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu, rd = (uint32_t)(meta >> 15) & 31u;
+                const uint32_t chk = s_chk[r];
+                const uint32_t cbase = chk & 15u, crem = chk >> 4;
                 uint32_t j = c * cbase + (c < crem ? c : crem);
                 const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
                 // k-mer j of the record: bases [j, j + k) of the 2-bit stream W[0..NBW)
@@ -820,9 +828,9 @@ struct FastPlan {
 static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
     if (k < 16 || k > 64) return false;
     pl->k = k; pl->p = fast_internal_p(k);
-    pl->nbw = std::max(2, (2 * k - pl->p + 31) / 32);           // base words per record
+    pl->nbw = std::max(2, (2 * (2 * k - pl->p) + META_BITS + 63) / 64);   // words per record: bases + META_BITS
     if (pl->nbw > 4) return false;
-    pl->rw = pl->nbw + 1;
+    pl->rw = pl->nbw;
     pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
     uint64_t target = 9500;                                     // k-mer instances per bin (about 0.15 distinct per instance)
     if (const char* e = getenv("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
@@ -906,6 +914,8 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         unsigned long long cur = 0;
         HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] scan done: nbw=%d rw=%d bins=%u slab_cap=%u tmp used %llu of %llu\n", nbw, rw, nbins, st->slab_cap,
+                                         cur, (unsigned long long)tmp_cap);
         if (cur > tmp_cap) {                                  // low-complexity input: more pieces than estimated
             if (attempt >= 2) return c->fail(133, "fast path: super-k-mer buffer estimate failed");
             tmp_cap = std::min<uint64_t>(n_kmers, cur) + chunk_slack;
@@ -1295,9 +1305,9 @@ extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, ui
     ALLOC_OR_FAIL(c, ovf_base, (size_t)nb + 1);
     c->t_begin("slab_compact", st->n_recs);
     const uint32_t blocks = cdiv((uint64_t)nb * 64, 256);
-    if (st->pl.rw == 3) slab_compact_kernel<3><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
-    else if (st->pl.rw == 4) slab_compact_kernel<4><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
-    else slab_compact_kernel<5><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
+    if (st->pl.rw == 2) slab_compact_kernel<2><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
+    else if (st->pl.rw == 3) slab_compact_kernel<3><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
+    else slab_compact_kernel<4><<<blocks, 256, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, bin_off_dev, nb, recs_out_dev, ovf_base.p);
     c->t_end();
     LAUNCH_CHECK(c, "slab_compact");
     st->slab.release(); st->cursor.release();
