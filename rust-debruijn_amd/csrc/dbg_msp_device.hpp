@@ -12,7 +12,12 @@ struct MspCfg {
     int lmer_words;
 };
 
-__device__ __forceinline__ uint32_t pmer_rc(uint32_t pm, int p) { return (uint32_t)kmer_rc(K128{0, pm}, p).lo; }
+// reverse complement of a right-aligned p-mer (p <= 16) held in 32 bits: reverse the bit pairs, complement, re-align
+__device__ __forceinline__ uint32_t pmer_rc(uint32_t pm, int p) {
+    uint32_t r = __brev(pm);
+    r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    return (~r) >> (32 - 2 * p);
+}
 
 __device__ __forceinline__ uint32_t pmer_score(const MspCfg& c, uint32_t pm) {          // msp.rs:305-311
     uint32_t a = c.perm ? c.perm[pm] : pm;
