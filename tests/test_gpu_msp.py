@@ -120,3 +120,17 @@ def test_msp_then_filter_equals_direct_filter(ctx):
     b, _ = dbg.filter_kmers([(s, 0, None) for s in reads], dbg.CountFilter(2), False, False, 4, k=k, ctx=ctx)
     assert a.keys() == b.keys()
     assert np.array_equal(a.exts, b.exts) and np.array_equal(a.count, b.count)
+
+
+@pytest.mark.parametrize("k,p,alphabet", [(21, 3, 2), (31, 4, 2), (25, 5, 3), (47, 6, 2), (40, 3, 4), (64, 8, 2)])
+def test_msp_tie_heavy_short_reads(ctx, k, p, alphabet):
+    """Small alphabets and tiny p make equal p-mers inside one window the normal case: every step of the wave-per-read
+    orbit (first strictly smaller entry vs rightmost minimum after expiry) is decided by the tie rule.  Lengths straddle the
+    256-position limit between the wave-per-read kernel and the literal lane-per-read scanner."""
+    rng = np.random.default_rng(1000 * k + p)
+    seqs = [rng.integers(0, alphabet, size=int(n)).astype(np.uint8) for n in rng.integers(k, 300, size=300)]
+    seqs += [rng.integers(0, alphabet, size=n).astype(np.uint8) for n in (255 + p, 256 + p - 1, 256 + p, 257 + p)]
+    perm = rng.permutation(4 ** p).astype(np.uint32)
+    check_batch(ctx, seqs, k, p, None, True)
+    check_batch(ctx, seqs, k, p, None, False)
+    check_batch(ctx, seqs, k, p, perm, True, lmer_words=0 if k > 47 else 3)
