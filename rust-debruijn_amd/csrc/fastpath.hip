@@ -1019,13 +1019,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
 #define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, 0, c->stream>>>( \
             recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
 #define GO(KW, NBW, SET) do { \
-            if (tb_env == 512 && nt_env == 128) L(KW, NBW, SET, 128, 512); \
-            else if (tb_env == 512) L(KW, NBW, SET, 256, 512); \
-            else if (tb_env == 1024 && nt_env == 128) L(KW, NBW, SET, 128, 1024); \
-            else if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
-            else if (tb_env == 1024) L(KW, NBW, SET, 512, 1024); \
-            else if (nt_env == 1024) L(KW, NBW, SET, 1024, TABLE); \
-            else if (nt_env == 256) L(KW, NBW, SET, 256, TABLE); \
+            if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
             else L(KW, NBW, SET, 512, TABLE); } while (0)
             if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
             else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
