@@ -386,6 +386,11 @@ struct FastOut {
     uint64_t* hi;       // null when k <= 32
     uint64_t* lo;
     uint32_t* pay;      // CountFilter: exts | min(count, 65535) << 8;  CountFilterSet: exts | colour mask << 8 (labels < 24)
+    // report_all_kmers (filter.rs:208-212): every distinct k-mer, valid or not; null = not requested
+    uint64_t* all_hi;
+    uint64_t* all_lo;
+    unsigned long long* all_cursor;
+    uint64_t all_cap;
 };
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -485,7 +490,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
 #endif
     __shared__ uint32_t s_wsum[NWV];
     __shared__ uint32_t s_flag[2];              // [0] table overflow, [1] claimed entries
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_base_all;
     __shared__ uint32_t s_stP[40], s_stR[40];
     __shared__ int s_sp;
 
@@ -733,25 +738,40 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         const bool ovf = s_flag[0] != 0;
         // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
         if (!ovf) {
-            uint32_t nvalid = 0;
+            uint32_t nvalid = 0, nall = 0;
             for (int i = tid; i < T; i += NT) {
                 if (!s_tag[i]) continue;
                 uint32_t c = s_cnt[i];
                 bool valid = IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs;
                 nvalid += valid ? 1u : 0u;
+                nall++;
             }
-            uint32_t tot_valid;
-            uint32_t incl = block_inclusive_scan<NT>(nvalid, s_wsum, &tot_valid);
+            // one scan for both lists: valid count in the low half, distinct count in the high half (each <= T < 65536)
+            uint32_t tot2;
+            const uint32_t incl2 = block_inclusive_scan<NT>(nvalid | (nall << 16), s_wsum, &tot2);
+            const uint32_t tot_valid = tot2 & 0xffffu, tot_all = tot2 >> 16;
+            const uint32_t incl = incl2 & 0xffffu, incl_all = incl2 >> 16;
             PH(4);
-            if (tid == 0) s_base = tot_valid ? atomicAdd(out_cursor, (unsigned long long)tot_valid) : 0ull;
+            if (tid == 0) {
+                s_base = tot_valid ? atomicAdd(out_cursor, (unsigned long long)tot_valid) : 0ull;
+                s_base_all = (out.all_lo && tot_all) ? atomicAdd(out.all_cursor, (unsigned long long)tot_all) : 0ull;
+            }
             __syncthreads();
             PH(5);
             uint64_t o = s_base + (incl - nvalid);
-            if (tot_valid && s_base + tot_valid > out_cap) {
-                if (tid == 0) atomicOr(&gflags[0], 1u);                    // output buffer too small: host retries
-            } else {
+            uint64_t oa = s_base_all + (incl_all - nall);
+            const bool fit = !(tot_valid && s_base + tot_valid > out_cap);
+            const bool fit_all = !(out.all_lo && tot_all && s_base_all + tot_all > out.all_cap);
+            if (!fit && tid == 0) atomicOr(&gflags[0], 1u);                // output buffer too small: host grows it and retries
+            if (!fit_all && tid == 0) atomicOr(&gflags[0], 8u);
+            if (fit && fit_all) {
                 for (int i = tid; i < T; i += NT) {
                     if (!s_tag[i]) continue;
+                    if (out.all_lo) {
+                        if (KW == 2) { out.all_hi[oa] = s_key[2 * i + 1]; out.all_lo[oa] = s_key[2 * i]; }
+                        else out.all_lo[oa] = s_key[i];
+                        oa++;
+                    }
                     uint32_t c = s_cnt[i];
                     uint32_t c16 = c > 65535u ? 65535u : c;
                     bool valid = IS_SET ? (uint64_t)c >= min_obs : (uint64_t)c16 >= min_obs;
@@ -967,7 +987,27 @@ struct FastCountState {
     DBuf<uint64_t> u_hi, u_lo;
     DBuf<uint32_t> u_pay, gflags;
     DBuf<unsigned long long> out_cursor;
+    // report_all_kmers: every distinct key
+    bool report_all = false;
+    uint64_t all_cap = 0, n_all = 0;
+    DBuf<uint64_t> a_hi, a_lo;
+    DBuf<unsigned long long> all_cursor;
 };
+
+static int fast_count_alloc_all(dbg_ctx* c, FastCountState* st, uint64_t cap) {
+    if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+    DBuf<uint64_t> n_hi, n_lo;
+    if (st->pl.has_hi) ALLOC_OR_FAIL(c, n_hi, cap);
+    ALLOC_OR_FAIL(c, n_lo, cap);
+    if (st->n_all) {
+        if (st->pl.has_hi) HIP_TRY(c, hipMemcpyAsync(n_hi.p, st->a_hi.p, st->n_all * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(n_lo.p, st->a_lo.p, st->n_all * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    std::swap(st->a_hi, n_hi); std::swap(st->a_lo, n_lo);
+    st->all_cap = cap;
+    return 0;
+}
 
 static int fast_count_alloc(dbg_ctx* c, FastCountState* st, uint64_t cap) {
     if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
@@ -987,9 +1027,15 @@ static int fast_count_alloc(dbg_ctx* c, FastCountState* st, uint64_t cap) {
     return 0;
 }
 
-static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, uint64_t n_kmers_hint, FastCountState* st) {
+static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, uint64_t n_kmers_hint, FastCountState* st,
+                            bool report_all = false) {
     st->pl = pl; st->min_obs = min_obs; st->n_out = 0; st->n_kmers_hint = n_kmers_hint;
+    st->report_all = report_all; st->n_all = 0;
     ALLOC_OR_FAIL(c, st->out_cursor, 1);
+    if (report_all) {
+        ALLOC_OR_FAIL(c, st->all_cursor, 1);
+        DBG_TRY(fast_count_alloc_all(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 4, 1u << 20)), 1)));
+    }
     ALLOC_OR_FAIL(c, st->gflags, 16);
     HIP_TRY(c, hipMemsetAsync(st->out_cursor.p, 0, 8, c->stream));
     return fast_count_alloc(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1));
@@ -1006,10 +1052,12 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
     constexpr uint32_t TABLE = 2048;
     for (int attempt = 0;; attempt++) {
         const uint64_t cap = st->cap;
-        unsigned long long start = st->n_out;
+        unsigned long long start = st->n_out, start_all = st->n_all;
         HIP_TRY(c, hipMemcpyAsync(st->out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
+        if (st->report_all) HIP_TRY(c, hipMemcpyAsync(st->all_cursor.p, &start_all, 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(st->gflags.p, 0, 64, c->stream));
-        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p};
+        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->report_all ? st->a_hi.p : nullptr, st->report_all ? st->a_lo.p : nullptr,
+                   st->report_all ? st->all_cursor.p : nullptr, st->all_cap};
         unsigned long long* out_cursor_p = st->out_cursor.p;
         uint32_t* gflags_p = st->gflags.p;
         if (nbins_local) {
@@ -1030,9 +1078,10 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
             c->t_end();
             LAUNCH_CHECK(c, "bin_count");
         }
-        unsigned long long cur = 0;
+        unsigned long long cur = 0, cur_all = 0;
         uint32_t flv[16] = {0};
         HIP_TRY(c, hipMemcpyAsync(&cur, st->out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        if (st->report_all) HIP_TRY(c, hipMemcpyAsync(&cur_all, st->all_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(flv, st->gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint32_t fl = flv[0];
@@ -1054,12 +1103,14 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
 #endif
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (fl & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
-        if (fl & 1u) {                                            // output buffer too small: grow (earlier chunks are kept) and redo this launch
-            if (attempt >= 3 || cur >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 valid k-mers");
-            DBG_TRY(fast_count_alloc(c, st, cur + cur / 16 + 1024));
+        if (fl & 9u) {                                            // an output buffer is too small: grow (earlier chunks are kept) and redo this launch
+            if (attempt >= 3 || cur >= (1ull << 32) || cur_all >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 k-mers in one table");
+            if (fl & 1u) DBG_TRY(fast_count_alloc(c, st, cur + cur / 16 + 1024));
+            if (fl & 8u) DBG_TRY(fast_count_alloc_all(c, st, cur_all + cur_all / 16 + 1024));
             continue;
         }
         st->n_out = cur;
+        st->n_all = cur_all;
         break;
     }
     return 0;
@@ -1105,15 +1156,34 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
     out->key_hi = o_hi.take(); out->key_lo = o_lo.take(); out->exts = o_exts.take(); out->count = o_count.take();
     out->set_off = o_set_off.take(); out->set_val = o_set_val.take(); out->n_set_val = n_setval;
     out->n_kmer_instances = n_kmers_hint; out->n_passes = 1; out->on_device = 1;
+    if (st->report_all) {
+        // all_kmers (filter.rs:208-212): every distinct key in the same ascending order; keys only, so the payload
+        // columns of the sorter are scratch
+        const uint64_t n_all = st->n_all;
+        const size_t naa = std::max<uint64_t>(n_all, 1);
+        DBuf<uint64_t> b_hi, b_lo, f_hi, f_lo;
+        DBuf<uint32_t> a_pay, b_pay;
+        DBuf<uint8_t> x_exts;
+        DBuf<uint16_t> x_count;
+        ALLOC_OR_FAIL(c, a_pay, naa); ALLOC_OR_FAIL(c, b_pay, naa); ALLOC_OR_FAIL(c, b_lo, naa);
+        ALLOC_OR_FAIL(c, f_hi, naa); ALLOC_OR_FAIL(c, f_lo, naa); ALLOC_OR_FAIL(c, x_exts, naa); ALLOC_OR_FAIL(c, x_count, naa);
+        if (has_hi) ALLOC_OR_FAIL(c, b_hi, naa);
+        HIP_TRY(c, hipMemsetAsync(a_pay.p, 0, naa * 4, c->stream));
+        RecArrays A2{has_hi ? st->a_hi.p : nullptr, st->a_lo.p, a_pay.p}, B2{has_hi ? b_hi.p : nullptr, b_lo.p, b_pay.p};
+        DBG_TRY(sort_table_hybrid(c, n_all, A2, B2, 2 * k, false, !getenv("DBG_NO_HYBRID_SORT"), f_hi.p, f_lo.p, x_exts.p, x_count.p, nullptr, nullptr));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        out->n_all = n_all;
+        out->all_hi = f_hi.take(); out->all_lo = f_lo.take();
+    }
     return 0;
 }
 
 static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
                       const uint64_t* seg_beg, const uint64_t* seg_end,
                       uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local, uint64_t n_kmers_hint, uint64_t n_recs_hint,
-                      dbg_kmer_table* out) {
+                      dbg_kmer_table* out, bool report_all = false) {
     FastCountState st;
-    DBG_TRY(fast_count_begin(c, pl, min_obs, n_kmers_hint, &st));
+    DBG_TRY(fast_count_begin(c, pl, min_obs, n_kmers_hint, &st, report_all));
     DBG_TRY(fast_count_bins(c, &st, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, nbins_local, n_kmers_hint, n_recs_hint));
     return fast_count_finish(c, &st, out);
 }
@@ -1162,7 +1232,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
                       bool* used) {
     *used = false;
     const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET;
-    if (prm->report_all_kmers || n_kmers == 0) return 0;
+    if (n_kmers == 0) return 0;
     FastPlan pl;
     if (!fast_make_plan((int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
     if (is_set) { bool ok; DBG_TRY(fast_labels_ok(c, s, &ok)); if (!ok) return 0; }
@@ -1192,7 +1262,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] direct slabs: cap=%u records/bin, %llu records, %llu took the overflow path\n", slab_cap,
                                      n_recs_total, (unsigned long long)st.n_recs);
     DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, st.n_recs ? 2u : 1u, (uint64_t)nb,
-                       pl.nbins, n_kmers, n_recs_total, out));
+                       pl.nbins, n_kmers, n_recs_total, out, prm->report_all_kmers != 0));
     *used = true;
     return 0;
 }

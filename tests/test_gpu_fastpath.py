@@ -122,3 +122,16 @@ def test_fast_path_refuses_unsupported_shapes(ctx):
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
     got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     assert_tables_equal(got, want, True)
+
+
+@pytest.mark.parametrize("k,stranded,kind", [(47, False, 0), (31, True, 0), (64, False, 0), (47, False, 1), (16, False, 0)])
+def test_fast_report_all_kmers(ctx, k, stranded, kind):
+    """report_all_kmers (filter.rs:208-212) through the fast path: every distinct k-mer, ascending, next to the valid table."""
+    hs = dbg.synth_reads_host(n_reads=3000, read_len=150, error_rate=0.004, stranded=stranded, n_colours=4)
+    summ = dbg.CountFilterSet(2) if kind else dbg.CountFilter(2)
+    t, allk = dbg.filter_kmers(hs, summ, stranded, True, 4, k=k, ctx=ctx)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if kind else None, 1 if kind else 0)
+    want = O.filter_kmers(ss, k, kind, 2, stranded=stranded, report_all=True)
+    assert np.array_equal(t.key_hi, want.key_hi) and np.array_equal(t.key_lo, want.key_lo) and np.array_equal(t.exts, want.exts)
+    assert np.array_equal(t.all_hi, want.all_hi) and np.array_equal(t.all_lo, want.all_lo)
+    assert len(allk) == len(want.all_lo) > len(t)

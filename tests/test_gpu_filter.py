@@ -38,6 +38,20 @@ def assert_tables_equal(got, want, is_set):
     assert np.array_equal(got.all_lo, want.all_lo)
 
 
+@pytest.fixture(autouse=True, params=["auto", "generic"])
+def path_mode(request):
+    """Every test runs through the default dispatch (fast path where it applies) and with the generic
+    extract -> radix sort -> reduce path forced."""
+    import os
+    old = os.environ.get("DBG_PATH")
+    os.environ["DBG_PATH"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("DBG_PATH", None)
+    else:
+        os.environ["DBG_PATH"] = old
+
+
 def run_both(ctx, ss, k, summarizer, min_obs, stranded, report_all=False, data_width=0):
     is_set = summarizer == O.COUNT_FILTER_SET
     want = O.filter_kmers(ss, k, summarizer, min_obs, stranded=stranded, report_all=report_all)
