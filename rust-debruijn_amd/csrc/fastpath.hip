@@ -12,8 +12,11 @@
 // if a bin holds more distinct k-mers than the table, the workgroup re-streams it in P hash-selected
 // passes (the same idea as the reference's bucket_ranges passes, filter.rs:156-168).
 //
-// The internal partition uses its own minimizer scheme (p up to 13, bijectively hashed canonical p-mers
-// for balance -- a `permutation` in the reference's terms, msp.rs:55-59); it is invisible in the result.
+// The internal partition uses its own minimizer scheme (p up to 15, canonical p-mers ordered by a bijective
+// hash -- a `permutation` in the reference's terms, msp.rs:55-59 -- pieces cut where the window's minimum VALUE
+// changes, so that the choice is the same on both strands); it is invisible in the result.
+// Records go straight from the scan into per-bin slabs; see DESIGN.md section 3.1 for the measurements behind
+// each structural choice.
 #include "dbg_internal.hpp"
 #include "dbg_msp_device.hpp"
 #include <algorithm>
