@@ -443,7 +443,7 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
 }
 
 // One workgroup (NT threads = NT/64 waves) owns one bin and one LDS hash table of T entries.
-// The workgroup streams the bin in batches of NT records, cut into chunks of <= 8 k-mers that are dealt to
+// The workgroup streams the bin in batches of NT records, cut into chunks of <= 4 k-mers that are dealt to
 // all lanes (see "stream the bin" below):
 //   * insert = bucketised linear probing on 32-bit tags (4 per bucket).  A free slot is claimed with
 //     CAS(tag, 0, tag|BUSY); the claimer writes the 64/128-bit key and then stores the final tag
@@ -482,9 +482,9 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ __attribute__((aligned(16))) uint64_t s_key[KW * T];   // KW == 2: {lo, hi} pairs, one ds_read_b128 per entry
     __shared__ uint32_t s_cnt[T];
     __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24)
-    constexpr uint32_t CAPC = (NBW == 4 ? 2 : 4) * NT;      // chunk-map capacity per batch
+    constexpr uint32_t CAPC = (NBW == 4 ? 4 : 6) * NT;      // chunk-map capacity per batch
     __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
-    __shared__ uint8_t s_chk[NT];               // per staged record: chunk length cb | remainder cr << 4
+    __shared__ uint8_t s_chk[NT];               // per staged record: chunk length cb | remainder cr << 3
     __shared__ uint16_t s_cmap[CAPC];           // chunk -> record slot | chunk index << 10
     __shared__ uint32_t s_m, s_cproc;
 #ifdef DBG_COUNT_STATS
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         //      re-creates the chunk's first k-mer from the staged record (one funnel shift + one reverse
         //      complement per chunk) and then rolls (extend_right on the forward strand, extend_left of the
         //      complement on the reverse strand).  The next batch is prefetched into registers meanwhile. ----
-        constexpr uint32_t CH = 8;
+        constexpr uint32_t CH = 4;
         // (scalars, not arrays: an indexed private array is placed in scratch memory by the compiler)
         uint64_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, P0 = 0, P1 = 0, P2 = 0, P3 = 0;
         uint64_t meta = 0, pmeta = 0;
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             s_slab[tid] = P0; s_slab[NT + tid] = P1;
             if (NBW > 2) s_slab[2 * NT + tid] = P2;
             if (NBW > 3) s_slab[3 * NT + tid] = P3;
-            s_chk[tid] = (uint8_t)(cb | (cr << 4));
+            s_chk[tid] = (uint8_t)(cb | (cr << 3));          // cb <= CH <= 7, cr < nch <= 17
             if (tid == 0) { s_m = NT; s_cproc = 0; }
             uint32_t totc;
             const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &totc);   // barriers inside
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 }
                 const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu, rd = (uint32_t)(meta >> 15) & 31u;
                 const uint32_t chk = s_chk[r];
-                const uint32_t cbase = chk & 15u, crem = chk >> 4;
+                const uint32_t cbase = chk & 7u, crem = chk >> 3;
                 uint32_t j = c * cbase + (c < crem ? c : crem);
                 const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
                 // k-mer j of the record: bases [j, j + k) of the 2-bit stream W[0..NBW)
