@@ -178,7 +178,7 @@ def main():
                     "whole_path_alg_frac": round(value * b_alg / HBM_PEAK_GBS, 4),
                     "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
             import oracle_lib as O
             n_s = 1500000                                      # ~156M k-mer instances: 10-30 s of single-thread CPU work
             hs = dbg.synth_reads_host(n_reads=n_s, read_len=L, genome_len=n_s * L // 30, error_rate=0.001,
