@@ -147,9 +147,10 @@ struct BitPusher {          // DnaString::push (dna_string.rs:303-310) into a gr
 };
 }  // namespace
 
+struct UnitigNodes;
 int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                           const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
-                          dbg_graph* out, bool* done);
+                          dbg_graph* out, bool* done, const UnitigNodes* nodes = nullptr);
 
 // builds the prefix index of an ascending key array (n < 2^32); *t gets the index attached
 static int attach_prefix_index(dbg_ctx* c, KeysDev* t, int k, DBuf<uint32_t>* store) {

@@ -67,6 +67,14 @@ int filter_kmers_fast(dbg_ctx* ctx, const SeqDev& s, const dbg_filter_params* pr
 int synth_reads_dev(dbg_ctx* ctx, const dbg_synth_params* p, uint64_t* words, uint64_t* start, uint32_t* length,
                     uint8_t* data);
 
+// ---- unitig.hip : chains of mutually linked elements -> BaseGraph (k-mers, or graph nodes for compress_graph) ----
+struct UnitigNodes {            // device arrays describing graph nodes as elements
+    const uint32_t* weight;     // k-mers per node (length - k + 1)
+    const uint64_t* words;      // packed node sequences
+    const uint64_t* start;
+    const uint32_t* length;
+};
+
 // ---- launch helpers -----------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx, name)                                                                 \
     do {                                                                                        \

@@ -12,6 +12,11 @@
 #include "dbg_internal.hpp"
 #include <algorithm>
 #include <deque>
+#include <cstring>
+
+int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
+                          const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
+                          dbg_graph* out, bool* done, const UnitigNodes* nodes);
 
 namespace {
 
@@ -161,6 +166,20 @@ __global__ void edges_kernel(EndIndex left, EndIndex right, const uint64_t* __re
         }
         target[(uint64_t)i * 8 + 4 + b] = t; info[(uint64_t)i * 8 + 4 + b] = (uint8_t)f;
     }
+}
+
+// node links -> the element-link format of unitig.hip ((next << 1) | side we leave `next` through; PANIC flag; TERM) + weights
+__global__ void node_links_to_unitig_kernel(const uint32_t* __restrict__ nl, const uint32_t* __restrict__ length, uint32_t n, int k,
+                                            uint32_t* __restrict__ ul, uint32_t* __restrict__ weight) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= 2 * n) return;
+    const uint32_t L = nl[s];
+    uint32_t o;
+    if (L == NL_TERM) o = 0xFFFFFFFFu;
+    else if (L == NL_NOKMER || L == NL_INCONSISTENT) o = 0x80000000u;          // the reference panics: the literal walk reports it
+    else o = ((L >> 2) << 1) | ((L >> 1) & 1u) | ((L & NL_PANIC_BIT) ? 0x80000000u : 0u);
+    ul[s] = o;
+    if (s < n) weight[s] = length[s] - (uint32_t)k + 1u;
 }
 
 // ---- host helpers --------------------------------------------------------------------------
@@ -316,6 +335,34 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
                                                                d.exts.p, d.data.p, d_link.p);
         c->t_end();
         LAUNCH_CHECK(c, "node_links");
+        // the whole walk on the device (same chain construction as compress_kmers_with_hash, elements = nodes), unless
+        // nodes are censored or the links are not mutual / carry a panic marker: then the literal host walk below runs
+        const char* mode = getenv("DBG_COMPRESS");
+        if (n_censor == 0 && !(mode && !strcmp(mode, "host"))) {
+            DBuf<uint32_t> u_link, u_weight;
+            ALLOC_OR_FAIL(c, u_link, 2 * (size_t)n);
+            ALLOC_OR_FAIL(c, u_weight, n);
+            node_links_to_unitig_kernel<<<cdiv(2 * (uint64_t)n, 256), 256, 0, c->stream>>>(d_link.p, d.length.p, n, k, u_link.p, u_weight.p);
+            LAUNCH_CHECK(c, "node_links_to_unitig");
+            UnitigNodes un{u_weight.p, d.words.p, d.start.p, d.length.p};
+            dbg_graph ng;
+            bool done = false;
+            DBG_TRY(compress_links_device(c, k, n, nullptr, nullptr, d.exts.p, d.data.p, u_link.p, nullptr, spec, stranded, &ng, &done, &un));
+            if (done) {
+                // ---- graph.finish(); dbg.fix_exts(None) (compression.rs:330-331) ----
+                DevGraph d2;
+                int r = dev_graph_build(c, k, &ng, &d2);
+                if (!r) r = dev_fix_exts(c, k, stranded, &d2, nullptr);
+                if (!r && ng.n_nodes) {
+                    if (hipMemcpyAsync(ng.exts, d2.exts.p, ng.n_nodes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                        hipStreamSynchronize(c->stream) != hipSuccess) r = c->fail(100, "copy of fixed exts failed");
+                }
+                if (r) { free(ng.seq_words); free(ng.start); free(ng.length); free(ng.exts); free(ng.data); return r; }
+                *out = ng;
+                return 0;
+            }
+            if (mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the node links are not mutual");
+        }
         HIP_TRY(c, hipMemcpyAsync(link.data(), d_link.p, 2 * (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(exts.data(), d.exts.p, n, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

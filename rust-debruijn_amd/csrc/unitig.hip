@@ -48,13 +48,15 @@ __global__ void check_links_kernel(const uint32_t* __restrict__ link, uint32_t n
     if (back != ((i << 1) | (1 - p))) atomicOr(flags, 2u);
 }
 
-__global__ void init_states_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, uint32_t n, Jump* __restrict__ J) {
+// weight[i] = k-mers element i stands for (null: every element is one k-mer); distances are counted in k-mers
+__global__ void init_states_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ weight,
+                                   uint32_t n, Jump* __restrict__ J) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= 2 * n) return;
     uint32_t i = s >> 1, p = s & 1;
     uint32_t L = link[(uint64_t)p * n + i];
     Jump o;
-    if (link_valid(L, i)) { uint32_t j = L >> 1, nd = L & 1; o.nxt = 2 * j + nd; o.dist = 1; o.minr = rank ? rank[j] : j; o.endst = ST_NONE; }
+    if (link_valid(L, i)) { uint32_t j = L >> 1, nd = L & 1; o.nxt = 2 * j + nd; o.dist = weight ? weight[j] : 1u; o.minr = rank ? rank[j] : j; o.endst = ST_NONE; }
     else { o.nxt = ST_NONE; o.dist = 0; o.minr = R_INF; o.endst = s; }
     J[s] = o;
 }
@@ -117,23 +119,23 @@ __global__ void cut_cycles_kernel(const Jump* __restrict__ J, const uint32_t* __
 }
 
 struct NodeInfo { uint32_t seedrank, pos, m; bool toA_is_left; };
-__device__ __forceinline__ NodeInfo node_info(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t i) {
+__device__ __forceinline__ NodeInfo node_info(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t i, uint32_t wi = 1u) {
     Jump a = J[2 * i], b = J[2 * i + 1];
     NodeInfo o;
     uint32_t r = rank ? rank[i] : i;
     uint32_t mr = a.minr < b.minr ? a.minr : b.minr;
     o.seedrank = r < mr ? r : mr;
-    o.m = a.dist + b.dist + 1;
+    o.m = a.dist + b.dist + wi;                                    // k-mers of the whole chain
     o.toA_is_left = a.endst < b.endst;                             // chain end A = the smaller terminal state
     o.pos = o.toA_is_left ? a.dist : b.dist;                       // distance from end A
     return o;
 }
 
-__global__ void mark_seeds_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t n, int k,
+__global__ void mark_seeds_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ weight, uint32_t n, int k,
                                   uint32_t* __restrict__ flag_by_rank, uint32_t* __restrict__ len_by_rank, uint8_t* __restrict__ rev_by_rank) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    NodeInfo f = node_info(J, rank, i);
+    NodeInfo f = node_info(J, rank, i, weight ? weight[i] : 1u);
     uint32_t r = rank ? rank[i] : i;
     if (r == f.seedrank) {
         flag_by_rank[r] = 1;
@@ -189,13 +191,63 @@ __global__ void emit_kernel(const Jump* __restrict__ J, const uint32_t* __restri
     else atomicAdd(&uacc[ui], (unsigned long long)d);
 }
 
+// reverse complement of nb (<= 32) bases held right-aligned in a u64
+__device__ __forceinline__ uint64_t rc_bases64(uint64_t x, uint32_t nb) {
+    uint64_t r = __brevll(x);
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    return (~r) >> (64 - 2 * nb);
+}
+
+// Same construction for compress_graph (compression.rs:100-349): the elements are graph nodes (weight = k-mers of the
+// node).  A node writes its (oriented) sequence -- everything when it opens the path, otherwise what follows the
+// (k-1)-base overlap (sequence_of_path, graph.rs:471-491) -- 32 bases at a time.
+__global__ void emit_nodes_kernel(const Jump* __restrict__ J, uint32_t n, int k, const uint32_t* __restrict__ weight,
+                                  const uint64_t* __restrict__ nwords, const uint64_t* __restrict__ nstart, const uint32_t* __restrict__ nlen,
+                                  const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data, int spec,
+                                  const uint32_t* __restrict__ uidx_by_rank, const uint8_t* __restrict__ rev_by_rank,
+                                  const uint64_t* __restrict__ ustart, uint64_t* __restrict__ words, uint32_t* __restrict__ uexts,
+                                  unsigned long long* __restrict__ uacc, uint32_t* __restrict__ ucnt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t wi = weight[i];
+    NodeInfo f = node_info(J, nullptr, i, wi);
+    const uint32_t ui = uidx_by_rank[f.seedrank];
+    const bool rev = rev_by_rank[f.seedrank] != 0;
+    const uint32_t u = rev ? f.m - f.pos - wi : f.pos;            // k-mer offset of the node's first k-mer in the path
+    const bool fwd = f.toA_is_left != rev;                         // stored orientation == path orientation?
+    uint32_t e = exts[i];
+    if (!fwd) e = exts_rc(e);
+    const uint32_t L = nlen[i];
+    const uint64_t ns = nstart[i];
+    const uint32_t skip = u == 0 ? 0u : (uint32_t)k - 1;           // bases already written by the previous node
+    const uint64_t dst = ustart[ui] + u + skip;
+    for (uint32_t o = skip; o < L; o += 32) {
+        const uint32_t nb = L - o < 32 ? L - o : 32;
+        uint64_t chunk;
+        if (fwd) chunk = packed_get_kmer(nwords, ns + o, (int)nb).lo;
+        else chunk = rc_bases64(packed_get_kmer(nwords, ns + (L - o - nb), (int)nb).lo, nb);   // DnaStringSlice::rc (dna_string.rs:572-578)
+        or_bits(words, dst + (o - skip), K128{0, chunk}, (int)nb);
+    }
+    uint32_t eo = 0;
+    if (u == 0) eo |= e & 0x0fu;
+    if (u + wi == f.m) eo |= e & 0xf0u;
+    if (eo) atomicOr(&uexts[ui], eo);
+    const uint32_t d = data ? data[i] : 0u;
+    if (spec == DBG_SPEC_SIMPLE_MAX_U16) __hip_atomic_fetch_max((uint32_t*)&uacc[ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (spec == DBG_SPEC_SCMAP_EQ) { if (i == f.seedrank) uacc[ui] = d; }
+    else atomicAdd(&uacc[ui], (unsigned long long)d);
+    atomicAdd(&ucnt[ui], 1u);
+}
+
+// ucnt (compress_graph only): elements joined into the node; null = one element per k-mer of the node
 __global__ void finish_nodes_kernel(uint32_t n_nodes, int spec, int k, const uint32_t* __restrict__ ulen, const uint32_t* __restrict__ uexts,
-                                    const unsigned long long* __restrict__ uacc, uint8_t* __restrict__ o_exts, uint32_t* __restrict__ o_data) {
+                                    const unsigned long long* __restrict__ uacc, const uint32_t* __restrict__ ucnt,
+                                    uint8_t* __restrict__ o_exts, uint32_t* __restrict__ o_data) {
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_nodes) return;
     o_exts[u] = (uint8_t)uexts[u];
     unsigned long long a = uacc[u];
-    uint32_t m = ulen[u] - (uint32_t)k + 1;
+    uint32_t m = ucnt ? ucnt[u] : ulen[u] - (uint32_t)k + 1;
     // (an if-chain: a switch with a `default` arm was miscompiled by hipcc 7.2 for gfx950 here)
     uint32_t d = (uint32_t)a;                                                              // max / ScmapCompress: the value itself
     if (spec == DBG_SPEC_SIMPLE_SAT_ADD_U16) d = a > 65535ull ? 65535u : (uint32_t)a;
@@ -213,8 +265,9 @@ __global__ void finish_nodes_kernel(uint32_t n_nodes, int spec, int k, const uin
 // when the links are not mutual or contain a panic marker: the caller then runs the literal host walk.
 int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                           const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
-                          dbg_graph* out, bool* done) {
+                          dbg_graph* out, bool* done, const UnitigNodes* nodes) {
     *done = false;
+    const uint32_t* weight = nodes ? nodes->weight : nullptr;
     if (n == 0 || n >= (1u << 30)) return 0;
     const uint32_t n2 = 2 * n;
     DBuf<uint32_t> flags;
@@ -236,7 +289,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     ALLOC_OR_FAIL(c, counters, 2);
     Jump* cur = nullptr;
     for (int phase = 0; phase < 2; phase++) {
-        init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, n, JA.p);
+        init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, weight, n, JA.p);
         LAUNCH_CHECK(c, "init_states");
         Jump *a = JA.p, *b = JB.p;
         uint32_t *la = nullptr, *lb = LB.p;                         // round 0 visits every state
@@ -275,7 +328,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
     ALLOC_OR_FAIL(c, rev_by_rank, n);
     HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
-    mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
+    mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, weight, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
     LAUNCH_CHECK(c, "mark_seeds");
     DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
     uint32_t n_nodes = 0;
@@ -302,13 +355,21 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     HIP_TRY(c, hipMemsetAsync(words.p, 0, (n_words + 3) * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(uacc.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(uexts.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 4, c->stream));
+    DBuf<uint32_t> ucnt;
     c->t_begin("unitig_emit", n);
-    emit_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, n, k, key_hi, key_lo, exts, data, spec, uidx_by_rank.p, rev_by_rank.p,
-                                                     ustart.p, words.p, uexts.p, uacc.p);
+    if (nodes) {
+        ALLOC_OR_FAIL(c, ucnt, std::max<uint32_t>(n_nodes, 1));
+        HIP_TRY(c, hipMemsetAsync(ucnt.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 4, c->stream));
+        emit_nodes_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, n, k, weight, nodes->words, nodes->start, nodes->length, exts, data, spec,
+                                                               uidx_by_rank.p, rev_by_rank.p, ustart.p, words.p, uexts.p, uacc.p, ucnt.p);
+    } else {
+        emit_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, n, k, key_hi, key_lo, exts, data, spec, uidx_by_rank.p, rev_by_rank.p,
+                                                         ustart.p, words.p, uexts.p, uacc.p);
+    }
     c->t_end();
     LAUNCH_CHECK(c, "emit");
     if (n_nodes) {
-        finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, o_exts.p, o_data.p);
+        finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, nodes ? ucnt.p : nullptr, o_exts.p, o_data.p);
         LAUNCH_CHECK(c, "finish_nodes");
     }
     if (getenv("DBG_DEBUG") && n_nodes) {
