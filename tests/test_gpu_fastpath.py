@@ -135,3 +135,19 @@ def test_fast_report_all_kmers(ctx, k, stranded, kind):
     assert np.array_equal(t.key_hi, want.key_hi) and np.array_equal(t.key_lo, want.key_lo) and np.array_equal(t.exts, want.exts)
     assert np.array_equal(t.all_hi, want.all_hi) and np.array_equal(t.all_lo, want.all_lo)
     assert len(allk) == len(want.all_lo) > len(t)
+
+
+@pytest.mark.parametrize("k", [31, 47, 64])
+def test_fast_long_sequences(ctx, k):
+    """Contig-length inputs: many 128-window tiles per sequence (minimizer runs and pieces carried across tile borders),
+    plus a long low-complexity stretch whose minimizer value never changes (pieces cut every W windows)."""
+    rng = np.random.default_rng(77 + k)
+    seqs = [R.random_dna(rng, int(n)) for n in (3000, 5000, 1234, 129 + k, 128 + k, 127 + k, 257 + k)]
+    rep = np.tile(R.random_dna(rng, 5), 400)                       # period-5 repeat, 2000 bp
+    seqs += [rep, np.concatenate([R.random_dna(rng, 300), np.zeros(900, np.uint8), R.random_dna(rng, 300)])]
+    seqs = seqs + [R.revcomp_bytes(s) for s in seqs[:4]]
+    for stranded in (False, True):
+        ss = O.SeqSet.from_byte_seqs(seqs)
+        want = O.filter_kmers(ss, k, O.COUNT_FILTER, 1, stranded=stranded)
+        got, _ = dbg.filter_kmers(to_host_seqs(ss, 0), dbg.CountFilter(1), stranded, False, 4, k=k, ctx=ctx)
+        assert_tables_equal(got, want, False)
