@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_kernel(RecArrays in, uin
             o_lo[g] = s_lo[i];
             const uint32_t p = s_pay[i];
             o_exts[g] = (uint8_t)(p & 0xffu);
-            if (IS_SET) { o_msk[g] = p >> 8; if (o_setn) o_setn[g] = __popc(p >> 8); }
+            if (IS_SET) { o_msk[g] = p >> 8; o_setn[g] = __popc(p >> 8); }
             else o_count[g] = (uint16_t)(p >> 8);
         }
     }
@@ -323,7 +323,7 @@ __global__ void decode_payload_kernel(uint32_t n, const uint32_t* __restrict__ p
     if (i >= n) return;
     const uint32_t p = pay[i];
     exts[i] = (uint8_t)(p & 0xffu);
-    if (IS_SET) { msk[i] = p >> 8; if (setn) setn[i] = __popc(p >> 8); }
+    if (IS_SET) { msk[i] = p >> 8; setn[i] = __popc(p >> 8); }
     else count[i] = (uint16_t)(p >> 8);
 }
 }  // namespace
@@ -343,9 +343,7 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
         int top_bits = 0;
         while (top_bits < key_bits && top_bits < 32 && (n64 >> top_bits) > 32) top_bits += 8;
         if (top_bits > key_bits) top_bits = key_bits;
-        // digit boundaries sit at multiples of 8 from bit 0 so that no digit straddles the two key words; rounding down
-        // adds up to 7 prefix bits (30 at k = 47: a 4th, 6-bit pass).  That is deliberate: with 24 prefix bits the groups
-        // hold ~30 records at 5e8 keys and the finisher's rank-by-comparison costs more (31 ms) than the pass saves (7 ms).
+        // digit boundaries sit at multiples of 8 from bit 0 so that no digit straddles the two key words
         const int s0 = top_bits ? ((key_bits - top_bits) / 8) * 8 : key_bits;
         top_bits = key_bits - s0;
         if (top_bits > 0) {
