@@ -151,3 +151,16 @@ def test_fast_long_sequences(ctx, k):
         want = O.filter_kmers(ss, k, O.COUNT_FILTER, 1, stranded=stranded)
         got, _ = dbg.filter_kmers(to_host_seqs(ss, 0), dbg.CountFilter(1), stranded, False, 4, k=k, ctx=ctx)
         assert_tables_equal(got, want, False)
+
+
+@pytest.mark.parametrize("k", [16, 17, 20, 21, 22, 23, 32, 33, 34, 35, 36, 48, 49, 50, 51, 52, 63, 64])
+def test_fast_k_sweep(ctx, k):
+    """Every k at which the internal layout changes: minimizer length (k = 21, 23), key width (33), words per
+    super-k-mer record incl. its 20 meta bits (35, 51)."""
+    hs = dbg.synth_reads_host(n_reads=4000, read_len=150, error_rate=0.003, stranded=False, n_colours=4)
+    for kind, stranded in ((0, False), (1, False), (0, True)):
+        ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if kind else None, 1 if kind else 0)
+        want = O.filter_kmers(ss, k, kind, 2, stranded=stranded)
+        summ = dbg.CountFilterSet(2) if kind else dbg.CountFilter(2)
+        got, _ = dbg.filter_kmers(hs if kind else dbg.HostSeqs(hs.words, hs.start, hs.length), summ, stranded, False, 4, k=k, ctx=ctx)
+        assert_tables_equal(got, want, kind == 1)
