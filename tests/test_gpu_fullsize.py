@@ -62,12 +62,12 @@ def env():
     ctx.close()
 
 
-def run_filter(e, first, n, summarizer, min_obs):
+def run_filter(e, first, n, summarizer, min_obs, report_all=0):
     capi, ctx, lib = e["capi"], e["ctx"], e["lib"]
     is_set = summarizer == 1
     ss = capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"][first:].data_ptr(), e["length"][first:].data_ptr(), None,
                      e["colour"][first:].data_ptr() if is_set else None, 1 if is_set else 0, n)
-    fp = capi.FilterParams(K, 0, summarizer, min_obs, 0, 4)
+    fp = capi.FilterParams(K, 0, summarizer, min_obs, report_all, 4)
     t = capi.KmerTable()
     ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
     return t
@@ -194,3 +194,25 @@ def test_fullsize_prefix_bit_exact(env):
     assert n == want.n
     assert np.array_equal(g_hi, want.key_hi) and np.array_equal(g_lo, want.key_lo) and np.array_equal(g_ex, want.exts)
     assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)
+
+
+def test_fullsize_report_all_kmers(env):
+    """report_all_kmers at full size (filter.rs:208-212): the all-list is strictly ascending, contains the valid table, and
+    with CountFilter(1) -- every distinct k-mer valid -- the two lists are identical."""
+    e = env
+    torch, lib, ctx = e["torch"], e["lib"], e["ctx"]
+    torch.cuda.empty_cache()             # the earlier tests' temporaries sit in torch's caching allocator; this run wants ~150 GB
+    t = run_filter(e, 0, N_READS, 0, 1, report_all=1)
+    assert t.n == t.n_all > 0
+    same = bool((dev_view(t.key_lo, t.n) == dev_view(t.all_lo, t.n_all)).all().item()) and \
+        bool((dev_view(t.key_hi, t.n) == dev_view(t.all_hi, t.n_all)).all().item())
+    n1 = int(t.n)
+    lib.dbg_free_table(ctx.h, C.byref(t))
+    assert same
+    t2 = run_filter(e, 0, N_READS, 0, 2, report_all=1)
+    hi, lo = dev_view(t2.all_hi, t2.n_all), dev_view(t2.all_lo, t2.n_all)
+    ulo = lo ^ (-9223372036854775808)
+    asc = bool(((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (ulo[1:] > ulo[:-1]))).all().item())
+    n_all2, n_valid2 = int(t2.n_all), int(t2.n)
+    lib.dbg_free_table(ctx.h, C.byref(t2))
+    assert asc and n_all2 == n1 and n_valid2 < n_all2                 # the distinct set does not depend on min_obs
