@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--summarizer", default="set", choices=["set", "count"])
     ap.add_argument("--min-obs", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device: several ranks on ONE GPU, payload staged through the host (a functional check of the "
+                         "N > 1 orchestration on a single-GPU box; its timings mean nothing)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0")
     ap.add_argument("--force-sharded", action="store_true",
                     help="time the multi-GPU pipeline (scan -> compaction -> exchange -> count) even on one GPU")
     ap.add_argument("--compress-reads", type=int, default=-1,
@@ -58,9 +62,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = dbg.Context(local_rank)
@@ -126,14 +135,17 @@ def main():
     ctx.enable_timing(False)
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = dev if args.backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cnt = torch.tensor([n_inst], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([n_inst, n_valid], dtype=torch.int64, device=rdev)
         dist.all_reduce(cnt)
-        n_inst_total = int(cnt.item())
+        n_inst_total = int(cnt[0].item())
+        n_valid_total = int(cnt[1].item())
     else:
         n_inst_total = n_inst
+        n_valid_total = n_valid
     ms_per_step = dt / args.steps * 1e3
     value = n_inst_total * args.steps / dt / 1e9
 
@@ -233,7 +245,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=0.001"
                                    % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs),
-                       "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid,
+                       "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid, "valid_kmers_all_ranks": n_valid_total,
                        "path": ("fast (minimizer scan -> super-k-mer slabs per bin -> per-bin LDS hash tables -> order-restoring hybrid sort)" if fast
                                 else "generic (extract -> global LSD radix sort -> segmented reduce)"),
                        "superkmer_records_per_step": n_recs,

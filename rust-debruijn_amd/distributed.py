@@ -97,6 +97,24 @@ def owner_bounds(n_bins, world, group=1):
     return [(r * (n_bins // group) // world) * group for r in range(world + 1)]
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_to_all(out, inp, out_splits, in_splits, group, async_op=False):
+    """all_to_all_single; with the gloo backend and device tensors (a debugging set-up: several ranks sharing one GPU)
+    the payload is staged through host memory, because gloo moves host buffers only."""
+    import torch.distributed as dist
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_out = out.new_empty(out.shape, device="cpu")
+        dist.all_to_all_single(h_out, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(h_out)
+        return _Done()
+    w = dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group, async_op=async_op)
+    return w if async_op else _Done()
+
+
 def chunk_bounds(n_local_bins, n_chunks, group=1):
     """split a rank's owned bins into n_chunks contiguous ranges (boundaries multiples of `group`)"""
     return [(c * (n_local_bins // group) // n_chunks) * group for c in range(n_chunks + 1)]
@@ -130,8 +148,7 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
     n_chunks = max(1, min(n_chunks, max(nb_local // grp, 1)))
     # 1) per-bin record counts of my bins from every source rank
     recv_hist = torch.empty(world * nb_local, dtype=hist.dtype, device=hist.device)
-    dist.all_to_all_single(recv_hist, hist, output_split_sizes=[nb_local] * world,
-                           input_split_sizes=[bounds[d + 1] - bounds[d] for d in range(world)], group=group)
+    _all_to_all(recv_hist, hist, [nb_local] * world, [bounds[d + 1] - bounds[d] for d in range(world)], group)
     recv_hist = recv_hist.view(world, nb_local).to(torch.int64)
     # 2) chunk geometry.  Chunk c of destination d = d's owned bins [cb_d[c], cb_d[c+1]); every rank computes the same cuts.
     cuts = [chunk_bounds(bounds[d + 1] - bounds[d], n_chunks, grp) for d in range(world)]
@@ -149,8 +166,7 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
         in_split = [p.numel() for p in parts]
         cnt = [recv_edge[s][c + 1] - recv_edge[s][c] for s in range(world)]
         recv = torch.empty(max(sum(cnt) * rw, 1), dtype=recs.dtype, device=recs.device)
-        work = dist.all_to_all_single(recv[:sum(cnt) * rw], send, output_split_sizes=[x * rw for x in cnt],
-                                      input_split_sizes=in_split, group=group, async_op=True)
+        work = _all_to_all(recv[:sum(cnt) * rw], send, [x * rw for x in cnt], in_split, group, async_op=True)
         return work, recv, cnt, send
 
     engine.sync()
@@ -183,7 +199,7 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
     n_local = engine.count_instances(ss, k)
     total = n_local
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        t = torch.tensor([n_local], dtype=torch.int64, device=engine.device)
+        t = torch.tensor([n_local], dtype=torch.int64, device="cpu" if dist.get_backend(group) == "gloo" else engine.device)
         dist.all_reduce(t, group=group)
         total = int(t.item())
     plan = engine.plan(k, stranded, summarizer_kind, min_obs, total)
