@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
     __shared__ uint8_t s_chk[NT];               // per staged record: chunk length cb | remainder cr << 3
     __shared__ uint16_t s_cmap[CAPC];           // chunk -> record slot | chunk index << 10
-    __shared__ uint32_t s_m, s_cproc;
+    __shared__ uint32_t s_m, s_cproc, s_nextq;
 #ifdef DBG_COUNT_STATS
     __shared__ uint32_t s_stat[16];
     if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (NBW > 2) s_slab[2 * NT + tid] = P2;
             if (NBW > 3) s_slab[3 * NT + tid] = P3;
             s_chk[tid] = (uint8_t)(cb | (cr << 3));          // cb <= CH <= 7, cr < nch <= 17
-            if (tid == 0) { s_m = NT; s_cproc = 0; }
+            if (tid == 0) { s_m = NT; s_cproc = 0; s_nextq = 0; }
             uint32_t totc;
             const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &totc);   // barriers inside
             if (incl <= CAPC) {
@@ -591,8 +591,12 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             const uint32_t cproc = s_cproc;
             // B. prefetch the next batch while this one is processed
             load_rec(bstart + m + tid);
-            // C. chunks, round-robin over the whole workgroup
-            for (uint32_t q0 = tid - lane; q0 < cproc; q0 += NT) {
+            // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
+            for (;;) {
+                uint32_t q0 = 0;
+                if (lane == 0) q0 = atomicAdd(&s_nextq, 64u);
+                q0 = __shfl(q0, 0);
+                if (q0 >= cproc) break;
                 const uint32_t q = q0 + lane;
                 const bool act = q < cproc;
                 const uint32_t e = act ? (uint32_t)s_cmap[q] : 0u;
