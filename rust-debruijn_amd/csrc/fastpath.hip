@@ -250,13 +250,25 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
             {
                 uint64_t l0[3], l1[3];
                 uint32_t sh[3];
+                // the clamps only matter for the last sequences of the buffer: one scalar test per tile picks the plain loads
+                if (((sb + t0 + 191u) >> 5) + 1u <= last_rel) {
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    const uint32_t rel = sb + t0 + ch * 64 + lane;
-                    const uint32_t wi = rel >> 5;
-                    sh[ch] = (rel & 31u) * 2u;
-                    l0[ch] = wr[wi < last_rel ? wi : last_rel];
-                    l1[ch] = wr[wi + 1 < last_rel ? wi + 1 : last_rel];
+                    for (int ch = 0; ch < 3; ch++) {
+                        const uint32_t rel = sb + t0 + ch * 64 + lane;
+                        const uint32_t wi = rel >> 5;
+                        sh[ch] = (rel & 31u) * 2u;
+                        l0[ch] = wr[wi];
+                        l1[ch] = wr[wi + 1];
+                    }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const uint32_t rel = sb + t0 + ch * 64 + lane;
+                        const uint32_t wi = rel >> 5;
+                        sh[ch] = (rel & 31u) * 2u;
+                        l0[ch] = wr[wi < last_rel ? wi : last_rel];
+                        l1[ch] = wr[wi + 1 < last_rel ? wi + 1 : last_rel];
+                    }
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
