@@ -73,6 +73,7 @@ struct UnitigNodes {            // device arrays describing graph nodes as eleme
     const uint64_t* words;      // packed node sequences
     const uint64_t* start;
     const uint32_t* length;
+    const uint8_t* avail;       // 0 = censored node (compression.rs:297-307); null = all available
 };
 
 // ---- launch helpers -----------------------------------------------------------------------

@@ -176,7 +176,7 @@ __global__ void node_links_to_unitig_kernel(const uint32_t* __restrict__ nl, con
     const uint32_t L = nl[s];
     uint32_t o;
     if (L == NL_TERM) o = 0xFFFFFFFFu;
-    else if (L == NL_NOKMER || L == NL_INCONSISTENT) o = 0x80000000u;          // the reference panics: the literal walk reports it
+    else if (L == NL_NOKMER || L == NL_INCONSISTENT) o = 0x80000000u | ((s % n) << 1);   // the reference panics (target = self: never censored away): the literal walk reports it
     else o = ((L >> 2) << 1) | ((L >> 1) & 1u) | ((L & NL_PANIC_BIT) ? 0x80000000u : 0u);
     ul[s] = o;
     if (s < n) weight[s] = length[s] - (uint32_t)k + 1u;
@@ -335,16 +335,17 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
                                                                d.exts.p, d.data.p, d_link.p);
         c->t_end();
         LAUNCH_CHECK(c, "node_links");
-        // the whole walk on the device (same chain construction as compress_kmers_with_hash, elements = nodes), unless
-        // nodes are censored or the links are not mutual / carry a panic marker: then the literal host walk below runs
+        // the whole walk on the device (same chain construction as compress_kmers_with_hash, elements = nodes; censored nodes
+        // are neither entered nor emitted), unless the links are not mutual / carry a panic marker: the literal host walk
+        // below then reproduces the reference's behaviour (including its panics)
         const char* mode = getenv("DBG_COMPRESS");
-        if (n_censor == 0 && !(mode && !strcmp(mode, "host"))) {
+        if (!(mode && !strcmp(mode, "host"))) {
             DBuf<uint32_t> u_link, u_weight;
             ALLOC_OR_FAIL(c, u_link, 2 * (size_t)n);
             ALLOC_OR_FAIL(c, u_weight, n);
             node_links_to_unitig_kernel<<<cdiv(2 * (uint64_t)n, 256), 256, 0, c->stream>>>(d_link.p, d.length.p, n, k, u_link.p, u_weight.p);
             LAUNCH_CHECK(c, "node_links_to_unitig");
-            UnitigNodes un{u_weight.p, d.words.p, d.start.p, d.length.p};
+            UnitigNodes un{u_weight.p, d.words.p, d.start.p, d.length.p, n_censor ? d_avail.p : nullptr};
             dbg_graph ng;
             bool done = false;
             DBG_TRY(compress_links_device(c, k, n, nullptr, nullptr, d.exts.p, d.data.p, u_link.p, nullptr, spec, stranded, &ng, &done, &un));

@@ -34,12 +34,16 @@ __device__ __forceinline__ bool link_valid(uint32_t L, uint32_t self) {
 }
 
 // flags: bit0 = a PANIC link exists, bit1 = a non-mutual link exists
-__global__ void check_links_kernel(const uint32_t* __restrict__ link, uint32_t n, uint32_t* __restrict__ flags) {
+// avail (compress_graph's censor list, compression.rs:297-307): 0 = the element may neither be entered nor emitted; a
+// link into it is terminal for the walk that meets it (compression.rs:173-182).  null = everything available.
+__global__ void check_links_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ avail, uint32_t n, uint32_t* __restrict__ flags) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= 2 * n) return;
     uint32_t i = s >> 1, p = s & 1;
+    if (avail && !avail[i]) return;
     uint32_t L = link[(uint64_t)p * n + i];
     if (L == U_TERM) return;
+    if (avail && !avail[(L & 0x7FFFFFFFu) >> 1]) return;                // terminal before the panic test is reached (compression.rs:173-195)
     if (L & U_PANIC) { atomicOr(flags, 1u); return; }
     uint32_t j = L >> 1, nd = L & 1;
     if (j == i) return;
@@ -50,13 +54,14 @@ __global__ void check_links_kernel(const uint32_t* __restrict__ link, uint32_t n
 
 // weight[i] = k-mers element i stands for (null: every element is one k-mer); distances are counted in k-mers
 __global__ void init_states_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ weight,
-                                   uint32_t n, Jump* __restrict__ J) {
+                                   const uint8_t* __restrict__ avail, uint32_t n, Jump* __restrict__ J) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= 2 * n) return;
     uint32_t i = s >> 1, p = s & 1;
     uint32_t L = link[(uint64_t)p * n + i];
     Jump o;
-    if (link_valid(L, i)) { uint32_t j = L >> 1, nd = L & 1; o.nxt = 2 * j + nd; o.dist = weight ? weight[j] : 1u; o.minr = rank ? rank[j] : j; o.endst = ST_NONE; }
+    const bool usable = link_valid(L, i) && (!avail || (avail[i] && avail[(L & 0x7FFFFFFFu) >> 1]));
+    if (usable) { uint32_t j = L >> 1, nd = L & 1; o.nxt = 2 * j + nd; o.dist = weight ? weight[j] : 1u; o.minr = rank ? rank[j] : j; o.endst = ST_NONE; }
     else { o.nxt = ST_NONE; o.dist = 0; o.minr = R_INF; o.endst = s; }
     J[s] = o;
 }
@@ -131,13 +136,14 @@ __device__ __forceinline__ NodeInfo node_info(const Jump* __restrict__ J, const 
     return o;
 }
 
-__global__ void mark_seeds_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ weight, uint32_t n, int k,
+__global__ void mark_seeds_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ weight,
+                                  const uint8_t* __restrict__ avail, uint32_t n, int k,
                                   uint32_t* __restrict__ flag_by_rank, uint32_t* __restrict__ len_by_rank, uint8_t* __restrict__ rev_by_rank) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     NodeInfo f = node_info(J, rank, i, weight ? weight[i] : 1u);
     uint32_t r = rank ? rank[i] : i;
-    if (r == f.seedrank) {
+    if (r == f.seedrank && (!avail || avail[i])) {
         flag_by_rank[r] = 1;
         len_by_rank[r] = f.m + (uint32_t)k - 1;
         rev_by_rank[r] = f.toA_is_left ? 0 : 1;                    // seed's left side must face the unitig's left end
@@ -201,14 +207,14 @@ __device__ __forceinline__ uint64_t rc_bases64(uint64_t x, uint32_t nb) {
 // Same construction for compress_graph (compression.rs:100-349): the elements are graph nodes (weight = k-mers of the
 // node).  A node writes its (oriented) sequence -- everything when it opens the path, otherwise what follows the
 // (k-1)-base overlap (sequence_of_path, graph.rs:471-491) -- 32 bases at a time.
-__global__ void emit_nodes_kernel(const Jump* __restrict__ J, uint32_t n, int k, const uint32_t* __restrict__ weight,
+__global__ void emit_nodes_kernel(const Jump* __restrict__ J, uint32_t n, int k, const uint32_t* __restrict__ weight, const uint8_t* __restrict__ avail,
                                   const uint64_t* __restrict__ nwords, const uint64_t* __restrict__ nstart, const uint32_t* __restrict__ nlen,
                                   const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data, int spec,
                                   const uint32_t* __restrict__ uidx_by_rank, const uint8_t* __restrict__ rev_by_rank,
                                   const uint64_t* __restrict__ ustart, uint64_t* __restrict__ words, uint32_t* __restrict__ uexts,
                                   unsigned long long* __restrict__ uacc, uint32_t* __restrict__ ucnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (avail && !avail[i])) return;
     const uint32_t wi = weight[i];
     NodeInfo f = node_info(J, nullptr, i, wi);
     const uint32_t ui = uidx_by_rank[f.seedrank];
@@ -268,12 +274,13 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
                           dbg_graph* out, bool* done, const UnitigNodes* nodes) {
     *done = false;
     const uint32_t* weight = nodes ? nodes->weight : nullptr;
+    const uint8_t* avail = nodes ? nodes->avail : nullptr;
     if (n == 0 || n >= (1u << 30)) return 0;
     const uint32_t n2 = 2 * n;
     DBuf<uint32_t> flags;
     ALLOC_OR_FAIL(c, flags, 2);
     HIP_TRY(c, hipMemsetAsync(flags.p, 0, 8, c->stream));
-    check_links_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, n, flags.p);
+    check_links_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, avail, n, flags.p);
     LAUNCH_CHECK(c, "check_links");
     uint32_t fl[2] = {0, 0};
     HIP_TRY(c, hipMemcpyAsync(fl, flags.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -289,7 +296,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     ALLOC_OR_FAIL(c, counters, 2);
     Jump* cur = nullptr;
     for (int phase = 0; phase < 2; phase++) {
-        init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, weight, n, JA.p);
+        init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, JA.p);
         LAUNCH_CHECK(c, "init_states");
         Jump *a = JA.p, *b = JB.p;
         uint32_t *la = nullptr, *lb = LB.p;                         // round 0 visits every state
@@ -328,7 +335,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
     ALLOC_OR_FAIL(c, rev_by_rank, n);
     HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
-    mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, weight, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
+    mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, weight, avail, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
     LAUNCH_CHECK(c, "mark_seeds");
     DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
     uint32_t n_nodes = 0;
@@ -360,7 +367,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     if (nodes) {
         ALLOC_OR_FAIL(c, ucnt, std::max<uint32_t>(n_nodes, 1));
         HIP_TRY(c, hipMemsetAsync(ucnt.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 4, c->stream));
-        emit_nodes_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, n, k, weight, nodes->words, nodes->start, nodes->length, exts, data, spec,
+        emit_nodes_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, n, k, weight, avail, nodes->words, nodes->start, nodes->length, exts, data, spec,
                                                                uidx_by_rank.p, rev_by_rank.p, ustart.p, words.p, uexts.p, uacc.p, ucnt.p);
     } else {
         emit_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, n, k, key_hi, key_lo, exts, data, spec, uidx_by_rank.p, rev_by_rank.p,
