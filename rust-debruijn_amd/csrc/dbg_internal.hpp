@@ -46,6 +46,10 @@ int radix_sort_records(dbg_ctx* ctx, uint64_t n, RecArrays a, RecArrays b, int k
 int sort_table_hybrid(dbg_ctx* ctx, uint64_t n, RecArrays a, RecArrays b, int key_bits, bool is_set, bool allow_hybrid,
                       uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts, uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk);
 
+// the same for keys of at most 96 bits held as 16-byte records {key 0..31, 32..63, 64..95, payload}
+int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n, uint4* a, uint4* b, int key_bits, bool is_set, bool allow_hybrid,
+                        uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts, uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk);
+
 // ---- reduce.hip : group_by key + KmerSummarizer::summarize (filter.rs:53-62, :85-100) -------
 struct ReduceOut {
     uint64_t n_valid = 0, n_all = 0, n_set_val = 0;

@@ -401,6 +401,7 @@ struct FastOut {
     uint64_t* hi;       // null when k <= 32
     uint64_t* lo;
     uint32_t* pay;      // CountFilter: exts | min(count, 65535) << 8;  CountFilterSet: exts | colour mask << 8 (labels < 24)
+    uint4* rec16;       // k <= 48: the same as one 16-byte record {key 0..31, 32..63, 64..95, pay} (hi/lo/pay unused)
     // report_all_kmers (filter.rs:208-212): every distinct k-mer, valid or not; null = not requested
     uint64_t* all_hi;
     uint64_t* all_lo;
@@ -795,9 +796,15 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     uint32_t c16 = c > 65535u ? 65535u : c;
                     bool valid = IS_SET ? (uint64_t)c >= min_obs : (uint64_t)c16 >= min_obs;
                     if (!valid) continue;
-                    if (KW == 2) { out.hi[o] = s_key[2 * i + 1]; out.lo[o] = s_key[2 * i]; }
-                    else out.lo[o] = s_key[i];
-                    out.pay[o] = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
+                    const uint32_t pay = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
+                    if (out.rec16) {
+                        const uint64_t klo = KW == 2 ? s_key[2 * i] : s_key[i], khi = KW == 2 ? s_key[2 * i + 1] : 0ull;
+                        out.rec16[o] = make_uint4((uint32_t)klo, (uint32_t)(klo >> 32), (uint32_t)khi, pay);
+                    } else {
+                        if (KW == 2) { out.hi[o] = s_key[2 * i + 1]; out.lo[o] = s_key[2 * i]; }
+                        else out.lo[o] = s_key[i];
+                        out.pay[o] = pay;
+                    }
                     o++;
                 }
             }
@@ -1005,6 +1012,8 @@ struct FastCountState {
     uint64_t min_obs = 0, cap = 0, n_out = 0, n_kmers_hint = 0;
     DBuf<uint64_t> u_hi, u_lo;
     DBuf<uint32_t> u_pay, gflags;
+    DBuf<uint4> u16;                       // k <= 48: 16-byte records instead of the three arrays
+    bool use16 = false;
     DBuf<unsigned long long> out_cursor;
     // report_all_kmers: every distinct key
     bool report_all = false;
@@ -1030,6 +1039,17 @@ static int fast_count_alloc_all(dbg_ctx* c, FastCountState* st, uint64_t cap) {
 
 static int fast_count_alloc(dbg_ctx* c, FastCountState* st, uint64_t cap) {
     if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+    if (st->use16) {
+        DBuf<uint4> n16;
+        ALLOC_OR_FAIL(c, n16, cap);
+        if (st->n_out) {
+            HIP_TRY(c, hipMemcpyAsync(n16.p, st->u16.p, st->n_out * 16, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        std::swap(st->u16, n16);
+        st->cap = cap;
+        return 0;
+    }
     DBuf<uint64_t> n_hi, n_lo;
     DBuf<uint32_t> n_pay;
     if (st->pl.has_hi) ALLOC_OR_FAIL(c, n_hi, cap);
@@ -1050,6 +1070,7 @@ static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, ui
                             bool report_all = false) {
     st->pl = pl; st->min_obs = min_obs; st->n_out = 0; st->n_kmers_hint = n_kmers_hint;
     st->report_all = report_all; st->n_all = 0;
+    st->use16 = 2 * pl.k <= 96 && !getenv("DBG_NO_REC16");
     ALLOC_OR_FAIL(c, st->out_cursor, 1);
     if (report_all) {
         ALLOC_OR_FAIL(c, st->all_cursor, 1);
@@ -1075,7 +1096,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         HIP_TRY(c, hipMemcpyAsync(st->out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
         if (st->report_all) HIP_TRY(c, hipMemcpyAsync(st->all_cursor.p, &start_all, 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(st->gflags.p, 0, 64, c->stream));
-        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->report_all ? st->a_hi.p : nullptr, st->report_all ? st->a_lo.p : nullptr,
+        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, st->report_all ? st->a_hi.p : nullptr, st->report_all ? st->a_lo.p : nullptr,
                    st->report_all ? st->all_cursor.p : nullptr, st->all_cap};
         unsigned long long* out_cursor_p = st->out_cursor.p;
         uint32_t* gflags_p = st->gflags.p;
@@ -1146,8 +1167,10 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
     DBuf<uint32_t> t_pay;
     DBuf<uint64_t> t_hi, t_lo;
     size_t na = std::max<uint64_t>(n_out, 1);
-    ALLOC_OR_FAIL(c, t_pay, na); ALLOC_OR_FAIL(c, t_lo, na);
-    if (has_hi) ALLOC_OR_FAIL(c, t_hi, na);
+    if (!st->use16) {
+        ALLOC_OR_FAIL(c, t_pay, na); ALLOC_OR_FAIL(c, t_lo, na);
+        if (has_hi) ALLOC_OR_FAIL(c, t_hi, na);
+    }
     RecArrays A{has_hi ? u_hi.p : nullptr, u_lo.p, u_pay.p}, B{has_hi ? t_hi.p : nullptr, t_lo.p, t_pay.p};
     DBuf<uint64_t> o_hi, o_lo, o_set_off;
     DBuf<uint8_t> o_exts;
@@ -1157,6 +1180,12 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
     if (is_set) { ALLOC_OR_FAIL(c, setn, na); ALLOC_OR_FAIL(c, msk_sorted, na); ALLOC_OR_FAIL(c, o_set_off, na + 1); }
     else ALLOC_OR_FAIL(c, o_count, na);
     uint64_t n_setval = 0;
+    if (st->use16) {
+        DBuf<uint4> t16;
+        ALLOC_OR_FAIL(c, t16, na);
+        DBG_TRY(sort_table_hybrid16(c, n_out, st->u16.p, t16.p, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
+                                    setn.p, msk_sorted.p));
+    } else
     DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
                               setn.p, msk_sorted.p));
     if (is_set) {

@@ -400,3 +400,278 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
     LAUNCH_CHECK(ctx, "finalize");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// 16-byte record form of the same hybrid sort, for keys of at most 96 bits (k <= 48): one record =
+// uint4 {key bits 0..31, 32..63, 64..95, payload}.  One 128-bit load/store per record instead of three
+// arrays, one LDS staging pass per tile instead of three, 16 B instead of 20 B of traffic per record and pass.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int R16_THREADS = 512;
+constexpr int R16_WAVES = R16_THREADS / DBG_WAVE;
+constexpr int R16_ITEMS = 8;
+constexpr int R16_TILE = R16_THREADS * R16_ITEMS;       // 4096 records = 64 KB of staging: ~16 records (256 B) per digit
+
+__device__ __forceinline__ uint32_t digit16(const uint4& r, int shift) {        // shift is a multiple of 8 below 96
+    const uint32_t w = shift < 32 ? r.x : (shift < 64 ? r.y : r.z);
+    return (w >> (shift & 31)) & 0xffu;
+}
+
+__global__ void __launch_bounds__(R16_THREADS) radix16_hist_kernel(const uint4* __restrict__ in, uint32_t n, int shift, uint32_t mask,
+                                                                   uint32_t* __restrict__ hist, uint32_t nblocks) {
+    __shared__ uint32_t h[256];
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * R16_TILE + wave * (R16_ITEMS * 64) + lane;
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(in) + (shift >> 5);
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        const uint32_t e = base + r * 64;
+        if (e < n) atomicAdd(&h[(w32[(size_t)e * 4] >> (shift & 31)) & mask], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(R16_THREADS) radix16_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
+                                                                      uint32_t mask, const uint32_t* __restrict__ hist_scanned, uint32_t nblocks) {
+    __shared__ uint4 stage[R16_TILE];                   // 64 KB; the per-wave counters alias its first 8 KB
+    __shared__ uint8_t s_dig[R16_TILE];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_ws[4];
+    uint32_t (*wc)[256] = reinterpret_cast<uint32_t (*)[256]>(stage);
+    for (int i = threadIdx.x; i < R16_WAVES * 256; i += R16_THREADS) (&wc[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile0 = blockIdx.x * R16_TILE;
+    const uint32_t base = tile0 + wave * (R16_ITEMS * 64) + lane;
+    const uint32_t tile_n = n - tile0 < (uint32_t)R16_TILE ? n - tile0 : (uint32_t)R16_TILE;
+    const uint64_t lt = lanemask_lt();
+    uint4 rec[R16_ITEMS];
+    uint32_t rank[R16_ITEMS];
+    volatile uint32_t* mywc = &wc[wave][0];
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        const uint32_t e = base + r * 64;
+        rec[r] = e < n ? in[e] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        const bool valid = base + r * 64 < n;
+        const uint32_t d = digit16(rec[r], shift) & mask;
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = __popcll(same & lt), cnt = __popcll(same);
+        uint32_t wbase = 0;
+        if (valid) wbase = mywc[d];
+        if (valid && before == 0) mywc[d] = wbase + cnt;
+        rank[r] = (d << 24) | (wbase + before);
+    }
+    __syncthreads();
+    {
+        uint32_t tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < R16_WAVES; w++) tot += wc[w][tid];
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { uint32_t o = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += o; }
+        if (tid < 256 && lane == 63) s_ws[wave] = incl;
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < wave; w++) off += s_ws[w];
+            uint32_t run = off + incl - tot;
+            s_gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - run;
+#pragma unroll
+            for (int w = 0; w < R16_WAVES; w++) { uint32_t t = wc[w][tid]; wc[w][tid] = run; run += t; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) rank[r] = wc[wave][rank[r] >> 24] + (rank[r] & 0xffffffu);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        if (base + r * 64 < n) { stage[rank[r]] = rec[r]; s_dig[rank[r]] = (uint8_t)(digit16(rec[r], shift) & mask); }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < tile_n; i += R16_THREADS) out[s_gbase[s_dig[i]] + i] = stage[i];
+}
+
+__device__ __forceinline__ uint32_t prefix16(const uint4& r, int key_bits, int top_bits) {
+    const uint64_t lo = ((uint64_t)r.y << 32) | r.x, hi = r.z;
+    const int sh = key_bits - top_bits;
+    if (sh >= 64) return (uint32_t)(hi >> (sh - 64));
+    if (sh == 0) return (uint32_t)lo;
+    return (uint32_t)((lo >> sh) | (hi << (64 - sh)));
+}
+__device__ __forceinline__ bool less16(const uint4& a, const uint4& b, bool or_equal) {
+    if (a.z != b.z) return a.z < b.z;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.x != b.x) return a.x < b.x;
+    return or_equal;
+}
+
+template <bool IS_SET>
+__global__ void __launch_bounds__(SS_THREADS) span_sort16_kernel(const uint4* __restrict__ in, uint32_t n, int key_bits, int top_bits,
+                                                                 uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
+                                                                 uint8_t* __restrict__ o_exts, uint16_t* __restrict__ o_count,
+                                                                 uint32_t* __restrict__ o_setn, uint32_t* __restrict__ o_msk,
+                                                                 uint32_t* __restrict__ flags) {
+    __shared__ uint4 s_rec[SS_CAP];                     // 48 KB
+    __shared__ uint32_t s_pre[SS_CAP];
+    __shared__ uint32_t s_start, s_end;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = blockIdx.x * SS_WINDOW;
+    const uint32_t avail = n - base < (uint32_t)SS_CAP ? n - base : (uint32_t)SS_CAP;
+    if (tid == 0) { s_start = 0xffffffffu; s_end = 0xffffffffu; }
+    __syncthreads();
+    uint4 rec[SS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i < avail) {
+            rec[r] = in[base + i];
+            s_pre[i] = prefix16(rec[r], key_bits, top_bits);
+            s_rec[i] = rec[r];
+        }
+    }
+    uint32_t prev0 = 0;
+    if (base > 0 && tid == 0) prev0 = prefix16(in[base - 1], key_bits, top_bits);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i < avail) {
+            const bool boundary = i == 0 ? (base == 0 || s_pre[0] != prev0) : s_pre[i] != s_pre[i - 1];
+            if (boundary) {
+                if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i);
+                else atomicMin(&s_end, i);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t start = s_start;
+    if (start == 0xffffffffu) return;
+    uint32_t end = s_end;
+    if (end == 0xffffffffu) {
+        if (avail == (uint32_t)SS_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
+        end = avail;
+    }
+    uint32_t pos[SS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        pos[r] = 0xffffffffu;
+        if (i >= start && i < end) {
+            const uint32_t pc = s_pre[i];
+            uint32_t less = 0, gs = i;
+            for (uint32_t j = i; j > start && s_pre[j - 1] == pc; j--) { less += less16(s_rec[j - 1], rec[r], true) ? 1u : 0u; gs = j - 1; }
+            for (uint32_t j = i + 1; j < end && s_pre[j] == pc; j++) less += less16(s_rec[j], rec[r], false) ? 1u : 0u;
+            pos[r] = gs + less;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) if (pos[r] != 0xffffffffu) s_rec[pos[r]] = rec[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i >= start && i < end) {
+            const uint32_t g = base + i;
+            const uint4 q = s_rec[i];
+            o_hi[g] = q.z;
+            o_lo[g] = ((uint64_t)q.y << 32) | q.x;
+            o_exts[g] = (uint8_t)(q.w & 0xffu);
+            if (IS_SET) { o_msk[g] = q.w >> 8; if (o_setn) o_setn[g] = __popc(q.w >> 8); }
+            else o_count[g] = (uint16_t)(q.w >> 8);
+        }
+    }
+}
+
+template <bool IS_SET>
+__global__ void decode16_kernel(uint32_t n, const uint4* __restrict__ in, uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
+                                uint8_t* __restrict__ exts, uint16_t* __restrict__ count, uint32_t* __restrict__ setn, uint32_t* __restrict__ msk) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 q = in[i];
+    o_hi[i] = q.z; o_lo[i] = ((uint64_t)q.y << 32) | q.x;
+    exts[i] = (uint8_t)(q.w & 0xffu);
+    if (IS_SET) { msk[i] = q.w >> 8; if (setn) setn[i] = __popc(q.w >> 8); }
+    else count[i] = (uint16_t)(q.w >> 8);
+}
+
+static int radix16_pass(dbg_ctx* ctx, const uint4* src, uint4* dst, uint32_t n, int shift, int bits, uint32_t* hist, uint32_t* hist_scanned, uint32_t nblocks) {
+    const uint32_t mask = (1u << bits) - 1;
+    ctx->t_begin("radix_hist", n);
+    radix16_hist_kernel<<<nblocks, R16_THREADS, 0, ctx->stream>>>(src, n, shift, mask, hist, nblocks);
+    ctx->t_end();
+    LAUNCH_CHECK(ctx, "radix16_hist");
+    DBG_TRY(scan_exclusive_u32(ctx, hist, hist_scanned, (uint64_t)256 * nblocks));
+    ctx->t_begin("radix_scatter", n);
+    radix16_scatter_kernel<<<nblocks, R16_THREADS, 0, ctx->stream>>>(src, dst, n, shift, mask, hist_scanned, nblocks);
+    ctx->t_end();
+    LAUNCH_CHECK(ctx, "radix16_scatter");
+    return 0;
+}
+}  // namespace
+
+// a = input (clobbered), b = scratch; key_bits <= 96
+int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_bits, bool is_set, bool allow_hybrid,
+                        uint64_t* o_hi, uint64_t* o_lo, uint8_t* o_exts, uint16_t* o_count, uint32_t* o_setn, uint32_t* o_msk) {
+    if (n64 == 0) return 0;
+    if (n64 >= (1ull << 32) - SS_CAP) return ctx->fail(110, "sort_table: more than 2^32-1 records in one call");
+    const uint32_t n = (uint32_t)n64;
+    const uint32_t nblocks = cdiv(n, R16_TILE);
+    DBuf<uint32_t> hist, hist_scanned;
+    ALLOC_OR_FAIL(ctx, hist, (size_t)256 * nblocks);
+    ALLOC_OR_FAIL(ctx, hist_scanned, (size_t)256 * nblocks + 1);
+    uint4 *src = a, *dst = b;
+    int sorted_from = key_bits;                              // bits [sorted_from, key_bits) are in order
+    if (allow_hybrid) {
+        int top_bits = 0;
+        while (top_bits < key_bits && top_bits < 32 && (n64 >> top_bits) > 32) top_bits += 8;
+        if (top_bits > key_bits) top_bits = key_bits;
+        const int s0 = top_bits ? ((key_bits - top_bits) / 8) * 8 : key_bits;
+        top_bits = key_bits - s0;
+        for (int s = s0; s < key_bits; s += 8) {
+            DBG_TRY(radix16_pass(ctx, src, dst, n, s, std::min(8, key_bits - s), hist.p, hist_scanned.p, nblocks));
+            std::swap(src, dst);
+        }
+        sorted_from = s0;
+        DBuf<uint32_t> flags;
+        ALLOC_OR_FAIL(ctx, flags, 1);
+        HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
+        const uint32_t nwg = cdiv(n, SS_WINDOW);
+        ctx->t_begin("span_sort", n);
+        if (is_set) span_sort16_kernel<true><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+        else span_sort16_kernel<false><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+        ctx->t_end();
+        LAUNCH_CHECK(ctx, "span_sort16");
+        uint32_t fl = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (fl == 0) return 0;
+    }
+    // plain LSD sort over every key bit (stable passes compose, so the top-bit passes above need not be undone: a full
+    // LSD from bit 0 re-sorts everything)
+    (void)sorted_from;
+    for (int s = 0; s < key_bits; s += 8) {
+        DBG_TRY(radix16_pass(ctx, src, dst, n, s, std::min(8, key_bits - s), hist.p, hist_scanned.p, nblocks));
+        std::swap(src, dst);
+    }
+    ctx->t_begin("finalize", n64);
+    if (is_set) decode16_kernel<true><<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, src, o_hi, o_lo, o_exts, nullptr, o_setn, o_msk);
+    else decode16_kernel<false><<<cdiv(n, 256), 256, 0, ctx->stream>>>(n, src, o_hi, o_lo, o_exts, o_count, nullptr, nullptr);
+    ctx->t_end();
+    LAUNCH_CHECK(ctx, "decode16");
+    return 0;
+}
