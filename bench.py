@@ -213,10 +213,13 @@ def main():
             ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss2), C.byref(fp2), C.byref(t2)))
             # (a) index kept in HBM between filter_kmers and compress (dbg_compress_kmers_with_hash_dev); graph to the host
             gd = capi.Graph()
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, 0, 0, t2.n, t2.key_hi, t2.key_lo, t2.exts, None, t2.count, C.byref(gd)))
-            ddt = time.perf_counter() - c0
+            for rep in range(2):                                   # first call warms the library's device-memory pool
+                if rep:
+                    lib.dbg_free_graph(ctx.h, C.byref(gd))
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, 0, 0, t2.n, t2.key_hi, t2.key_lo, t2.exts, None, t2.count, C.byref(gd)))
+                ddt = time.perf_counter() - c0
             dev_nodes = gd.n_nodes
             lib.dbg_free_graph(ctx.h, C.byref(gd))
             # (b) the reference's boundary: index in host memory
