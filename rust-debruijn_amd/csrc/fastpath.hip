@@ -822,13 +822,52 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
 }
 
 // CSR helper for the order-restoring stage
-__global__ void set_values_kernel(uint32_t n, const uint32_t* __restrict__ msk_sorted, const uint64_t* __restrict__ set_off,
-                                  uint32_t* __restrict__ set_val) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t m = msk_sorted[i];
-    uint64_t o = set_off[i];
-    while (m) { uint32_t b = __ffs(m) - 1; set_val[o++] = b; m &= m - 1; }   // ascending = sort(); dedup() (filter.rs:97-98)
+// CountFilterSet output as CSR (sorted, deduplicated labels: filter.rs:97-98) straight from the colour masks: block sums of
+// the popcounts, a scan of the block sums, then one pass that writes set_off and set_val together.  Entries are dealt to
+// lanes round-robin inside a wave (entry = wave base + r*64 + lane), so loads, set_off stores and -- because neighbouring
+// lanes own neighbouring output ranges -- set_val stores are all coalesced.
+constexpr int CSR_THREADS = 256, CSR_ITEMS = 8, CSR_TILE = CSR_THREADS * CSR_ITEMS;
+__global__ void __launch_bounds__(CSR_THREADS) csr_partials_kernel(const uint32_t* __restrict__ msk, uint32_t n, uint64_t* __restrict__ partial) {
+    __shared__ uint32_t s_w[CSR_THREADS / 64];
+    const uint32_t base = blockIdx.x * CSR_TILE + threadIdx.x;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < CSR_ITEMS; i++) { const uint32_t e = base + i * CSR_THREADS; if (e < n) s += __popc(msk[e]); }
+    for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (uint64_t)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const uint32_t* __restrict__ msk, uint32_t n, const uint64_t* __restrict__ partial_scanned,
+                                                                uint64_t* __restrict__ set_off, uint32_t* __restrict__ set_val) {
+    __shared__ uint32_t s_w[CSR_THREADS / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t wbase = blockIdx.x * CSR_TILE + wave * (64 * CSR_ITEMS);
+    uint32_t m[CSR_ITEMS], s = 0;
+#pragma unroll
+    for (int r = 0; r < CSR_ITEMS; r++) { const uint32_t e = wbase + r * 64 + lane; m[r] = e < n ? msk[e] : 0u; s += __popc(m[r]); }
+    uint32_t wtot = s;
+    for (int d = 32; d; d >>= 1) wtot += __shfl_xor(wtot, d);
+    if (lane == 0) s_w[wave] = wtot;
+    __syncthreads();
+    uint64_t run = partial_scanned[blockIdx.x];
+    for (uint32_t w = 0; w < wave; w++) run += s_w[w];
+#pragma unroll
+    for (int r = 0; r < CSR_ITEMS; r++) {
+        const uint32_t e = wbase + r * 64 + lane;
+        const uint32_t c = __popc(m[r]);
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        uint64_t o = run + incl - c;
+        if (e < n) {
+            set_off[e] = o;
+            uint32_t x = m[r];
+            while (x) { set_val[o++] = (uint32_t)__ffs((int)x) - 1u; x &= x - 1; }   // ascending = sort(); dedup()
+        }
+        run += __shfl(incl, 63);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) set_off[n] = partial_scanned[gridDim.x];      // total = the scan's last entry
 }
 __global__ void __launch_bounds__(256) max_label_kernel(const void* data, uint32_t width, uint64_t n, uint32_t* out) {
     // grid-stride maximum of the D1 labels; one atomic per workgroup
@@ -1177,26 +1216,31 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
     DBuf<uint16_t> o_count;
     DBuf<uint32_t> o_set_val, setn, msk_sorted;
     ALLOC_OR_FAIL(c, o_hi, na); ALLOC_OR_FAIL(c, o_lo, na); ALLOC_OR_FAIL(c, o_exts, na);
-    if (is_set) { ALLOC_OR_FAIL(c, setn, na); ALLOC_OR_FAIL(c, msk_sorted, na); ALLOC_OR_FAIL(c, o_set_off, na + 1); }
+    if (is_set) { ALLOC_OR_FAIL(c, msk_sorted, na); ALLOC_OR_FAIL(c, o_set_off, na + 1); }
     else ALLOC_OR_FAIL(c, o_count, na);
     uint64_t n_setval = 0;
     if (st->use16) {
         DBuf<uint4> t16;
         ALLOC_OR_FAIL(c, t16, na);
         DBG_TRY(sort_table_hybrid16(c, n_out, st->u16.p, t16.p, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
-                                    setn.p, msk_sorted.p));
+                                    nullptr, msk_sorted.p));
     } else
     DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
-                              setn.p, msk_sorted.p));
+                              nullptr, msk_sorted.p));
     if (is_set) {
-        DBG_TRY(scan_exclusive_u32_u64(c, setn.p, o_set_off.p, n_out));
-        HIP_TRY(c, hipMemcpyAsync(&n_setval, o_set_off.p + n_out, 8, hipMemcpyDeviceToHost, c->stream));
+        const uint32_t nb = cdiv(std::max<uint64_t>(n_out, 1), CSR_TILE);
+        DBuf<uint64_t> part, part_sc;
+        ALLOC_OR_FAIL(c, part, nb); ALLOC_OR_FAIL(c, part_sc, (size_t)nb + 1);
+        csr_partials_kernel<<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part.p);
+        LAUNCH_CHECK(c, "csr_partials");
+        DBG_TRY(scan_exclusive_u64(c, part.p, part_sc.p, nb));
+        HIP_TRY(c, hipMemcpyAsync(&n_setval, part_sc.p + nb, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         ALLOC_OR_FAIL(c, o_set_val, std::max<uint64_t>(n_setval, 1));
-        if (n_out) {
-            set_values_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, msk_sorted.p, o_set_off.p, o_set_val.p);
-            LAUNCH_CHECK(c, "set_values");
-        }
+        c->t_begin("set_csr", n_out);
+        csr_apply_kernel<<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part_sc.p, o_set_off.p, o_set_val.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "csr_apply");
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memset(out, 0, sizeof(*out));

@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_kernel(RecArrays in, uin
             o_lo[g] = s_lo[i];
             const uint32_t p = s_pay[i];
             o_exts[g] = (uint8_t)(p & 0xffu);
-            if (IS_SET) { o_msk[g] = p >> 8; o_setn[g] = __popc(p >> 8); }
+            if (IS_SET) { o_msk[g] = p >> 8; if (o_setn) o_setn[g] = __popc(p >> 8); }
             else o_count[g] = (uint16_t)(p >> 8);
         }
     }
@@ -323,7 +323,7 @@ __global__ void decode_payload_kernel(uint32_t n, const uint32_t* __restrict__ p
     if (i >= n) return;
     const uint32_t p = pay[i];
     exts[i] = (uint8_t)(p & 0xffu);
-    if (IS_SET) { msk[i] = p >> 8; setn[i] = __popc(p >> 8); }
+    if (IS_SET) { msk[i] = p >> 8; if (setn) setn[i] = __popc(p >> 8); }
     else count[i] = (uint16_t)(p >> 8);
 }
 }  // namespace
