@@ -164,3 +164,25 @@ def test_fast_k_sweep(ctx, k):
         summ = dbg.CountFilterSet(2) if kind else dbg.CountFilter(2)
         got, _ = dbg.filter_kmers(hs if kind else dbg.HostSeqs(hs.words, hs.start, hs.length), summ, stranded, False, 4, k=k, ctx=ctx)
         assert_tables_equal(got, want, kind == 1)
+
+
+@pytest.mark.parametrize("env", [{"DBG_NO_HYBRID_SORT": "1"}, {"DBG_NO_REC16": "1"}, {"DBG_NO_REC16": "1", "DBG_NO_HYBRID_SORT": "1"}])
+@pytest.mark.parametrize("k,kind", [(47, 1), (31, 0), (63, 0)])
+def test_fast_sort_variants(ctx, env, k, kind):
+    """The order-restoring sort has four code paths (16-byte records or three arrays; prefix passes + LDS finisher or the
+    plain LSD sort that also serves as its fall-back): all must give the same table."""
+    hs = dbg.synth_reads_host(n_reads=3000, read_len=150, error_rate=0.003, stranded=False, n_colours=4)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if kind else None, 1 if kind else 0)
+    want = O.filter_kmers(ss, k, kind, 2, stranded=False)
+    old = {v: os.environ.get(v) for v in env}
+    os.environ.update(env)
+    try:
+        summ = dbg.CountFilterSet(2) if kind else dbg.CountFilter(2)
+        got, _ = dbg.filter_kmers(hs if kind else dbg.HostSeqs(hs.words, hs.start, hs.length), summ, False, False, 4, k=k, ctx=ctx)
+    finally:
+        for v, o in old.items():
+            if o is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = o
+    assert_tables_equal(got, want, kind == 1)
