@@ -973,9 +973,14 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         // bin; what does not fit (heavy minimizers of low-complexity sequence) goes through the read-order buffer
         const double mean = (double)tmp_cap / (double)nbins;
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
-        ALLOC_OR_FAIL(c, st->slab, (uint64_t)nbins * st->slab_cap * rw);
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        tmp_cap = tmp_cap / 16 + 4096;
+        if (!getenv("DBG_FAST_NO_SLAB") && st->slab.alloc(c, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
+        else {
+            // not enough memory for slabs (1.3x the records + slack): every record takes the read-order buffer and the
+            // scatter pass instead -- slab capacity 0 routes them all there
+            st->slab_cap = 0;
+            ALLOC_OR_FAIL(c, st->slab, 4);
+        }
     }
     const uint32_t scan_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 255) / 256, 256ull * 32));
     const uint64_t chunk_slack = (uint64_t)scan_blocks * 4 * SCAN_CHUNK;      // every wave may strand one partial chunk

@@ -166,10 +166,12 @@ def test_fast_k_sweep(ctx, k):
         assert_tables_equal(got, want, kind == 1)
 
 
-@pytest.mark.parametrize("env", [{"DBG_NO_HYBRID_SORT": "1"}, {"DBG_NO_REC16": "1"}, {"DBG_NO_REC16": "1", "DBG_NO_HYBRID_SORT": "1"}])
+@pytest.mark.parametrize("env", [{"DBG_NO_HYBRID_SORT": "1"}, {"DBG_NO_REC16": "1"}, {"DBG_NO_REC16": "1", "DBG_NO_HYBRID_SORT": "1"},
+                                 {"DBG_FAST_NO_SLAB": "1"}])
 @pytest.mark.parametrize("k,kind", [(47, 1), (31, 0), (63, 0)])
 def test_fast_sort_variants(ctx, env, k, kind):
-    """The order-restoring sort has four code paths (16-byte records or three arrays; prefix passes + LDS finisher or the
+    """DBG_FAST_NO_SLAB: what happens when the slabs do not fit in memory (every record through the read-order buffer and
+    the scatter pass).  The order-restoring sort has four code paths (16-byte records or three arrays; prefix passes + LDS finisher or the
     plain LSD sort that also serves as its fall-back): all must give the same table."""
     hs = dbg.synth_reads_host(n_reads=3000, read_len=150, error_rate=0.003, stranded=False, n_colours=4)
     ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if kind else None, 1 if kind else 0)
