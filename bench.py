@@ -201,6 +201,30 @@ def main():
                    "sample": "first %d reads of an equally-parameterised stream (%.1fM k-mer instances), "
                              "oracle filter_kmers single thread, %.1f s" % (n_s, n_s * (L - k + 1) / 1e6, sec),
                    "host_cores_available": os.cpu_count()}
+            # the same port on every host core, parallelised the way callers parallelise the crate (which has no
+            # parallel path of its own): msp_sequence -> shards -> filter_kmers per shard (test.rs:418-504)
+            nt = len(os.sched_getaffinity(0))
+            if nt > 1:
+                n_m = min(reads_per_gpu, max(n_s, 40000 * nt))      # a few seconds of wall time, < 16 GB of host memory
+                pm = dbg.synth_params(n_reads=n_m, read_len=L, genome_len=n_m * L // 30, error_rate=0.001,
+                                      stranded=False, n_colours=4)
+                nwm = lib.dbg_synth_words(C.byref(pm))
+                wm = torch.empty(nwm, dtype=torch.int64, device=dev)
+                sm = torch.empty(n_m, dtype=torch.int64, device=dev)
+                lm = torch.empty(n_m, dtype=torch.int32, device=dev)
+                cm = torch.empty(n_m, dtype=torch.uint8, device=dev)
+                ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(pm), wm.data_ptr(), sm.data_ptr(), lm.data_ptr(), cm.data_ptr()))
+                som = O.SeqSet(wm.cpu().numpy().view(np.uint64), sm.cpu().numpy().view(np.uint64),
+                               lm.cpu().numpy().view(np.uint32), None,
+                               cm.cpu().numpy().astype(np.uint32) if is_set else None, 1 if is_set else 0)
+                del wm, sm, lm, cm
+                msec, mnv = O.time_filter_kmers_sharded_mt(som, k, O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER,
+                                                           args.min_obs, False, nt, 16 * nt)
+                cpu["all_cores"] = {"value": round(n_m * (L - k + 1) / msec / 1e9, 5), "unit": "Gkmer/s", "cores": nt,
+                                    "kind": "port", "valid_kmers": int(mnv),
+                                    "sample": "%d reads of an equally-parameterised stream (%.0fM k-mer instances), oracle "
+                                              "msp_sequence(p=8) -> %d shards -> filter_kmers per shard on %d threads, %.1f s"
+                                              % (n_m, n_m * (L - k + 1) / 1e6, 16 * nt, nt, msec)}
         comp = None
         if args.compress_reads and world == 1:
             # second half of the metric ("+ unitigs/s compressed"): CountFilter(2) table of a prefix of the same

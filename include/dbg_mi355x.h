@@ -203,6 +203,17 @@ void dbg_free_text(char* text);
  * [first_base, first_base + n).  _dev: device pointers in and out. */
 int  dbg_pack_acgt(dbg_ctx* ctx, const uint8_t* ascii, uint64_t n, uint64_t* words, uint64_t* n_invalid);
 int  dbg_pack_acgt_dev(dbg_ctx* ctx, const uint8_t* ascii_dev, uint64_t n, uint64_t* words_dev, uint64_t* n_invalid);
+/* DnaString::from_acgt_bytes_hashn (src/dna_string.rs:255-278) for a batch of reads: read i =
+ * ascii[seq_off[i], seq_off[i+1]) (seq_off[0] = 0, n = seq_off[n_seqs] characters), its name =
+ * names[name_off[i], name_off[i+1]).  [aAcCgGtT] pack as above; any other character at position pos of read i
+ * becomes DefaultHasher::new() fed read_name.hash() then pos.hash(), finish() % 4 -- Rust std's SipHash-1-3 with
+ * the zero key over (len(name) as u64 LE, name bytes, pos as u64 LE).  Output layout as dbg_pack_acgt.
+ * *n_replaced (host, may be NULL) = number of hashed characters. */
+int  dbg_pack_acgt_hashn(dbg_ctx* ctx, const uint8_t* ascii, const uint64_t* seq_off, uint64_t n_seqs,
+                         const uint8_t* names, const uint64_t* name_off, uint64_t* words, uint64_t* n_replaced);
+int  dbg_pack_acgt_hashn_dev(dbg_ctx* ctx, const uint8_t* ascii_dev, uint64_t n, const uint64_t* seq_off_dev,
+                             uint64_t n_seqs, const uint8_t* names_dev, const uint64_t* name_off_dev,
+                             uint64_t* words_dev, uint64_t* n_replaced);
 int  dbg_unpack_acgt(dbg_ctx* ctx, const uint64_t* words, uint64_t first_base, uint64_t n, uint8_t* ascii);
 int  dbg_unpack_acgt_dev(dbg_ctx* ctx, const uint64_t* words_dev, uint64_t first_base, uint64_t n, uint8_t* ascii_dev);
 

@@ -296,6 +296,17 @@ inline DnaString from_acgt_bytes(Context& ctx, const std::string& ascii) {
     return d;
 }
 
+// DnaString::from_acgt_bytes_hashn (dna_string.rs:255-278): non-ACGT -> DefaultHasher(read_name, pos) % 4
+inline DnaString from_acgt_bytes_hashn(Context& ctx, const std::string& ascii, const std::string& read_name) {
+    DnaString d;
+    d.storage.assign((ascii.size() + 31) / 32, 0);
+    d.len = ascii.size();
+    const uint64_t seq_off[2] = {0, ascii.size()}, name_off[2] = {0, read_name.size()};
+    ctx.check(dbg_pack_acgt_hashn(ctx.raw(), (const uint8_t*)ascii.data(), seq_off, 1, (const uint8_t*)read_name.data(), name_off,
+                                  d.storage.data(), nullptr));
+    return d;
+}
+
 // compress_graph (compression.rs:338-349)
 template <class K, class D, class S>
 BaseGraph<K, D> compress_graph(Context& ctx, bool stranded, const S& spec, const BaseGraph<K, D>& old_graph,

@@ -191,6 +191,57 @@ DnaString DnaString::from_acgt_bytes(const uint8_t* b, size_t n) {     // dna_st
     for (size_t i = 0; i < n; i++) d.push(base_to_bits(b[i]));
     return d;
 }
+uint64_t siphash(int c_rounds, int d_rounds, uint64_t k0, uint64_t k1, const uint8_t* msg, size_t len) {
+    uint64_t v0 = k0 ^ 0x736f6d6570736575ull, v1 = k1 ^ 0x646f72616e646f6dull;
+    uint64_t v2 = k0 ^ 0x6c7967656e657261ull, v3 = k1 ^ 0x7465646279746573ull;
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    auto round = [&]() {
+        v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+        v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+        v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+        v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+    };
+    size_t full = len & ~(size_t)7;
+    for (size_t i = 0; i < full; i += 8) {
+        uint64_t m = 0;
+        for (int j = 0; j < 8; j++) m |= (uint64_t)msg[i + j] << (8 * j);
+        v3 ^= m;
+        for (int r = 0; r < c_rounds; r++) round();
+        v0 ^= m;
+    }
+    uint64_t b = (uint64_t)(len & 0xff) << 56;
+    for (size_t j = full; j < len; j++) b |= (uint64_t)msg[j] << (8 * (j - full));
+    v3 ^= b;
+    for (int r = 0; r < c_rounds; r++) round();
+    v0 ^= b;
+    v2 ^= 0xff;
+    for (int r = 0; r < d_rounds; r++) round();
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+DnaString DnaString::from_acgt_bytes_hashn(const uint8_t* b, size_t n, const uint8_t* read_name, size_t name_len) {
+    // dna_string.rs:255-278.  `read_name.hash(&mut hasher)` on a &[u8] feeds the length as a usize (8 bytes, little
+    // endian) and then the bytes (impl Hash for [T], core/src/hash/mod.rs); `pos.hash(..)` feeds pos as a usize;
+    // the streaming hasher equals SipHash-1-3 of the concatenation.
+    std::vector<uint8_t> msg(8 + name_len + 8);
+    for (int j = 0; j < 8; j++) msg[j] = (uint8_t)((uint64_t)name_len >> (8 * j));
+    for (size_t j = 0; j < name_len; j++) msg[8 + j] = read_name[j];
+    DnaString d;
+    for (size_t pos = 0; pos < n; pos++) {
+        uint8_t v;
+        switch (b[pos]) {                                           // :262-266
+            case 'A': case 'a': v = 0; break;
+            case 'C': case 'c': v = 1; break;
+            case 'G': case 'g': v = 2; break;
+            case 'T': case 't': v = 3; break;
+            default: {                                              // :267-271
+                for (int j = 0; j < 8; j++) msg[8 + name_len + j] = (uint8_t)((uint64_t)pos >> (8 * j));
+                v = (uint8_t)(siphash(1, 3, 0, 0, msg.data(), msg.size()) % 4);
+            }
+        }
+        d.push(v);
+    }
+    return d;
+}
 std::vector<uint8_t> DnaString::to_ascii_vec() const {                  // dna_string.rs:297-299, bits_to_ascii lib.rs:53-61
     std::vector<uint8_t> v(len);
     for (size_t i = 0; i < len; i++) v[i] = (uint8_t)"ACGT"[get(i)];

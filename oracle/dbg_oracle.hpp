@@ -158,6 +158,8 @@ struct DnaString {
     static DnaString from_bytes(const uint8_t* b, size_t n);       // dna_string.rs (extend over bytes)
     static DnaString from_dna_string(const char* s);               // dna_string.rs:187-195
     static DnaString from_acgt_bytes(const uint8_t* b, size_t n);  // dna_string.rs:222-250 (scalar branch :247-249)
+    // dna_string.rs:255-278: non-ACGT -> DefaultHasher(read_name, pos).finish() % 4
+    static DnaString from_acgt_bytes_hashn(const uint8_t* b, size_t n, const uint8_t* read_name, size_t name_len);
     std::vector<uint8_t> to_ascii_vec() const;                     // dna_string.rs:297-299
     std::string to_string() const;
 };
@@ -165,6 +167,11 @@ struct DnaString {
 // A borrowed view of a sequence inside a packed word array: the common shape
 // of DnaString (start=0), DnaStringSlice (dna_string.rs:542-627, is_rc=false)
 // and PackedDnaStringSet::get (dna_string.rs:779-786).
+// SipHash-c-d (Aumasson & Bernstein 2012) of msg under key (k0, k1).  std::collections::hash_map::DefaultHasher::new()
+// is SipHash-1-3 with the all-zero key (third-party to the crate: Rust std, library/std/src/hash/random.rs and
+// library/core/src/hash/sip.rs); pinned against the paper's 2-4 vectors and the std test-suite's first 1-3 vector.
+uint64_t siphash(int c_rounds, int d_rounds, uint64_t k0, uint64_t k1, const uint8_t* msg, size_t len);
+
 struct SeqView {
     const uint64_t* words;
     size_t start;     // base offset

@@ -9,6 +9,8 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <atomic>
 
 using namespace orc;
 
@@ -227,6 +229,11 @@ void orc_pack_acgt(const uint8_t* ascii, uint64_t n, uint64_t* words) {
     DnaString d = DnaString::from_acgt_bytes(ascii, n);
     for (size_t i = 0; i < d.storage.size(); i++) words[i] = d.storage[i];
 }
+void orc_pack_acgt_hashn(const uint8_t* ascii, uint64_t n, const uint8_t* name, uint64_t name_len, uint64_t* words) {
+    DnaString d = DnaString::from_acgt_bytes_hashn(ascii, n, name, name_len);
+    for (size_t i = 0; i < d.storage.size(); i++) words[i] = d.storage[i];
+}
+uint64_t orc_siphash(int c, int d, uint64_t k0, uint64_t k1, const uint8_t* msg, uint64_t len) { return siphash(c, d, k0, k1, msg, len); }
 void orc_unpack_acgt(const uint64_t* words, uint64_t first_base, uint64_t n, uint8_t* ascii) {
     SeqView v{words, (size_t)first_base, (size_t)n};
     for (uint64_t i = 0; i < n; i++) ascii[i] = (uint8_t)"ACGT"[v.get(i)];
@@ -244,6 +251,68 @@ double orc_time_filter_kmers(const uint64_t* words, const uint64_t* start, const
     auto t1 = std::chrono::steady_clock::now();
     if (n_valid_out) *n_valid_out = t.keys.size();
     if (r) return -1.0;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---- many-core CPU baseline: the parallelisation downstream users put around the crate ----
+// (the crate itself has no parallel path).  It is the sharded pipeline of the reference's own end-to-end test
+// (test.rs:418-504): every read is cut by msp_sequence (msp.rs:279-324, p-mer order = identity permutation) into
+// pieces whose k-mers share a minimizer bucket, the pieces are grouped into shards by bucket, and filter_kmers
+// (filter.rs:139-231) runs on each shard independently.  Phase 1 threads over read slices, phase 2 threads over
+// shards; returns wall seconds, *n_valid_out = total valid k-mers over the shards (equals the unsharded count).
+double orc_time_filter_kmers_sharded_mt(const uint64_t* words, const uint64_t* start, const uint32_t* length,
+                                        const uint32_t* data, uint64_t n_seqs, uint32_t sizeof_d1, int k, int p,
+                                        int summarizer, uint64_t min_obs, int stranded, uint32_t n_threads,
+                                        uint32_t n_shards, uint64_t* n_valid_out) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_shards < 1) n_shards = 1;
+    struct Piece { uint64_t start; uint32_t len; uint8_t exts; uint32_t d; };
+    std::vector<uint64_t> perm((size_t)1 << (2 * p));
+    for (size_t i = 0; i < perm.size(); i++) perm[i] = i;
+    std::vector<std::vector<std::vector<Piece>>> lists(n_threads, std::vector<std::vector<Piece>>(n_shards));
+    std::atomic<int> failed{0};
+    auto t0 = std::chrono::steady_clock::now();
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; t++) th.emplace_back([&, t]() {
+            const uint64_t lo = n_seqs * t / n_threads, hi = n_seqs * (t + 1) / n_threads;
+            std::vector<uint8_t> bases; std::vector<MspPiece> pc; std::string err;
+            for (uint64_t i = lo; i < hi; i++) {
+                SeqView v{words, (size_t)start[i], (size_t)length[i]};
+                if (v.length < (size_t)k) continue;
+                bases.resize(v.length);
+                for (size_t j = 0; j < v.length; j++) bases[j] = v.get(j);
+                pc.clear();
+                if (msp_sequence(bases.data(), bases.size(), k, p, perm.data(), stranded == 0, 1u << 20, pc, err)) { failed = 1; return; }
+                for (const MspPiece& q : pc)
+                    lists[t][q.bucket % n_shards].push_back(Piece{start[i] + q.start, q.len, q.exts.val, data ? data[i] : 0});
+            }
+        });
+        for (auto& x : th) x.join();
+    }
+    std::atomic<uint32_t> next{0};
+    std::atomic<uint64_t> valid{0};
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; t++) th.emplace_back([&]() {
+            std::vector<uint64_t> st; std::vector<uint32_t> ln, dd; std::vector<uint8_t> ex; std::string err;
+            for (;;) {
+                const uint32_t sh = next.fetch_add(1);
+                if (sh >= n_shards) break;
+                st.clear(); ln.clear(); dd.clear(); ex.clear();
+                for (uint32_t u = 0; u < n_threads; u++)
+                    for (const Piece& q : lists[u][sh]) { st.push_back(q.start); ln.push_back(q.len); ex.push_back(q.exts); dd.push_back(q.d); }
+                SeqSet s{words, st.data(), ln.data(), ex.data(), data ? dd.data() : nullptr, st.size(), (size_t)sizeof_d1};
+                KmerTable tb;
+                if (filter_kmers(s, k, (Summarizer)summarizer, (size_t)min_obs, stranded != 0, false, 1u << 20, tb, err)) { failed = 1; return; }
+                valid += tb.keys.size();
+            }
+        });
+        for (auto& x : th) x.join();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (n_valid_out) *n_valid_out = valid.load();
+    if (failed) return -1.0;
     return std::chrono::duration<double>(t1 - t0).count();
 }
 

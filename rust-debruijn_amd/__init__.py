@@ -533,6 +533,28 @@ def pack_acgt(ascii_bytes, ctx=None):
     return words, int(bad.value)
 
 
+def pack_acgt_hashn(reads, names, ctx=None):
+    """DnaString::from_acgt_bytes_hashn (src/dna_string.rs:255-278) for a batch: reads[i] packed with every non-ACGT
+    character replaced by DefaultHasher(names[i], pos) % 4 -> (packed u64 words of the concatenation, start offsets,
+    number of replaced characters)."""
+    ctx = ctx or default_context()
+    if len(reads) != len(names):
+        raise ValueError("one name per read")
+    seq_off = np.zeros(len(reads) + 1, np.uint64)
+    name_off = np.zeros(len(reads) + 1, np.uint64)
+    if len(reads):
+        seq_off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        name_off[1:] = np.cumsum([len(r) for r in names], dtype=np.uint64)
+    a = np.frombuffer(b"".join(bytes(r) for r in reads), np.uint8)
+    nm = np.frombuffer(b"".join(bytes(r) for r in names), np.uint8)
+    words = np.zeros((len(a) + 31) // 32, np.uint64)
+    rep = C.c_uint64()
+    ctx.check(ctx.lib.dbg_pack_acgt_hashn(ctx.h, _np_ptr(a) if len(a) else None, _np_ptr(seq_off), len(reads),
+                                          _np_ptr(nm) if len(nm) else None, _np_ptr(name_off),
+                                          _np_ptr(words) if len(words) else None, C.byref(rep)))
+    return words, seq_off[:-1].copy(), int(rep.value)
+
+
 def unpack_acgt(words, first_base, n, ctx=None):
     """DnaString::to_ascii_vec (src/dna_string.rs:297-299) of bases [first_base, first_base + n) -> bytes."""
     ctx = ctx or default_context()
@@ -543,13 +565,17 @@ def unpack_acgt(words, first_base, n, ctx=None):
     return out.tobytes()
 
 
-def seqs_from_acgt(reads, exts=None, data=None, ctx=None):
-    """A batch of ASCII reads -> HostSeqs in PackedDnaStringSet layout (dna_string.rs:811-821), packed on the GPU."""
+def seqs_from_acgt(reads, exts=None, data=None, ctx=None, names=None):
+    """A batch of ASCII reads -> HostSeqs in PackedDnaStringSet layout (dna_string.rs:811-821), packed on the GPU.
+    With `names`, non-ACGT characters become the repeatable pseudo-random bases of from_acgt_bytes_hashn instead of A."""
     lens = np.array([len(r) for r in reads], np.uint32)
     start = np.zeros(len(reads), np.uint64)
     if len(reads):
         start[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
-    words, _ = pack_acgt(b"".join(bytes(r) for r in reads), ctx)
+    if names is None:
+        words, _ = pack_acgt(b"".join(bytes(r) for r in reads), ctx)
+    else:
+        words, _, _ = pack_acgt_hashn(reads, names, ctx)
     d = None if data is None else np.ascontiguousarray(data, np.uint8)
     e = None if exts is None else np.ascontiguousarray(exts, np.uint8)
     return HostSeqs(words, start, lens, e, d, 0 if d is None else 1)

@@ -126,6 +126,13 @@ int main() {
             std::string a = "ACGTAAAAAAAAAATTATATAACGTacgtNNACGTACGTACGTACGTACGTACGTACGTACGTACGTAC";
             DnaString x = from_acgt_bytes(ctx, a), y = DnaString::from_dna_string(a);
             if (x.len != y.len || x.storage != y.storage) return 6;
+            // from_acgt_bytes_hashn (dna_string.rs:255-278): valid characters as above, the others repeatable per (name, pos)
+            DnaString h1 = from_acgt_bytes_hashn(ctx, a, "read1"), h2 = from_acgt_bytes_hashn(ctx, a, "read1");
+            if (h1.len != y.len || h1.storage != h2.storage) return 60;
+            for (size_t i = 0; i < a.size(); i++)
+                if (a[i] != 'N' && h1.get(i) != y.get(i)) return 61;
+            std::string clean = "ACGTACGTTTGACCA";
+            if (from_acgt_bytes_hashn(ctx, clean, "r").storage != DnaString::from_dna_string(clean).storage) return 62;
         }
         // GFA text of a compressed graph: header, one S line per node, every L line overlaps by k-1 (graph.rs:537-611)
         {

@@ -46,6 +46,8 @@ def lib():
         _lib.orc_msp_scan.restype = C.c_int64
         _lib.orc_msp_sequence.restype = C.c_int64
         _lib.orc_time_filter_kmers.restype = C.c_double
+        _lib.orc_siphash.restype = C.c_uint64
+        _lib.orc_time_filter_kmers_sharded_mt.restype = C.c_double
         _lib.orc_exts_rc.restype = C.c_uint8
         _lib.orc_exts_complement.restype = C.c_uint8
     return _lib
@@ -232,6 +234,19 @@ def time_filter_kmers(ss, k, summarizer, min_obs, stranded, memory_size=4):
     return t, nv.value
 
 
+def time_filter_kmers_sharded_mt(ss, k, summarizer, min_obs, stranded, n_threads, n_shards=None, p=8):
+    """msp_sequence -> shards -> filter_kmers per shard on n_threads host threads (the pipeline of the reference's
+    test.rs:418-504, which is how callers parallelise the crate); returns (seconds, total valid k-mers)"""
+    nv = C.c_uint64()
+    n_shards = n_shards or 8 * n_threads
+    t = lib().orc_time_filter_kmers_sharded_mt(_p(ss.words), _p(ss.start), _p(ss.length), _p(ss.data), C.c_uint64(ss.n),
+                                               C.c_uint32(ss.sizeof_d1), k, p, summarizer, C.c_uint64(min_obs),
+                                               int(stranded), C.c_uint32(n_threads), C.c_uint32(n_shards), C.byref(nv))
+    if t < 0:
+        raise _err()
+    return t, nv.value
+
+
 # ---------------------------------------------------------------- MSP
 def msp_scan(seq, k, p, perm=None, rc=False, score_mode=0):
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -351,6 +366,20 @@ def pack_acgt(ascii_bytes):
     if len(a):
         lib().orc_pack_acgt(_p(a), C.c_uint64(len(a)), _p(words))
     return words
+
+
+def pack_acgt_hashn(ascii_bytes, name):
+    a = np.frombuffer(bytes(ascii_bytes), np.uint8)
+    nm = np.frombuffer(bytes(name), np.uint8)
+    words = np.zeros((len(a) + 31) // 32, np.uint64)
+    lib().orc_pack_acgt_hashn(_p(a) if len(a) else None, C.c_uint64(len(a)), _p(nm) if len(nm) else None,
+                              C.c_uint64(len(nm)), _p(words) if len(words) else None)
+    return words
+
+
+def siphash(c, d, k0, k1, msg):
+    m = np.frombuffer(bytes(msg), np.uint8)
+    return int(lib().orc_siphash(c, d, C.c_uint64(k0), C.c_uint64(k1), _p(m) if len(m) else None, C.c_uint64(len(m))))
 
 
 def unpack_acgt(words, first_base, n):

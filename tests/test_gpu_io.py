@@ -47,6 +47,33 @@ def test_pack_random_bytes(ctx):
         assert dbg.unpack_acgt(w, first, m, ctx) == O.unpack_acgt(w, first, m)
 
 
+def test_pack_hashn_batch(ctx):
+    """dbg_pack_acgt_hashn vs the oracle's from_acgt_bytes_hashn (dna_string.rs:255-278), read by read"""
+    rng = np.random.default_rng(21)
+    reads, names = [], []
+    for i in range(300):
+        n = int(rng.choice([0, 1, 5, 31, 32, 33, 100, 150, 151, 400]))
+        a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        a[rng.random(n) < 0.1] |= 0x20
+        p_junk = float(rng.choice([0.0, 0.01, 0.3, 1.0]))
+        junk = rng.random(n) < p_junk
+        a[junk] = rng.integers(0, 256, int(junk.sum())).astype(np.uint8)
+        reads.append(a.tobytes())
+        names.append(b"" if i % 17 == 0 else b"@run7:%d:%d/1" % (i, int(rng.integers(0, 10 ** int(rng.integers(1, 12))))))
+    words, start, rep = dbg.pack_acgt_hashn(reads, names, ctx)
+    assert rep == sum(1 for r in reads for c in r if c not in b"ACGTacgt")
+    for r, nm, st in zip(reads, names, start):
+        want = O.unpack_acgt(O.pack_acgt_hashn(r, nm), 0, len(r))
+        assert dbg.unpack_acgt(words, int(st), len(r), ctx) == want
+    # no invalid characters: identical to dbg_pack_acgt
+    clean = [bytes(b"ACGT"[x] for x in rng.integers(0, 4, 150)) for _ in range(50)]
+    w1, _, rep = dbg.pack_acgt_hashn(clean, [b"n"] * 50, ctx)
+    assert rep == 0 and np.array_equal(w1, dbg.pack_acgt(b"".join(clean), ctx)[0])
+    assert dbg.pack_acgt_hashn([], [], ctx)[2] == 0
+    hs = dbg.seqs_from_acgt(reads, ctx=ctx, names=names)
+    assert np.array_equal(hs.words, words)
+
+
 def test_ascii_reads_through_filter(ctx):
     """ASCII reads -> GPU packer -> filter_kmers equals the same reads given as 0-3 bytes."""
     rng = np.random.default_rng(5)

@@ -41,6 +41,78 @@ def test_pack_invalid_and_lowercase():
         assert np.array_equal(O.pack_acgt(a.tobytes()), want)
 
 
+def _py_siphash(c, d, k0, k1, msg):
+    """independent statement of SipHash-c-d (Aumasson & Bernstein 2012, figure 2.1) in Python integers"""
+    M = (1 << 64) - 1
+    rotl = lambda x, b: ((x << b) | (x >> (64 - b))) & M
+    v = [k0 ^ 0x736f6d6570736575, k1 ^ 0x646f72616e646f6d, k0 ^ 0x6c7967656e657261, k1 ^ 0x7465646279746573]
+
+    def rnd():
+        v[0] = (v[0] + v[1]) & M; v[1] = rotl(v[1], 13) ^ v[0]; v[0] = rotl(v[0], 32)
+        v[2] = (v[2] + v[3]) & M; v[3] = rotl(v[3], 16) ^ v[2]
+        v[0] = (v[0] + v[3]) & M; v[3] = rotl(v[3], 21) ^ v[0]
+        v[2] = (v[2] + v[1]) & M; v[1] = rotl(v[1], 17) ^ v[2]; v[2] = rotl(v[2], 32)
+    n = len(msg)
+    for i in range(0, n - n % 8, 8):
+        m = int.from_bytes(msg[i:i + 8], "little")
+        v[3] ^= m
+        for _ in range(c):
+            rnd()
+        v[0] ^= m
+    b = ((n & 0xff) << 56) | int.from_bytes(msg[n - n % 8:], "little")
+    v[3] ^= b
+    for _ in range(c):
+        rnd()
+    v[0] ^= b
+    v[2] ^= 0xff
+    for _ in range(d):
+        rnd()
+    return v[0] ^ v[1] ^ v[2] ^ v[3]
+
+
+def test_siphash_published_vectors():
+    """DefaultHasher is third-party to the crate (Rust std: SipHash-1-3, zero key).  The round function and the
+    padding are pinned by the SipHash paper's 2-4 test values (appendix A: key 00..0f, message 00..0e ->
+    a129ca6149be45e5; empty message -> 726fdb47dd0e0e31) and by the first SipHash-1-3 value of the std test-suite
+    (library/core/tests/hash/sip.rs, key 00..0f, empty message -> bytes dc c4 0f 05 58 01 ac ab)."""
+    k0 = int.from_bytes(bytes(range(8)), "little")
+    k1 = int.from_bytes(bytes(range(8, 16)), "little")
+    assert O.siphash(2, 4, k0, k1, bytes(range(15))) == 0xa129ca6149be45e5
+    assert O.siphash(2, 4, k0, k1, b"") == 0x726fdb47dd0e0e31
+    assert O.siphash(1, 3, k0, k1, b"").to_bytes(8, "little").hex() == "dcc40f055801acab"
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 40)) + [63, 64, 65, 200]:
+        msg = rng.integers(0, 256, n).astype(np.uint8).tobytes()
+        for c, d, a, b in ((1, 3, 0, 0), (2, 4, k0, k1), (1, 3, k0, k1)):
+            assert O.siphash(c, d, a, b, msg) == _py_siphash(c, d, a, b, msg)
+
+
+def test_pack_hashn():
+    """from_acgt_bytes_hashn (dna_string.rs:255-278): ACGT as from_acgt_bytes; any other character at pos becomes
+    SipHash-1-3(0,0)(len(name) u64 LE || name || pos u64 LE) % 4 (impl Hash for [u8] and usize in core::hash)."""
+    rng = np.random.default_rng(4)
+    for name in [b"", b"r", b"read_000001/1", b"@A00519:12:HXXXX:1:1101:1000:2000 1:N:0:ACGT"]:
+        for n in [1, 31, 32, 33, 150, 301]:
+            a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+            a[rng.random(n) < 0.1] |= 0x20
+            junk = rng.random(n) < 0.2
+            a[junk] = np.frombuffer(b"NnRY.-*x", np.uint8)[rng.integers(0, 8, int(junk.sum()))]
+            got = O.pack_acgt_hashn(a.tobytes(), name)
+            bits = []
+            for pos, c in enumerate(a.tobytes()):
+                v = {65: 0, 97: 0, 67: 1, 99: 1, 71: 2, 103: 2, 84: 3, 116: 3}.get(c)
+                if v is None:
+                    v = _py_siphash(1, 3, 0, 0, len(name).to_bytes(8, "little") + name + pos.to_bytes(8, "little")) % 4
+                bits.append(v)
+            assert np.array_equal(got, O.dnastring_pack(bits))
+    # without invalid characters it is from_acgt_bytes; the replacement depends on the name and on the position
+    s = b"ACGTTGCAACGTTGCAACGTTGCAACGTTGCAACG"
+    assert np.array_equal(O.pack_acgt_hashn(s, b"x"), O.pack_acgt(s))
+    n_run = b"N" * 64
+    a, b = O.unpack_acgt(O.pack_acgt_hashn(n_run, b"read1"), 0, 64), O.unpack_acgt(O.pack_acgt_hashn(n_run, b"read2"), 0, 64)
+    assert a != b and len(set(a)) == 4 and a == O.unpack_acgt(O.pack_acgt_hashn(n_run, b"read1"), 0, 64)
+
+
 def test_write_gfa_small_graph():
     """Hand-checkable GFA: two overlapping reads sharing a branch (k = 5)."""
     k = 5

@@ -147,6 +147,25 @@ def test_filter_multipass_equals_single():
         O.filter_kmers(ss, 31, O.COUNT_FILTER, 1, stranded=False, memory_size=0)
 
 
+@pytest.mark.parametrize("stranded", [False, True])
+@pytest.mark.parametrize("summ", ["count", "set"])
+def test_threaded_sharded_baseline_counts_like_unsharded(stranded, summ):
+    """bench.py's many-core CPU leg (msp_sequence -> shards -> filter_kmers per shard on threads, the pipeline of
+    test.rs:418-504) keeps exactly the k-mers the unsharded filter_kmers keeps."""
+    rng = np.random.default_rng(11)
+    genome = R.random_dna(rng, 3000)
+    seqs = []
+    for _ in range(400):
+        a = int(rng.integers(0, 3000 - 150))
+        seqs.append(genome[a:a + 150].copy())
+    ss = O.SeqSet.from_byte_seqs(seqs, data=np.arange(400) % 4, sizeof_d1=1)
+    which = O.COUNT_FILTER if summ == "count" else O.COUNT_FILTER_SET
+    want = len(O.filter_kmers(ss, 47, which, 2, stranded=stranded).key_lo)
+    for nt, ns in ((1, 1), (3, 7), (4, 64)):
+        _, got = O.time_filter_kmers_sharded_mt(ss, 47, which, 2, stranded, nt, ns)
+        assert got == want
+
+
 def test_count_filter_saturates():
     s = R.random_dna(np.random.default_rng(3), 40)
     n = 70000
