@@ -203,9 +203,17 @@ def main():
                    "host_cores_available": os.cpu_count()}
             # the same port on every host core, parallelised the way callers parallelise the crate (which has no
             # parallel path of its own): msp_sequence -> shards -> filter_kmers per shard (test.rs:418-504)
-            nt = len(os.sched_getaffinity(0))
-            if nt > 1:
-                n_m = min(reads_per_gpu, max(n_s, 40000 * nt))      # a few seconds of wall time, < 16 GB of host memory
+            cores = len(os.sched_getaffinity(0))
+            try:                                               # container CPU quota (cgroup v2), if any
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    cores = max(1, min(cores, -(-int(q) // int(per))))
+            except (OSError, ValueError):
+                pass
+            cpu["host_cores_granted"] = cores
+            nt = 2 * cores                                     # two threads per granted core measured best on the GPU box
+            if cores > 1:
+                n_m = min(reads_per_gpu, max(n_s, 125000 * nt))     # a few seconds of wall time, a few GB of host memory
                 pm = dbg.synth_params(n_reads=n_m, read_len=L, genome_len=n_m * L // 30, error_rate=0.001,
                                       stranded=False, n_colours=4)
                 nwm = lib.dbg_synth_words(C.byref(pm))
@@ -220,8 +228,8 @@ def main():
                 del wm, sm, lm, cm
                 msec, mnv = O.time_filter_kmers_sharded_mt(som, k, O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER,
                                                            args.min_obs, False, nt, 16 * nt)
-                cpu["all_cores"] = {"value": round(n_m * (L - k + 1) / msec / 1e9, 5), "unit": "Gkmer/s", "cores": nt,
-                                    "kind": "port", "valid_kmers": int(mnv),
+                cpu["all_cores"] = {"value": round(n_m * (L - k + 1) / msec / 1e9, 5), "unit": "Gkmer/s", "cores": cores,
+                                    "threads": nt, "kind": "port", "valid_kmers": int(mnv),
                                     "sample": "%d reads of an equally-parameterised stream (%.0fM k-mer instances), oracle "
                                               "msp_sequence(p=8) -> %d shards -> filter_kmers per shard on %d threads, %.1f s"
                                               % (n_m, n_m * (L - k + 1) / 1e6, 16 * nt, nt, msec)}

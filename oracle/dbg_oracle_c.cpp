@@ -263,7 +263,7 @@ double orc_time_filter_kmers(const uint64_t* words, const uint64_t* start, const
 double orc_time_filter_kmers_sharded_mt(const uint64_t* words, const uint64_t* start, const uint32_t* length,
                                         const uint32_t* data, uint64_t n_seqs, uint32_t sizeof_d1, int k, int p,
                                         int summarizer, uint64_t min_obs, int stranded, uint32_t n_threads,
-                                        uint32_t n_shards, uint64_t* n_valid_out) {
+                                        uint32_t n_shards, uint64_t* n_valid_out, double* phase1_seconds) {
     if (n_threads < 1) n_threads = 1;
     if (n_shards < 1) n_shards = 1;
     struct Piece { uint64_t start; uint32_t len; uint8_t exts; uint32_t d; };
@@ -290,6 +290,7 @@ double orc_time_filter_kmers_sharded_mt(const uint64_t* words, const uint64_t* s
         });
         for (auto& x : th) x.join();
     }
+    if (phase1_seconds) *phase1_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::atomic<uint32_t> next{0};
     std::atomic<uint64_t> valid{0};
     {

@@ -234,6 +234,9 @@ def time_filter_kmers(ss, k, summarizer, min_obs, stranded, memory_size=4):
     return t, nv.value
 
 
+_PH1 = C.c_double()      # seconds of the msp_sequence phase of the last sharded run
+
+
 def time_filter_kmers_sharded_mt(ss, k, summarizer, min_obs, stranded, n_threads, n_shards=None, p=8):
     """msp_sequence -> shards -> filter_kmers per shard on n_threads host threads (the pipeline of the reference's
     test.rs:418-504, which is how callers parallelise the crate); returns (seconds, total valid k-mers)"""
@@ -241,7 +244,7 @@ def time_filter_kmers_sharded_mt(ss, k, summarizer, min_obs, stranded, n_threads
     n_shards = n_shards or 8 * n_threads
     t = lib().orc_time_filter_kmers_sharded_mt(_p(ss.words), _p(ss.start), _p(ss.length), _p(ss.data), C.c_uint64(ss.n),
                                                C.c_uint32(ss.sizeof_d1), k, p, summarizer, C.c_uint64(min_obs),
-                                               int(stranded), C.c_uint32(n_threads), C.c_uint32(n_shards), C.byref(nv))
+                                               int(stranded), C.c_uint32(n_threads), C.c_uint32(n_shards), C.byref(nv), C.byref(_PH1))
     if t < 0:
         raise _err()
     return t, nv.value
