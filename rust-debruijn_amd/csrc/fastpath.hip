@@ -455,6 +455,30 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
     return base + incl;
 }
 
+// the same over four 16-bit counters packed in a u64 (no field may reach 65536 in the block total)
+template <int NT>
+__device__ __forceinline__ uint64_t block_inclusive_scan64(uint64_t v, uint64_t* s_wsum, uint64_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+        uint64_t x = s_wsum[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl;
+}
+
 // One workgroup (NT threads = NT/64 waves) owns one bin and one LDS hash table of T entries.
 // The workgroup streams the bin in batches of NT records, cut into chunks of <= 4 k-mers that are dealt to
 // all lanes (see "stream the bin" below):
@@ -505,6 +529,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
 #endif
     __shared__ uint32_t s_wsum[NWV];
+    __shared__ uint64_t s_wsum64[NWV];
     __shared__ uint32_t s_flag[2];              // [0] table overflow, [1] claimed entries
     __shared__ unsigned long long s_base, s_base_all;
     __shared__ uint32_t s_stP[40], s_stR[40];
@@ -592,16 +617,41 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (NBW > 3) s_slab[3 * NT + tid] = P3;
             s_chk[tid] = (uint8_t)(cb | (cr << 3));          // cb <= CH <= 7, cr < nch <= 17
             if (tid == 0) { s_m = NT; s_cproc = 0; s_nextq = 0; }
-            uint32_t totc;
-            const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &totc);   // barriers inside
-            if (incl <= CAPC) {
-                if (nch) atomicMax(&s_cproc, incl);
-                for (uint32_t c = 0; c < nch; c++) s_cmap[incl - nch + c] = (uint16_t)(tid | (c << 10));
-            } else if (have) atomicMin(&s_m, tid);
+            // Chunks are entered into the map by length (CH, CH-1, ..., 1): the 64 chunks a wave takes then roll the
+            // same number of k-mers, where record order mixes lengths cb and cb+1 in every wave (11 % idle lanes).
+            // One scan of four packed 16-bit counters gives every record its place in both of its length classes.
+            const uint32_t cl_hi = CH - cb - 1, cl_lo = CH - cb;             // class of the cr longer / nch-cr shorter chunks
+            uint64_t contrib = 0;
+            if (nch) contrib = (cr ? (uint64_t)cr << (16 * cl_hi) : 0ull) + ((uint64_t)(nch - cr) << (16 * cl_lo));
+            uint64_t tot64;
+            const uint64_t incl64 = block_inclusive_scan64<NT>(contrib, s_wsum64, &tot64);   // barriers inside
+            auto fsum = [](uint64_t x) { return (uint32_t)(x & 0xffff) + (uint32_t)((x >> 16) & 0xffff) + (uint32_t)((x >> 32) & 0xffff) + (uint32_t)(x >> 48); };
+            const uint32_t totc = fsum(tot64);
+            const bool all_fit = totc <= CAPC;                               // uniform
+            if (all_fit) {
+                if (nch) {
+                    const uint64_t excl64 = incl64 - contrib;
+                    // class c starts after the totals of classes 0..c-1
+                    const uint64_t below_lo = tot64 & ((1ull << (16 * cl_lo)) - 1);
+                    const uint32_t pos_lo = fsum(below_lo) + (uint32_t)((excl64 >> (16 * cl_lo)) & 0xffff);
+                    for (uint32_t c = cr; c < nch; c++) s_cmap[pos_lo + c - cr] = (uint16_t)(tid | (c << 10));
+                    if (cr) {
+                        const uint64_t below_hi = tot64 & ((1ull << (16 * cl_hi)) - 1);
+                        const uint32_t pos_hi = fsum(below_hi) + (uint32_t)((excl64 >> (16 * cl_hi)) & 0xffff);
+                        for (uint32_t c = 0; c < cr; c++) s_cmap[pos_hi + c] = (uint16_t)(tid | (c << 10));
+                    }
+                }
+            } else {                                                          // long records: record order, as many records as fit
+                const uint32_t incl = fsum(incl64);
+                if (incl <= CAPC) {
+                    if (nch) atomicMax(&s_cproc, incl);
+                    for (uint32_t c = 0; c < nch; c++) s_cmap[incl - nch + c] = (uint16_t)(tid | (c << 10));
+                } else if (have) atomicMin(&s_m, tid);
+            }
             __syncthreads();
             const uint32_t nrec = total_recs - bstart < (uint32_t)NT ? total_recs - bstart : (uint32_t)NT;
-            const uint32_t m = s_m < nrec ? s_m : nrec;             // records of this batch whose chunks fit the map (>= 1)
-            const uint32_t cproc = s_cproc;
+            const uint32_t m = all_fit ? nrec : (s_m < nrec ? s_m : nrec);  // records of this batch whose chunks fit the map (>= 1)
+            const uint32_t cproc = all_fit ? totc : s_cproc;
             // B. prefetch the next batch while this one is processed
             load_rec(bstart + m + tid);
             // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
