@@ -522,8 +522,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     constexpr uint32_t CAPC = (NBW == 4 ? 4 : 6) * NT;      // chunk-map capacity per batch
     __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
     __shared__ uint8_t s_chk[NT];               // per staged record: chunk length cb | remainder cr << 3
-    __shared__ uint16_t s_cmap[CAPC];           // chunk -> record slot | chunk index << 10
-    __shared__ uint32_t s_m, s_cproc, s_nextq;
+    __shared__ __attribute__((aligned(4))) uint16_t s_cmap[CAPC];   // chunk -> record slot | chunk index << 10
+    constexpr uint32_t DD = NT >= 512 ? 1024 : 512;                 // slots of the duplicate filter (>= 2 per staged record)
+    static_assert(CAPC * 2 >= DD * 4 && DD >= 2 * NT && NT <= 1023, "the duplicate filter borrows s_cmap");
+    uint32_t* const s_dd = reinterpret_cast<uint32_t*>(s_cmap);      // duplicate filter of the batch (dead before s_cmap is filled)
+    __shared__ uint32_t s_w[NT];                // per staged record: how many identical records of the batch it stands for
+    __shared__ uint32_t s_cmk[IS_SET ? NT : 1]; // ... and the union of their colours (CountFilterSet)
+    __shared__ uint32_t s_m, s_cproc, s_nextq, s_pre;
 #ifdef DBG_COUNT_STATS
     __shared__ uint32_t s_stat[16];
     if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
@@ -571,7 +576,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         __syncthreads();
         if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_pre = 0; }
         __syncthreads();
         PH(1);
 
@@ -610,11 +615,57 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             // A. stage this batch's records (prefetched) + per-record chunking
             const bool have = bstart + tid < total_recs;
             uint32_t nkr = have ? (uint32_t)(pmeta & 0x7f) - (uint32_t)k + 1u : 0u;
-            const uint32_t nch = (nkr + CH - 1) / CH;
-            const uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;     // chunk c: cb + (c < cr) k-mers
             s_slab[tid] = P0; s_slab[NT + tid] = P1;
             if (NBW > 2) s_slab[2 * NT + tid] = P2;
             if (NBW > 3) s_slab[3 * NT + tid] = P3;
+            // A'. identical records of the batch are counted once.  Reads that cover the same stretch of the genome cut
+            //     it into the same super-k-mers (the cut points depend on the sequence alone), so at 30x most records
+            //     that do not touch a read end have a dozen exact copies in their bin.  A record that finds an equal one
+            //     (bases, length, boundary Exts) already entered in the batch's filter adds 1 to that record's weight and
+            //     its colour to that record's colour set and contributes no chunks; the k-mers of the surviving record
+            //     are inserted with count += weight.  The filter (open addressing on DD slots, entry = staged slot + 1
+            //     | 22 hash bits) lives in s_cmap, which is not in use until the chunk map is built.
+            constexpr uint64_t COLOUR_BITS = 31ull << 15;
+            s_w[tid] = have ? 1u : 0u;
+            if (IS_SET) s_cmk[tid] = 1u << ((uint32_t)(pmeta >> 15) & 31u);
+            for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
+            {   // chunks the batch would need without the filter (it is skipped when they do not all fit the map)
+                uint32_t pc = (nkr + CH - 1) / CH;
+                for (int o = 32; o > 0; o >>= 1) pc += __shfl_down(pc, o, 64);
+                if (lane == 0 && pc) atomicAdd(&s_pre, pc);
+            }
+            __syncthreads();
+            if (s_pre <= CAPC && have) {
+                const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);           // word holding the meta bits
+                const uint64_t lastw = PL0 & ~COLOUR_BITS;
+                uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
+                if (NBW == 3) ha += lastw * 0x9E3779B97F4A7C15ull;
+                if (NBW == 4) { ha += P2 * 0x9E3779B97F4A7C15ull; hb += lastw * 0xC2B2AE3D27D4EB4Full; }
+                const uint64_t h = hash_key(ha, hb);
+                const uint32_t mine = (tid + 1u) | ((uint32_t)(h >> 42) << 10);
+                uint32_t sl = (uint32_t)h & (DD - 1);
+                for (;;) {
+                    asm volatile("" ::: "memory");
+                    uint32_t v = s_dd[sl];
+                    if (v == 0u) { v = atomicCAS(&s_dd[sl], 0u, mine); if (v == 0u) break; }     // first of its kind
+                    if ((v >> 10) == (mine >> 10)) {
+                        const uint32_t r = (v & 1023u) - 1u;
+                        bool same = s_slab[r] == P0;
+                        if (NBW > 2) same = same && s_slab[NT + r] == P1;
+                        if (NBW > 3) same = same && s_slab[2 * NT + r] == P2;
+                        same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
+                        if (same) {
+                            atomicAdd(&s_w[r], 1u);
+                            if (IS_SET) atomicOr(&s_cmk[r], 1u << ((uint32_t)(pmeta >> 15) & 31u));
+                            nkr = 0;                                                     // no chunks of its own
+                            break;
+                        }
+                    }
+                    sl = (sl + 1u) & (DD - 1);
+                }
+            }
+            const uint32_t nch = (nkr + CH - 1) / CH;
+            const uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;     // chunk c: cb + (c < cr) k-mers
             s_chk[tid] = (uint8_t)(cb | (cr << 3));          // cb <= CH <= 7, cr < nch <= 17
             if (tid == 0) { s_m = NT; s_cproc = 0; s_nextq = 0; }
             // Chunks are entered into the map by length (CH, CH-1, ..., 1): the 64 chunks a wave takes then roll the
@@ -652,6 +703,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             const uint32_t nrec = total_recs - bstart < (uint32_t)NT ? total_recs - bstart : (uint32_t)NT;
             const uint32_t m = all_fit ? nrec : (s_m < nrec ? s_m : nrec);  // records of this batch whose chunks fit the map (>= 1)
             const uint32_t cproc = all_fit ? totc : s_cproc;
+            if (tid == 0) s_pre = 0;                         // every thread read it before the scan's barriers
             // B. prefetch the next batch while this one is processed
             load_rec(bstart + m + tid);
             // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
@@ -672,7 +724,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     meta = WL & ((1ull << META_BITS) - 1);
                     WL &= ~((1ull << META_BITS) - 1);
                 }
-                const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu, rd = (uint32_t)(meta >> 15) & 31u;
+                const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu;
+                const uint32_t wgt = s_w[r], cset = IS_SET ? s_cmk[r] << 8 : 0u;
                 const uint32_t chk = s_chk[r];
                 const uint32_t cbase = chk & 7u, crem = chk >> 3;
                 uint32_t j = c * cbase + (c < crem ? c : crem);
@@ -768,8 +821,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                             if (++nprobe >= (uint32_t)(T / 4)) break;                // table full
                         }
                         if (hit) {
-                            atomicAdd(&s_cnt[slot], 1u);
-                            atomicOr(&s_aux[slot], IS_SET ? (ex | (256u << (rd & 31u))) : ex);
+                            atomicAdd(&s_cnt[slot], wgt);
+                            atomicOr(&s_aux[slot], ex | cset);
                         } else {
                             __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full: the pass is re-split
                         }
