@@ -521,14 +521,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24)
     constexpr uint32_t CAPC = (NBW == 4 ? 4 : 6) * NT;      // chunk-map capacity per batch
     __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
-    __shared__ uint8_t s_chk[NT];               // per staged record: chunk length cb | remainder cr << 3
     __shared__ __attribute__((aligned(4))) uint16_t s_cmap[CAPC];   // chunk -> record slot | chunk index << 10
     constexpr uint32_t DD = NT >= 512 ? 1024 : 512;                 // slots of the duplicate filter (>= 2 per staged record)
     static_assert(CAPC * 2 >= DD * 4 && DD >= 2 * NT && NT <= 1023, "the duplicate filter borrows s_cmap");
     uint32_t* const s_dd = reinterpret_cast<uint32_t*>(s_cmap);      // duplicate filter of the batch (dead before s_cmap is filled)
-    __shared__ uint32_t s_w[NT];                // per staged record: how many identical records of the batch it stands for
+    __shared__ uint32_t s_w[NT / 2];            // per staged record: how many identical records of the batch it stands for (u16 halves)
     __shared__ uint32_t s_cmk[IS_SET ? NT : 1]; // ... and the union of their colours (CountFilterSet)
-    __shared__ uint32_t s_m, s_cproc, s_nextq, s_pre;
+    __shared__ uint32_t s_m, s_cproc, s_nextq;
 #ifdef DBG_COUNT_STATS
     __shared__ uint32_t s_stat[16];
     if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
@@ -547,13 +546,12 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     // The bin's records arrive as n_src segments (one per source rank after the all-to-all; the bin's slab plus
     // its overflow in the single-GPU case): segment s spans records [seg_beg[s*stride + bin], seg_end[s*stride + bin])
     // of `recs` (of `recs_alt` for s >= alt_from).
-    __shared__ uint64_t s_segbase[65];          // first record of segment s in `recs`
     __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
     if (tid == 0) {
         uint32_t acc = 0;
         for (uint32_t sg = 0; sg < n_src; sg++) {
             uint64_t a = seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[sg * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
-            s_segbase[sg] = a; s_segpre[sg] = acc; acc += (uint32_t)(b - a);
+            s_segpre[sg] = acc; acc += (uint32_t)(b - a);
         }
         s_segpre[n_src] = acc;
     }
@@ -576,7 +574,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         __syncthreads();
         if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_pre = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
         __syncthreads();
         PH(1);
 
@@ -601,7 +599,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (ridx < total_recs) {
                 uint32_t sg = 0;
                 while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
-                const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + (s_segbase[sg] + (ridx - s_segpre[sg])) * RW;
+                const uint64_t sbase = seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS];    // first record of the segment
+                const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + (sbase + (ridx - s_segpre[sg])) * RW;
                 P0 = g[0]; P1 = g[1];
                 if (NBW > 2) P2 = g[2];
                 if (NBW > 3) P3 = g[3];
@@ -626,16 +625,12 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             //     are inserted with count += weight.  The filter (open addressing on DD slots, entry = staged slot + 1
             //     | 22 hash bits) lives in s_cmap, which is not in use until the chunk map is built.
             constexpr uint64_t COLOUR_BITS = 31ull << 15;
-            s_w[tid] = have ? 1u : 0u;
+            if (tid < NT / 2) s_w[tid] = 0x00010001u;       // weight 1 in both halves (slots past the bin's end are never read)
             if (IS_SET) s_cmk[tid] = 1u << ((uint32_t)(pmeta >> 15) & 31u);
             for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
-            {   // chunks the batch would need without the filter (it is skipped when they do not all fit the map)
-                uint32_t pc = (nkr + CH - 1) / CH;
-                for (int o = 32; o > 0; o >>= 1) pc += __shfl_down(pc, o, 64);
-                if (lane == 0 && pc) atomicAdd(&s_pre, pc);
-            }
+            const uint32_t nkr0 = nkr;
             __syncthreads();
-            if (s_pre <= CAPC && have) {
+            if (have) {
                 const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);           // word holding the meta bits
                 const uint64_t lastw = PL0 & ~COLOUR_BITS;
                 uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
@@ -655,7 +650,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                         if (NBW > 3) same = same && s_slab[2 * NT + r] == P2;
                         same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
                         if (same) {
-                            atomicAdd(&s_w[r], 1u);
+                            atomicAdd(&s_w[r >> 1], 1u << (16 * (r & 1u)));           // <= NT per half: no carry
                             if (IS_SET) atomicOr(&s_cmk[r], 1u << ((uint32_t)(pmeta >> 15) & 31u));
                             nkr = 0;                                                     // no chunks of its own
                             break;
@@ -664,13 +659,12 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     sl = (sl + 1u) & (DD - 1);
                 }
             }
-            const uint32_t nch = (nkr + CH - 1) / CH;
-            const uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;     // chunk c: cb + (c < cr) k-mers
-            s_chk[tid] = (uint8_t)(cb | (cr << 3));          // cb <= CH <= 7, cr < nch <= 17
             if (tid == 0) { s_m = NT; s_cproc = 0; s_nextq = 0; }
             // Chunks are entered into the map by length (CH, CH-1, ..., 1): the 64 chunks a wave takes then roll the
             // same number of k-mers, where record order mixes lengths cb and cb+1 in every wave (11 % idle lanes).
             // One scan of four packed 16-bit counters gives every record its place in both of its length classes.
+            uint32_t nch = (nkr + CH - 1) / CH;
+            uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;          // chunk c: cb + (c < cr) k-mers
             const uint32_t cl_hi = CH - cb - 1, cl_lo = CH - cb;             // class of the cr longer / nch-cr shorter chunks
             uint64_t contrib = 0;
             if (nch) contrib = (cr ? (uint64_t)cr << (16 * cl_hi) : 0ull) + ((uint64_t)(nch - cr) << (16 * cl_lo));
@@ -692,8 +686,15 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                         for (uint32_t c = 0; c < cr; c++) s_cmap[pos_hi + c] = (uint16_t)(tid | (c << 10));
                     }
                 }
-            } else {                                                          // long records: record order, as many records as fit
-                const uint32_t incl = fsum(incl64);
+            } else {
+                // Even the distinct records of the batch need more chunks than the map holds (long records with few
+                // copies): the filter is undone -- every record counts for itself again -- and as many records as fit
+                // are taken in record order; the rest is staged again with the next batch.
+                if (tid < NT / 2) s_w[tid] = 0x00010001u;
+                if (IS_SET) s_cmk[tid] = 1u << ((uint32_t)(pmeta >> 15) & 31u);
+                nch = (nkr0 + CH - 1) / CH;
+                uint32_t dummy;
+                const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &dummy);
                 if (incl <= CAPC) {
                     if (nch) atomicMax(&s_cproc, incl);
                     for (uint32_t c = 0; c < nch; c++) s_cmap[incl - nch + c] = (uint16_t)(tid | (c << 10));
@@ -703,7 +704,6 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             const uint32_t nrec = total_recs - bstart < (uint32_t)NT ? total_recs - bstart : (uint32_t)NT;
             const uint32_t m = all_fit ? nrec : (s_m < nrec ? s_m : nrec);  // records of this batch whose chunks fit the map (>= 1)
             const uint32_t cproc = all_fit ? totc : s_cproc;
-            if (tid == 0) s_pre = 0;                         // every thread read it before the scan's barriers
             // B. prefetch the next batch while this one is processed
             load_rec(bstart + m + tid);
             // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
@@ -725,9 +725,11 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     WL &= ~((1ull << META_BITS) - 1);
                 }
                 const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu;
-                const uint32_t wgt = s_w[r], cset = IS_SET ? s_cmk[r] << 8 : 0u;
-                const uint32_t chk = s_chk[r];
-                const uint32_t cbase = chk & 7u, crem = chk >> 3;
+                const uint32_t wgt = (s_w[r >> 1] >> (16 * (r & 1u))) & 0xffffu, cset = IS_SET ? s_cmk[r] << 8 : 0u;
+                // the record's chunking, as stage A cut it: ceil(nk/4) chunks of cbase (+1 for the first crem) k-mers
+                static_assert(CH == 4, "closed form of nk / ceil(nk / CH)");
+                const uint32_t rnk = rlen - (uint32_t)k + 1u, rnch = (rnk + 3u) >> 2;
+                const uint32_t cbase = rnk < 4u ? rnk : (rnk == 5u ? 2u : ((rnk & 3u) ? 3u : 4u)), crem = rnk - cbase * rnch;
                 uint32_t j = c * cbase + (c < crem ? c : crem);
                 const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
                 // k-mer j of the record: bases [j, j + k) of the 2-bit stream W[0..NBW)
@@ -1020,7 +1022,11 @@ static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kme
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw;
     pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
-    uint64_t target = 9500;                                     // k-mer instances per bin (about 0.15 distinct per instance)
+    // k-mer instances per bin.  The table holds T = 2048 distinct k-mers and works best about half full; the share of
+    // distinct k-mers among the instances grows with k (every sequencing error spoils k k-mers), so the bins shrink
+    // with k: measured optima on 30x reads with e = 0.1 %: k=31 8-12k, k=47 8k, k=51 7-8k, k=63 6k (a bin that
+    // overflows is only re-split, at the price of streaming it again).
+    uint64_t target = std::min<uint64_t>(10000, std::max<uint64_t>(5000, 380000 / (uint64_t)k));
     if (const char* e = getenv("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
