@@ -495,6 +495,9 @@ __device__ __forceinline__ uint64_t block_inclusive_scan64(uint64_t v, uint64_t*
 // 1 % BUSY re-reads); the kernel is VALU-bound (~65 % of SIMD cycles) once the probe is kept to one
 // dependent LDS access per branch.
 constexpr uint32_t TAG_BUSY = 0x80000000u;
+#ifndef DBG_SKIP_EMIT
+#define DBG_SKIP_EMIT 0
+#endif
 
 #ifdef DBG_COUNT_STATS
 #define STAT(i, v) atomicAdd(&s_stat[i], (uint32_t)(v))
@@ -547,13 +550,20 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     // its overflow in the single-GPU case): segment s spans records [seg_beg[s*stride + bin], seg_end[s*stride + bin])
     // of `recs` (of `recs_alt` for s >= alt_from).
     __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
-    if (tid == 0) {
-        uint32_t acc = 0;
-        for (uint32_t sg = 0; sg < n_src; sg++) {
-            uint64_t a = seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[sg * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
-            s_segpre[sg] = acc; acc += (uint32_t)(b - a);
+    if (tid < 64) {                             // n_src <= 64: one lane per segment, prefix sum by shuffles
+        uint32_t len = 0;
+        if (tid < n_src) {
+            const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[tid * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
+            len = (uint32_t)(b - a);
         }
-        s_segpre[n_src] = acc;
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += o;
+        }
+        if (tid < n_src) s_segpre[tid] = incl - len;
+        if (tid == 63) s_segpre[n_src] = incl;
     }
     __syncthreads();
     const uint32_t total_recs = s_segpre[n_src];
@@ -573,18 +583,6 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         const uint32_t P = s_stP[sp - 1], pr = s_stR[sp - 1];
         __syncthreads();
         if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
-        for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-        __syncthreads();
-        PH(1);
-
-        // ---- stream the bin, chunk-parallel.  A super-k-mer record holds 1..W k-mers; handing whole records to
-        //      lanes leaves the waves of the workgroup badly balanced (a bin is only ~1.3 records per lane).  So
-        //      the workgroup stages a batch of NT records in LDS, cuts every record into ceil(nk/CH) nearly equal
-        //      chunks (block prefix sum -> chunk map), and deals the chunks round-robin to all NT lanes.  A lane
-        //      re-creates the chunk's first k-mer from the staged record (one funnel shift + one reverse
-        //      complement per chunk) and then rolls (extend_right on the forward strand, extend_left of the
-        //      complement on the reverse strand).  The next batch is prefetched into registers meanwhile. ----
         constexpr uint32_t CH = 4;
         // (scalars, not arrays: an indexed private array is placed in scratch memory by the compiler)
         uint64_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, P0 = 0, P1 = 0, P2 = 0, P3 = 0;
@@ -607,7 +605,19 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 pmeta = (NBW == 2 ? P1 : (NBW == 3 ? P2 : P3)) & ((1ull << META_BITS) - 1);
             }
         };
-        load_rec(tid);
+        load_rec(tid);                                  // the first batch is on its way while the table is cleared
+        for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        __syncthreads();
+        PH(1);
+
+        // ---- stream the bin, chunk-parallel.  A super-k-mer record holds 1..W k-mers; handing whole records to
+        //      lanes leaves the waves of the workgroup badly balanced (a bin is only ~1.3 records per lane).  So
+        //      the workgroup stages a batch of NT records in LDS, cuts every record into ceil(nk/CH) nearly equal
+        //      chunks (block prefix sum -> chunk map), and deals the chunks round-robin to all NT lanes.  A lane
+        //      re-creates the chunk's first k-mer from the staged record (one funnel shift + one reverse
+        //      complement per chunk) and then rolls (extend_right on the forward strand, extend_left of the
+        //      complement on the reverse strand).  The next batch is prefetched into registers meanwhile. ----
         bool pass_ovf = false;
 
         for (uint32_t bstart = 0; bstart < total_recs && !pass_ovf;) {
@@ -706,6 +716,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             const uint32_t cproc = all_fit ? totc : s_cproc;
             // B. prefetch the next batch while this one is processed
             load_rec(bstart + m + tid);
+            PH(7);
             // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
             for (;;) {
                 uint32_t q0 = 0;
@@ -862,7 +873,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         PH(3);                 // waiting for the slowest wave
         const bool ovf = s_flag[0] != 0;
         // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
-        if (!ovf) {
+        if (!ovf && !DBG_SKIP_EMIT) {
             uint32_t nvalid = 0, nall = 0;
             for (int i = tid; i < T; i += NT) {
                 if (!s_tag[i]) continue;
@@ -1284,8 +1295,8 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         if (getenv("DBG_DEBUG")) {
             unsigned long long ph[8];
             (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_cycles), sizeof(ph));
-            fprintf(stderr, "[fastpath-phases] (100MHz ticks, summed over bins) prologue=%llu clear=%llu stream(w0)=%llu wait=%llu scan=%llu cursor=%llu write=%llu\n",
-                    ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+            fprintf(stderr, "[fastpath-phases] (100MHz ticks, summed over bins) prologue=%llu clear=%llu stage+filter+map=%llu chunks(w0)=%llu wait=%llu scan=%llu cursor=%llu write=%llu\n",
+                    ph[0], ph[1], ph[7], ph[2], ph[3], ph[4], ph[5], ph[6]);
             unsigned long long z[8] = {0};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z));
         }
