@@ -5,7 +5,17 @@ import csv, glob, json, os, sys, collections
 root, out, n_inst = sys.argv[1], sys.argv[2], float(sys.argv[3])
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(int)
-for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+def newest_per_pass(root):
+    """gpurun merges every call's files into the same local directory: keep only the newest run of each pass"""
+    best = {}
+    for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
+for f in newest_per_pass(root):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
