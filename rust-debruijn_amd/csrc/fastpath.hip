@@ -700,6 +700,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 // Even the distinct records of the batch need more chunks than the map holds (long records with few
                 // copies): the filter is undone -- every record counts for itself again -- and as many records as fit
                 // are taken in record order; the rest is staged again with the next batch.
+                if (tid == 0) atomicAdd(&gflags[12], 1u);
                 if (tid < NT / 2) s_w[tid] = 0x00010001u;
                 if (IS_SET) s_cmk[tid] = 1u << ((uint32_t)(pmeta >> 15) & 31u);
                 nch = (nkr0 + CH - 1) / CH;
@@ -1289,8 +1290,8 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         HIP_TRY(c, hipMemcpyAsync(flv, st->gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint32_t fl = flv[0];
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u wd=%u\n",
-                                         nbins_local, n_src, (unsigned long long)n_recs_hint, cur, fl, flv[1], flv[2], flv[3]);
+        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u filter_undone=%u wd=%u\n",
+                                         nbins_local, n_src, (unsigned long long)n_recs_hint, cur, fl, flv[1], flv[2], flv[12], flv[3]);
 #ifdef DBG_PHASE_TIMES
         if (getenv("DBG_DEBUG")) {
             unsigned long long ph[8];

@@ -188,3 +188,58 @@ def test_fast_sort_variants(ctx, env, k, kind):
             else:
                 os.environ[v] = o
     assert_tables_equal(got, want, kind == 1)
+
+
+def _with_env(env, fn):
+    old = {v: os.environ.get(v) for v in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for v, o in old.items():
+            if o is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = o
+
+
+@pytest.mark.parametrize("k", [31, 47, 63])
+def test_fast_duplicate_records_weights_and_colours(ctx, k):
+    """bin_count counts identical super-k-mer records of a batch once (weight + colour union).  Hundreds of copies of a
+    few reads, on both strands and in every colour, make weights of several hundred per staged record; the counts
+    (saturating u16 for CountFilter), the Exts and the label sets must still be the reference's."""
+    rng = np.random.default_rng(77 + k)
+    base = [R.random_dna(rng, 150) for _ in range(6)]
+    seqs, data = [], []
+    for i in range(2400):
+        b = base[int(rng.integers(0, 6))] if i % 9 else R.random_dna(rng, 150)
+        if rng.random() < 0.5:
+            b = (3 - b)[::-1].copy()
+        seqs.append(b)
+        data.append(int(rng.integers(0, 24)))
+    for target in ("8000", "200000"):
+        _with_env({"DBG_FAST_TARGET": target}, lambda: (
+            run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, 2, False),
+            run_fast(ctx, O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1), k, O.COUNT_FILTER_SET, 3, False, data_width=1),
+            run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, 1, True)))
+
+
+@pytest.mark.parametrize("k,kind", [(63, 0), (63, 1), (51, 1), (47, 0)])
+def test_fast_large_bins_of_distinct_records(ctx, k, kind):
+    """Bins far larger than a batch whose records are all different: the distinct records of a batch need more chunks than
+    the chunk map holds (the duplicate filter is undone for that batch and the rest is staged again), and the table
+    overflows into hash-selected passes."""
+    rng = np.random.default_rng(5 + k + kind)
+    seqs = random_reads(rng, 2500, 2000000, 150, False, err=0.0)
+    data = rng.integers(0, 5, size=len(seqs)) if kind else None
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1) if kind else O.SeqSet.from_byte_seqs(seqs)
+    _with_env({"DBG_FAST_TARGET": "60000"},
+              lambda: run_fast(ctx, ss, k, O.COUNT_FILTER_SET if kind else O.COUNT_FILTER, 1, False, data_width=1 if kind else 0))
+
+
+def test_fast_large_bins_high_coverage(ctx):
+    hs = dbg.synth_reads_host(n_reads=6000, read_len=150, error_rate=0.002, stranded=False, n_colours=4)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
+    want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 2, stranded=False)
+    got = _with_env({"DBG_FAST_TARGET": "40000"}, lambda: dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=47, ctx=ctx)[0])
+    assert_tables_equal(got, want, True)
