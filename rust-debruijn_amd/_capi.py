@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdbg_mi355x.so")
+LIB_PATH = os.environ.get("DBG_LIB") or os.path.join(HERE, "libdbg_mi355x.so")   # DBG_LIB: an experimental build, for measurements
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
