@@ -108,6 +108,103 @@ __global__ void jump_kernel(const Jump* __restrict__ in, Jump* __restrict__ out,
     if (threadIdx.x == 0 && s_walk) atomicOr(&counters[1], 1u);
 }
 
+// ---- fast route: every chain end walks its chain once -------------------------------------------------------------
+// Chains are short on sequencing data (a few dozen k-mers between branch points), so the doubling above -- rounds over
+// all 2n states -- does far more memory traffic than the chains have links.  Here every terminal state T = (k-mer, side
+// it cannot be left through) walks inwards and leaves, in the state of each k-mer it passes that faces back towards T,
+// the finished Jump value of that state: {ST_NONE, k-mers between it and T, their minimum rank, T}.  The two ends of a
+// chain fill the two states of each of its k-mers between them; states on cycles are never reached, which the count of
+// written states shows (the caller then runs the doubling, which also serves chains longer than WALK_CAP).
+constexpr uint32_t WALK_CAP = 1u << 14;
+
+__device__ __forceinline__ bool state_usable(const uint32_t* __restrict__ link, const uint8_t* __restrict__ avail, uint32_t n, uint32_t i, uint32_t p,
+                                             uint32_t* L_out) {
+    const uint32_t L = link[(uint64_t)p * n + i];
+    *L_out = L;
+    return link_valid(L, i) && (!avail || (avail[i] && avail[(L & 0x7FFFFFFFu) >> 1]));
+}
+
+// ordered append of the terminal states (one global atomic per 1024-thread block)
+__global__ void collect_ends_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ avail, uint32_t n, uint32_t* __restrict__ ends,
+                                    uint32_t* __restrict__ n_ends) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool term = false;
+    if (s < 2 * n) { uint32_t L; term = !state_usable(link, avail, n, s >> 1, s & 1, &L); }
+    __shared__ uint32_t s_cnt[16], s_base;
+    const uint64_t km = __ballot(term);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; w++) { uint32_t x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
+        s_base = tot ? atomicAdd(n_ends, tot) : 0u;
+    }
+    __syncthreads();
+    if (term) ends[s_base + s_cnt[wave] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = s;
+}
+
+// Persistent wavefronts: chain lengths differ widely, so a lane that finishes its chain takes the next chain end at once
+// (each wave reserves WALK_GRAB ends per global atomic and deals them to its idle lanes by ballot) -- every lane keeps
+// one dependent random read in flight instead of idling until the longest chain of its wave is done.
+constexpr uint32_t WALK_GRAB = 256;
+__global__ void __launch_bounds__(256) walk_ends_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank,
+                                                        const uint32_t* __restrict__ weight, const uint8_t* __restrict__ avail, uint32_t n,
+                                                        const uint32_t* __restrict__ ends, uint32_t n_ends, Jump* __restrict__ J,
+                                                        uint32_t* __restrict__ next, unsigned long long* __restrict__ written,
+                                                        uint32_t* __restrict__ capped) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t wpos = 0, wend = 0;                                   // this wave's reserved range of `ends` (wave-uniform)
+    bool exhausted = false, active = false;
+    uint32_t total = 0, steps = 0, cur = 0, side = 0;
+    Jump o; o.nxt = ST_NONE; o.dist = 0; o.minr = R_INF; o.endst = 0;
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle && !(exhausted && wpos == wend)) {
+            if (wpos == wend) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(next, WALK_GRAB);
+                base = __shfl(base, 0);
+                wpos = base < n_ends ? base : n_ends;
+                wend = base + WALK_GRAB < n_ends ? base + WALK_GRAB : n_ends;
+                if (base + WALK_GRAB >= n_ends) exhausted = true;
+            }
+            const uint32_t have = wend - wpos, want = (uint32_t)__popcll(idle), mine = (uint32_t)__popcll(idle & lt);
+            if (!active && mine < have) {
+                const uint32_t T = ends[wpos + mine];
+                o.nxt = ST_NONE; o.dist = 0; o.minr = R_INF; o.endst = T;
+                J[T] = o;                                          // what init_states_kernel gives a terminal state
+                total++;
+                steps = 1;
+                cur = T >> 1; side = 1u - (T & 1u);                // leave the end k-mer through its other side
+                active = true;
+            }
+            wpos += want < have ? want : have;
+        }
+        if (!__any(active)) {
+            if (exhausted && wpos == wend) break;
+            continue;
+        }
+        if (active) {
+            uint32_t L;
+            if (!state_usable(link, avail, n, cur, side, &L)) active = false;   // (cur, side) is the far terminal state: its own walker writes it
+            else {
+                o.dist += weight ? weight[cur] : 1u;               // cur is now behind the walker
+                const uint32_t r = rank ? rank[cur] : cur;
+                o.minr = r < o.minr ? r : o.minr;
+                const uint32_t j = L >> 1, nd = L & 1u;            // arrive at j, to be left through nd
+                J[2 * j + (1u - nd)] = o;                          // j's state that faces back
+                total++;
+                cur = j; side = nd;
+                if (++steps > WALK_CAP) { atomicOr(capped, 1u); active = false; }
+            }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) total += __shfl_down(total, d, 64);
+    if (lane == 0 && total) atomicAdd(written, (unsigned long long)total);
+}
+
 // after the doubling has covered 2n steps, any state still walking sits on a cycle; cut it at its seed's right side
 __global__ void cut_cycles_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t* __restrict__ link, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,12 +387,39 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     DBuf<Jump> JA, JB;
     DBuf<uint32_t> LA, LB, counters;
     ALLOC_OR_FAIL(c, JA, n2);
-    ALLOC_OR_FAIL(c, JB, n2);
     ALLOC_OR_FAIL(c, LA, n2);
-    ALLOC_OR_FAIL(c, LB, n2);
-    ALLOC_OR_FAIL(c, counters, 2);
+    ALLOC_OR_FAIL(c, counters, 6);
     Jump* cur = nullptr;
-    for (int phase = 0; phase < 2; phase++) {
+    bool walked = false;
+    if (!getenv("DBG_UNITIG_NO_WALK")) {
+        HIP_TRY(c, hipMemsetAsync(counters.p, 0, 24, c->stream));
+        c->t_begin("unitig_walk_ends", n);
+        collect_ends_kernel<<<cdiv(n2, 1024), 1024, 0, c->stream>>>(link_dev, avail, n, LA.p, counters.p);
+        LAUNCH_CHECK(c, "collect_ends");
+        uint32_t n_ends = 0;
+        HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (n_ends) {
+            const uint32_t wblocks = std::min<uint32_t>(cdiv(n_ends, 256), 2048);        // 8 resident blocks per CU
+            walk_ends_kernel<<<wblocks, 256, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, LA.p, n_ends, JA.p, counters.p + 4,
+                                                             (unsigned long long*)(counters.p + 2), counters.p + 1);
+            LAUNCH_CHECK(c, "walk_ends");
+        }
+        uint32_t res[4] = {0, 0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(res, counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->t_end();
+        const uint64_t written = (uint64_t)res[2] | ((uint64_t)res[3] << 32);
+        walked = res[1] == 0 && written == n2;                      // no walker gave up, no state on a cycle
+        if (getenv("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends wrote %llu of %u states%s\n", n_ends, (unsigned long long)written, n2,
+                                         walked ? "" : " -> doubling");
+        if (walked) cur = JA.p;
+    }
+    if (!walked) {
+        ALLOC_OR_FAIL(c, JB, n2);
+        ALLOC_OR_FAIL(c, LB, n2);
+    }
+    for (int phase = 0; phase < 2 && !walked; phase++) {
         init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, JA.p);
         LAUNCH_CHECK(c, "init_states");
         Jump *a = JA.p, *b = JB.p;
