@@ -156,7 +156,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
 static int attach_prefix_index(dbg_ctx* c, KeysDev* t, int k, DBuf<uint32_t>* store) {
     t->key_bits = 2 * k;
     int pb = 8;
-    while (pb < 24 && pb < 2 * k && (t->n >> pb) > 4) pb++;          // ~4 keys per bucket, at most 2^24 buckets
+    while (pb < 27 && pb < 2 * k && (t->n >> pb) > 4) pb++;          // ~4 keys per bucket, at most 2^27 buckets (512 MB)
     if (pb > 2 * k) pb = 2 * k;
     ALLOC_OR_FAIL(c, (*store), ((size_t)1 << pb) + 1);
     KeysDev plain = *t;
