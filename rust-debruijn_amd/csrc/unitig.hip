@@ -363,6 +363,169 @@ __global__ void finish_nodes_kernel(uint32_t n_nodes, int spec, int k, const uin
 // only hold equal data, so nothing to check.  For SimpleCompress specs join_test is always true.
 }  // namespace
 
+namespace {
+// ---- chain route for compress_kmers_with_hash (elements = k-mers) -----------------------------------------------------
+// The same end walk, taken one step further: no per-state table at all.  Pass 1 (chain_scan_kernel): every chain end T
+// walks to the far end and learns the chain's length, its seed (minimum rank) and whether the seed's left side faces T.
+// Both ends of a chain see the same seed, and the seed's left side faces exactly one of them: that end is the unitig's
+// left end ("nodes are read in the seed's stored orientation") and records {length, T} under the seed's rank.  After the
+// scans that turn seed ranks into node numbers and lengths into offsets, pass 2 (chain_emit_kernel) lets one lane per
+// node walk its chain from the left end and write the sequence front to back (first k-mer whole, then one base per
+// k-mer, gathered into 64-bit words), the Exts of the two ends and the data fold.  Per link one random 4-byte read in
+// each pass plus one 8-byte key read and one 4-byte data read in pass 2 -- no table of 2n x 16 bytes, no random atomics.
+// Chains on cycles have no ends: the k-mers of all recorded chains then do not add up to n and the caller takes the
+// general route.
+struct WaveFeed {                                  // hands out items [0, n_items) to the idle lanes of persistent waves
+    uint32_t wpos = 0, wend = 0;
+    bool exhausted = false;
+    // returns true in lanes that received item *out
+    __device__ __forceinline__ bool feed(bool idle_lane, uint32_t n_items, uint32_t* __restrict__ next, uint32_t* out) {
+        const uint32_t lane = threadIdx.x & 63;
+        const uint64_t idle = __ballot(idle_lane);
+        if (!idle || (exhausted && wpos == wend)) return false;
+        if (wpos == wend) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(next, WALK_GRAB);
+            base = __shfl(base, 0);
+            wpos = base < n_items ? base : n_items;
+            wend = base + WALK_GRAB < n_items ? base + WALK_GRAB : n_items;
+            if (base + WALK_GRAB >= n_items) exhausted = true;
+        }
+        const uint32_t have = wend - wpos, want = (uint32_t)__popcll(idle), mine = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        const bool got = idle_lane && mine < have;
+        if (got) *out = wpos + mine;
+        wpos += want < have ? want : have;
+        return got;
+    }
+    __device__ __forceinline__ bool done() const { return exhausted && wpos == wend; }
+};
+
+__global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, uint32_t n,
+                                                         const uint32_t* __restrict__ ends, uint32_t n_ends, int k,
+                                                         uint32_t* __restrict__ flag_by_rank, uint32_t* __restrict__ len_by_rank,
+                                                         uint32_t* __restrict__ start_by_rank, uint32_t* __restrict__ seed_by_rank,
+                                                         uint32_t* __restrict__ next, unsigned long long* __restrict__ kmers_seen,
+                                                         uint32_t* __restrict__ capped) {
+    WaveFeed wf;
+    bool active = false;
+    uint32_t T = 0, cur = 0, face = 0, m = 0, best = R_INF, seed = 0;
+    bool seed_left_faces_T = false;
+    unsigned long long total = 0;
+    for (;;) {
+        uint32_t item;
+        if (wf.feed(!active, n_ends, next, &item)) {
+            T = ends[item];
+            cur = T >> 1; face = T & 1u;                          // `face` = the side of cur that points towards T
+            m = 0; best = R_INF;
+            active = true;
+        }
+        if (!__any(active)) {
+            if (wf.done()) break;
+            continue;
+        }
+        if (active) {
+            const uint32_t r = rank ? rank[cur] : cur;
+            if (r < best) { best = r; seed = cur; seed_left_faces_T = face == 0; }
+            m++;
+            uint32_t L;
+            if (!state_usable(link, nullptr, n, cur, 1u - face, &L)) {      // far end reached
+                if (seed_left_faces_T) {                           // T is the left end of the unitig
+                    flag_by_rank[best] = 1;
+                    len_by_rank[best] = m + (uint32_t)k - 1;
+                    start_by_rank[best] = T;
+                    seed_by_rank[best] = seed;
+                    total += m;
+                }
+                active = false;
+            } else {
+                cur = L >> 1; face = 1u - (L & 1u);
+                if (m > WALK_CAP) { atomicOr(capped, 1u); active = false; }
+            }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) total += __shfl_down(total, d, 64);
+    if ((threadIdx.x & 63) == 0 && total) atomicAdd(kmers_seen, total);
+}
+
+__global__ void gather_chains_kernel(const uint32_t* __restrict__ flag_by_rank, const uint32_t* __restrict__ uidx_by_rank,
+                                     const uint32_t* __restrict__ len_by_rank, const uint32_t* __restrict__ start_by_rank,
+                                     const uint32_t* __restrict__ seed_by_rank, uint32_t n, uint32_t* __restrict__ ulen,
+                                     uint32_t* __restrict__ ufirst, uint32_t* __restrict__ useed) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && flag_by_rank[r]) { const uint32_t u = uidx_by_rank[r]; ulen[u] = len_by_rank[r]; ufirst[u] = start_by_rank[r]; useed[u] = seed_by_rank[r]; }
+}
+
+__global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restrict__ link, uint32_t n, int k, const uint64_t* __restrict__ key_hi,
+                                                         const uint64_t* __restrict__ key_lo, const uint8_t* __restrict__ exts,
+                                                         const uint32_t* __restrict__ data, int spec, uint32_t n_nodes,
+                                                         const uint32_t* __restrict__ ufirst, const uint32_t* __restrict__ useed,
+                                                         const uint64_t* __restrict__ ustart, uint64_t* __restrict__ words,
+                                                         uint32_t* __restrict__ uexts, unsigned long long* __restrict__ uacc, uint32_t* __restrict__ next) {
+    WaveFeed wf;
+    bool active = false;
+    uint32_t ui = 0, cur = 0, face = 0, u = 0, seed = 0, eo = 0;
+    uint64_t pos = 0, wacc = 0, widx = 0;
+    unsigned long long acc = 0;
+    const int top_shift = 2 * (k - 1) - (k > 32 ? 64 : 0);          // position of a key's first base inside hi (k > 32) or lo
+    for (;;) {
+        uint32_t item;
+        if (wf.feed(!active, n_nodes, next, &item)) {
+            ui = item;
+            const uint32_t T = ufirst[ui];
+            cur = T >> 1; face = T & 1u;
+            seed = useed[ui];
+            pos = ustart[ui];
+            u = 0; acc = 0; wacc = 0; widx = 0; eo = 0;
+            active = true;
+        }
+        if (!__any(active)) {
+            if (wf.done()) break;
+            continue;
+        }
+        if (active) {
+            const bool fwd = face == 0;                            // the k-mer's left side points to the unitig's left end
+            if (u == 0) {                                          // the first k-mer contributes all k bases
+                K128 km{key_hi ? key_hi[cur] : 0ull, key_lo[cur]};
+                uint32_t e = exts[cur];
+                if (!fwd) { km = kmer_rc(km, k); e = exts_rc(e); }
+                or_bits(words, pos, km, k);
+                eo = e & 0x0fu;                                    // the left end keeps its outward (hanging) exts
+                pos += (uint32_t)k;
+                widx = pos >> 5;
+            } else {                                               // every other one its last base
+                uint64_t b;
+                if (fwd) b = key_lo[cur] & 3ull;
+                else b = 3ull - (((k > 32 ? key_hi[cur] : key_lo[cur]) >> top_shift) & 3ull);
+                if ((pos >> 5) != widx) {
+                    if (wacc) atomicOr((unsigned long long*)&words[widx], (unsigned long long)wacc);
+                    wacc = 0; widx = pos >> 5;
+                }
+                wacc |= b << (62 - 2 * (uint32_t)(pos & 31));
+                pos++;
+            }
+            const uint32_t d = data ? data[cur] : 0u;
+            if (spec == DBG_SPEC_SIMPLE_MAX_U16) acc = d > acc ? d : acc;
+            else if (spec == DBG_SPEC_SCMAP_EQ) { if (cur == seed) acc = d; }
+            else acc += d;
+            u++;
+            uint32_t L;
+            if (!state_usable(link, nullptr, n, cur, 1u - face, &L)) {      // the right end
+                uint32_t e = exts[cur];
+                if (!fwd) e = exts_rc(e);
+                eo |= e & 0xf0u;
+                if (wacc) atomicOr((unsigned long long*)&words[widx], (unsigned long long)wacc);
+                uexts[ui] = eo;
+                uacc[ui] = acc;
+                active = false;
+            } else {
+                cur = L >> 1; face = 1u - (L & 1u);
+            }
+        }
+    }
+}
+
+}  // namespace
+
 // Builds the BaseGraph on the device from the neighbour links.  rank_dev: seed rank of every (sorted) k-mer id,
 // or null for the identity.  link_dev is modified when cycles are cut.  *done = false (nothing produced)
 // when the links are not mutual or contain a panic marker: the caller then runs the literal host walk.
@@ -384,11 +547,80 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (fl[0]) return 0;
 
-    DBuf<Jump> JA, JB;
-    DBuf<uint32_t> LA, LB, counters;
-    ALLOC_OR_FAIL(c, JA, n2);
+    DBuf<uint32_t> LA, counters;
     ALLOC_OR_FAIL(c, LA, n2);
-    ALLOC_OR_FAIL(c, counters, 6);
+    ALLOC_OR_FAIL(c, counters, 8);
+    // results of either route
+    DBuf<uint32_t> flag_by_rank, len_by_rank, uidx_by_rank, ulen, uexts, o_data;
+    DBuf<uint64_t> ustart, words;
+    DBuf<unsigned long long> uacc;
+    DBuf<uint8_t> o_exts;
+    uint32_t n_nodes = 0;
+    uint64_t total_bases = 0, n_words = 0;
+    bool emitted = false;
+
+    // ---- chain route (k-mers only): two walks per chain, no per-state table ----
+    if (!nodes && !getenv("DBG_UNITIG_NO_CHAINS") && !getenv("DBG_UNITIG_NO_WALK")) {
+        DBuf<uint32_t> start_by_rank, seed_by_rank, ufirst, useed;
+        ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
+        ALLOC_OR_FAIL(c, start_by_rank, n); ALLOC_OR_FAIL(c, seed_by_rank, n);
+        HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(counters.p, 0, 32, c->stream));
+        c->t_begin("unitig_chain_scan", n);
+        collect_ends_kernel<<<cdiv(n2, 1024), 1024, 0, c->stream>>>(link_dev, nullptr, n, LA.p, counters.p);
+        LAUNCH_CHECK(c, "collect_ends");
+        uint32_t n_ends = 0;
+        HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (n_ends) {
+            chain_scan_kernel<<<std::min<uint32_t>(cdiv(n_ends, 256), 2048), 256, 0, c->stream>>>(
+                link_dev, rank_dev, n, LA.p, n_ends, k, flag_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p,
+                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1);
+            LAUNCH_CHECK(c, "chain_scan");
+        }
+        uint32_t res[4] = {0, 0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(res, counters.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->t_end();
+        const uint64_t seen = (uint64_t)res[2] | ((uint64_t)res[3] << 32);
+        const bool ok = res[1] == 0 && seen == n;                  // no walker gave up, every k-mer sits on an open chain
+        if (getenv("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
+                                         ok ? "" : " -> general route");
+        if (ok) {
+            DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
+            HIP_TRY(c, hipMemcpyAsync(&n_nodes, uidx_by_rank.p + n, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const uint32_t nn = std::max<uint32_t>(n_nodes, 1);
+            ALLOC_OR_FAIL(c, ulen, nn); ALLOC_OR_FAIL(c, ufirst, nn); ALLOC_OR_FAIL(c, useed, nn);
+            ALLOC_OR_FAIL(c, ustart, (size_t)n_nodes + 1);
+            ALLOC_OR_FAIL(c, uexts, nn); ALLOC_OR_FAIL(c, uacc, nn); ALLOC_OR_FAIL(c, o_exts, nn); ALLOC_OR_FAIL(c, o_data, nn);
+            gather_chains_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(flag_by_rank.p, uidx_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p, n,
+                                                                      ulen.p, ufirst.p, useed.p);
+            LAUNCH_CHECK(c, "gather_chains");
+            DBG_TRY(scan_exclusive_u32_u64(c, ulen.p, ustart.p, n_nodes));
+            HIP_TRY(c, hipMemcpyAsync(&total_bases, ustart.p + n_nodes, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            n_words = (total_bases + 31) / 32;
+            ALLOC_OR_FAIL(c, words, n_words + 3);
+            HIP_TRY(c, hipMemsetAsync(words.p, 0, (n_words + 3) * 8, c->stream));
+            HIP_TRY(c, hipMemsetAsync(counters.p + 6, 0, 4, c->stream));
+            c->t_begin("unitig_emit", n);
+            if (n_nodes) {
+                chain_emit_kernel<<<std::min<uint32_t>(cdiv(n_nodes, 256), 2048), 256, 0, c->stream>>>(
+                    link_dev, n, k, key_hi, key_lo, exts, data, spec, n_nodes, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 6);
+                LAUNCH_CHECK(c, "chain_emit");
+                finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, nullptr, o_exts.p, o_data.p);
+                LAUNCH_CHECK(c, "finish_nodes");
+            }
+            c->t_end();
+            emitted = true;
+        }
+    }
+
+    if (!emitted) {
+    DBuf<Jump> JA, JB;
+    DBuf<uint32_t> LB;
+    ALLOC_OR_FAIL(c, JA, n2);
     Jump* cur = nullptr;
     bool walked = false;
     if (!getenv("DBG_UNITIG_NO_WALK")) {
@@ -453,16 +685,13 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         LAUNCH_CHECK(c, "cut_cycles");
     }
     // ---- seeds -> node order -> offsets ----
-    DBuf<uint32_t> flag_by_rank, len_by_rank, uidx_by_rank, ulen, uexts;
     DBuf<uint8_t> rev_by_rank;
-    DBuf<uint64_t> ustart;
     ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
     ALLOC_OR_FAIL(c, rev_by_rank, n);
     HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
     mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, weight, avail, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
     LAUNCH_CHECK(c, "mark_seeds");
     DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
-    uint32_t n_nodes = 0;
     HIP_TRY(c, hipMemcpyAsync(&n_nodes, uidx_by_rank.p + n, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     ALLOC_OR_FAIL(c, ulen, std::max<uint32_t>(n_nodes, 1));
@@ -471,14 +700,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     gather_lens_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(flag_by_rank.p, uidx_by_rank.p, len_by_rank.p, n, ulen.p);
     LAUNCH_CHECK(c, "gather_lens");
     DBG_TRY(scan_exclusive_u32_u64(c, ulen.p, ustart.p, n_nodes));
-    uint64_t total_bases = 0;
     HIP_TRY(c, hipMemcpyAsync(&total_bases, ustart.p + n_nodes, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint64_t n_words = (total_bases + 31) / 32;
-    DBuf<uint64_t> words;
-    DBuf<unsigned long long> uacc;
-    DBuf<uint8_t> o_exts;
-    DBuf<uint32_t> o_data;
+    n_words = (total_bases + 31) / 32;
     ALLOC_OR_FAIL(c, words, n_words + 3);
     ALLOC_OR_FAIL(c, uacc, std::max<uint32_t>(n_nodes, 1));
     ALLOC_OR_FAIL(c, o_exts, std::max<uint32_t>(n_nodes, 1));
@@ -510,6 +734,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         fprintf(stderr, "[unitig] nodes=%u spec=%d uacc[0]=%llx o_data[0]=%x uexts[0]=%x uacc.p=%p o_data.p=%p uexts.p=%p\n", n_nodes, spec, a0, d0, e0,
                 (void*)uacc.p, (void*)o_data.p, (void*)uexts.p);
     }
+    }   // general route
     // ---- to the host BaseGraph ----
     memset(out, 0, sizeof(*out));
     out->stranded = stranded ? 1 : 0;
