@@ -15,6 +15,7 @@
 // on visiting order) the caller falls back to the literal host walk.
 #include "dbg_internal.hpp"
 #include <algorithm>
+#include <sys/mman.h>
 
 namespace {
 constexpr uint32_t U_TERM = 0xFFFFFFFFu;
@@ -739,11 +740,21 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     memset(out, 0, sizeof(*out));
     out->stranded = stranded ? 1 : 0;
     out->n_nodes = n_nodes; out->n_seq_words = n_words; out->seq_len_bases = total_bases;
-    out->seq_words = (uint64_t*)malloc(std::max<uint64_t>(n_words, 1) * 8);
-    out->start = (uint64_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
-    out->length = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    // large result arrays: 2 MB-aligned and advised for transparent huge pages -- a fresh 350 MB malloc otherwise takes
+    // ~10^5 page faults while the copy from the device fills it (free() releases these like any malloc block)
+    auto big_alloc = [](size_t bytes) -> void* {
+        if (bytes < (8u << 20)) return malloc(bytes ? bytes : 1);
+        const size_t al = 2u << 20, sz = (bytes + al - 1) / al * al;
+        void* q = aligned_alloc(al, sz);
+        if (q) (void)madvise(q, sz, MADV_HUGEPAGE);
+        return q;
+    };
+    out->seq_words = (uint64_t*)big_alloc(std::max<uint64_t>(n_words, 1) * 8);
+    out->start = (uint64_t*)big_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
+    out->length = (uint32_t*)big_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
     out->exts = (uint8_t*)malloc(std::max<uint32_t>(n_nodes, 1));
     out->data = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    c->t_begin("graph_to_host", n_nodes);
     if (n_words) HIP_TRY(c, hipMemcpyAsync(out->seq_words, words.p, n_words * 8, hipMemcpyDeviceToHost, c->stream));
     if (n_nodes) {
         HIP_TRY(c, hipMemcpyAsync(out->start, ustart.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, c->stream));
@@ -751,6 +762,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         HIP_TRY(c, hipMemcpyAsync(out->exts, o_exts.p, (size_t)n_nodes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(out->data, o_data.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    c->t_end();
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *done = true;
     return 0;
