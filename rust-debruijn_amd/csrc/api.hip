@@ -153,7 +153,7 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     return 0;
 }
 
-static void* xmalloc(size_t n) { return malloc(n ? n : 1); }
+static void* xmalloc(size_t n) { return dbg_host_alloc(n); }
 
 extern "C" int dbg_table_to_host(dbg_ctx* c, const dbg_kmer_table* d, dbg_kmer_table* h) {
     *h = *d;

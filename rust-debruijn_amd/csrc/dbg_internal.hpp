@@ -2,6 +2,18 @@
 #pragma once
 #include "dbg_ctx.hpp"
 #include "dbg_device.hpp"
+#include <cstdlib>
+#include <sys/mman.h>
+// Host arrays handed to the caller (released with free()).  Large ones are 2 MB-aligned and advised for transparent huge
+// pages: a fresh multi-hundred-MB malloc otherwise takes ~10^5 page faults while the copy from the device fills it.
+static inline void* dbg_host_alloc(size_t bytes) {
+    if (bytes < (8u << 20)) return malloc(bytes ? bytes : 1);
+    const size_t al = 2u << 20, sz = (bytes + al - 1) / al * al;
+    void* q = aligned_alloc(al, sz);
+    if (q) (void)madvise(q, sz, MADV_HUGEPAGE);
+    return q;
+}
+
 
 // device view of &[(V, Exts, D1)] in PackedDnaStringSet layout
 struct SeqDev {

@@ -15,7 +15,6 @@
 // on visiting order) the caller falls back to the literal host walk.
 #include "dbg_internal.hpp"
 #include <algorithm>
-#include <sys/mman.h>
 
 namespace {
 constexpr uint32_t U_TERM = 0xFFFFFFFFu;
@@ -740,18 +739,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     memset(out, 0, sizeof(*out));
     out->stranded = stranded ? 1 : 0;
     out->n_nodes = n_nodes; out->n_seq_words = n_words; out->seq_len_bases = total_bases;
-    // large result arrays: 2 MB-aligned and advised for transparent huge pages -- a fresh 350 MB malloc otherwise takes
-    // ~10^5 page faults while the copy from the device fills it (free() releases these like any malloc block)
-    auto big_alloc = [](size_t bytes) -> void* {
-        if (bytes < (8u << 20)) return malloc(bytes ? bytes : 1);
-        const size_t al = 2u << 20, sz = (bytes + al - 1) / al * al;
-        void* q = aligned_alloc(al, sz);
-        if (q) (void)madvise(q, sz, MADV_HUGEPAGE);
-        return q;
-    };
-    out->seq_words = (uint64_t*)big_alloc(std::max<uint64_t>(n_words, 1) * 8);
-    out->start = (uint64_t*)big_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
-    out->length = (uint32_t*)big_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    out->seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
+    out->start = (uint64_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
+    out->length = (uint32_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
     out->exts = (uint8_t*)malloc(std::max<uint32_t>(n_nodes, 1));
     out->data = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
     c->t_begin("graph_to_host", n_nodes);
