@@ -216,3 +216,82 @@ def test_fullsize_report_all_kmers(env):
     n_all2, n_valid2 = int(t2.n_all), int(t2.n)
     lib.dbg_free_table(ctx.h, C.byref(t2))
     assert asc and n_all2 == n1 and n_valid2 < n_all2                 # the distinct set does not depend on min_obs
+
+
+def _lookup(torch, hi_t, lo_t, qhi, qlo):
+    """positions of the (hi, lo) queries in the ascending device table, -1 where absent (hi holds 2k-64 = 30 bits at k = 47)"""
+    q_hi = torch.tensor(np.array(qhi, dtype=np.int64), device="cuda")
+    q_lo = torch.tensor(np.array(qlo, dtype=np.uint64).view(np.int64), device="cuda")
+    a = torch.searchsorted(hi_t, q_hi, right=False)
+    b = torch.searchsorted(hi_t, q_hi, right=True)
+    out = torch.full_like(a, -1)
+    width = int((b - a).max().item()) if len(qhi) else 0
+    for j in range(width):                                 # equal-hi runs are a handful of keys long
+        pos = torch.clamp(a + j, max=hi_t.numel() - 1)
+        hit = (a + j < b) & (lo_t[pos] == q_lo)
+        out = torch.where(hit, pos, out)
+    return out.cpu().numpy()
+
+
+def test_fullsize_compress_invariants(env):
+    """BASELINE config 3 at full size: CountFilter(2) table -> compress_kmers_with_hash on the device (index left in HBM).
+    Size-independent properties of the reference's result (compression.rs:355-583; the tests of test.rs:236-349 check the
+    same on small graphs): the nodes partition the valid k-mers (the k-mer counts add up, sampled nodes consist of table
+    k-mers only and no k-mer of two different sampled nodes coincides), a node's data is the saturating sum of its
+    k-mers' counts, its Exts are the outward Exts of its end k-mers, and inside a node every k-mer has exactly the one
+    neighbour the path takes."""
+    torch, capi, ctx, lib = env["torch"], env["capi"], env["ctx"], env["lib"]
+    torch.cuda.empty_cache()
+    t = run_filter(env, 0, N_READS, 0, 2)
+    g = capi.Graph()
+    ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, K, 0, 0, t.n, t.key_hi, t.key_lo, t.exts, None, t.count, C.byref(g)))
+    n_nodes = int(g.n_nodes)
+    assert n_nodes > 0
+    def host(ptr, ctype, n):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(int(n),))
+    length = host(g.length, C.c_uint32, n_nodes)
+    start = host(g.start, C.c_uint64, n_nodes)
+    gexts = host(g.exts, C.c_uint8, n_nodes)
+    gdata = host(g.data, C.c_uint32, n_nodes)
+    words = host(g.seq_words, C.c_uint64, g.n_seq_words)
+    assert int(length.min()) >= K
+    assert int((length.astype(np.int64) - (K - 1)).sum()) == int(t.n)                 # every valid k-mer sits in exactly one node
+    assert np.array_equal(start[1:], np.cumsum(length[:-1], dtype=np.uint64) + start[0]) and int(start[0]) == 0
+    hi_t, lo_t = dev_view(t.key_hi, t.n), dev_view(t.key_lo, t.n)
+    ex_t, cn_t = dev_view(t.exts, t.n, "|u1"), dev_view(t.count, t.n, "<i2")      # int16 view: uint16 cannot be indexed on the device
+    rng = np.random.default_rng(3)
+    # a sample of ordinary nodes plus the longest ones
+    pick = np.unique(np.concatenate([rng.integers(0, n_nodes, 300), np.argsort(length)[-20:]]))
+    mask = (1 << (2 * K)) - 1
+    seen = set()
+    for u in pick:
+        s0, ln = int(start[u]), int(length[u])
+        bases = [int((int(words[(s0 + i) >> 5]) >> (62 - 2 * ((s0 + i) & 31))) & 3) for i in range(ln)]
+        qhi, qlo, flips = [], [], []
+        v = 0
+        for i, b in enumerate(bases):
+            v = ((v << 2) | b) & mask
+            if i >= K - 1:
+                rc = 0
+                x = v
+                for _ in range(K):
+                    rc = (rc << 2) | (3 - (x & 3)); x >>= 2
+                c = min(v, rc)
+                flips.append(rc < v)
+                assert c not in seen                                               # no k-mer in two places
+                seen.add(c)
+                qhi.append(c >> 64); qlo.append(c & 0xFFFFFFFFFFFFFFFF)
+        pos = _lookup(torch, hi_t, lo_t, qhi, qlo)
+        assert (pos >= 0).all()                                                    # only valid k-mers
+        idx = torch.tensor(pos, device="cuda")
+        ex = ex_t[idx].cpu().numpy()
+        cn = cn_t[idx].cpu().numpy().view(np.uint16).astype(np.int64)
+        assert int(gdata[u]) == min(int(cn.sum()), 65535)                          # SimpleCompress(saturating_add)
+        def orient(e, f):                                                          # Exts::rc = byte bit-reversal
+            return int(f"{int(e):08b}"[::-1], 2) if f else int(e)
+        oe = [orient(e, f) for e, f in zip(ex, flips)]
+        assert (int(gexts[u]) & 0x0f) == (oe[0] & 0x0f) and (int(gexts[u]) & 0xf0) == (oe[-1] & 0xf0)
+        for i in range(len(oe) - 1):                                               # the path follows the unique extensions
+            assert (oe[i] >> 4) == 1 << bases[i + K] and (oe[i + 1] & 0x0f) == 1 << bases[i]
+    lib.dbg_free_graph(ctx.h, C.byref(g))
+    lib.dbg_free_table(ctx.h, C.byref(t))
