@@ -38,6 +38,7 @@ extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

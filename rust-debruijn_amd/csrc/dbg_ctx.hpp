@@ -19,6 +19,11 @@ struct dbg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    hipStream_t copy_stream = nullptr;     // created on first use: result copies that overlap kernels of `stream`
+    hipStream_t get_copy_stream() {
+        if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) copy_stream = nullptr;
+        return copy_stream;
+    }
     std::string err;
     uint64_t scratch_budget = 0;
     bool timing = false;

@@ -457,7 +457,7 @@ __global__ void gather_chains_kernel(const uint32_t* __restrict__ flag_by_rank, 
 
 __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restrict__ link, uint32_t n, int k, const uint64_t* __restrict__ key_hi,
                                                          const uint64_t* __restrict__ key_lo, const uint8_t* __restrict__ exts,
-                                                         const uint32_t* __restrict__ data, int spec, uint32_t n_nodes,
+                                                         const uint32_t* __restrict__ data, int spec, uint32_t node_lo, uint32_t n_nodes,
                                                          const uint32_t* __restrict__ ufirst, const uint32_t* __restrict__ useed,
                                                          const uint64_t* __restrict__ ustart, uint64_t* __restrict__ words,
                                                          uint32_t* __restrict__ uexts, unsigned long long* __restrict__ uacc, uint32_t* __restrict__ next) {
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
     for (;;) {
         uint32_t item;
         if (wf.feed(!active, n_nodes, next, &item)) {
-            ui = item;
+            ui = node_lo + item;
             const uint32_t T = ufirst[ui];
             cur = T >> 1; face = T & 1u;
             seed = useed[ui];
@@ -557,7 +557,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     DBuf<uint8_t> o_exts;
     uint32_t n_nodes = 0;
     uint64_t total_bases = 0, n_words = 0;
-    bool emitted = false;
+    bool emitted = false, early_nodes = false;
+    uint64_t early_words = 0;
+    dbg_graph out_early{};                                         // host arrays the chain route fills while its kernels run
 
     // ---- chain route (k-mers only): two walks per chain, no per-state table ----
     if (!nodes && !getenv("DBG_UNITIG_NO_CHAINS") && !getenv("DBG_UNITIG_NO_WALK")) {
@@ -604,13 +606,45 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             ALLOC_OR_FAIL(c, words, n_words + 3);
             HIP_TRY(c, hipMemsetAsync(words.p, 0, (n_words + 3) * 8, c->stream));
             HIP_TRY(c, hipMemsetAsync(counters.p + 6, 0, 4, c->stream));
+            // The nodes are emitted in two halves so that results can leave while kernels still run: offsets and lengths are
+            // final already, the first half of the sequence words is final when the second half starts.  (A copy into pageable
+            // host memory blocks the host thread, not the device: it is issued on a second stream after the kernels it overlaps.)
+            out_early.seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
+            out_early.start = (uint64_t*)dbg_host_alloc((size_t)nn * 8);
+            out_early.length = (uint32_t*)dbg_host_alloc((size_t)nn * 4);
+            hipStream_t cs = c->get_copy_stream();
             c->t_begin("unitig_emit", n);
             if (n_nodes) {
-                chain_emit_kernel<<<std::min<uint32_t>(cdiv(n_nodes, 256), 2048), 256, 0, c->stream>>>(
-                    link_dev, n, k, key_hi, key_lo, exts, data, spec, n_nodes, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 6);
+                const uint32_t half = n_nodes / 2;
+                uint64_t first_half_bases = 0;
+                if (half) HIP_TRY(c, hipMemcpyAsync(&first_half_bases, ustart.p + half, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemsetAsync(counters.p + 6, 0, 8, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                hipEvent_t ev = c->get_event();
+                if (half) {
+                    chain_emit_kernel<<<std::min<uint32_t>(cdiv(half, 256), 2048), 256, 0, c->stream>>>(
+                        link_dev, n, k, key_hi, key_lo, exts, data, spec, 0, half, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 6);
+                    LAUNCH_CHECK(c, "chain_emit");
+                }
+                HIP_TRY(c, hipEventRecord(ev, c->stream));
+                chain_emit_kernel<<<std::min<uint32_t>(cdiv(n_nodes - half, 256), 2048), 256, 0, c->stream>>>(
+                    link_dev, n, k, key_hi, key_lo, exts, data, spec, half, n_nodes - half, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 7);
                 LAUNCH_CHECK(c, "chain_emit");
                 finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, nullptr, o_exts.p, o_data.p);
                 LAUNCH_CHECK(c, "finish_nodes");
+                if (cs) {
+                    HIP_TRY(c, hipMemcpyAsync(out_early.start, ustart.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, cs));
+                    HIP_TRY(c, hipMemcpyAsync(out_early.length, ulen.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, cs));
+                    early_nodes = true;
+                    // words wholly inside the first half: the word that holds the boundary base may still receive bits
+                    early_words = first_half_bases / 32;
+                    if (early_words) {
+                        HIP_TRY(c, hipStreamWaitEvent(cs, ev, 0));
+                        HIP_TRY(c, hipMemcpyAsync(out_early.seq_words, words.p, early_words * 8, hipMemcpyDeviceToHost, cs));
+                    }
+                    HIP_TRY(c, hipStreamSynchronize(cs));
+                }
+                c->event_pool.push_back(ev);
             }
             c->t_end();
             emitted = true;
@@ -739,16 +773,19 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     memset(out, 0, sizeof(*out));
     out->stranded = stranded ? 1 : 0;
     out->n_nodes = n_nodes; out->n_seq_words = n_words; out->seq_len_bases = total_bases;
-    out->seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
-    out->start = (uint64_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
-    out->length = (uint32_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    out->seq_words = out_early.seq_words ? out_early.seq_words : (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
+    out->start = out_early.start ? out_early.start : (uint64_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
+    out->length = out_early.length ? out_early.length : (uint32_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
     out->exts = (uint8_t*)malloc(std::max<uint32_t>(n_nodes, 1));
     out->data = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
     c->t_begin("graph_to_host", n_nodes);
-    if (n_words) HIP_TRY(c, hipMemcpyAsync(out->seq_words, words.p, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_words > early_words)
+        HIP_TRY(c, hipMemcpyAsync(out->seq_words + early_words, words.p + early_words, (n_words - early_words) * 8, hipMemcpyDeviceToHost, c->stream));
     if (n_nodes) {
-        HIP_TRY(c, hipMemcpyAsync(out->start, ustart.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(out->length, ulen.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+        if (!early_nodes) {
+            HIP_TRY(c, hipMemcpyAsync(out->start, ustart.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(out->length, ulen.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
+        }
         HIP_TRY(c, hipMemcpyAsync(out->exts, o_exts.p, (size_t)n_nodes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(out->data, o_data.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, c->stream));
     }
