@@ -124,24 +124,37 @@ __device__ __forceinline__ bool state_usable(const uint32_t* __restrict__ link, 
     return link_valid(L, i) && (!avail || (avail[i] && avail[(L & 0x7FFFFFFFu) >> 1]));
 }
 
-// ordered append of the terminal states (one global atomic per 1024-thread block)
-__global__ void collect_ends_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ avail, uint32_t n, uint32_t* __restrict__ ends,
-                                    uint32_t* __restrict__ n_ends) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    bool term = false;
-    if (s < 2 * n) { uint32_t L; term = !state_usable(link, avail, n, s >> 1, s & 1, &L); }
+// appends the terminal states to `ends` (any order).  A block covers 8192 states and reserves its share with one global
+// atomic: one atomic per 1024 states on a single address (10^6 of them at config 3) was what this kernel waited for.
+constexpr uint32_t ENDS_ITEMS = 8;
+__global__ void __launch_bounds__(1024) collect_ends_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ avail, uint32_t n,
+                                                            uint32_t* __restrict__ ends, uint32_t* __restrict__ n_ends) {
+    const uint64_t base = (uint64_t)blockIdx.x * (1024 * ENDS_ITEMS);
+    uint32_t mask = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < ENDS_ITEMS; j++) {
+        const uint64_t s = base + j * 1024 + threadIdx.x;
+        uint32_t L;
+        if (s < 2ull * n && !state_usable(link, avail, n, (uint32_t)(s >> 1), (uint32_t)(s & 1), &L)) mask |= 1u << j;
+    }
+    const uint32_t cnt = (uint32_t)__popc(mask);
     __shared__ uint32_t s_cnt[16], s_base;
-    const uint64_t km = __ballot(term);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+    if (lane == 63) s_cnt[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
-        for (uint32_t w = 0; w < blockDim.x / 64; w++) { uint32_t x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
+        for (uint32_t w = 0; w < 16; w++) { uint32_t x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
         s_base = tot ? atomicAdd(n_ends, tot) : 0u;
     }
     __syncthreads();
-    if (term) ends[s_base + s_cnt[wave] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = s;
+    uint32_t o = s_base + s_cnt[wave] + incl - cnt;
+#pragma unroll
+    for (uint32_t j = 0; j < ENDS_ITEMS; j++)
+        if (mask & (1u << j)) ends[o++] = (uint32_t)(base + j * 1024 + threadIdx.x);
 }
 
 // Persistent wavefronts: chain lengths differ widely, so a lane that finishes its chain takes the next chain end at once
@@ -569,7 +582,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(counters.p, 0, 32, c->stream));
         c->t_begin("unitig_chain_scan", n);
-        collect_ends_kernel<<<cdiv(n2, 1024), 1024, 0, c->stream>>>(link_dev, nullptr, n, LA.p, counters.p);
+        collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, nullptr, n, LA.p, counters.p);
         LAUNCH_CHECK(c, "collect_ends");
         uint32_t n_ends = 0;
         HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -660,7 +673,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     if (!getenv("DBG_UNITIG_NO_WALK")) {
         HIP_TRY(c, hipMemsetAsync(counters.p, 0, 24, c->stream));
         c->t_begin("unitig_walk_ends", n);
-        collect_ends_kernel<<<cdiv(n2, 1024), 1024, 0, c->stream>>>(link_dev, avail, n, LA.p, counters.p);
+        collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, avail, n, LA.p, counters.p);
         LAUNCH_CHECK(c, "collect_ends");
         uint32_t n_ends = 0;
         HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
