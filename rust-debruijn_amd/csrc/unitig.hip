@@ -279,32 +279,75 @@ __device__ __forceinline__ void or_bits(uint64_t* __restrict__ words, uint64_t b
     if (p2) atomicOr((unsigned long long*)&words[w + 2], (unsigned long long)p2);
 }
 
+// Folding an element's data into its node's accumulator.  A long node (clean sequence: chains of 10^8 k-mers) would receive
+// every lane's atomic on one address (88 per microsecond): the lanes of a wavefront that feed the same node fold first and
+// issue one atomic -- for the (up to four) most frequent nodes of the wave; whoever is left (short nodes: all different)
+// uses its own atomic.  Must be reached by all 64 lanes (no early returns before it).  ucnt: element counter or null.
+__device__ __forceinline__ void fold_into_node(bool valid, uint32_t ui, uint32_t d, int spec, bool is_seed,
+                                               unsigned long long* __restrict__ uacc, uint32_t* __restrict__ ucnt) {
+    if (spec == DBG_SPEC_SCMAP_EQ) {                               // the seed's value, stored by the seed
+        if (valid && is_seed) uacc[ui] = d;
+        if (!ucnt) return;
+    }
+    bool todo = valid;
+    for (int round = 0; round < 4; round++) {
+        const uint64_t vm = __ballot(todo);
+        if (__popcll(vm) < 2) break;
+        const int lead = __ffsll((long long)vm) - 1;
+        const uint32_t ui0 = __shfl(ui, lead);
+        const bool mine = todo && ui == ui0;
+        if (__popcll(__ballot(mine)) < 8) break;                   // short nodes: folding would cost more than it saves
+        unsigned long long sum = mine ? d : 0ull;
+        uint32_t mx = mine ? d : 0u, cn = mine ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            const uint32_t m2 = __shfl_xor(mx, o);
+            mx = m2 > mx ? m2 : mx;
+            cn += __shfl_xor(cn, o);
+        }
+        if ((int)(threadIdx.x & 63) == lead) {
+            if (spec == DBG_SPEC_SIMPLE_MAX_U16) __hip_atomic_fetch_max((uint32_t*)&uacc[ui0], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (spec != DBG_SPEC_SCMAP_EQ) atomicAdd(&uacc[ui0], sum);
+            if (ucnt) atomicAdd(&ucnt[ui0], cn);
+        }
+        todo = todo && !mine;
+    }
+    if (!todo) return;
+    if (spec == DBG_SPEC_SIMPLE_MAX_U16) __hip_atomic_fetch_max((uint32_t*)&uacc[ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // low word of the zeroed accumulator
+    else if (spec != DBG_SPEC_SCMAP_EQ) atomicAdd(&uacc[ui], (unsigned long long)d);
+    if (ucnt) atomicAdd(&ucnt[ui], 1u);
+}
+
 __global__ void emit_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t n, int k,
                             const uint64_t* __restrict__ key_hi, const uint64_t* __restrict__ key_lo, const uint8_t* __restrict__ exts,
                             const uint32_t* __restrict__ data, int spec, const uint32_t* __restrict__ uidx_by_rank,
                             const uint8_t* __restrict__ rev_by_rank, const uint64_t* __restrict__ ustart,
                             uint64_t* __restrict__ words, uint32_t* __restrict__ uexts, unsigned long long* __restrict__ uacc) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    NodeInfo f = node_info(J, rank, i);
-    const uint32_t ui = uidx_by_rank[f.seedrank];
-    const bool rev = rev_by_rank[f.seedrank] != 0;
-    const uint32_t u = rev ? f.m - 1 - f.pos : f.pos;              // position in the unitig
-    const bool fwd = f.toA_is_left != rev;                         // stored orientation == unitig orientation?
-    K128 km{key_hi ? key_hi[i] : 0ull, key_lo[i]};
-    uint32_t e = exts[i];
-    if (!fwd) { km = kmer_rc(km, k); e = exts_rc(e); }
-    const uint64_t st = ustart[ui];
-    if (u == 0) or_bits(words, st, km, k);                         // the first k-mer contributes all k bases
-    else or_bits(words, st + u + (uint32_t)k - 1, K128{0, km.lo & 3ull}, 1);   // every other one its last base
-    uint32_t eo = 0;
-    if (u == 0) eo |= e & 0x0fu;                                   // left end keeps its outward (hanging) exts
-    if (u == f.m - 1) eo |= e & 0xf0u;
-    if (eo) atomicOr(&uexts[ui], eo);
-    const uint32_t d = data ? data[i] : 0u;
-    if (spec == DBG_SPEC_SIMPLE_MAX_U16) __hip_atomic_fetch_max((uint32_t*)&uacc[ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // low word of the zeroed accumulator
-    else if (spec == DBG_SPEC_SCMAP_EQ) { if ((rank ? rank[i] : i) == f.seedrank) uacc[ui] = d; }
-    else atomicAdd(&uacc[ui], (unsigned long long)d);
+    const bool valid = i < n;
+    uint32_t ui = 0, d = 0;
+    bool is_seed = false;
+    if (valid) {
+        NodeInfo f = node_info(J, rank, i);
+        ui = uidx_by_rank[f.seedrank];
+        const bool rev = rev_by_rank[f.seedrank] != 0;
+        const uint32_t u = rev ? f.m - 1 - f.pos : f.pos;              // position in the unitig
+        const bool fwd = f.toA_is_left != rev;                         // stored orientation == unitig orientation?
+        K128 km{key_hi ? key_hi[i] : 0ull, key_lo[i]};
+        uint32_t e = exts[i];
+        if (!fwd) { km = kmer_rc(km, k); e = exts_rc(e); }
+        const uint64_t st = ustart[ui];
+        if (u == 0) or_bits(words, st, km, k);                         // the first k-mer contributes all k bases
+        else or_bits(words, st + u + (uint32_t)k - 1, K128{0, km.lo & 3ull}, 1);   // every other one its last base
+        uint32_t eo = 0;
+        if (u == 0) eo |= e & 0x0fu;                                   // left end keeps its outward (hanging) exts
+        if (u == f.m - 1) eo |= e & 0xf0u;
+        if (eo) atomicOr(&uexts[ui], eo);
+        d = data ? data[i] : 0u;
+        is_seed = (rank ? rank[i] : i) == f.seedrank;
+    }
+    fold_into_node(valid, ui, d, spec, is_seed, uacc, nullptr);
 }
 
 // reverse complement of nb (<= 32) bases held right-aligned in a u64
@@ -324,35 +367,37 @@ __global__ void emit_nodes_kernel(const Jump* __restrict__ J, uint32_t n, int k,
                                   const uint64_t* __restrict__ ustart, uint64_t* __restrict__ words, uint32_t* __restrict__ uexts,
                                   unsigned long long* __restrict__ uacc, uint32_t* __restrict__ ucnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (avail && !avail[i])) return;
-    const uint32_t wi = weight[i];
-    NodeInfo f = node_info(J, nullptr, i, wi);
-    const uint32_t ui = uidx_by_rank[f.seedrank];
-    const bool rev = rev_by_rank[f.seedrank] != 0;
-    const uint32_t u = rev ? f.m - f.pos - wi : f.pos;            // k-mer offset of the node's first k-mer in the path
-    const bool fwd = f.toA_is_left != rev;                         // stored orientation == path orientation?
-    uint32_t e = exts[i];
-    if (!fwd) e = exts_rc(e);
-    const uint32_t L = nlen[i];
-    const uint64_t ns = nstart[i];
-    const uint32_t skip = u == 0 ? 0u : (uint32_t)k - 1;           // bases already written by the previous node
-    const uint64_t dst = ustart[ui] + u + skip;
-    for (uint32_t o = skip; o < L; o += 32) {
-        const uint32_t nb = L - o < 32 ? L - o : 32;
-        uint64_t chunk;
-        if (fwd) chunk = packed_get_kmer(nwords, ns + o, (int)nb).lo;
-        else chunk = rc_bases64(packed_get_kmer(nwords, ns + (L - o - nb), (int)nb).lo, nb);   // DnaStringSlice::rc (dna_string.rs:572-578)
-        or_bits(words, dst + (o - skip), K128{0, chunk}, (int)nb);
+    const bool valid = i < n && !(avail && !avail[i]);
+    uint32_t ui = 0, d = 0;
+    bool is_seed = false;
+    if (valid) {
+        const uint32_t wi = weight[i];
+        NodeInfo f = node_info(J, nullptr, i, wi);
+        ui = uidx_by_rank[f.seedrank];
+        const bool rev = rev_by_rank[f.seedrank] != 0;
+        const uint32_t u = rev ? f.m - f.pos - wi : f.pos;            // k-mer offset of the node's first k-mer in the path
+        const bool fwd = f.toA_is_left != rev;                         // stored orientation == path orientation?
+        uint32_t e = exts[i];
+        if (!fwd) e = exts_rc(e);
+        const uint32_t L = nlen[i];
+        const uint64_t ns = nstart[i];
+        const uint32_t skip = u == 0 ? 0u : (uint32_t)k - 1;           // bases already written by the previous node
+        const uint64_t dst = ustart[ui] + u + skip;
+        for (uint32_t o = skip; o < L; o += 32) {
+            const uint32_t nb = L - o < 32 ? L - o : 32;
+            uint64_t chunk;
+            if (fwd) chunk = packed_get_kmer(nwords, ns + o, (int)nb).lo;
+            else chunk = rc_bases64(packed_get_kmer(nwords, ns + (L - o - nb), (int)nb).lo, nb);   // DnaStringSlice::rc (dna_string.rs:572-578)
+            or_bits(words, dst + (o - skip), K128{0, chunk}, (int)nb);
+        }
+        uint32_t eo = 0;
+        if (u == 0) eo |= e & 0x0fu;
+        if (u + wi == f.m) eo |= e & 0xf0u;
+        if (eo) atomicOr(&uexts[ui], eo);
+        d = data ? data[i] : 0u;
+        is_seed = i == f.seedrank;
     }
-    uint32_t eo = 0;
-    if (u == 0) eo |= e & 0x0fu;
-    if (u + wi == f.m) eo |= e & 0xf0u;
-    if (eo) atomicOr(&uexts[ui], eo);
-    const uint32_t d = data ? data[i] : 0u;
-    if (spec == DBG_SPEC_SIMPLE_MAX_U16) __hip_atomic_fetch_max((uint32_t*)&uacc[ui], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else if (spec == DBG_SPEC_SCMAP_EQ) { if (i == f.seedrank) uacc[ui] = d; }
-    else atomicAdd(&uacc[ui], (unsigned long long)d);
-    atomicAdd(&ucnt[ui], 1u);
+    fold_into_node(valid, ui, d, spec, is_seed, uacc, ucnt);
 }
 
 // ucnt (compress_graph only): elements joined into the node; null = one element per k-mer of the node

@@ -183,3 +183,20 @@ def test_device_resident_index(ctx, compress_mode):
         assert n == len(t)
         want = O.compress_kmers(k, stranded, SPECS[0][1], t.key_hi, t.key_lo, t.exts, t.count, None)
         assert graphs_equal(got.arrays(), want.arrays())
+
+
+@pytest.mark.parametrize("k,stranded,spec_i", [(47, False, 0), (31, True, 2), (63, False, 1)])
+def test_compress_long_chains(ctx, compress_mode, k, stranded, spec_i):
+    """Error-free reads of a random genome: a handful of nodes, each tens of thousands of k-mers long.  The chain route
+    gives up on chains longer than 2^14 k-mers and the doubling route builds them; every wavefront of its emit kernel
+    then feeds one or two nodes (data folded per wavefront, not per k-mer)."""
+    if compress_mode != "device":
+        pytest.skip("device route")
+    rng = np.random.default_rng(900 + k)
+    genome = R.random_dna(rng, 60000)
+    contigs = [genome[a:a + 3000] for a in range(0, 60000 - 3000 + 1, 1000)]      # overlapping pieces: every k-mer 3 times
+    if not stranded:
+        contigs = [c if i % 2 else (3 - c)[::-1].copy() for i, c in enumerate(contigs)]
+    t = gpu_table(ctx, contigs, k, 2, stranded)
+    got, want = compare(ctx, t, k, stranded, SPECS[spec_i])
+    assert max(int(x) for x in got.arrays()["length"]) > (1 << 14) + k

@@ -5,9 +5,10 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch
 dbg = importlib.import_module("rust-debruijn_amd"); capi = importlib.import_module("rust-debruijn_amd._capi")
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+err = float(os.environ.get("DBG_BENCH_ERR", 0.001))          # 0: no branch points, the genome is one chain
 k = 47
 ctx = dbg.Context(0); lib = ctx.lib; dev = torch.device("cuda", 0)
-p = dbg.synth_params(n_reads=n_reads, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.001, stranded=False, n_colours=0)
+p = dbg.synth_params(n_reads=n_reads, read_len=150, genome_len=n_reads * 150 // 30, error_rate=err, stranded=False, n_colours=0)
 nw = lib.dbg_synth_words(C.byref(p))
 words = torch.empty(nw, dtype=torch.int64, device=dev); start = torch.empty(n_reads, dtype=torch.int64, device=dev)
 length = torch.empty(n_reads, dtype=torch.int32, device=dev)
@@ -28,6 +29,8 @@ n = h.n
 print("valid kmers", n, flush=True)
 data = np.ctypeslib.as_array(C.cast(h.count, C.POINTER(C.c_uint16)), shape=(n,)).astype(np.uint32)
 for mode in (sys.argv[2:] or ["device"]):
+    if mode == "none":
+        break
     os.environ["DBG_COMPRESS"] = mode
     ctx.enable_timing(True)
     g = capi.Graph()
