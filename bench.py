@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--k", type=int, default=47)
     ap.add_argument("--summarizer", default="set", choices=["set", "count"])
     ap.add_argument("--min-obs", type=int, default=2)
+    ap.add_argument("--error-rate", type=float, default=0.001, help="substitution error rate of the synthetic reads (SURVEY 8d: 0.001, also 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device: several ranks on ONE GPU, payload staged through the host (a functional check of the "
@@ -82,7 +83,7 @@ def main():
     genome_len = n_reads_total * L // 30
 
     # ---- synthetic input, generated directly in HBM ----
-    p = dbg.synth_params(n_reads=reads_per_gpu, read_len=L, genome_len=genome_len, error_rate=0.001,
+    p = dbg.synth_params(n_reads=reads_per_gpu, read_len=L, genome_len=genome_len, error_rate=args.error_rate,
                          stranded=False, n_colours=4, first_read=rank * reads_per_gpu)
     nw = lib.dbg_synth_words(C.byref(p))
     words = torch.empty(nw, dtype=torch.int64, device=dev)
@@ -193,7 +194,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
             import oracle_lib as O
             n_s = 1500000                                      # ~156M k-mer instances: 10-30 s of single-thread CPU work
-            hs = dbg.synth_reads_host(n_reads=n_s, read_len=L, genome_len=n_s * L // 30, error_rate=0.001,
+            hs = dbg.synth_reads_host(n_reads=n_s, read_len=L, genome_len=n_s * L // 30, error_rate=args.error_rate,
                                       stranded=False, n_colours=4)
             so = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if is_set else None, 1 if is_set else 0)
             sec, nv = O.time_filter_kmers(so, k, O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER, args.min_obs, False)
@@ -214,7 +215,7 @@ def main():
             nt = 2 * cores                                     # two threads per granted core measured best on the GPU box
             if cores > 1:
                 n_m = min(reads_per_gpu, max(n_s, 125000 * nt))     # a few seconds of wall time, a few GB of host memory
-                pm = dbg.synth_params(n_reads=n_m, read_len=L, genome_len=n_m * L // 30, error_rate=0.001,
+                pm = dbg.synth_params(n_reads=n_m, read_len=L, genome_len=n_m * L // 30, error_rate=args.error_rate,
                                       stranded=False, n_colours=4)
                 nwm = lib.dbg_synth_words(C.byref(pm))
                 wm = torch.empty(nwm, dtype=torch.int64, device=dev)
@@ -278,8 +279,8 @@ def main():
             "unit": "Gkmer/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=0.001"
-                                   % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs),
+            "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=%g"
+                                   % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs, args.error_rate),
                        "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid, "valid_kmers_all_ranks": n_valid_total,
                        "path": ("fast (minimizer scan -> super-k-mer slabs per bin -> per-bin LDS hash tables -> order-restoring hybrid sort)" if fast
                                 else "generic (extract -> global LSD radix sort -> segmented reduce)"),
