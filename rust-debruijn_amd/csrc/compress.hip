@@ -76,12 +76,13 @@ __device__ __forceinline__ uint32_t num_ext_dir(uint32_t e, int dir) { return __
 __device__ __forceinline__ bool join_test(int spec, uint32_t a, uint32_t b) { return spec == DBG_SPEC_SCMAP_EQ ? a == b : true; }
 
 __global__ void link_kernel(KeysDev t, const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data, int k,
-                            int stranded, int spec, uint32_t* __restrict__ link /* [2][n] */) {
+                            int stranded, int spec, uint32_t* __restrict__ link /* [2][n] */, NodeRec* __restrict__ nrec /* or null */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n) return;
     K128 kmer = key_at(t, i);
     uint32_t e = exts[i];
     bool self_pal = !stranded && is_palindrome(kmer, k);
+    uint32_t both[2];
     for (int dir = 0; dir < 2; dir++) {
         uint32_t out = LINK_TERM;
         if (num_ext_dir(e, dir) == 1 && !self_pal) {                                   // compression.rs:386
@@ -107,6 +108,12 @@ __global__ void link_kernel(KeysDev t, const uint8_t* __restrict__ exts, const u
             }
         }
         link[(uint64_t)dir * t.n + i] = out;
+        both[dir] = out;
+    }
+    if (nrec) {
+        NodeRec r;
+        r.lo = kmer.lo; r.hi = kmer.hi; r.link[0] = both[0]; r.link[1] = both[1]; r.data = data ? data[i] : 0u; r.exts = e;
+        nrec[i] = r;
     }
 }
 
@@ -176,7 +183,7 @@ struct BitPusher {          // DnaString::push (dna_string.rs:303-310) into a gr
 struct UnitigNodes;
 int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                           const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
-                          dbg_graph* out, bool* done, const UnitigNodes* nodes = nullptr);
+                          dbg_graph* out, bool* done, const UnitigNodes* nodes = nullptr, const NodeRec* nrec = nullptr);
 
 // packed {key, Exts} records for the link builder's probes (k <= 60); *t gets them attached
 static int attach_key_records(dbg_ctx* c, KeysDev* t, int k, const uint8_t* exts_dev, DBuf<ulonglong2>* store) {
@@ -272,7 +279,9 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
         DBuf<ulonglong2> d_rec;
         DBG_TRY(attach_key_records(c, &t, k, d_exts.p, &d_rec));
         c->t_begin("compress_links", n);
-        link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p);
+        DBuf<NodeRec> d_nrec;                                      // optional: without it the chain walks read the separate arrays
+        if (!getenv("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
+        link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p, d_nrec.p);
         c->t_end();
         LAUNCH_CHECK(c, "link_kernel");
         d_rec.release();                                           // back to the pool; later users are ordered behind the kernel on the stream
@@ -295,7 +304,7 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
             }
             bool done = false;
             DBG_TRY(compress_links_device(c, k, (uint32_t)n, has_hi ? d_hi.p : nullptr, d_lo.p, d_exts.p, d_data.p, d_link.p,
-                                          rank_h.empty() ? nullptr : d_rank.p, spec, stranded, out, &done));
+                                          rank_h.empty() ? nullptr : d_rank.p, spec, stranded, out, &done, nullptr, d_nrec.p));
             if (done) return 0;
             if (mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the neighbour links are not mutual");
             // links were only modified if cycles were cut, which happens after the mutuality check passed
@@ -415,12 +424,14 @@ extern "C" int dbg_compress_kmers_with_hash_dev(dbg_ctx* c, uint32_t k_, int str
     DBuf<ulonglong2> d_rec;
     DBG_TRY(attach_key_records(c, &t, k, exts_dev, &d_rec));
     c->t_begin("compress_links", n);
-    link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, d_data, k, stranded, spec, d_link.p);
+    DBuf<NodeRec> d_nrec;
+    if (!getenv("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
+    link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, d_data, k, stranded, spec, d_link.p, d_nrec.p);
     c->t_end();
     LAUNCH_CHECK(c, "link_kernel");
     d_rec.release();
     bool done = false;
-    DBG_TRY(compress_links_device(c, k, (uint32_t)n, t.hi, t.lo, exts_dev, d_data, d_link.p, nullptr, spec, stranded, out, &done));
+    DBG_TRY(compress_links_device(c, k, (uint32_t)n, t.hi, t.lo, exts_dev, d_data, d_link.p, nullptr, spec, stranded, out, &done, nullptr, d_nrec.p));
     if (done) return 0;
     // inconsistent Exts (non-mutual links): the literal walk needs the index on the host
     std::vector<uint64_t> h_hi(has_hi ? n : 0), h_lo(n); std::vector<uint8_t> h_ex(n); std::vector<uint32_t> h_da(d_data ? n : 0);

@@ -92,6 +92,15 @@ struct UnitigNodes {            // device arrays describing graph nodes as eleme
     const uint8_t* avail;       // 0 = censored node (compression.rs:297-307); null = all available
 };
 
+// One k-mer of the index with everything the chain walks of unitig.hip read per step, in half a cache line (the separate
+// key / link / data arrays cost three lines per step).  Written by link_kernel next to the plain link array.
+struct __attribute__((aligned(32))) NodeRec {
+    uint64_t lo, hi;
+    uint32_t link[2];      // as link[side * n + i]
+    uint32_t data;
+    uint32_t exts;
+};
+
 // ---- launch helpers -----------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx, name)                                                                 \
     do {                                                                                        \

@@ -16,7 +16,7 @@
 
 int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                           const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
-                          dbg_graph* out, bool* done, const UnitigNodes* nodes);
+                          dbg_graph* out, bool* done, const UnitigNodes* nodes, const NodeRec* nrec = nullptr);
 
 namespace {
 

@@ -518,7 +518,8 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ data, int spec, uint32_t node_lo, uint32_t n_nodes,
                                                          const uint32_t* __restrict__ ufirst, const uint32_t* __restrict__ useed,
                                                          const uint64_t* __restrict__ ustart, uint64_t* __restrict__ words,
-                                                         uint32_t* __restrict__ uexts, unsigned long long* __restrict__ uacc, uint32_t* __restrict__ next) {
+                                                         uint32_t* __restrict__ uexts, unsigned long long* __restrict__ uacc, uint32_t* __restrict__ next,
+                                                         const NodeRec* __restrict__ nrec /* or null: read the separate arrays */) {
     WaveFeed wf;
     bool active = false;
     uint32_t ui = 0, cur = 0, face = 0, u = 0, seed = 0, eo = 0;
@@ -542,18 +543,34 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
         }
         if (active) {
             const bool fwd = face == 0;                            // the k-mer's left side points to the unitig's left end
+            // everything this step needs about the k-mer: one 32-byte record, or the separate arrays
+            uint64_t klo, khi = 0;
+            uint32_t e, d, L;
+            if (nrec) {
+                const ulonglong2 a = reinterpret_cast<const ulonglong2*>(nrec + cur)[0];
+                const uint4 b = reinterpret_cast<const uint4*>(nrec + cur)[1];
+                klo = a.x; khi = a.y; L = face == 0 ? b.y : b.x; d = b.z; e = b.w;       // leave through side 1 - face
+            } else {
+                klo = (u == 0 || fwd || k <= 32) ? key_lo[cur] : 0ull;
+                if (key_hi && (u == 0 || !fwd)) khi = key_hi[cur];
+                L = link[(uint64_t)(1u - face) * n + cur];
+                d = data ? data[cur] : 0u;
+                e = 0;
+            }
+            const bool more = link_valid(L, cur);
+            if (!nrec && (u == 0 || !more)) e = exts[cur];
+            if (!fwd) e = exts_rc(e);
             if (u == 0) {                                          // the first k-mer contributes all k bases
-                K128 km{key_hi ? key_hi[cur] : 0ull, key_lo[cur]};
-                uint32_t e = exts[cur];
-                if (!fwd) { km = kmer_rc(km, k); e = exts_rc(e); }
+                K128 km{khi, klo};
+                if (!fwd) km = kmer_rc(km, k);
                 or_bits(words, pos, km, k);
                 eo = e & 0x0fu;                                    // the left end keeps its outward (hanging) exts
                 pos += (uint32_t)k;
                 widx = pos >> 5;
             } else {                                               // every other one its last base
                 uint64_t b;
-                if (fwd) b = key_lo[cur] & 3ull;
-                else b = 3ull - (((k > 32 ? key_hi[cur] : key_lo[cur]) >> top_shift) & 3ull);
+                if (fwd) b = klo & 3ull;
+                else b = 3ull - (((k > 32 ? khi : klo) >> top_shift) & 3ull);
                 if ((pos >> 5) != widx) {
                     if (wacc) atomicOr((unsigned long long*)&words[widx], (unsigned long long)wacc);
                     wacc = 0; widx = pos >> 5;
@@ -561,15 +578,11 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
                 wacc |= b << (62 - 2 * (uint32_t)(pos & 31));
                 pos++;
             }
-            const uint32_t d = data ? data[cur] : 0u;
             if (spec == DBG_SPEC_SIMPLE_MAX_U16) acc = d > acc ? d : acc;
             else if (spec == DBG_SPEC_SCMAP_EQ) { if (cur == seed) acc = d; }
             else acc += d;
             u++;
-            uint32_t L;
-            if (!state_usable(link, nullptr, n, cur, 1u - face, &L)) {      // the right end
-                uint32_t e = exts[cur];
-                if (!fwd) e = exts_rc(e);
+            if (!more) {                                           // the right end
                 eo |= e & 0xf0u;
                 if (wacc) atomicOr((unsigned long long*)&words[widx], (unsigned long long)wacc);
                 uexts[ui] = eo;
@@ -589,7 +602,7 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
 // when the links are not mutual or contain a panic marker: the caller then runs the literal host walk.
 int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi, const uint64_t* key_lo, const uint8_t* exts,
                           const uint32_t* data, uint32_t* link_dev, const uint32_t* rank_dev, int spec, int stranded,
-                          dbg_graph* out, bool* done, const UnitigNodes* nodes) {
+                          dbg_graph* out, bool* done, const UnitigNodes* nodes, const NodeRec* nrec) {
     *done = false;
     const uint32_t* weight = nodes ? nodes->weight : nullptr;
     const uint8_t* avail = nodes ? nodes->avail : nullptr;
@@ -681,12 +694,12 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
                 hipEvent_t ev = c->get_event();
                 if (half) {
                     chain_emit_kernel<<<std::min<uint32_t>(cdiv(half, 256), 2048), 256, 0, c->stream>>>(
-                        link_dev, n, k, key_hi, key_lo, exts, data, spec, 0, half, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 6);
+                        link_dev, n, k, key_hi, key_lo, exts, data, spec, 0, half, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 6, nrec);
                     LAUNCH_CHECK(c, "chain_emit");
                 }
                 HIP_TRY(c, hipEventRecord(ev, c->stream));
                 chain_emit_kernel<<<std::min<uint32_t>(cdiv(n_nodes - half, 256), 2048), 256, 0, c->stream>>>(
-                    link_dev, n, k, key_hi, key_lo, exts, data, spec, half, n_nodes - half, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 7);
+                    link_dev, n, k, key_hi, key_lo, exts, data, spec, half, n_nodes - half, ufirst.p, useed.p, ustart.p, words.p, uexts.p, uacc.p, counters.p + 7, nrec);
                 LAUNCH_CHECK(c, "chain_emit");
                 finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, nullptr, o_exts.p, o_data.p);
                 LAUNCH_CHECK(c, "finish_nodes");
