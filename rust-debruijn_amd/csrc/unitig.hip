@@ -128,14 +128,18 @@ __device__ __forceinline__ bool state_usable(const uint32_t* __restrict__ link, 
 // atomic: one atomic per 1024 states on a single address (10^6 of them at config 3) was what this kernel waited for.
 constexpr uint32_t ENDS_ITEMS = 8;
 __global__ void __launch_bounds__(1024) collect_ends_kernel(const uint32_t* __restrict__ link, const uint8_t* __restrict__ avail, uint32_t n,
-                                                            uint32_t* __restrict__ ends, uint32_t* __restrict__ n_ends) {
+                                                            uint32_t* __restrict__ ends, uint32_t* __restrict__ n_ends,
+                                                            uint32_t* __restrict__ link_flags = nullptr /* |= 1 when a panic link exists */) {
     const uint64_t base = (uint64_t)blockIdx.x * (1024 * ENDS_ITEMS);
     uint32_t mask = 0;
 #pragma unroll
     for (uint32_t j = 0; j < ENDS_ITEMS; j++) {
         const uint64_t s = base + j * 1024 + threadIdx.x;
         uint32_t L;
-        if (s < 2ull * n && !state_usable(link, avail, n, (uint32_t)(s >> 1), (uint32_t)(s & 1), &L)) mask |= 1u << j;
+        if (s < 2ull * n && !state_usable(link, avail, n, (uint32_t)(s >> 1), (uint32_t)(s & 1), &L)) {
+            mask |= 1u << j;
+            if (link_flags && L != U_TERM && (L & U_PANIC)) atomicOr(link_flags, 1u);
+        }
     }
     const uint32_t cnt = (uint32_t)__popc(mask);
     __shared__ uint32_t s_cnt[16], s_base;
@@ -463,10 +467,14 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ flag_by_rank, uint32_t* __restrict__ len_by_rank,
                                                          uint32_t* __restrict__ start_by_rank, uint32_t* __restrict__ seed_by_rank,
                                                          uint32_t* __restrict__ next, unsigned long long* __restrict__ kmers_seen,
-                                                         uint32_t* __restrict__ capped) {
+                                                         uint32_t* __restrict__ capped,
+                                                         const NodeRec* __restrict__ nrec /* or null */, uint32_t* __restrict__ link_flags) {
+    // With node records both links of a k-mer arrive in the one line a step reads, so the walk itself verifies that every link
+    // it takes is answered by the facing link of its target (check_links_kernel's test; every link of an open chain is taken
+    // by one of the chain's two walkers): *link_flags |= 2 on a mismatch.
     WaveFeed wf;
     bool active = false;
-    uint32_t T = 0, cur = 0, face = 0, m = 0, best = R_INF, seed = 0;
+    uint32_t T = 0, cur = 0, face = 0, m = 0, best = R_INF, seed = 0, expect_back = U_TERM;
     bool seed_left_faces_T = false;
     unsigned long long total = 0;
     for (;;) {
@@ -474,7 +482,7 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
         if (wf.feed(!active, n_ends, next, &item)) {
             T = ends[item];
             cur = T >> 1; face = T & 1u;                          // `face` = the side of cur that points towards T
-            m = 0; best = R_INF;
+            m = 0; best = R_INF; expect_back = U_TERM;
             active = true;
         }
         if (!__any(active)) {
@@ -486,7 +494,15 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
             if (r < best) { best = r; seed = cur; seed_left_faces_T = face == 0; }
             m++;
             uint32_t L;
-            if (!state_usable(link, nullptr, n, cur, 1u - face, &L)) {      // far end reached
+            bool more;
+            if (nrec) {
+                const uint4 b = reinterpret_cast<const uint4*>(nrec + cur)[1];           // {link[0], link[1], data, exts}
+                L = face == 0 ? b.y : b.x;
+                more = link_valid(L, cur);
+                if (expect_back != U_TERM && (face == 0 ? b.x : b.y) != expect_back) atomicOr(link_flags, 2u);
+                expect_back = (cur << 1) | face;                   // what the next k-mer's facing link must say
+            } else more = state_usable(link, nullptr, n, cur, 1u - face, &L);
+            if (!more) {                                           // far end reached
                 if (seed_left_faces_T) {                           // T is the left end of the unitig
                     flag_by_rank[best] = 1;
                     len_by_rank[best] = m + (uint32_t)k - 1;
@@ -611,12 +627,28 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     DBuf<uint32_t> flags;
     ALLOC_OR_FAIL(c, flags, 2);
     HIP_TRY(c, hipMemsetAsync(flags.p, 0, 8, c->stream));
-    check_links_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, avail, n, flags.p);
-    LAUNCH_CHECK(c, "check_links");
-    uint32_t fl[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(fl, flags.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (fl[0]) return 0;
+    const bool try_chains = !nodes && !getenv("DBG_UNITIG_NO_CHAINS") && !getenv("DBG_UNITIG_NO_WALK");
+    // the chain route with node records checks the links while it walks them; everything else checks them first
+    bool links_checked = false;
+    auto check_links = [&]() -> int {
+        check_links_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, avail, n, flags.p);
+        LAUNCH_CHECK(c, "check_links");
+        links_checked = true;
+        return 0;
+    };
+    auto links_bad = [&](bool* bad) -> int {
+        uint32_t fl[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(fl, flags.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *bad = fl[0] != 0;
+        return 0;
+    };
+    if (!(try_chains && nrec)) {
+        DBG_TRY(check_links());
+        bool bad = false;
+        DBG_TRY(links_bad(&bad));
+        if (bad) return 0;
+    }
 
     DBuf<uint32_t> LA, counters;
     ALLOC_OR_FAIL(c, LA, n2);
@@ -633,14 +665,14 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     dbg_graph out_early{};                                         // host arrays the chain route fills while its kernels run
 
     // ---- chain route (k-mers only): two walks per chain, no per-state table ----
-    if (!nodes && !getenv("DBG_UNITIG_NO_CHAINS") && !getenv("DBG_UNITIG_NO_WALK")) {
+    if (try_chains) {
         DBuf<uint32_t> start_by_rank, seed_by_rank, ufirst, useed;
         ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
         ALLOC_OR_FAIL(c, start_by_rank, n); ALLOC_OR_FAIL(c, seed_by_rank, n);
         HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(counters.p, 0, 32, c->stream));
         c->t_begin("unitig_chain_scan", n);
-        collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, nullptr, n, LA.p, counters.p);
+        collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, nullptr, n, LA.p, counters.p, links_checked ? nullptr : flags.p);
         LAUNCH_CHECK(c, "collect_ends");
         uint32_t n_ends = 0;
         HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -648,7 +680,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         if (n_ends) {
             chain_scan_kernel<<<std::min<uint32_t>(cdiv(n_ends, 256), 2048), 256, 0, c->stream>>>(
                 link_dev, rank_dev, n, LA.p, n_ends, k, flag_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p,
-                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1);
+                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, links_checked ? nullptr : nrec, flags.p);
             LAUNCH_CHECK(c, "chain_scan");
         }
         uint32_t res[4] = {0, 0, 0, 0};
@@ -656,6 +688,11 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->t_end();
         const uint64_t seen = (uint64_t)res[2] | ((uint64_t)res[3] << 32);
+        if (!links_checked) {                                      // the walk checked the links of the chains it covered
+            bool bad = false;
+            DBG_TRY(links_bad(&bad));
+            if (bad) return 0;
+        }
         const bool ok = res[1] == 0 && seen == n;                  // no walker gave up, every k-mer sits on an open chain
         if (getenv("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
                                          ok ? "" : " -> general route");
@@ -723,6 +760,12 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     }
 
     if (!emitted) {
+    if (!links_checked) {                                          // links off the walked chains (cycles, long chains) are unchecked so far
+        DBG_TRY(check_links());
+        bool bad = false;
+        DBG_TRY(links_bad(&bad));
+        if (bad) return 0;
+    }
     DBuf<Jump> JA, JB;
     DBuf<uint32_t> LB;
     ALLOC_OR_FAIL(c, JA, n2);

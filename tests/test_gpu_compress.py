@@ -200,3 +200,33 @@ def test_compress_long_chains(ctx, compress_mode, k, stranded, spec_i):
     t = gpu_table(ctx, contigs, k, 2, stranded)
     got, want = compare(ctx, t, k, stranded, SPECS[spec_i])
     assert max(int(x) for x in got.arrays()["length"]) > (1 << 14) + k
+
+
+def test_compress_non_mutual_links(ctx, compress_mode):
+    """Inconsistent Exts: A's only right extension leads to B and B has a single left extension, but to a k-mer that is
+    not A.  The reference walks such input in visiting order (compression.rs:450-541); the device routes refuse it
+    (the link from A is not answered by B's facing link -- found while the chains are walked) and the literal host walk
+    reproduces the reference."""
+    import os
+    if compress_mode != "device":
+        pytest.skip("sets the mode itself")
+    rng = np.random.default_rng(31)
+    k = 31
+    contigs = R.simple_random_contigs(rng)
+    t = gpu_table(ctx, contigs, k, 1, True)
+    ex = t.exts.copy()
+    changed = 0
+    for i in range(len(ex)):
+        left = int(ex[i]) & 0x0f
+        if bin(left).count("1") == 1 and changed < 5 and i % 7 == 3:
+            ex[i] = (int(ex[i]) & 0xf0) | (((left << 1) | (left >> 3)) & 0x0f)      # the one left extension now names another base
+            changed += 1
+    assert changed
+    t.exts[:] = ex
+    want = O.compress_kmers(k, True, O.SPEC_SAT_ADD, t.key_hi, t.key_lo, t.exts, t.count, None)
+    os.environ["DBG_COMPRESS"] = "auto"
+    got = dbg.compress_kmers_with_hash(True, SPECS[0][0], t, k=k, data=t.count, ctx=ctx)
+    assert graphs_equal(got.arrays(), want.arrays())
+    os.environ["DBG_COMPRESS"] = "device"
+    with pytest.raises(dbg.DbgError):
+        dbg.compress_kmers_with_hash(True, SPECS[0][0], t, k=k, data=t.count, ctx=ctx)
