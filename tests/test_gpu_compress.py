@@ -230,3 +230,31 @@ def test_compress_non_mutual_links(ctx, compress_mode):
     os.environ["DBG_COMPRESS"] = "device"
     with pytest.raises(dbg.DbgError):
         dbg.compress_kmers_with_hash(True, SPECS[0][0], t, k=k, data=t.count, ctx=ctx)
+
+
+@pytest.mark.parametrize("env", [{}, {"DBG_UNITIG_NO_CHAINS": "1"}, {"DBG_UNITIG_NO_WALK": "1"},
+                                 {"DBG_NO_KEY_RECORDS": "1", "DBG_NO_NODE_RECORDS": "1"}])
+@pytest.mark.parametrize("k,stranded", [(47, False), (31, True), (63, False)])
+def test_compress_routes(ctx, compress_mode, env, k, stranded):
+    """The device construction has three routes (chain walks on packed records or on the separate arrays; end walk into a
+    per-state table; doubling) -- all must give the reference's BaseGraph, cycles and seed orders included."""
+    import os
+    if compress_mode != "device":
+        pytest.skip("device routes")
+    rng = np.random.default_rng(5 * k + stranded)
+    contigs = R.random_contigs(rng)
+    cyc = R.random_dna(rng, 3 * k)
+    contigs.append(np.concatenate([cyc, cyc[:k - 1]]))                       # an isolated cycle among the chains
+    t = gpu_table(ctx, contigs, k, 1, stranded)
+    old = {v: os.environ.get(v) for v in env}
+    os.environ.update(env)
+    try:
+        compare(ctx, t, k, stranded, SPECS[0])
+        order = rng.permutation(len(t)).astype(np.uint64)
+        compare(ctx, t, k, stranded, SPECS[2], seed_order=order)
+    finally:
+        for v, o in old.items():
+            if o is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = o
