@@ -8,11 +8,17 @@
 //   * a chain becomes one node; its seed is the member with the smallest seed rank; the node's sequence is
 //     read in the seed's stored orientation; nodes are emitted in increasing seed rank;
 //   * an isolated cycle is cut at the right side of its seed (the left walk consumes the whole cycle first).
-// That makes the construction data-parallel: pointer jumping over the 2n directed states "(k-mer, side I
-// leave through)" gives every k-mer its distance to both chain ends, the end states and the minimum rank on
-// either side; everything else is per-k-mer arithmetic, two prefix sums and atomic ORs into the packed
-// output.  If the links are not mutual (inconsistent Exts, which also makes the reference panic or depend
-// on visiting order) the caller falls back to the literal host walk.
+// That makes the construction data-parallel.  Three routes, fastest first (compress_links_device picks):
+//   1. chain route (k-mer tables): every chain end walks its chain (chain_scan_kernel: length, seed, which end is the
+//      unitig's left end); after two prefix sums one lane per node walks it again and writes it front to back
+//      (chain_emit_kernel).  No per-state table; one cache line per step when link_kernel left NodeRec records.
+//   2. end walk into a table (compress_graph, or route 1 switched off): walk_ends_kernel leaves in every state "(element,
+//      side I leave through)" its distance to the chain end it faces, that end and the minimum rank on the way; then
+//      per-element arithmetic, two prefix sums and atomic ORs into the packed output (emit_kernel / emit_nodes_kernel).
+//   3. doubling (jump_kernel): the same table by pointer jumping -- for cycles (cut at their seed, then redone) and for
+//      chains too long to walk (WALK_CAP).
+// If the links are not mutual (inconsistent Exts, which also makes the reference panic or depend on visiting order)
+// the caller falls back to the literal host walk.
 #include "dbg_internal.hpp"
 #include <algorithm>
 
