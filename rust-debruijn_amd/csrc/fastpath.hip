@@ -15,8 +15,9 @@
 // The internal partition uses its own minimizer scheme (p up to 15, canonical p-mers ordered by a bijective
 // hash -- a `permutation` in the reference's terms, msp.rs:55-59 -- pieces cut where the window's minimum VALUE
 // changes, so that the choice is the same on both strands); it is invisible in the result.
-// Records go straight from the scan into per-bin slabs; see DESIGN.md section 3.1 for the measurements behind
-// each structural choice.
+// Records go straight from the scan into per-bin slabs.  Because the cut points depend on the sequence alone, reads that
+// cover the same stretch of the genome produce identical records: the counting workgroup merges them (weight + colour
+// union) before expanding k-mers.  See DESIGN.md section 3.1 for the measurements behind each structural choice.
 #include "dbg_internal.hpp"
 #include "dbg_msp_device.hpp"
 #include <algorithm>
