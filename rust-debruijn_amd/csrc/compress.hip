@@ -199,7 +199,9 @@ static int attach_key_records(dbg_ctx* c, KeysDev* t, int k, const uint8_t* exts
 static int attach_prefix_index(dbg_ctx* c, KeysDev* t, int k, DBuf<uint32_t>* store) {
     t->key_bits = 2 * k;
     int pb = 8;
-    while (pb < 27 && pb < 2 * k && (t->n >> pb) > 4) pb++;          // ~4 keys per bucket, at most 2^27 buckets (512 MB)
+    int pb_max = 27;                                                 // ~4 keys per bucket, at most 2^27 buckets (512 MB)
+    if (const char* e = getenv("DBG_PIDX_BITS")) pb_max = std::max(8, std::min(28, atoi(e)));
+    while (pb < pb_max && pb < 2 * k && (t->n >> pb) > 4) pb++;
     if (pb > 2 * k) pb = 2 * k;
     ALLOC_OR_FAIL(c, (*store), ((size_t)1 << pb) + 1);
     KeysDev plain = *t;
