@@ -8,7 +8,7 @@
  * (src/compression.rs:588-594) plus the sibling `msp_sequence`
  * (src/msp.rs:279-288).  Traits and closures cannot cross a C ABI, so this
  * header monomorphises over a closed set:
- *   K   : VarIntKmer<u64|u128, K> with run-time k, 4 <= k <= 64; every key
+ *   K   : VarIntKmer<u64|u128, K> with run-time k, 1 <= k <= 64; every key
  *         crosses the ABI as a (hi, lo) u64 pair, right-aligned in 2k bits,
  *         base 0 most significant (src/kmer.rs:429-437).
  *   V   : any Vmer, flattened to PackedDnaStringSet layout
@@ -50,6 +50,10 @@ const char* dbg_version(void);
 int         dbg_ctx_set_stream(dbg_ctx* ctx, void* hip_stream);
 /* scratch budget in bytes for intermediate k-mer records (0 = 60% of free HBM) */
 int         dbg_ctx_set_scratch_budget(dbg_ctx* ctx, uint64_t bytes);
+/* Diagnostic knobs (DBG_PATH, DBG_COMPRESS, ...).  The library reads the environment exactly once,
+ * in dbg_ctx_create, into the ctx; this call changes one knob of one ctx afterwards (value NULL = unset).  Knobs select
+ * among device routes that all produce the same result; unknown names are rejected. */
+int         dbg_ctx_set_option(dbg_ctx* ctx, const char* name, const char* value);
 
 /* ---- input: &[(V, Exts, D1)]  (src/filter.rs:140) flattened -------------- */
 typedef struct {
@@ -72,7 +76,9 @@ typedef struct {
     int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min) */
     uint64_t min_kmer_obs;      /* filter.rs:41,69 */
     int32_t  report_all_kmers;  /* filter.rs:143 */
-    uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero) */
+    uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero).  Otherwise IGNORED: in the
+                                   reference it only sets the number of bucket-range passes (filter.rs:156-168), never the
+                                   result; here the device decides its own passes from free HBM */
 } dbg_filter_params;
 
 /* The vectors the reference hands to BoomHashMap2::new (filter.rs:227-230), i.e. ascending
@@ -90,7 +96,8 @@ typedef struct {
     uint64_t* all_hi;
     uint64_t* all_lo;
     uint64_t  n_kmer_instances; /* input_kmers (filter.rs:152-155) */
-    uint32_t  n_passes;         /* bucket-range passes actually run on the device */
+    uint32_t  n_passes;         /* passes over the input the device needed (1 unless the input was streamed in several
+                                   prefix ranges); unrelated to memory_size */
     int32_t   on_device;        /* 1 when the arrays are device pointers */
 } dbg_kmer_table;
 
@@ -229,7 +236,8 @@ typedef struct {
     int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (labels < 24) */
     uint64_t min_kmer_obs;
     uint64_t total_kmers;       /* k-mer instances over ALL ranks: fixes the bin count */
-    uint32_t n_bins;            /* in: 0 = derive from total_kmers; out of dbg_shard_plan_make: bins */
+    uint32_t n_bins;            /* in: 0 = derive from total_kmers, otherwise the bin count to use (every rank must pass the
+                                   same value); out of dbg_shard_plan_make: bins */
     uint32_t rec_words;         /* out: u64 words per super-k-mer record */
     uint32_t bin_group;         /* out: ownership boundaries must be multiples of this many bins */
 } dbg_shard_plan;

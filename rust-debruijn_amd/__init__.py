@@ -229,6 +229,31 @@ class Context:
         if r:
             raise DbgError(self.lib.dbg_last_error(None).decode())
         self.h = h
+        self._opts = {}
+
+    def set_option(self, name, value):
+        """dbg_ctx_set_option: one diagnostic knob of this ctx (the library reads the environment only in dbg_ctx_create).
+        value None = unset.  Returns the value the knob had (as far as this wrapper knows: the environment at creation or
+        an earlier set_option)."""
+        import os
+        old = self._opts.get(name, os.environ.get(name))
+        self.check(self.lib.dbg_ctx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+        self._opts[name] = value
+        return old
+
+    def options(self, **kw):
+        """context manager: set knobs for the duration of a with-block"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {n: self.set_option(n, v) for n, v in kw.items()}
+            try:
+                yield self
+            finally:
+                for n, v in old.items():
+                    self.set_option(n, v)
+        return cm()
 
     def close(self):
         if getattr(self, "h", None):

@@ -20,6 +20,8 @@ extern "C" int dbg_ctx_create(int device, dbg_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return 3; }
     dbg_ctx* c = new dbg_ctx();
     c->device = device;
+    for (const char* name : DBG_OPTION_NAMES)               // the only place the library reads the environment
+        if (const char* v = getenv(name)) c->opts[name] = v;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c; g_create_err = "hipStreamCreate failed"; return 4;
     }
@@ -27,12 +29,10 @@ extern "C" int dbg_ctx_create(int device, dbg_ctx** out) {
     return 0;
 }
 
-void fast_drop_state(dbg_ctx* c);
-
 extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
     if (!c) return;
-    fast_drop_state(c);
     (void)hipSetDevice(c->device);
+    c->shard_scan.reset(); c->shard_count.reset();          // they hold pool blocks of this ctx
     (void)hipStreamSynchronize(c->stream);
     c->t_clear();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -54,6 +54,15 @@ extern "C" int dbg_ctx_set_stream(dbg_ctx* c, void* s) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    return 0;
+}
+
+extern "C" int dbg_ctx_set_option(dbg_ctx* c, const char* name, const char* value) {
+    if (!name) return c->fail(10, "null option name");
+    bool known = false;
+    for (const char* n : DBG_OPTION_NAMES) known = known || !strcmp(n, name);
+    if (!known) return c->fail(18, std::string("unknown option ") + name);
+    if (value) c->opts[name] = value; else c->opts.erase(name);
     return 0;
 }
 
@@ -122,7 +131,7 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     HIP_TRY(c, hipMemcpyAsync(&n_kmers, koff.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     {   // fast path: super-k-mer bins + LDS hash tables (fastpath.hip); DBG_PATH=generic|fast|auto overrides
-        const char* force = getenv("DBG_PATH");
+        const char* force = c->opt("DBG_PATH");
         bool want_fast = !(force && !strcmp(force, "generic"));
         if (want_fast) {
             bool used = false;

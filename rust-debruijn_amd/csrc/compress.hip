@@ -187,7 +187,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
 
 // packed {key, Exts} records for the link builder's probes (k <= 60); *t gets them attached
 static int attach_key_records(dbg_ctx* c, KeysDev* t, int k, const uint8_t* exts_dev, DBuf<ulonglong2>* store) {
-    if (k > 60 || !t->n || getenv("DBG_NO_KEY_RECORDS")) return 0;
+    if (k > 60 || !t->n || c->opt("DBG_NO_KEY_RECORDS")) return 0;
     ALLOC_OR_FAIL(c, (*store), t->n);
     pack_keys_kernel<<<cdiv(t->n, 256), 256, 0, c->stream>>>(*t, exts_dev, store->p);
     LAUNCH_CHECK(c, "pack_keys");
@@ -200,7 +200,7 @@ static int attach_prefix_index(dbg_ctx* c, KeysDev* t, int k, DBuf<uint32_t>* st
     t->key_bits = 2 * k;
     int pb = 8;
     int pb_max = 27;                                                 // ~4 keys per bucket, at most 2^27 buckets (512 MB)
-    if (const char* e = getenv("DBG_PIDX_BITS")) pb_max = std::max(8, std::min(28, atoi(e)));
+    if (const char* e = c->opt("DBG_PIDX_BITS")) pb_max = std::max(8, std::min(28, atoi(e)));
     while (pb < pb_max && pb < 2 * k && (t->n >> pb) > 4) pb++;
     if (pb > 2 * k) pb = 2 * k;
     ALLOC_OR_FAIL(c, (*store), ((size_t)1 << pb) + 1);
@@ -282,12 +282,12 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
         DBG_TRY(attach_key_records(c, &t, k, d_exts.p, &d_rec));
         c->t_begin("compress_links", n);
         DBuf<NodeRec> d_nrec;                                      // optional: without it the chain walks read the separate arrays
-        if (!getenv("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
+        if (!c->opt("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
         link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p, d_nrec.p);
         c->t_end();
         LAUNCH_CHECK(c, "link_kernel");
         d_rec.release();                                           // back to the pool; later users are ordered behind the kernel on the stream
-        const char* mode = getenv("DBG_COMPRESS");                 // device | host | (default) auto
+        const char* mode = c->opt("DBG_COMPRESS");                 // device | host | (default) auto
         const bool want_device = !(mode && !strcmp(mode, "host"));
         if (want_device) {
             // seed rank of every sorted id: position at which the reference's loop (compression.rs:574) visits it
@@ -427,7 +427,7 @@ extern "C" int dbg_compress_kmers_with_hash_dev(dbg_ctx* c, uint32_t k_, int str
     DBG_TRY(attach_key_records(c, &t, k, exts_dev, &d_rec));
     c->t_begin("compress_links", n);
     DBuf<NodeRec> d_nrec;
-    if (!getenv("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
+    if (!c->opt("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
     link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, d_data, k, stranded, spec, d_link.p, d_nrec.p);
     c->t_end();
     LAUNCH_CHECK(c, "link_kernel");

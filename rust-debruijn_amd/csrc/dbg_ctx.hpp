@@ -15,8 +15,31 @@ struct dbg_timing_rec {
     uint64_t units;
 };
 
+// State that one API call leaves for the next one of the same ctx (dbg_shard_scan_dev -> dbg_shard_scatter_dev,
+// dbg_shard_count_begin -> _bins_dev -> _finish).  Owned by the ctx: the library has no globals.
+struct dbg_state_slot {
+    void* p = nullptr;
+    void (*del)(void*) = nullptr;
+    void reset(void* q = nullptr, void (*d)(void*) = nullptr) { if (p && del) del(p); p = q; del = d; }
+    void* release() { void* q = p; p = nullptr; del = nullptr; return q; }
+    ~dbg_state_slot() { reset(); }
+};
+
+// Diagnostic knobs.  The environment is read ONCE, in dbg_ctx_create; afterwards
+// dbg_ctx_set_option changes a knob of one ctx.  Names are those of the environment variables.
+static const char* const DBG_OPTION_NAMES[] = {
+    "DBG_PATH", "DBG_COMPRESS", "DBG_FAST_TARGET", "DBG_FAST_NT", "DBG_FAST_TABLE", "DBG_NO_HYBRID_SORT", "DBG_NO_REC16",
+    "DBG_FAST_NO_SLAB", "DBG_DEBUG", "DBG_UNITIG_NO_WALK", "DBG_UNITIG_NO_CHAINS", "DBG_NO_KEY_RECORDS", "DBG_NO_NODE_RECORDS",
+    "DBG_PIDX_BITS", "DBG_SORT", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP"};
+
 struct dbg_ctx {
     int device = 0;
+    std::map<std::string, std::string> opts;
+    const char* opt(const char* name) const {
+        auto it = opts.find(name);
+        return it == opts.end() ? nullptr : it->second.c_str();
+    }
+    dbg_state_slot shard_scan, shard_count;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipStream_t copy_stream = nullptr;     // created on first use: result copies that overlap kernels of `stream`

@@ -1028,7 +1028,7 @@ struct FastPlan {
     uint32_t nbins;
 };
 
-static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
+static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
     if (k < 16 || k > 64) return false;
     pl->k = k; pl->p = fast_internal_p(k);
     pl->nbw = std::max(2, (2 * (2 * k - pl->p) + META_BITS + 63) / 64);   // words per record: bases + META_BITS
@@ -1040,7 +1040,7 @@ static bool fast_make_plan(int k, bool stranded, bool is_set, uint64_t total_kme
     // with k: measured optima on 30x reads with e = 0.1 %: k=31 8-12k, k=47 8k, k=51 7-8k, k=63 6k (a bin that
     // overflows is only re-split, at the price of streaming it again).
     uint64_t target = std::min<uint64_t>(10000, std::max<uint64_t>(5000, 380000 / (uint64_t)k));
-    if (const char* e = getenv("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
+    if (const char* e = c->opt("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
     if (nb64 > (1u << 24)) nb64 = 1u << 24;
     pl->nbins = (uint32_t)nb64;
@@ -1096,7 +1096,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         const double mean = (double)tmp_cap / (double)nbins;
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        if (!getenv("DBG_FAST_NO_SLAB") && st->slab.alloc(c, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
+        if (!c->opt("DBG_FAST_NO_SLAB") && st->slab.alloc(c, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
         else {
             // not enough memory for slabs (1.3x the records + slack): every record takes the read-order buffer and the
             // scatter pass instead -- slab capacity 0 routes them all there
@@ -1126,7 +1126,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         unsigned long long cur = 0;
         HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] scan done: nbw=%d rw=%d bins=%u slab_cap=%u tmp used %llu of %llu\n", nbw, rw, nbins, st->slab_cap,
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] scan done: nbw=%d rw=%d bins=%u slab_cap=%u tmp used %llu of %llu\n", nbw, rw, nbins, st->slab_cap,
                                          cur, (unsigned long long)tmp_cap);
         if (cur > tmp_cap) {                                  // low-complexity input: more pieces than estimated
             if (attempt >= 2) return c->fail(133, "fast path: super-k-mer buffer estimate failed");
@@ -1236,7 +1236,7 @@ static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, ui
                             bool report_all = false) {
     st->pl = pl; st->min_obs = min_obs; st->n_out = 0; st->n_kmers_hint = n_kmers_hint;
     st->report_all = report_all; st->n_all = 0;
-    st->use16 = 2 * pl.k <= 96 && !getenv("DBG_NO_REC16");
+    st->use16 = 2 * pl.k <= 96 && !c->opt("DBG_NO_REC16");
     ALLOC_OR_FAIL(c, st->out_cursor, 1);
     if (report_all) {
         ALLOC_OR_FAIL(c, st->all_cursor, 1);
@@ -1268,8 +1268,8 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         uint32_t* gflags_p = st->gflags.p;
         if (nbins_local) {
             c->t_begin("bin_count", n_kmers_units);
-            static const int nt_env = getenv("DBG_FAST_NT") ? atoi(getenv("DBG_FAST_NT")) : 512;
-            static const int tb_env = getenv("DBG_FAST_TABLE") ? atoi(getenv("DBG_FAST_TABLE")) : 2048;
+            const int nt_env = c->opt("DBG_FAST_NT") ? atoi(c->opt("DBG_FAST_NT")) : 512;
+            const int tb_env = c->opt("DBG_FAST_TABLE") ? atoi(c->opt("DBG_FAST_TABLE")) : 2048;
 #define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, 0, c->stream>>>( \
             recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
 #define GO(KW, NBW, SET) do { \
@@ -1291,10 +1291,10 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         HIP_TRY(c, hipMemcpyAsync(flv, st->gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const uint32_t fl = flv[0];
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u filter_undone=%u wd=%u\n",
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] bins=%u srcs=%u recs=%llu valid=%llu flags=%u maxP=%u split_passes=%u filter_undone=%u wd=%u\n",
                                          nbins_local, n_src, (unsigned long long)n_recs_hint, cur, fl, flv[1], flv[2], flv[12], flv[3]);
 #ifdef DBG_PHASE_TIMES
-        if (getenv("DBG_DEBUG")) {
+        if (c->opt("DBG_DEBUG")) {
             unsigned long long ph[8];
             (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_cycles), sizeof(ph));
             fprintf(stderr, "[fastpath-phases] (100MHz ticks, summed over bins) prologue=%llu clear=%llu stage+filter+map=%llu chunks(w0)=%llu wait=%llu scan=%llu cursor=%llu write=%llu\n",
@@ -1304,7 +1304,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         }
 #endif
 #ifdef DBG_COUNT_STATS
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath-stats] wave-iterations=%u active lanes=%u (%.1f/64); lane-rounds=%u next-bucket=%u tag-collision=%u busy=%u cas-lost=%u inserts=%u\n",
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath-stats] wave-iterations=%u active lanes=%u (%.1f/64); lane-rounds=%u next-bucket=%u tag-collision=%u busy=%u cas-lost=%u inserts=%u\n",
                                          flv[4], flv[5], flv[4] ? (double)flv[5] / flv[4] : 0.0, flv[6], flv[7], flv[8], flv[9], flv[10], flv[11]);
 #endif
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
@@ -1349,10 +1349,10 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
     if (st->use16) {
         DBuf<uint4> t16;
         ALLOC_OR_FAIL(c, t16, na);
-        DBG_TRY(sort_table_hybrid16(c, n_out, st->u16.p, t16.p, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
+        DBG_TRY(sort_table_hybrid16(c, n_out, st->u16.p, t16.p, 2 * k, is_set, !c->opt("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
                                     nullptr, msk_sorted.p));
     } else
-    DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, !getenv("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
+    DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, !c->opt("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
                               nullptr, msk_sorted.p));
     if (is_set) {
         const uint32_t nb = cdiv(std::max<uint64_t>(n_out, 1), CSR_TILE);
@@ -1389,7 +1389,7 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
         if (has_hi) ALLOC_OR_FAIL(c, b_hi, naa);
         HIP_TRY(c, hipMemsetAsync(a_pay.p, 0, naa * 4, c->stream));
         RecArrays A2{has_hi ? st->a_hi.p : nullptr, st->a_lo.p, a_pay.p}, B2{has_hi ? b_hi.p : nullptr, b_lo.p, b_pay.p};
-        DBG_TRY(sort_table_hybrid(c, n_all, A2, B2, 2 * k, false, !getenv("DBG_NO_HYBRID_SORT"), f_hi.p, f_lo.p, x_exts.p, x_count.p, nullptr, nullptr));
+        DBG_TRY(sort_table_hybrid(c, n_all, A2, B2, 2 * k, false, !c->opt("DBG_NO_HYBRID_SORT"), f_hi.p, f_lo.p, x_exts.p, x_count.p, nullptr, nullptr));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         out->n_all = n_all;
         out->all_hi = f_hi.take(); out->all_lo = f_lo.take();
@@ -1453,7 +1453,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET;
     if (n_kmers == 0) return 0;
     FastPlan pl;
-    if (!fast_make_plan((int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
+    if (!fast_make_plan(c, (int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
     if (is_set) { bool ok; DBG_TRY(fast_labels_ok(c, s, &ok)); if (!ok) return 0; }
     FastScan st;
     DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
@@ -1478,7 +1478,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->t_begin("sk_records", n_recs_total);    // bookkeeping entry: units = super-k-mer records (no kernel)
     c->t_end();
-    if (getenv("DBG_DEBUG")) fprintf(stderr, "[fastpath] direct slabs: cap=%u records/bin, %llu records, %llu took the overflow path\n", slab_cap,
+    if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] direct slabs: cap=%u records/bin, %llu records, %llu took the overflow path\n", slab_cap,
                                      n_recs_total, (unsigned long long)st.n_recs);
     DBG_TRY(fast_count(c, pl, prm->min_kmer_obs, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, st.n_recs ? 2u : 1u, (uint64_t)nb,
                        pl.nbins, n_kmers, n_recs_total, out, prm->report_all_kmers != 0));
@@ -1494,18 +1494,9 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
 // contiguous.  The caller exchanges the slabs (RCCL all-to-all over xGMI) and hands stage 2 the
 // received records as n_src bin-ordered segments.
 // ------------------------------------------------------------------------------------------------
-#include <map>
 #include <memory>
-#include <mutex>
-static std::mutex g_shard_mu;
-static std::map<dbg_ctx*, std::unique_ptr<FastScan>> g_shard_state;
-static std::map<dbg_ctx*, std::unique_ptr<FastCountState>> g_count_state;
-
-void fast_drop_state(dbg_ctx* c) {
-    std::lock_guard<std::mutex> g(g_shard_mu);
-    g_shard_state.erase(c);
-    g_count_state.erase(c);
-}
+// The state one call leaves for the next lives in the ctx (dbg_state_slot): the library has no globals.
+template <class T> static void slot_delete(void* p) { delete static_cast<T*>(p); }
 
 extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t k, uint64_t* n_out) {
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1523,15 +1514,14 @@ extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, ui
 
 static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
     if (sp->n_bins % NCLS) return c->fail(144, "n_bins must be a multiple of bin_group");
-    if (!fast_make_plan((int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
+    if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
         return c->fail(140, "sharded counting supports 16 <= k <= 64");
     return 0;
 }
 
 extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
     FastPlan pl;
-    sp->n_bins = 0;
-    DBG_TRY(plan_from(c, sp, &pl));
+    DBG_TRY(plan_from(c, sp, &pl));                 // n_bins = 0: derived from total_kmers; otherwise the caller's bin count is kept
     sp->n_bins = pl.nbins * NCLS;
     sp->rec_words = (uint32_t)pl.rw;
     sp->bin_group = NCLS;
@@ -1568,21 +1558,14 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     c->t_begin("sk_records", st->n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
     c->t_end();
     *n_recs = st->n_recs;
-    std::lock_guard<std::mutex> g(g_shard_mu);
-    g_shard_state[c] = std::move(st);
+    c->shard_scan.reset(st.release(), slot_delete<FastScan>);
     return 0;
 }
 
 extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, uint64_t* recs_out_dev) {
     HIP_TRY(c, hipSetDevice(c->device));
-    std::unique_ptr<FastScan> st;
-    {
-        std::lock_guard<std::mutex> g(g_shard_mu);
-        auto it = g_shard_state.find(c);
-        if (it == g_shard_state.end()) return c->fail(142, "dbg_shard_scatter_dev without a preceding dbg_shard_scan_dev");
-        st = std::move(it->second);
-        g_shard_state.erase(it);
-    }
+    if (!c->shard_scan.p) return c->fail(142, "dbg_shard_scatter_dev without a preceding dbg_shard_scan_dev");
+    std::unique_ptr<FastScan> st(static_cast<FastScan*>(c->shard_scan.release()));
     const uint32_t nb = st->pl.nbins * NCLS;
     DBuf<uint64_t> ovf_base;
     ALLOC_OR_FAIL(c, ovf_base, (size_t)nb + 1);
@@ -1604,7 +1587,7 @@ extern "C" int dbg_shard_count_dev(dbg_ctx* c, const dbg_shard_plan* sp, const u
     HIP_TRY(c, hipSetDevice(c->device));
     FastPlan pl;
     DBG_TRY(plan_from(c, sp, &pl));
-    if (n_src == 0) return c->fail(143, "n_src must be >= 1");
+    if (n_src == 0 || n_src > 64) return c->fail(143, "n_src must be in 1..=64 (one record segment per source rank)");
     if (n_bins_local % NCLS) return c->fail(144, "n_bins_local must be a multiple of bin_group");
     DBG_TRY(fast_count(c, pl, sp->min_kmer_obs, recs_dev, recs_dev, n_src, seg_off_dev, seg_off_dev + 1, n_src, (uint64_t)n_bins_local + 1, n_bins_local / NCLS,
                        std::max<uint64_t>(n_kmers_hint, 1), 0, out));
@@ -1619,22 +1602,16 @@ extern "C" int dbg_shard_count_begin(dbg_ctx* c, const dbg_shard_plan* sp, uint6
     DBG_TRY(plan_from(c, sp, &pl));
     std::unique_ptr<FastCountState> st(new FastCountState());
     DBG_TRY(fast_count_begin(c, pl, sp->min_kmer_obs, std::max<uint64_t>(n_kmers_hint, 1), st.get()));
-    std::lock_guard<std::mutex> g(g_shard_mu);
-    g_count_state[c] = std::move(st);
+    c->shard_count.reset(st.release(), slot_delete<FastCountState>);
     return 0;
 }
 
 extern "C" int dbg_shard_count_bins_dev(dbg_ctx* c, const uint64_t* recs_dev, const uint64_t* seg_off_dev, uint32_t n_src,
                                         uint32_t n_bins_chunk, uint64_t n_kmers_units) {
     HIP_TRY(c, hipSetDevice(c->device));
-    FastCountState* st = nullptr;
-    {
-        std::lock_guard<std::mutex> g(g_shard_mu);
-        auto it = g_count_state.find(c);
-        if (it == g_count_state.end()) return c->fail(145, "dbg_shard_count_bins_dev without dbg_shard_count_begin");
-        st = it->second.get();
-    }
-    if (n_src == 0) return c->fail(143, "n_src must be >= 1");
+    FastCountState* st = static_cast<FastCountState*>(c->shard_count.p);
+    if (!st) return c->fail(145, "dbg_shard_count_bins_dev without dbg_shard_count_begin");
+    if (n_src == 0 || n_src > 64) return c->fail(143, "n_src must be in 1..=64 (one record segment per source rank)");
     if (n_bins_chunk % NCLS) return c->fail(144, "n_bins_chunk must be a multiple of bin_group");
     return fast_count_bins(c, st, recs_dev, recs_dev, n_src, seg_off_dev, seg_off_dev + 1, n_src, (uint64_t)n_bins_chunk + 1,
                            n_bins_chunk / NCLS, n_kmers_units, 0);
@@ -1642,13 +1619,7 @@ extern "C" int dbg_shard_count_bins_dev(dbg_ctx* c, const uint64_t* recs_dev, co
 
 extern "C" int dbg_shard_count_finish(dbg_ctx* c, dbg_kmer_table* out) {
     HIP_TRY(c, hipSetDevice(c->device));
-    std::unique_ptr<FastCountState> st;
-    {
-        std::lock_guard<std::mutex> g(g_shard_mu);
-        auto it = g_count_state.find(c);
-        if (it == g_count_state.end()) return c->fail(145, "dbg_shard_count_finish without dbg_shard_count_begin");
-        st = std::move(it->second);
-        g_count_state.erase(it);
-    }
+    if (!c->shard_count.p) return c->fail(145, "dbg_shard_count_finish without dbg_shard_count_begin");
+    std::unique_ptr<FastCountState> st(static_cast<FastCountState*>(c->shard_count.release()));
     return fast_count_finish(c, st.get(), out);
 }

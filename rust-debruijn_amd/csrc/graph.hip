@@ -157,6 +157,7 @@ __global__ void edges_kernel(EndIndex left, EndIndex right, const uint64_t* __re
         if (e & (1u << b)) {
             Link L = find_link(left, right, kmer_extend_left(lk, k, b), 0, stranded, k);
             if (L.node >= 0) { t = (uint32_t)L.node; f = (uint32_t)L.side | ((uint32_t)L.flip << 1); }
+            // no link: "this edge doesn't exist within this shard, so ignore it" (graph.rs:231-236; the expect is commented out)
         }
         target[(uint64_t)i * 8 + b] = t; info[(uint64_t)i * 8 + b] = (uint8_t)f;
         t = EDGE_NONE; f = 0;
@@ -338,7 +339,7 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
         // the whole walk on the device (same chain construction as compress_kmers_with_hash, elements = nodes; censored nodes
         // are neither entered nor emitted), unless the links are not mutual / carry a panic marker: the literal host walk
         // below then reproduces the reference's behaviour (including its panics)
-        const char* mode = getenv("DBG_COMPRESS");
+        const char* mode = c->opt("DBG_COMPRESS");
         if (!(mode && !strcmp(mode, "host"))) {
             DBuf<uint32_t> u_link, u_weight;
             ALLOC_OR_FAIL(c, u_link, 2 * (size_t)n);
@@ -450,19 +451,9 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
     return 0;
 }
 
-// Node::l_edges / r_edges (graph.rs:1041-1049) of every node of a (finished) graph, computed on the device.
-extern "C" int dbg_graph_edges(dbg_ctx* c, uint32_t k_, const dbg_graph* g, dbg_edges* out) {
-    const int k = (int)k_;
-    memset(out, 0, sizeof(*out));
-    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
-    if (g->n_nodes >= (1ull << 30)) return c->fail(51, "graph_edges: at most 2^30-1 nodes per call in this build");
-    HIP_TRY(c, hipSetDevice(c->device));
+extern "C" void dbg_free_edges(dbg_edges* e);
+static int graph_edges_impl(dbg_ctx* c, int k, const dbg_graph* g, dbg_edges* out) {
     const uint32_t n = (uint32_t)g->n_nodes;
-    for (uint32_t i = 0; i < n; i++) if (g->length[i] < (uint32_t)k) return c->fail(52, "node shorter than k");
-    out->n_nodes = n;
-    out->target = (uint32_t*)malloc(std::max<size_t>((size_t)n * 8 * 4, 1));
-    out->info = (uint8_t*)malloc(std::max<size_t>((size_t)n * 8, 1));
-    if (!n) return 0;
     DevGraph d;
     DBG_TRY(dev_graph_build(c, k, g, &d));
     DBuf<uint32_t> d_t;
@@ -477,6 +468,28 @@ extern "C" int dbg_graph_edges(dbg_ctx* c, uint32_t k_, const dbg_graph* g, dbg_
     HIP_TRY(c, hipMemcpyAsync(out->info, d_i.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
+}
+
+// Node::l_edges / r_edges (graph.rs:1041-1049) of every node of a (finished) graph, computed on the device.
+extern "C" int dbg_graph_edges(dbg_ctx* c, uint32_t k_, const dbg_graph* g, dbg_edges* out) {
+    const int k = (int)k_;
+    memset(out, 0, sizeof(*out));
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (g->n_nodes >= (1ull << 30)) return c->fail(51, "graph_edges: at most 2^30-1 nodes per call in this build");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n = (uint32_t)g->n_nodes;
+    for (uint32_t i = 0; i < n; i++) {
+        if (g->length[i] < (uint32_t)k) return c->fail(52, "node shorter than k");
+        if (g->start[i] + g->length[i] > g->seq_len_bases) return c->fail(54, "node runs past seq_len_bases");
+    }
+    out->n_nodes = n;
+    out->target = (uint32_t*)malloc(std::max<size_t>((size_t)n * 8 * 4, 1));
+    out->info = (uint8_t*)malloc(std::max<size_t>((size_t)n * 8, 1));
+    if (!out->target || !out->info) { dbg_free_edges(out); return c->fail(101, "out of host memory"); }
+    if (!n) return 0;
+    const int r = graph_edges_impl(c, k, g, out);
+    if (r) dbg_free_edges(out);                                  // nothing is handed out on failure
+    return r;
 }
 extern "C" void dbg_free_edges(dbg_edges* e) {
     if (!e) return;

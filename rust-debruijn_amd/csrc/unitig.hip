@@ -633,7 +633,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     DBuf<uint32_t> flags;
     ALLOC_OR_FAIL(c, flags, 2);
     HIP_TRY(c, hipMemsetAsync(flags.p, 0, 8, c->stream));
-    const bool try_chains = !nodes && !getenv("DBG_UNITIG_NO_CHAINS") && !getenv("DBG_UNITIG_NO_WALK");
+    const bool try_chains = !nodes && !c->opt("DBG_UNITIG_NO_CHAINS") && !c->opt("DBG_UNITIG_NO_WALK");
     // the chain route with node records checks the links while it walks them; everything else checks them first
     bool links_checked = false;
     auto check_links = [&]() -> int {
@@ -700,7 +700,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             if (bad) return 0;
         }
         const bool ok = res[1] == 0 && seen == n;                  // no walker gave up, every k-mer sits on an open chain
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
                                          ok ? "" : " -> general route");
         if (ok) {
             DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
@@ -777,7 +777,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     ALLOC_OR_FAIL(c, JA, n2);
     Jump* cur = nullptr;
     bool walked = false;
-    if (!getenv("DBG_UNITIG_NO_WALK")) {
+    if (!c->opt("DBG_UNITIG_NO_WALK")) {
         HIP_TRY(c, hipMemsetAsync(counters.p, 0, 24, c->stream));
         c->t_begin("unitig_walk_ends", n);
         collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, avail, n, LA.p, counters.p);
@@ -797,7 +797,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         c->t_end();
         const uint64_t written = (uint64_t)res[2] | ((uint64_t)res[3] << 32);
         walked = res[1] == 0 && written == n2;                      // no walker gave up, no state on a cycle
-        if (getenv("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends wrote %llu of %u states%s\n", n_ends, (unsigned long long)written, n2,
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends wrote %llu of %u states%s\n", n_ends, (unsigned long long)written, n2,
                                          walked ? "" : " -> doubling");
         if (walked) cur = JA.p;
     }
@@ -881,7 +881,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         finish_nodes_kernel<<<cdiv(n_nodes, 256), 256, 0, c->stream>>>(n_nodes, spec, k, ulen.p, uexts.p, uacc.p, nodes ? ucnt.p : nullptr, o_exts.p, o_data.p);
         LAUNCH_CHECK(c, "finish_nodes");
     }
-    if (getenv("DBG_DEBUG") && n_nodes) {
+    if (c->opt("DBG_DEBUG") && n_nodes) {
         unsigned long long a0 = 0; uint32_t d0 = 0, e0 = 0;
         (void)hipMemcpy(&a0, uacc.p, 8, hipMemcpyDeviceToHost); (void)hipMemcpy(&d0, o_data.p, 4, hipMemcpyDeviceToHost);
         (void)hipMemcpy(&e0, uexts.p, 4, hipMemcpyDeviceToHost);

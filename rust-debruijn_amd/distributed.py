@@ -28,7 +28,9 @@ class HipEngine:
         self.device = device
 
     def seqset(self, words, start, length, data=None, data_width=0):
-        """torch cuda tensors -> dbg_seqset (device pointers)."""
+        """torch cuda tensors -> dbg_seqset (device pointers).  The library runs on the ctx's own stream: whatever torch's
+        current stream still has in flight for these tensors (an H2D copy, a generator kernel) is waited for here."""
+        self.sync()
         self._keep = (words, start, length, data)
         return _capi.SeqSet(words.data_ptr(), words.numel(), start.data_ptr(), length.data_ptr(), None,
                             data.data_ptr() if data is not None else None, data_width if data is not None else 0,
@@ -145,7 +147,8 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
         return engine.count_finish(plan)
     if n_chunks is None:
         n_chunks = 4
-    n_chunks = max(1, min(n_chunks, max(nb_local // grp, 1)))
+    # the number of exchange rounds and every cut must be the same on all ranks: derive them from the smallest owned range
+    n_chunks = max(1, min(n_chunks, max(min(bounds[d + 1] - bounds[d] for d in range(world)) // grp, 1)))
     # 1) per-bin record counts of my bins from every source rank
     recv_hist = torch.empty(world * nb_local, dtype=hist.dtype, device=hist.device)
     _all_to_all(recv_hist, hist, [nb_local] * world, [bounds[d + 1] - bounds[d] for d in range(world)], group)
@@ -196,6 +199,7 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
     ascending by key) and the global k-mer instance count."""
     import torch
     import torch.distributed as dist
+    engine.sync()                                  # the reads may still be in flight on torch's current stream
     n_local = engine.count_instances(ss, k)
     total = n_local
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -11,20 +11,23 @@ P = 8
 
 
 class Plan:
-    def __init__(self, k, stranded, kind, min_obs, total):
+    def __init__(self, k, stranded, kind, min_obs, total, n_bins=None):
         self.k, self.stranded, self.summarizer, self.min_kmer_obs = k, stranded, kind, min_obs
-        self.n_bins = max(4, total // 400)
+        self.n_bins = n_bins or max(4, total // 400)
         self.rec_words = RW
 
 
 class OracleEngine:
     device = torch.device("cpu")
 
+    def __init__(self, n_bins=None):
+        self.n_bins = n_bins                      # force a (tiny) bin count: ranks then own different numbers of bins
+
     def count_instances(self, ss, k):
         return int(sum(max(0, int(l) - k + 1) for l in ss.length))
 
     def plan(self, k, stranded, kind, min_obs, total):
-        return Plan(k, stranded, kind, min_obs, total)
+        return Plan(k, stranded, kind, min_obs, total, self.n_bins)
 
     def scan(self, ss, plan):
         rows, bins = [], []

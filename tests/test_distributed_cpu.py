@@ -16,7 +16,7 @@ WORLD = 2
 N_READS = 120
 
 
-def _worker(rank, world, port, kind, stranded, out_dir, chunks):
+def _worker(rank, world, port, kind, stranded, out_dir, chunks, n_bins=None):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import importlib
@@ -31,7 +31,7 @@ def _worker(rank, world, port, kind, stranded, out_dir, chunks):
     hs = dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005,
                               stranded=stranded, n_colours=4, first_read=rank * per)
     ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
-    tab, total, n_local, n_recs = D.sharded_filter_kmers(OracleEngine(), ss, 47, stranded, kind, 2, n_chunks=chunks)
+    tab, total, n_local, n_recs = D.sharded_filter_kmers(OracleEngine(n_bins), ss, 47, stranded, kind, 2, n_chunks=chunks)
     assert total == N_READS * 104 and n_local == per * 104
     res = dict(keys=tab.keys(), exts=tab.exts.tolist(), count=tab.count.tolist(), set_off=tab.set_off.tolist(),
                set_val=tab.set_val.tolist())
@@ -40,15 +40,18 @@ def _worker(rank, world, port, kind, stranded, out_dir, chunks):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,stranded,chunks", [(0, False, None), (1, False, 1), (0, True, 3)])
-def test_sharded_counting_gloo_world2(tmp_path, kind, stranded, chunks):
-    """chunks = ranges the owned bins are exchanged and counted in (None = the default pipeline depth)"""
+@pytest.mark.parametrize("kind,stranded,chunks,n_bins", [(0, False, None, None), (1, False, 1, None), (0, True, 3, None),
+                                                         (0, False, None, 5), (1, False, 3, 3)])
+def test_sharded_counting_gloo_world2(tmp_path, kind, stranded, chunks, n_bins):
+    """chunks = ranges the owned bins are exchanged and counted in (None = the default pipeline depth); n_bins = 5 or 3:
+    the two ranks own different numbers of bins (2 + 3, 1 + 2), fewer than the pipeline depth -- every rank must still
+    arrive at the same number of exchange rounds and the same cuts"""
     import importlib
     import oracle_lib as O
     O.build()
     dbg = importlib.import_module("rust-debruijn_amd")
-    port = 29600 + kind * 2 + int(stranded) + (os.getpid() % 200)
-    mp.spawn(_worker, args=(WORLD, port, kind, stranded, str(tmp_path), chunks), nprocs=WORLD, join=True)
+    port = 29600 + kind * 2 + int(stranded) + (n_bins or 0) * 4 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(WORLD, port, kind, stranded, str(tmp_path), chunks, n_bins), nprocs=WORLD, join=True)
     parts = [pickle.load(open(tmp_path / ("rank%d.pkl" % r), "rb")) for r in range(WORLD)]
     hs = dbg.synth_reads_host(n_reads=N_READS, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005,
                               stranded=stranded, n_colours=4)

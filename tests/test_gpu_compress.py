@@ -25,17 +25,13 @@ def ctx():
 
 
 @pytest.fixture(autouse=True, params=["device", "host"])
-def compress_mode(request):
+def compress_mode(request, ctx):
     """Every test runs twice: DBG_COMPRESS=device (pointer-jumping unitig construction on the GPU; fails loudly
     instead of falling back) and DBG_COMPRESS=host (device links + literal greedy walk on the host)."""
     import os
-    old = os.environ.get("DBG_COMPRESS")
-    os.environ["DBG_COMPRESS"] = request.param
+    old = ctx.set_option("DBG_COMPRESS", request.param)
     yield request.param
-    if old is None:
-        os.environ.pop("DBG_COMPRESS", None)
-    else:
-        os.environ["DBG_COMPRESS"] = old
+    ctx.set_option("DBG_COMPRESS", old)
 
 
 def gpu_table(ctx, contigs, k, min_obs, stranded, dup=1):
@@ -224,10 +220,10 @@ def test_compress_non_mutual_links(ctx, compress_mode):
     assert changed
     t.exts[:] = ex
     want = O.compress_kmers(k, True, O.SPEC_SAT_ADD, t.key_hi, t.key_lo, t.exts, t.count, None)
-    os.environ["DBG_COMPRESS"] = "auto"
+    ctx.set_option("DBG_COMPRESS", "auto")
     got = dbg.compress_kmers_with_hash(True, SPECS[0][0], t, k=k, data=t.count, ctx=ctx)
     assert graphs_equal(got.arrays(), want.arrays())
-    os.environ["DBG_COMPRESS"] = "device"
+    ctx.set_option("DBG_COMPRESS", "device")
     with pytest.raises(dbg.DbgError):
         dbg.compress_kmers_with_hash(True, SPECS[0][0], t, k=k, data=t.count, ctx=ctx)
 
@@ -246,15 +242,7 @@ def test_compress_routes(ctx, compress_mode, env, k, stranded):
     cyc = R.random_dna(rng, 3 * k)
     contigs.append(np.concatenate([cyc, cyc[:k - 1]]))                       # an isolated cycle among the chains
     t = gpu_table(ctx, contigs, k, 1, stranded)
-    old = {v: os.environ.get(v) for v in env}
-    os.environ.update(env)
-    try:
+    with ctx.options(**env):
         compare(ctx, t, k, stranded, SPECS[0])
         order = rng.permutation(len(t)).astype(np.uint64)
         compare(ctx, t, k, stranded, SPECS[2], seed_order=order)
-    finally:
-        for v, o in old.items():
-            if o is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = o

@@ -22,14 +22,10 @@ def ctx():
 
 
 @pytest.fixture(autouse=True)
-def force_fast():
-    old = os.environ.get("DBG_PATH")
-    os.environ["DBG_PATH"] = "fast"
+def force_fast(ctx):
+    old = ctx.set_option("DBG_PATH", "fast")
     yield
-    if old is None:
-        os.environ.pop("DBG_PATH", None)
-    else:
-        os.environ["DBG_PATH"] = old
+    ctx.set_option("DBG_PATH", old)
 
 
 def run_fast(ctx, ss, k, summarizer, min_obs, stranded, data_width=0):
@@ -99,9 +95,9 @@ def test_fast_ragged_and_boundary_exts(ctx):
 def test_fast_equals_generic_on_synthetic_stream(ctx):
     hs = dbg.synth_reads_host(n_reads=30000, read_len=150, error_rate=0.002, stranded=False, n_colours=4)
     for summ in (dbg.CountFilter(2), dbg.CountFilterSet(2)):
-        os.environ["DBG_PATH"] = "fast"
+        ctx.set_option("DBG_PATH", "fast")
         a, _ = dbg.filter_kmers(hs, summ, False, False, 4, k=47, ctx=ctx)
-        os.environ["DBG_PATH"] = "generic"
+        ctx.set_option("DBG_PATH", "generic")
         b, _ = dbg.filter_kmers(hs, summ, False, False, 4, k=47, ctx=ctx)
         assert np.array_equal(a.key_hi, b.key_hi) and np.array_equal(a.key_lo, b.key_lo)
         assert np.array_equal(a.exts, b.exts)
@@ -118,7 +114,7 @@ def test_fast_path_refuses_unsupported_shapes(ctx):
     ss = O.SeqSet.from_byte_seqs(seqs, data=rng.integers(40, 300, size=50), sizeof_d1=2)
     with pytest.raises(dbg.DbgError):           # labels >= 24 need the generic (sort-based) CountFilterSet
         dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
-    os.environ["DBG_PATH"] = "auto"
+    ctx.set_option("DBG_PATH", "auto")
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
     got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     assert_tables_equal(got, want, True)
@@ -176,31 +172,15 @@ def test_fast_sort_variants(ctx, env, k, kind):
     hs = dbg.synth_reads_host(n_reads=3000, read_len=150, error_rate=0.003, stranded=False, n_colours=4)
     ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if kind else None, 1 if kind else 0)
     want = O.filter_kmers(ss, k, kind, 2, stranded=False)
-    old = {v: os.environ.get(v) for v in env}
-    os.environ.update(env)
-    try:
+    with ctx.options(**env):
         summ = dbg.CountFilterSet(2) if kind else dbg.CountFilter(2)
         got, _ = dbg.filter_kmers(hs if kind else dbg.HostSeqs(hs.words, hs.start, hs.length), summ, False, False, 4, k=k, ctx=ctx)
-    finally:
-        for v, o in old.items():
-            if o is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = o
     assert_tables_equal(got, want, kind == 1)
 
 
-def _with_env(env, fn):
-    old = {v: os.environ.get(v) for v in env}
-    os.environ.update(env)
-    try:
+def _with_env(ctx, env, fn):
+    with ctx.options(**env):
         return fn()
-    finally:
-        for v, o in old.items():
-            if o is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = o
 
 
 @pytest.mark.parametrize("k", [31, 47, 63])
@@ -218,7 +198,7 @@ def test_fast_duplicate_records_weights_and_colours(ctx, k):
         seqs.append(b)
         data.append(int(rng.integers(0, 24)))
     for target in ("8000", "200000"):
-        _with_env({"DBG_FAST_TARGET": target}, lambda: (
+        _with_env(ctx, {"DBG_FAST_TARGET": target}, lambda: (
             run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, 2, False),
             run_fast(ctx, O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1), k, O.COUNT_FILTER_SET, 3, False, data_width=1),
             run_fast(ctx, O.SeqSet.from_byte_seqs(seqs), k, O.COUNT_FILTER, 1, True)))
@@ -233,7 +213,7 @@ def test_fast_large_bins_of_distinct_records(ctx, k, kind):
     seqs = random_reads(rng, 2500, 2000000, 150, False, err=0.0)
     data = rng.integers(0, 5, size=len(seqs)) if kind else None
     ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1) if kind else O.SeqSet.from_byte_seqs(seqs)
-    _with_env({"DBG_FAST_TARGET": "60000"},
+    _with_env(ctx, {"DBG_FAST_TARGET": "60000"},
               lambda: run_fast(ctx, ss, k, O.COUNT_FILTER_SET if kind else O.COUNT_FILTER, 1, False, data_width=1 if kind else 0))
 
 
@@ -241,5 +221,5 @@ def test_fast_large_bins_high_coverage(ctx):
     hs = dbg.synth_reads_host(n_reads=6000, read_len=150, error_rate=0.002, stranded=False, n_colours=4)
     ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 2, stranded=False)
-    got = _with_env({"DBG_FAST_TARGET": "40000"}, lambda: dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=47, ctx=ctx)[0])
+    got = _with_env(ctx, {"DBG_FAST_TARGET": "40000"}, lambda: dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=47, ctx=ctx)[0])
     assert_tables_equal(got, want, True)

@@ -39,17 +39,13 @@ def assert_tables_equal(got, want, is_set):
 
 
 @pytest.fixture(autouse=True, params=["auto", "generic"])
-def path_mode(request):
+def path_mode(request, ctx):
     """Every test runs through the default dispatch (fast path where it applies) and with the generic
     extract -> radix sort -> reduce path forced."""
     import os
-    old = os.environ.get("DBG_PATH")
-    os.environ["DBG_PATH"] = request.param
+    old = ctx.set_option("DBG_PATH", request.param)
     yield request.param
-    if old is None:
-        os.environ.pop("DBG_PATH", None)
-    else:
-        os.environ["DBG_PATH"] = old
+    ctx.set_option("DBG_PATH", old)
 
 
 def run_both(ctx, ss, k, summarizer, min_obs, stranded, report_all=False, data_width=0):

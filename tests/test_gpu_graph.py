@@ -14,17 +14,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["device", "host"])
-def compress_mode(request):
+def compress_mode(request, ctx):
     """Every test runs with the node walk of compress_graph (and the k-mer walk of compress_kmers_with_hash) on the
     device (DBG_COMPRESS=device: chains by pointer jumping; it fails instead of falling back) and on the host."""
     import os
-    old = os.environ.get("DBG_COMPRESS")
-    os.environ["DBG_COMPRESS"] = request.param
+    old = ctx.set_option("DBG_COMPRESS", request.param)
     yield request.param
-    if old is None:
-        os.environ.pop("DBG_COMPRESS", None)
-    else:
-        os.environ["DBG_COMPRESS"] = old
+    ctx.set_option("DBG_COMPRESS", old)
 
 
 @pytest.fixture(scope="module")

@@ -31,7 +31,7 @@ data = np.ctypeslib.as_array(C.cast(h.count, C.POINTER(C.c_uint16)), shape=(n,))
 for mode in (sys.argv[2:] or ["device"]):
     if mode == "none":
         break
-    os.environ["DBG_COMPRESS"] = mode
+    ctx.set_option("DBG_COMPRESS", mode)
     ctx.enable_timing(True)
     g = capi.Graph()
     t0 = time.perf_counter()
