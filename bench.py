@@ -51,9 +51,25 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0")
     ap.add_argument("--force-sharded", action="store_true",
                     help="time the multi-GPU pipeline (scan -> compaction -> exchange -> count) even on one GPU")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with one rank: initialise a 1-rank process group and run the pipelined all-to-all route anyway (exercises "
+                         "the RCCL calls of the N > 1 path on a one-GPU box; implies --force-sharded)")
+    ap.add_argument("--digest", action="store_true",
+                    help="report an order-independent digest of the result table(s): per-rank digests of a sharded run add up to the "
+                         "single-GPU digest over the same reads (tools/check_multirank.sh)")
     ap.add_argument("--compress-reads", type=int, default=-1,
                     help="reads of the stream used for the secondary unitigs/s measurement (0 = skip, -1 = all: BASELINE config 3)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand as `python bench.py --gpus N`: become the launcher the driver would have used, one rank per GPU
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     import numpy as np
     import torch
@@ -63,14 +79,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.one_device:
         local_rank = 0
+    elif world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks but only %d GPU(s) visible (--one-device --backend gloo shares cuda:0 for a functional check)"
+                 % (world, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+    elif args.force_exchange:
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        kw = dict(device_id=torch.device("cuda", local_rank)) if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+        args.force_sharded = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ctx = dbg.Context(local_rank)
@@ -98,18 +128,23 @@ def main():
 
     D = importlib.import_module("rust-debruijn_amd.distributed")
     engine = D.HipEngine(ctx, dev)
+    xstats = {}
 
     def step():
         if world == 1 and not args.force_sharded:
             # the drop-in entry point: filter_kmers, device-resident in and out
             t = capi.KmerTable()
             ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
-            res = (t.n, t.n_kmer_instances)
+            res = (t.n, t.n_kmer_instances, D.table_digest(t, dev) if args.digest else 0)
             lib.dbg_free_table(ctx.h, C.byref(t))
             return res
         # N > 1: scan local reads -> all-to-all of minimizer-bin slabs (RCCL over xGMI) -> count owned bins
-        tab, total, n_local, n_recs = D.sharded_filter_kmers(engine, ss, k, False, 1 if is_set else 0, args.min_obs)
-        res = (tab.n, n_local)
+        st = {}
+        tab, total, n_local, n_recs = D.sharded_filter_kmers(engine, ss, k, False, 1 if is_set else 0, args.min_obs, stats=st,
+                                                                 force_exchange=args.force_exchange)
+        for kk, v in st.items():
+            xstats[kk] = xstats.get(kk, 0) + v
+        res = (tab.n, n_local, D.table_digest(tab, dev) if args.digest else 0)
         engine.free_table(tab)
         return res
 
@@ -121,13 +156,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    xstats.clear()
     ctx.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
-    n_valid = n_inst = 0
+    n_valid = n_inst = digest = 0
     ktimes = {}
     for _ in range(args.steps):
-        n_valid, n_inst = step()
+        n_valid, n_inst, digest = step()
         for kt in ctx.timings():
             a = ktimes.setdefault(kt["name"], dict(ms=0.0, launches=0, units=0))
             a["ms"] += kt["ms"]; a["launches"] += kt["launches"]; a["units"] += kt["units"]
@@ -140,13 +176,23 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        cnt = torch.tensor([n_inst, n_valid], dtype=torch.int64, device=rdev)
+        cnt = torch.tensor([n_inst, n_valid, 1, int(xstats.get("exchange_bytes_sent", 0))], dtype=torch.int64, device=rdev)
         dist.all_reduce(cnt)
         n_inst_total = int(cnt[0].item())
         n_valid_total = int(cnt[1].item())
+        ranks_seen = int(cnt[2].item())
+        xbytes_total = int(cnt[3].item())
+        xe = torch.tensor([xstats.get("exchange_exposed_ms", 0.0)], dtype=torch.float64, device=rdev)
+        dist.all_reduce(xe, op=dist.ReduceOp.MAX)
+        exposed_ms = float(xe.item())
+        if args.digest:                                    # sum of the per-rank digests mod 2^64 (two 32-bit halves: no overflow)
+            dg = torch.tensor([digest & 0xFFFFFFFF, digest >> 32], dtype=torch.int64, device=rdev)
+            dist.all_reduce(dg)
+            digest = (int(dg[0].item()) + (int(dg[1].item()) << 32)) & ((1 << 64) - 1)
     else:
         n_inst_total = n_inst
         n_valid_total = n_valid
+        ranks_seen, xbytes_total, exposed_ms = 1, 0, 0.0
     ms_per_step = dt / args.steps * 1e3
     value = n_inst_total * args.steps / dt / 1e9
 
@@ -287,11 +333,16 @@ def main():
                        "superkmer_records_per_step": n_recs,
                        "multi_gpu": ("reads sharded by index; one all-to-all of super-k-mer bin slabs; each rank counts "
                                      "the bins it owns" if world > 1 else "n/a")},
+            "table_digest": ("%016x" % digest) if args.digest else None,
+            "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
+            "exchange": ({"bytes_sent_per_step_all_ranks": xbytes_total // max(args.steps, 1),
+                          "exposed_ms_per_step_max_rank": round(exposed_ms / max(args.steps, 1), 3),
+                          "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1)} if world > 1 else None),
             "roofline": roof, "cpu_baseline": cpu, "compress": comp,
         }
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         dist.destroy_process_group()
 

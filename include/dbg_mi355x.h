@@ -177,6 +177,28 @@ int  dbg_compress_kmers_with_hash_dev(dbg_ctx* ctx, uint32_t k, int stranded, in
                                       const uint32_t* data_dev, const uint16_t* count16_dev, dbg_graph* out);
 void dbg_free_graph(dbg_ctx* ctx, dbg_graph* g);
 
+/* ---- CountFilterSet payload as ScmapCompress data (BASELINE config 5) ------------------------
+ * After filter_kmers(CountFilterSet) the reference's index is BoomHashMap2<K, Exts, Vec<D1>> (src/filter.rs:68-101) and
+ * ScmapCompress<Vec<D1>>::join_test compares the label lists of two k-mers for equality; reduce returns the common list
+ * (src/compression.rs:68-98).  Only equality is used, so a dense class id per distinct list carries the same information.
+ * dbg_label_classes_dev writes class_dev[i] (u32) for every k-mer of a CSR label table -- equal lists <=> equal ids; ids
+ * are ranks in ascending order of the colour bitmask when all labels are < 64 (of a verified 64-bit hash otherwise) -- and
+ * returns the class table (id -> sorted label list) on the host, so that a node's Vec<D1> is classes[node data]. */
+typedef struct {
+    uint64_t  n_classes;
+    uint64_t* set_off;          /* [n_classes + 1] */
+    uint32_t* set_val;          /* [set_off[n_classes]] */
+    uint64_t  n_set_val;
+} dbg_label_classes;
+int  dbg_label_classes_dev(dbg_ctx* ctx, uint64_t n, const uint64_t* set_off_dev, const uint32_t* set_val_dev, uint64_t n_set_val,
+                           uint32_t* class_dev, dbg_label_classes* classes /* may be NULL */);
+void dbg_free_label_classes(dbg_label_classes* classes);
+/* compress_kmers_with_hash (src/compression.rs:588-594) on the table dbg_filter_kmers_dev left in HBM: D = the count
+ * column (CountFilter) or the class id of the label list (CountFilterSet; *classes receives the class table, may be NULL).
+ * Seed order = ascending key.  The graph is returned on the host. */
+int  dbg_compress_table_dev(dbg_ctx* ctx, uint32_t k, int stranded, int spec, const dbg_kmer_table* table_dev, dbg_graph* out,
+                            dbg_label_classes* classes);
+
 /* ---- sharded second stage: BaseGraph::combine (src/graph.rs:71-100) and compress_graph
  *      (src/compression.rs:338-349, which implies finish (graph.rs:116-142) + fix_exts (:337-377)) ---- */
 int  dbg_graph_combine(dbg_ctx* ctx, const dbg_graph* graphs, uint32_t n_graphs, dbg_graph* out);

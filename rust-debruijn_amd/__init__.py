@@ -192,6 +192,7 @@ class BaseGraph:
         self.exts = exts
         self.data = data
         self.stranded = stranded
+        self.classes = None         # class id -> label tuple when data holds label-list classes (compress_table_dev)
 
     def __len__(self):
         return len(self.sequences)
@@ -229,6 +230,7 @@ class Context:
         if r:
             raise DbgError(self.lib.dbg_last_error(None).decode())
         self.h = h
+        self.device = device
         self._opts = {}
 
     def set_option(self, name, value):
@@ -450,29 +452,70 @@ def compress_kmers_with_hash(stranded, spec, index, k=None, seed_order=None, dat
     return out
 
 
-def filter_and_compress_dev(seqs, summarizer, stranded, spec, k, ctx=None):
-    """filter_kmers (CountFilter) followed by compress_kmers_with_hash with the index kept in HBM between the two calls
-    (dbg_filter_kmers_dev -> dbg_compress_kmers_with_hash_dev); data = the count column.  -> (BaseGraph, n_valid_kmers)"""
+def upload_seqs(hs, device=0):
+    """HostSeqs -> (dbg_seqset of device pointers, tensors that must stay alive)"""
     import torch
-    ctx = ctx or default_context()
-    hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples(seqs)
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", device)
     w = torch.from_numpy(np.concatenate([hs.words, np.zeros(2, np.uint64)]).view(np.int64)).to(dev)
     st = torch.from_numpy(hs.start.view(np.int64)).to(dev)
     ln = torch.from_numpy(hs.length.view(np.int32)).to(dev)
     ex = None if hs.exts is None else torch.from_numpy(hs.exts).to(dev)
-    ss = _capi.SeqSet(w.data_ptr(), w.numel(), st.data_ptr(), ln.data_ptr(), None if ex is None else ex.data_ptr(), None, 0, len(hs.start))
-    fp = _capi.FilterParams(k, int(bool(stranded)), 0, summarizer.min_kmer_obs, 0, 4)
+    da = None if hs.data is None else torch.from_numpy(hs.data.view({1: np.uint8, 2: np.int16, 4: np.int32}[hs.data_width])).to(dev)
+    torch.cuda.synchronize(dev)
+    ss = _capi.SeqSet(w.data_ptr(), w.numel(), st.data_ptr(), ln.data_ptr(), None if ex is None else ex.data_ptr(),
+                      None if da is None else da.data_ptr(), hs.data_width if da is not None else 0, len(hs.start))
+    return ss, (w, st, ln, ex, da)
+
+
+def filter_kmers_dev(ss, summarizer, stranded, k, report_all_kmers=False, ctx=None):
+    """dbg_filter_kmers_dev: device-resident reads in, device-resident table out (a _capi.KmerTable the caller releases
+    with ctx.lib.dbg_free_table)."""
+    ctx = ctx or default_context()
+    fp = _capi.FilterParams(k, int(bool(stranded)), summarizer.kind, summarizer.min_kmer_obs, int(bool(report_all_kmers)), 4)
     t = _capi.KmerTable()
     ctx.check(ctx.lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
-    g = _capi.Graph()
+    return t
+
+
+def _classes_from_c(cl):
+    """dbg_label_classes -> [tuple of labels] indexed by class id; releases the C arrays"""
     try:
-        ctx.check(ctx.lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, int(bool(stranded)), spec.kind, t.n, t.key_hi, t.key_lo, t.exts,
-                                                           None, t.count, C.byref(g)))
+        off = _copy(cl.set_off, cl.n_classes + 1, np.uint64)
+        val = _copy(cl.set_val, cl.n_set_val, np.uint32)
+        return [tuple(int(x) for x in val[int(off[i]):int(off[i + 1])]) for i in range(int(cl.n_classes))]
+    finally:
+        _capi.load().dbg_free_label_classes(C.byref(cl))
+
+
+def compress_table_dev(stranded, spec, table_dev, k, ctx=None):
+    """compress_kmers_with_hash on a device-resident table (dbg_compress_table_dev).  CountFilter table: D = count.
+    CountFilterSet table: D = class id of the k-mer's label list (what ScmapCompress<Vec<D1>> compares); the returned
+    graph carries `classes` (class id -> label tuple) so that a node's Vec<D1> is graph.classes[graph.data[i]]."""
+    ctx = ctx or default_context()
+    g = _capi.Graph()
+    cl = _capi.LabelClasses()
+    ctx.check(ctx.lib.dbg_compress_table_dev(ctx.h, k, int(bool(stranded)), spec.kind, C.byref(table_dev), C.byref(g), C.byref(cl)))
+    out = _graph_from_c(ctx, g, k)
+    out.classes = _classes_from_c(cl) if table_dev.set_off else None
+    return out
+
+
+def filter_and_compress_dev(seqs, summarizer, stranded, spec, k, ctx=None):
+    """filter_kmers followed by compress_kmers_with_hash with the index kept in HBM between the two calls
+    (dbg_filter_kmers_dev -> dbg_compress_table_dev); data = the count column, or the label-list class for
+    CountFilterSet.  -> (BaseGraph, n_valid_kmers)"""
+    ctx = ctx or default_context()
+    hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples(seqs)
+    if summarizer.kind == 0 and hs.data is not None:
+        hs = HostSeqs(hs.words, hs.start, hs.length, hs.exts)
+    ss, keep = upload_seqs(hs, ctx.device)
+    t = filter_kmers_dev(ss, summarizer, stranded, k, ctx=ctx)
+    try:
         n = int(t.n)
+        g = compress_table_dev(stranded, spec, t, k, ctx=ctx)
     finally:
         ctx.lib.dbg_free_table(ctx.h, C.byref(t))
-    return _graph_from_c(ctx, g, k), n
+    return g, n
 
 
 def _graph_to_c(g):

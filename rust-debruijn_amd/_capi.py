@@ -45,6 +45,10 @@ class Graph(C.Structure):
                 ("data", C.c_void_p), ("stranded", C.c_int32)]
 
 
+class LabelClasses(C.Structure):
+    _fields_ = [("n_classes", C.c_uint64), ("set_off", C.c_void_p), ("set_val", C.c_void_p), ("n_set_val", C.c_uint64)]
+
+
 class Edges(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("target", C.c_void_p), ("info", C.c_void_p)]
 
@@ -69,7 +73,7 @@ EXPORTS = [
     "dbg_ctx_create", "dbg_ctx_destroy", "dbg_last_error", "dbg_version", "dbg_ctx_set_stream",
     "dbg_ctx_set_scratch_budget", "dbg_ctx_set_option", "dbg_filter_kmers", "dbg_filter_kmers_dev", "dbg_free_table", "dbg_table_to_host",
     "dbg_remove_censored_exts", "dbg_msp_sequence", "dbg_msp_sequence_dev", "dbg_free_pieces",
-    "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_free_graph", "dbg_synth_words", "dbg_synth_reads_dev",
+    "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_free_graph", "dbg_label_classes_dev", "dbg_free_label_classes", "dbg_compress_table_dev", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
@@ -120,6 +124,11 @@ def load():
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Graph)]
     lib.dbg_free_graph.argtypes = [C.c_void_p, C.POINTER(Graph)]
     lib.dbg_free_graph.restype = None
+    lib.dbg_label_classes_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(LabelClasses)]
+    lib.dbg_free_label_classes.argtypes = [C.POINTER(LabelClasses)]
+    lib.dbg_free_label_classes.restype = None
+    lib.dbg_compress_table_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(KmerTable), C.POINTER(Graph),
+                                           C.POINTER(LabelClasses)]
     lib.dbg_graph_combine.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_uint32, C.POINTER(Graph)]
     lib.dbg_compress_graph.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Graph), C.c_void_p, C.c_uint64,
                                        C.POINTER(Graph)]

@@ -79,6 +79,10 @@ int reduce_sorted_records(dbg_ctx* ctx, uint64_t n, RecArrays sorted, bool has_h
 int filter_kmers_fast(dbg_ctx* ctx, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
                       bool* used);
 
+// ---- classes.hip : label lists of a CountFilterSet table -> dense class ids ---------------------
+int label_classes_device(dbg_ctx* ctx, uint64_t n, const uint64_t* set_off_dev, const uint32_t* set_val_dev, uint64_t n_set_val,
+                         uint32_t* class_dev, dbg_label_classes* classes);
+
 // ---- synth.hip ----------------------------------------------------------------------------
 int synth_reads_dev(dbg_ctx* ctx, const dbg_synth_params* p, uint64_t* words, uint64_t* start, uint32_t* length,
                     uint8_t* data);

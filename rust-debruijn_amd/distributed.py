@@ -92,6 +92,20 @@ class HipEngine:
     def free_table(self, tab):
         self.lib.dbg_free_table(self.ctx.h, C.byref(tab))
 
+    # ---- the rank-spanning end of the pipeline (test.rs:459-470): per-shard compress, combine, compress_graph ----
+    def compress_table(self, tab, k, stranded, spec):
+        """compress_kmers_with_hash on this rank's device-resident table -> host BaseGraph (+ .classes for label sets)"""
+        from . import compress_table_dev
+        return compress_table_dev(stranded, spec, tab, k, ctx=self.ctx)
+
+    def combine(self, graphs):
+        from . import combine_graphs
+        return combine_graphs(graphs, ctx=self.ctx)
+
+    def compress_graph(self, stranded, spec, graph):
+        from . import compress_graph
+        return compress_graph(stranded, spec, graph, ctx=self.ctx)
+
 
 def owner_bounds(n_bins, world, group=1):
     """rank r owns bins [bounds[r], bounds[r+1]); boundaries are multiples of `group` (a bin's length
@@ -122,81 +136,126 @@ def chunk_bounds(n_local_bins, n_chunks, group=1):
     return [(c * (n_local_bins // group) // n_chunks) * group for c in range(n_chunks + 1)]
 
 
-def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n_chunks=None):
-    """All-to-all of bin-ordered super-k-mer slabs, then count the owned bins.  Works for any
-    world size (including 1) and any torch.distributed backend that implements all_to_all_single.
+def exchange_geometry(n_bins, world, grp=1, n_chunks=None, force=False):
+    """Ownership and pipeline cuts of the exchange, from globally known values only (every rank computes the same):
+    bounds[r]..bounds[r+1] = bins rank r owns; the owned range of every rank is cut into the same number of chunks
+    (cuts[d][c] relative to bounds[d]); chunk c of all destinations travels in exchange round c."""
+    bounds = owner_bounds(n_bins, world, grp)
+    if n_chunks is None:
+        n_chunks = 4
+    n_chunks = max(1, min(n_chunks, max(min(bounds[d + 1] - bounds[d] for d in range(world)) // grp, 1)))
+    if world == 1 and not force:
+        n_chunks = 1
+    cuts = [chunk_bounds(bounds[d + 1] - bounds[d], n_chunks, grp) for d in range(world)]
+    return bounds, n_chunks, cuts
 
+
+def send_layout(bin_off, bounds, cuts, n_chunks):
+    """Record offsets for the scatter such that everything exchange round c sends is ONE contiguous range, ordered by
+    destination: layout order = (chunk, destination, bin).  The all-to-all of round c then reads straight from the
+    scattered buffer with per-destination split sizes -- no gather copy of the send data.
+    -> (per-bin offsets [n_bins + 1 entries, last = total], round edges [n_chunks + 1], in-round splits [c][d])"""
+    import torch
+    world = len(bounds) - 1
+    hist = (bin_off[1:] - bin_off[:-1]).to(torch.int64)
+    order = []
+    for c in range(n_chunks):
+        for d in range(world):
+            order.append(torch.arange(bounds[d] + cuts[d][c], bounds[d] + cuts[d][c + 1], device=hist.device))
+    perm = torch.cat(order) if order else torch.zeros(0, dtype=torch.int64, device=hist.device)
+    csum = torch.zeros(len(perm) + 1, dtype=torch.int64, device=hist.device)
+    csum[1:] = torch.cumsum(hist[perm], 0)
+    off = torch.zeros(len(hist) + 1, dtype=torch.int64, device=hist.device)
+    off[perm] = csum[:-1]
+    off[-1] = csum[-1]
+    # edges of the (chunk, destination) blocks in the permuted order
+    sizes = [cuts[d][c + 1] - cuts[d][c] for c in range(n_chunks) for d in range(world)]
+    pos = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    edges = csum[torch.from_numpy(pos).to(csum.device)].tolist()
+    round_edge = [edges[c * world] for c in range(n_chunks)] + [edges[-1]]
+    splits = [[edges[c * world + d + 1] - edges[c * world + d] for d in range(world)] for c in range(n_chunks)]
+    return off, round_edge, splits
+
+
+def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n_chunks=None, layout=None, stats=None, force=False):
+    """All-to-all of super-k-mer records, then count the owned bins.  Works for any world size (including 1) and any
+    torch.distributed backend that implements all_to_all_single.
+
+    bin_off = natural per-bin record offsets of the local scan (only its differences -- records per bin -- are used);
+    recs = the records laid out by send_layout (layout = its result; None: natural bin order, world 1 only).
     The owned bin range of every rank is cut into n_chunks ranges; the records of range c+1 are exchanged
     (asynchronous all-to-all) while range c is being counted, and the table is sorted once at the end."""
+    import time
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     rw = plan.rec_words
     grp = getattr(plan, "bin_group", 1) or 1
-    bounds = owner_bounds(plan.n_bins, world, grp)
+    force = force and dist.is_initialized()          # force: take the collective route even at world size 1 (a functional check)
+    bounds, n_chunks, cuts = exchange_geometry(plan.n_bins, world, grp, n_chunks, force)
     nb_local = bounds[rank + 1] - bounds[rank]
     hint = max(n_local_kmers, 1)
     hist = (bin_off[1:] - bin_off[:-1]).contiguous()                         # records per bin (local reads)
-    if world == 1:
+    if stats is not None:
+        stats.update(exchange_bytes_sent=0, exchange_exposed_ms=0.0, exchange_rounds=n_chunks if (world > 1 or force) else 0)
+    if world == 1 and not force:
         seg_off = torch.zeros(1, nb_local + 1, dtype=torch.int64, device=hist.device)
         seg_off[0, 1:] = torch.cumsum(hist.to(torch.int64), 0)
         engine.sync()
         engine.count_begin(plan, hint)
         engine.count_bins(plan, recs, seg_off, 1, nb_local, hint)
         return engine.count_finish(plan)
-    if n_chunks is None:
-        n_chunks = 4
-    # the number of exchange rounds and every cut must be the same on all ranks: derive them from the smallest owned range
-    n_chunks = max(1, min(n_chunks, max(min(bounds[d + 1] - bounds[d] for d in range(world)) // grp, 1)))
+    if layout is None:
+        raise ValueError("the collective route needs the records in send_layout order")
+    _, round_edge, splits = layout
     # 1) per-bin record counts of my bins from every source rank
     recv_hist = torch.empty(world * nb_local, dtype=hist.dtype, device=hist.device)
     _all_to_all(recv_hist, hist, [nb_local] * world, [bounds[d + 1] - bounds[d] for d in range(world)], group)
     recv_hist = recv_hist.view(world, nb_local).to(torch.int64)
-    # 2) chunk geometry.  Chunk c of destination d = d's owned bins [cb_d[c], cb_d[c+1]); every rank computes the same cuts.
-    cuts = [chunk_bounds(bounds[d + 1] - bounds[d], n_chunks, grp) for d in range(world)]
-    gidx = torch.tensor([[bounds[d] + cuts[d][c] for c in range(n_chunks + 1)] for d in range(world)], device=bin_off.device)
-    send_edge = bin_off[gidx].tolist()                                       # [d][c] record offset in my bin-ordered `recs`
     my = cuts[rank]
     csum = torch.zeros(world, nb_local + 1, dtype=torch.int64, device=recv_hist.device)
     csum[:, 1:] = torch.cumsum(recv_hist, dim=1)
     recv_edge = csum[:, torch.tensor(my, device=csum.device)].tolist()       # [s][c] records source s holds before my chunk c
 
     def launch(c):
-        """start the exchange of chunk c; returns (work, recv tensor, per-source record counts)"""
-        parts = [recs[send_edge[d][c] * rw: send_edge[d][c + 1] * rw] for d in range(world)]
-        send = torch.cat(parts) if sum(p.numel() for p in parts) else torch.zeros(0, dtype=recs.dtype, device=recs.device)
-        in_split = [p.numel() for p in parts]
+        """start exchange round c straight from the scattered buffer; returns (work, recv tensor, per-source record counts)"""
+        send = recs[round_edge[c] * rw: round_edge[c + 1] * rw]
+        in_split = [x * rw for x in splits[c]]
         cnt = [recv_edge[s][c + 1] - recv_edge[s][c] for s in range(world)]
         recv = torch.empty(max(sum(cnt) * rw, 1), dtype=recs.dtype, device=recs.device)
         work = _all_to_all(recv[:sum(cnt) * rw], send, [x * rw for x in cnt], in_split, group, async_op=True)
-        return work, recv, cnt, send
+        if stats is not None:
+            stats["exchange_bytes_sent"] += (sum(in_split) - in_split[rank]) * 8
+        return work, recv, cnt
 
     engine.sync()
     engine.count_begin(plan, hint)
     pending = launch(0)
     for c in range(n_chunks):
-        work, recv, cnt, send = pending
+        work, recv, cnt = pending
+        t0 = time.perf_counter()
         work.wait()
         engine.sync()                                                        # chunk c is complete in device memory
+        if stats is not None:
+            stats["exchange_exposed_ms"] += (time.perf_counter() - t0) * 1e3  # time the counting kernels could not hide
         if c + 1 < n_chunks:
             pending = launch(c + 1)                                          # goes on the wire while chunk c is counted
         lo, hi = my[c], my[c + 1]
         # segment table of the chunk: records of its bin b from source s = [seg[s, b], seg[s, b+1])
         seg = csum[:, lo:hi + 1] - csum[:, lo:lo + 1]
         base = torch.zeros(world, dtype=torch.int64, device=seg.device)
-        if world > 1:
-            base[1:] = torch.cumsum(torch.tensor(cnt[:-1], dtype=torch.int64, device=seg.device), 0)
+        base[1:] = torch.cumsum(torch.tensor(cnt[:-1], dtype=torch.int64, device=seg.device), 0)
         seg = (seg + base[:, None]).contiguous()
         engine.sync()
         engine.count_bins(plan, recv, seg, world, hi - lo, hint // n_chunks)
-        del send
     return engine.count_finish(plan)
 
 
-def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None, n_chunks=None):
+def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None, n_chunks=None, stats=None, force_exchange=False):
     """Distributed filter_kmers: returns this rank's table (the valid k-mers of the bins it owns,
-    ascending by key) and the global k-mer instance count."""
+    ascending by key) and the global k-mer instance count.  stats (a dict, optional) receives the exchange volume and the
+    exchange time the counting kernels could not hide."""
     import torch
     import torch.distributed as dist
     engine.sync()                                  # the reads may still be in flight on torch's current stream
@@ -208,6 +267,152 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
         total = int(t.item())
     plan = engine.plan(k, stranded, summarizer_kind, min_obs, total)
     bin_off, n_recs = engine.scan(ss, plan)
-    recs = engine.scatter(plan, bin_off, n_recs)
-    tab = exchange_and_count(engine, plan, bin_off, recs, n_local, group, n_chunks)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    layout = None
+    force = force_exchange and dist.is_initialized()
+    if world > 1 or force:
+        bounds, nch, cuts = exchange_geometry(plan.n_bins, world, getattr(plan, "bin_group", 1) or 1, n_chunks, force)
+        layout = send_layout(bin_off, bounds, cuts, nch)
+    recs = engine.scatter(plan, layout[0] if layout else bin_off, n_recs)
+    tab = exchange_and_count(engine, plan, bin_off, recs, n_local, group, n_chunks, layout, stats, force)
     return tab, total, n_local, n_recs
+
+
+# ------------------------------------------------------------------------------------------------
+# Rank-spanning end of the pipeline.  The reference's sharded flow ends with per-shard compress_kmers_with_hash,
+# BaseGraph::combine over the shard graphs and compress_graph across the shard boundaries
+# (src/test.rs:459-470, src/graph.rs:71-100, src/compression.rs:291-349).  Here a shard = the bins a rank owns.
+# ------------------------------------------------------------------------------------------------
+def unify_classes(class_tables):
+    """Per-rank label-list class tables (lists of label tuples, rank-local ids) -> (global table, one remap array per
+    rank).  Global ids are ranks in the sorted order of the distinct label tuples, so every rank -- and a checker --
+    arrives at the same ids without looking at the k-mers."""
+    glob = sorted(set(t for tab in class_tables for t in tab))
+    pos = {t: i for i, t in enumerate(glob)}
+    return glob, [np.array([pos[t] for t in tab], dtype=np.uint32) for tab in class_tables]
+
+
+def _graph_payload(g):
+    a = g.arrays()
+    return dict(k=g.k, stranded=g.stranded, n_bases=a["n_bases"], classes=g.classes,
+                **{n: np.ascontiguousarray(a[n]) for n in ("words", "start", "length", "exts", "data")})
+
+
+def _graph_from_payload(p):
+    from . import BaseGraph, PackedDnaStringSet
+    g = BaseGraph(p["k"], PackedDnaStringSet(p["words"], p["start"], p["length"], p["n_bases"]), p["exts"], p["data"], p["stranded"])
+    g.classes = p["classes"]
+    return g
+
+
+def _gather_payloads(payload, dst, group):
+    """every rank's graph arrays to rank dst: sizes by all_gather_object, the arrays as point-to-point tensor transfers
+    (device tensors with the nccl backend = RCCL over xGMI, host tensors with gloo)"""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    names = ("words", "start", "length", "exts", "data")
+    meta = {n: (payload[n].dtype.str, len(payload[n])) for n in names}
+    small = {k_: v for k_, v in payload.items() if k_ not in names}
+    metas = [None] * world
+    dist.all_gather_object(metas, (meta, small), group=group)
+    on_dev = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_dev else torch.device("cpu")
+    if rank != dst:
+        reqs = []
+        for n in names:
+            if len(payload[n]):
+                t = torch.from_numpy(payload[n].view(np.uint8)).to(dev)
+                reqs.append(dist.isend(t, dist.get_global_rank(group, dst) if group is not None else dst, group=group))
+        for r in reqs:
+            r.wait()
+        return None
+    out = []
+    for src in range(world):
+        m, sm = metas[src]
+        if src == rank:
+            out.append(payload)
+            continue
+        p = dict(sm)
+        for n in names:
+            dt, ln = np.dtype(m[n][0]), m[n][1]
+            if ln:
+                t = torch.empty(ln * dt.itemsize, dtype=torch.uint8, device=dev)
+                dist.recv(t, dist.get_global_rank(group, src) if group is not None else src, group=group)
+                p[n] = t.cpu().numpy().view(dt).copy()
+            else:
+                p[n] = np.zeros(0, dt)
+        out.append(p)
+    return out
+
+
+def second_stage(engine, graphs, stranded, spec):
+    """BaseGraph::combine + compress_graph over per-shard graphs (test.rs:468-470); label-list classes are first brought
+    to one global numbering.  -> the final graph (classes attached when the data are label-list classes)."""
+    glob = None
+    if graphs and graphs[0].classes is not None:
+        glob, remaps = unify_classes([g.classes for g in graphs])
+        for g, m in zip(graphs, remaps):
+            g.data = m[np.asarray(g.data, dtype=np.int64)] if len(g.data) else np.zeros(0, np.uint32)
+    out = engine.compress_graph(stranded, spec, engine.combine(graphs))
+    out.classes = glob
+    return out
+
+
+def sharded_compress(engine, tab, k, stranded, spec, group=None, dst=0, second_spec=None):
+    """The compress stage of the sharded pipeline: every rank compresses the table of the bins it owns
+    (compress_kmers_with_hash, index resident in HBM), the per-rank unitig graphs travel to rank `dst`, which runs
+    BaseGraph::combine + compress_graph across the shard boundaries.  Returns (final graph on dst / None elsewhere,
+    this rank's own shard graph)."""
+    import torch.distributed as dist
+    local = engine.compress_table(tab, k, stranded, spec)
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return second_stage(engine, [local], stranded, second_spec or spec), local
+    rank = dist.get_rank(group)
+    payloads = _gather_payloads(_graph_payload(local), dst, group)
+    if rank != dst:
+        return None, local
+    graphs = [_graph_from_payload(p) for p in payloads]
+    return second_stage(engine, graphs, stranded, second_spec or spec), local
+
+
+# ------------------------------------------------------------------------------------------------
+# Order-independent digest of a device-resident table: a sum over rows of a hash of (key, Exts, count | label list).
+# Every k-mer lives on exactly one rank, so the per-rank digests of a sharded run add up (mod 2^64) to the digest of
+# the single-GPU table over the same reads -- a whole-table comparison that needs no gather.
+# ------------------------------------------------------------------------------------------------
+class _DevArray:
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _dev_tensor(ptr, n, typestr, device):
+    import torch
+    if not ptr or n == 0:
+        return torch.zeros(0, dtype={"<i8": torch.int64, "<i4": torch.int32, "<i2": torch.int16, "|u1": torch.uint8}[typestr], device=device)
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
+
+
+def _mix(x, c):
+    x = x * c
+    return x ^ (x >> 29)
+
+
+def table_digest(tab, device):
+    """tab: _capi.KmerTable with device pointers -> python int in [0, 2^64)"""
+    import torch
+    n = int(tab.n)
+    lo = _dev_tensor(tab.key_lo, n, "<i8", device)
+    hi = _dev_tensor(tab.key_hi, n, "<i8", device)
+    ex = _dev_tensor(tab.exts, n, "|u1", device).to(torch.int64)
+    row = _mix(lo, -7046029254386353131) + _mix(hi + 1, -4417276706812531889) + _mix(ex + 5, 1609587929392839161)
+    if tab.count:
+        cnt = _dev_tensor(tab.count, n, "<i2", device).to(torch.int64) & 0xFFFF
+        row = row + _mix(cnt + 11, -3750763034362895579)
+    d = int(row.sum().item()) if n else 0
+    if tab.set_off and n:
+        off = _dev_tensor(tab.set_off, n + 1, "<i8", device)
+        val = _dev_tensor(tab.set_val, int(tab.n_set_val), "<i4", device).to(torch.int64)
+        owner = torch.repeat_interleave(_mix(lo, 6364136223846793005) + hi, off[1:] - off[:-1])
+        d += int(_mix(owner + (val + 1) * 1442695040888963407, -7046029254386353131).sum().item())
+    return d & ((1 << 64) - 1)

@@ -54,8 +54,15 @@ class OracleEngine:
         return torch.from_numpy(bin_off), len(rows)
 
     def scatter(self, plan, bin_off, n_recs):
+        """records of bin b go to [bin_off[b], bin_off[b] + count_b): any layout the caller asks for"""
+        off = bin_off.numpy()
         order = np.argsort(self._bins, kind="stable")
-        return torch.from_numpy(self._rows[order].astype(np.int64).reshape(-1))
+        sb = self._bins[order]
+        first = np.searchsorted(sb, sb, side="left")                 # position of each record's bin in the sorted run
+        dest = off[sb] + (np.arange(len(sb)) - first)
+        out = np.zeros((len(sb), RW), dtype=np.uint64)
+        out[dest] = self._rows[order]
+        return torch.from_numpy(out.astype(np.int64).reshape(-1))
 
     # chunked form used by the pipelined exchange
     def sync(self):
@@ -107,3 +114,37 @@ class OracleEngine:
         ss = O.SeqSet.from_byte_seqs(seqs, exts=exts, data=data if plan.summarizer == O.COUNT_FILTER_SET else None,
                                      sizeof_d1=1)
         return O.filter_kmers(ss, plan.k, plan.summarizer, plan.min_kmer_obs, stranded=plan.stranded)
+
+    # ---- rank-spanning compress stage (distributed.sharded_compress) with the oracle as the engine ----
+    @staticmethod
+    def _to_base_graph(og, k, stranded, classes=None):
+        from pkg import dbg
+        a = og.arrays()
+        g = dbg.BaseGraph(k, dbg.PackedDnaStringSet(a["words"][:a["n_words"]], a["start"], a["length"], a["n_bases"]), a["exts"], a["data"],
+                          stranded)
+        g.classes = classes
+        return g
+
+    @staticmethod
+    def _to_oracle_graph(g):
+        a = g.arrays()
+        return O.graph_from_arrays(g.k, g.stranded, np.concatenate([a["words"], np.zeros(2, np.uint64)]), a["start"], a["length"],
+                                   a["exts"], a["data"])
+
+    def compress_table(self, tab, k, stranded, spec):
+        classes, data = None, tab.count
+        if spec.kind == O.SPEC_SCMAP_EQ:                       # label lists -> rank-local class ids (any injective numbering)
+            sets = [tuple(int(x) for x in tab.set_val[int(tab.set_off[i]):int(tab.set_off[i + 1])]) for i in range(tab.n)]
+            classes = sorted(set(sets), reverse=True)          # deliberately NOT the product's order: ids are rank-local
+            pos = {t: i for i, t in enumerate(classes)}
+            data = np.array([pos[t] for t in sets], dtype=np.uint32)
+        og = O.compress_kmers(k, stranded, spec.kind, tab.key_hi, tab.key_lo, tab.exts, data)
+        return self._to_base_graph(og, k, stranded, classes)
+
+    def combine(self, graphs):
+        og = O.graph_combine([self._to_oracle_graph(g) for g in graphs])
+        return self._to_base_graph(og, graphs[0].k, graphs[0].stranded)
+
+    def compress_graph(self, stranded, spec, graph):
+        og = self._to_oracle_graph(graph).finish().compress_graph(stranded, spec.kind)
+        return self._to_base_graph(og, graph.k, stranded)

@@ -72,3 +72,71 @@ def test_sharded_counting_gloo_world2(tmp_path, kind, stranded, chunks, n_bins):
             assert v == [int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]]
         else:
             assert v == int(want.count[i])
+
+
+def _compress_worker(rank, world, port, kind, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib
+    import oracle_lib as O
+    from oracle_engine import OracleEngine
+    dbg = importlib.import_module("rust-debruijn_amd")
+    D = importlib.import_module("rust-debruijn_amd.distributed")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = N_READS // world
+    k = 51 if kind == 1 else 47
+    hs = dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005,
+                              stranded=False, n_colours=3, first_read=rank * per)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
+    eng = OracleEngine()
+    tab, total, n_local, n_recs = D.sharded_filter_kmers(eng, ss, k, False, kind, 2)
+    spec = dbg.ScmapCompress() if kind == 1 else dbg.SimpleCompress("saturating_add")
+    final, local = D.sharded_compress(eng, tab, k, False, spec, dst=0, second_spec=spec if kind == 1 else dbg.SimpleCompress("max"))
+    res = dict(local=D._graph_payload(local), tab=dict(key_hi=tab.key_hi, key_lo=tab.key_lo, exts=tab.exts, count=tab.count,
+                                                       set_off=tab.set_off, set_val=tab.set_val))
+    if rank == 0:
+        assert final is not None
+        res["final"] = D._graph_payload(final)
+    else:
+        assert final is None
+    pickle.dump(res, open(os.path.join(out_dir, "crank%d.pkl" % rank), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_sharded_compress_gloo_world2(tmp_path, kind):
+    """The rank-spanning end of the pipeline (test.rs:459-470) over gloo, world size 2: per-rank compress of the owned bins,
+    graphs gathered on rank 0, BaseGraph::combine + compress_graph there.  kind 1 = the config-5 shape: k = 51,
+    CountFilterSet labels -> rank-local classes -> ScmapCompress, classes unified before the second stage.  The result must
+    be what the same flow gives when it is run in one process straight on the oracle."""
+    import importlib
+    import oracle_lib as O
+    from graph_canon import graphs_equal
+    O.build()
+    D = importlib.import_module("rust-debruijn_amd.distributed")
+    port = 29900 + kind + (os.getpid() % 90)
+    mp.spawn(_compress_worker, args=(WORLD, port, kind, str(tmp_path)), nprocs=WORLD, join=True)
+    parts = [pickle.load(open(tmp_path / ("crank%d.pkl" % r), "rb")) for r in range(WORLD)]
+    k = 51 if kind == 1 else 47
+    # the same flow, single process: per-rank tables -> compress_kmers -> combine -> compress_graph
+    glob = sorted(set(tuple(int(x) for x in p["tab"]["set_val"][int(p["tab"]["set_off"][i]):int(p["tab"]["set_off"][i + 1])])
+                      for p in parts for i in range(len(p["tab"]["key_lo"])))) if kind == 1 else None
+    shard_graphs = []
+    for p in parts:
+        t = p["tab"]
+        if kind == 1:
+            pos = {s: i for i, s in enumerate(glob)}
+            data = np.array([pos[tuple(int(x) for x in t["set_val"][int(t["set_off"][i]):int(t["set_off"][i + 1])])] for i in range(len(t["key_lo"]))],
+                            dtype=np.uint32)
+        else:
+            data = t["count"]
+        shard_graphs.append(O.compress_kmers(k, False, O.SPEC_SCMAP_EQ if kind == 1 else O.SPEC_SAT_ADD, t["key_hi"], t["key_lo"], t["exts"], data))
+    want = O.graph_combine(shard_graphs).finish().compress_graph(False, O.SPEC_SCMAP_EQ if kind == 1 else O.SPEC_MAX)
+    got = parts[0]["final"]
+    assert graphs_equal(got, want.arrays())
+    if kind == 1:
+        assert got["classes"] == glob and len(glob) > 1
+    assert len(got["start"]) < sum(len(p["local"]["start"]) for p in parts)     # the second stage joined unitigs across shards

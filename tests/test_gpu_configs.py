@@ -1,0 +1,155 @@
+"""GPU: the BASELINE configurations that are a pipeline rather than one call, at sizes the CPU oracle finishes in seconds
+("scaled-down variants (/100) of every config are the CI-sized versions"), bit-exact.
+
+config 3 / 100   10^6 reads x 150 bp, G = 5*10^6, e = 0.001, k = 47, non-stranded: CountFilter(2) -> compress_kmers_with_hash
+                 with the index kept in HBM; literal BaseGraph equality with the oracle; and, with remove_censored_exts between
+                 the two (the stage real pipelines run there, filter.rs:233-306), is_compressed == None (test.rs:248-254).
+config 5 shape   k = 51, CountFilterSet<u8> -> label-list class -> ScmapCompress per rank (2 virtual ranks own the bins), then
+                 BaseGraph::combine + compress_graph across the shard boundaries (test.rs:459-470, compression.rs:68-98).
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from graph_canon import graphs_equal
+from pkg import dbg, capi
+from virtual_ranks import owner_tables
+
+pytestmark = pytest.mark.gpu
+D = importlib.import_module("rust-debruijn_amd.distributed")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = dbg.Context(0)
+    old = c.set_option("DBG_COMPRESS", "device")          # fail instead of falling back to the literal host walk
+    yield c
+    c.set_option("DBG_COMPRESS", old)
+    c.close()
+
+
+def table_to_host(ctx, tab, k):
+    h = capi.KmerTable()
+    ctx.check(ctx.lib.dbg_table_to_host(ctx.h, C.byref(tab), C.byref(h)))
+    out = dbg._table_from_c(h, k)
+    ctx.lib.dbg_free_table(None, C.byref(h))
+    return out
+
+
+def test_config3_div100_bit_exact(ctx):
+    k, n_reads = 47, 1_000_000
+    hs = dbg.synth_reads_host(n_reads=n_reads, read_len=150, genome_len=5_000_000, error_rate=0.001, stranded=False, n_colours=0)
+    ss, keep = dbg.upload_seqs(hs, 0)
+    t = dbg.filter_kmers_dev(ss, dbg.CountFilter(2), False, k, ctx=ctx)
+    try:
+        spec = dbg.SimpleCompress("saturating_add")
+        got = dbg.compress_table_dev(False, spec, t, k, ctx=ctx)
+        th = table_to_host(ctx, t, k)
+        # the oracle's table from the same reads (about 15 s of single-thread CPU work), then its compress_kmers
+        want_t = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, None, 0), k, O.COUNT_FILTER, 2, stranded=False)
+        assert th.n_kmer_instances == n_reads * 104 and len(th) == want_t.n > 4_000_000
+        assert np.array_equal(th.key_hi, want_t.key_hi) and np.array_equal(th.key_lo, want_t.key_lo)
+        assert np.array_equal(th.exts, want_t.exts) and np.array_equal(th.count, want_t.count)
+        want = O.compress_kmers(k, False, O.SPEC_SAT_ADD, want_t.key_hi, want_t.key_lo, want_t.exts, want_t.count)
+        assert len(got) == len(want) > 50_000
+        assert graphs_equal(got.arrays(), want.arrays()), "config 3 / 100: BaseGraph differs from the oracle"
+        # with the censored extensions removed the compressed graph has no unbranched edge left (test.rs:248-254)
+        ctx.check(ctx.lib.dbg_remove_censored_exts(ctx.h, k, 0, C.byref(t), 0))
+        got2 = dbg.compress_table_dev(False, spec, t, k, ctx=ctx)
+        ex2 = O.remove_censored_exts(k, False, want_t.key_hi, want_t.key_lo, want_t.exts)
+        assert np.array_equal(table_to_host(ctx, t, k).exts, ex2) and not np.array_equal(ex2, want_t.exts)
+        want2 = O.compress_kmers(k, False, O.SPEC_SAT_ADD, want_t.key_hi, want_t.key_lo, ex2, want_t.count)
+        assert graphs_equal(got2.arrays(), want2.arrays())
+        assert want2.is_compressed(O.SPEC_SAT_ADD) is None
+        assert len(got2) < len(got)
+    finally:
+        ctx.lib.dbg_free_table(ctx.h, C.byref(t))
+
+
+def label_sets(t):
+    return [tuple(int(x) for x in t.set_val[int(t.set_off[i]):int(t.set_off[i + 1])]) for i in range(len(t))]
+
+
+@pytest.mark.parametrize("world,n_reads,colours", [(2, 40000, 4), (3, 9000, 7)])
+def test_config5_shape(ctx, world, n_reads, colours):
+    k = 51
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    per = n_reads // world
+    host = [dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.001, stranded=False,
+                                 n_colours=colours, first_read=r * per) for r in range(world)]
+    tabs, total = owner_tables(eng, host, k, False, 1, 2)
+    spec = dbg.ScmapCompress()
+    try:
+        shard_graphs = [eng.compress_table(t, k, False, spec) for t in tabs]
+        host_tabs = [table_to_host(ctx, t, k) for t in tabs]
+    finally:
+        for t in tabs:
+            eng.free_table(t)
+    # the union of the owners' tables is filter_kmers(CountFilterSet(2)) over all reads
+    hs_all = dbg.synth_reads_host(n_reads=per * world, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.001, stranded=False,
+                                  n_colours=colours)
+    want_t = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data, 1), k, O.COUNT_FILTER_SET, 2, stranded=False)
+    merged = {}
+    for t in host_tabs:
+        for key, e, s in zip(t.keys(), t.exts, label_sets(t)):
+            assert key not in merged
+            merged[key] = (int(e), s)
+    ws = label_sets(want_t)
+    assert sorted(merged) == want_t.keys() and all(merged[key] == (int(want_t.exts[i]), ws[i]) for i, key in enumerate(want_t.keys()))
+    # per-rank classes are rank-local and complete; equal label lists <=> equal ids
+    for g, t in zip(shard_graphs, host_tabs):
+        assert g.classes == sorted(set(label_sets(t)), key=lambda s: sum(1 << v for v in s))
+    got = D.second_stage(eng, shard_graphs, False, spec)
+    # the oracle's same flow (test.rs:459-470) on the same per-rank tables, classes in the global numbering
+    glob = sorted(set(s for t in host_tabs for s in label_sets(t)))
+    pos = {s: i for i, s in enumerate(glob)}
+    o_shards = []
+    for t, g in zip(host_tabs, shard_graphs):
+        data = np.array([pos[s] for s in label_sets(t)], dtype=np.uint32)
+        og = O.compress_kmers(k, False, O.SPEC_SCMAP_EQ, t.key_hi, t.key_lo, t.exts, data)
+        assert graphs_equal(g.arrays(), og.arrays()), "per-rank ScmapCompress graph differs from the oracle"   # g.data was remapped by second_stage
+        o_shards.append(og)
+    want = O.graph_combine(o_shards).finish().compress_graph(False, O.SPEC_SCMAP_EQ)
+    assert got.classes == glob and len(glob) >= colours
+    assert graphs_equal(got.arrays(), want.arrays()), "config 5 shape: combine + compress_graph differs from the oracle"
+    assert len(got) < sum(len(g) for g in shard_graphs)
+    # every node's k-mers share the node's label list (ScmapCompress::reduce never saw unequal data)
+    a = got.arrays()
+    lut = {key: s for t in host_tabs for key, s in zip(t.keys(), label_sets(t))}
+    import refgen as R
+    for i in np.random.default_rng(1).choice(len(got), size=min(200, len(got)), replace=False):
+        b = O.unpack_bases(a["words"], int(a["start"][i]), int(a["length"][i]))
+        for v in R.kmers_of(b, k):
+            assert lut[R.canon(k, v)] == glob[int(a["data"][i])]
+
+
+@pytest.mark.parametrize("labels", [[0, 1, 2, 3], [5, 40, 63], [3, 64, 200, 70000, 1 << 23]])
+def test_label_classes(ctx, labels):
+    """dbg_label_classes_dev on hand-made CSR label tables: labels < 64 take the exact bitmask key, larger ones the verified
+    hash; equal lists <=> equal ids; the class table returns every list once."""
+    rng = np.random.default_rng(len(labels))
+    n = 5000
+    sets = []
+    for i in range(n):
+        m = int(rng.integers(1, 1 << len(labels)))
+        sets.append(tuple(l for j, l in enumerate(labels) if (m >> j) & 1))
+    sets[7] = ()                                                  # an empty list is a class of its own
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in sets], dtype=np.uint64)
+    val = np.array([v for s in sets for v in s], dtype=np.uint32)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    d_val = torch.from_numpy(val.view(np.int32)).cuda()
+    d_cls = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    cl = capi.LabelClasses()
+    ctx.check(ctx.lib.dbg_label_classes_dev(ctx.h, n, d_off.data_ptr(), d_val.data_ptr(), len(val), d_cls.data_ptr(), C.byref(cl)))
+    classes = dbg._classes_from_c(cl)
+    ids = d_cls.cpu().numpy()
+    assert sorted(classes) == sorted(set(sets)) and len(set(classes)) == len(classes)
+    assert all(classes[ids[i]] == sets[i] for i in range(n))
+    if max(labels) < 64:
+        assert classes == sorted(classes, key=lambda s: sum(1 << v for v in s))     # ids = ranks of the colour bitmask

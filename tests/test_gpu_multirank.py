@@ -15,3 +15,47 @@ def test_bench_multirank_one_gpu():
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "check_multirank.sh"), "300000"], cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "multirank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_collective_route_world1_nccl():
+    """The RCCL calls of the N > 1 path (all_to_all_single with split sizes, asynchronous, pipelined in rounds) on the one GPU
+    of the test box: a 1-rank nccl process group, the exchange route forced.  Same table digest as the plain call."""
+    import json
+    def run(extra):
+        r = subprocess.run(["python", "bench.py", "--reads", "400000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                            "--compress-reads", "0", "--digest"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = run([]), run(["--force-exchange", "--backend", "nccl"])
+    assert a["table_digest"] == b["table_digest"] and a["config"]["valid_kmers_all_ranks"] == b["config"]["valid_kmers_all_ranks"]
+    assert b["config"]["path"].startswith("fast")
+
+
+def test_two_gpus_nccl():
+    """Real multi-GPU run (skips on a one-GPU box): 2 ranks, nccl = RCCL over xGMI; per-rank tables add up to the single-GPU
+    table, and the rank-spanning compress stage gives the single-process result."""
+    import json
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    def run(extra, reads):
+        r = subprocess.run(["python", "bench.py", "--reads", str(reads), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                            "--compress-reads", "0", "--digest"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    a, b = run([], 600000), run(["--gpus", "2"], 300000)
+    assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["backend"] == "nccl"
+    assert a["table_digest"] == b["table_digest"] and a["config"]["valid_kmers_all_ranks"] == b["config"]["valid_kmers_all_ranks"]
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29733", os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "nccl"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sharded_compress_two_ranks_one_gpu():
+    """distributed.sharded_compress with the product engine: 2 ranks share cuda:0 (gloo), per-rank compress of the owned bins,
+    graphs gathered on rank 0, combine + compress_graph; rank 0 checks the result against the oracle's same flow."""
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo", "--one-device"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
