@@ -340,11 +340,15 @@ def main():
                           "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1)} if world > 1 else None),
             "roofline": roof, "cpu_baseline": cpu, "compress": comp,
         }
-        print(json.dumps(out))
     ctx.close()
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if out is not None:
+        # after the process group is gone: RCCL writes a "Librccl path" line to stdout when it shuts down, and the JSON line
+        # is meant to be the last thing rank 0 prints
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

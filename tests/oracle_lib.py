@@ -179,6 +179,9 @@ class SeqSet:
 
 # ---------------------------------------------------------------- filter_kmers
 class Table:
+    def __len__(self):
+        return int(self.n)
+
     def key(self, i):
         return (int(self.key_hi[i]) << 64) | int(self.key_lo[i])
 

@@ -25,7 +25,7 @@ def test_collective_route_world1_nccl():
         r = subprocess.run(["python", "bench.py", "--reads", "400000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                             "--compress-reads", "0", "--digest"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     a, b = run([]), run(["--force-exchange", "--backend", "nccl"])
     assert a["table_digest"] == b["table_digest"] and a["config"]["valid_kmers_all_ranks"] == b["config"]["valid_kmers_all_ranks"]
     assert b["config"]["path"].startswith("fast")
@@ -42,7 +42,7 @@ def test_two_gpus_nccl():
         r = subprocess.run(["python", "bench.py", "--reads", str(reads), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                             "--compress-reads", "0", "--digest"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     a, b = run([], 600000), run(["--gpus", "2"], 300000)
     assert b["n_gpus"] == 2 and b["ranks_seen"] == 2 and b["backend"] == "nccl"
     assert a["table_digest"] == b["table_digest"] and a["config"]["valid_kmers_all_ranks"] == b["config"]["valid_kmers_all_ranks"]

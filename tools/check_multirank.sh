@@ -5,8 +5,8 @@
 # (keys, Exts, label lists of every row; every k-mer lives on exactly one rank).
 set -e
 R=${1:-2000000}
-one() { timeout 300 python bench.py --reads $1 --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0 --digest 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['valid_kmers_all_ranks'], d['table_digest'])"; }
-many() { timeout 600 python bench.py --gpus $1 --reads $R --steps 1 --warmup 0 --no-cpu-baseline --backend gloo --one-device --digest 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); assert d['n_gpus'] == $1 and d['ranks_seen'] == $1, d; print(d['config']['valid_kmers_all_ranks'], d['table_digest'])"; }
+one() { timeout 300 python bench.py --reads $1 --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0 --digest 2>&1 | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['valid_kmers_all_ranks'], d['table_digest'])"; }
+many() { timeout 600 python bench.py --gpus $1 --reads $R --steps 1 --warmup 0 --no-cpu-baseline --backend gloo --one-device --digest 2>&1 | grep '^{' | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); assert d['n_gpus'] == $1 and d['ranks_seen'] == $1, d; print(d['config']['valid_kmers_all_ranks'], d['table_digest'])"; }
 for W in 2 3; do
   a=$(one $((R * W))); b=$(many $W)
   echo "world $W: single-GPU valid,digest=$a  sharded=$b"
