@@ -122,18 +122,141 @@ constexpr int META_BITS = 20;
 constexpr uint32_t NCLS = 1;                    // length classes per bin: records of similar k-mer count sit together
                                                 // so that the 64 records a wave processes finish at about the same time
 
+// Pending pieces (start window, end window, minimizer hash, lane of the read in the current batch of 64) wait in a per-wave
+// LDS ring and are turned into records 64 at a time, on full wavefronts (record building is the longest code of the scan).
 // DIRECT: a record goes straight to slot atomicAdd(cursor[bin]) of its bin's fixed-capacity slab (slab_cap records per
 // bin); only the records of bins that outgrow their slab take the read-order temporary buffer and the scatter kernel.
+constexpr uint32_t PLC = 256;                   // ring slots per wave (wave-per-read kernel: 4 words per piece)
+constexpr uint32_t PLC_PACKED = 512;            // lane-per-read kernel: 2 words per piece {start | end << 11 | lane << 22, hash}
+template <int NBW, bool DIRECT, bool PACKED = false>
+struct PieceEmitter {
+    static constexpr int RW = NBW;
+    static constexpr uint32_t CAP = PACKED ? PLC_PACKED : PLC;
+    const SeqDev& s;
+    const FastCfg& c;
+    uint32_t* __restrict__ hist;
+    uint64_t* __restrict__ tmp_recs;
+    uint32_t* __restrict__ tmp_bin;
+    unsigned long long* __restrict__ tmp_cursor;
+    uint64_t tmp_cap;
+    uint32_t* __restrict__ flags;
+    uint64_t* __restrict__ slab;
+    uint32_t slab_cap;
+    uint32_t* __restrict__ cursor;
+    uint32_t* PL;                               // this wave's ring: 4 x PLC words (PACKED: 2 x PLC_PACKED)
+    uint32_t lane;
+    uint64_t lt;
+    uint64_t last_word;
+    uint32_t pl_head = 0, pl_n = 0;             // wave-uniform
+    uint64_t chunk_base = 0;                    // wave-uniform sub-allocator over reserved chunks of the temporary buffer
+    uint32_t chunk_used = SCAN_CHUNK;
+
+    // lanes with `on` append one piece each (ring order = lane order); the counters stay in scalar registers
+    __device__ __forceinline__ void push(bool on, uint32_t ps, uint32_t pe, uint32_t pa, uint32_t pr) {
+        const uint64_t em = __ballot(on);
+        if (on) {
+            const uint32_t q = (pl_head + pl_n + (uint32_t)__popcll(em & lt)) & (CAP - 1);
+            if (PACKED) { PL[q] = ps | (pe << 11) | (pr << 22); PL[CAP + q] = pa; }
+            else { PL[q] = ps; PL[CAP + q] = pe; PL[2 * CAP + q] = pa; PL[3 * CAP + q] = pr; }
+        }
+        pl_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pl_n + (uint32_t)__popcll(em)));
+    }
+
+    // v_*: metadata of the batch's reads, one read per lane (a piece's read is fetched back from the owning lane)
+    __device__ __forceinline__ void flush(uint32_t cnt, uint32_t v_m, uint64_t v_st, uint32_t v_ex, uint32_t v_d1) {
+#ifdef DBG_ABL_NO_FLUSH
+        pl_head = (pl_head + cnt) & (CAP - 1); pl_n -= cnt; return;
+#endif
+        const int k = c.k;
+        const uint32_t W = (uint32_t)(c.k - c.p + 1);
+        const uint64_t* __restrict__ w = s.words;
+        const uint32_t q = (pl_head + lane) & (CAP - 1);
+        const bool act = lane < cnt;
+        uint32_t ps, pe, pa, pr;
+        if (PACKED) {
+            const uint32_t x = PL[q];
+            ps = x & 2047u; pe = (x >> 11) & 2047u; pr = act ? x >> 22 : 0u; pa = PL[CAP + q];
+        } else {
+            ps = PL[q]; pe = PL[CAP + q]; pa = PL[2 * CAP + q]; pr = act ? PL[3 * CAP + q] : 0u;
+        }
+        const uint32_t m = __shfl(v_m, pr);
+        const uint64_t st = __shfl(v_st, pr);
+        const uint32_t sexts = __shfl(v_ex, pr), d1 = __shfl(v_d1, pr);
+        pl_head = (uint32_t)__builtin_amdgcn_readfirstlane((int)((pl_head + cnt) & (CAP - 1)));
+        pl_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pl_n - cnt));
+        uint32_t b = 0;
+        uint64_t rv[RW];
+#pragma unroll
+        for (int qq = 0; qq < RW; qq++) rv[qq] = 0;
+        if (act) {
+            const uint32_t nwin = m - (uint32_t)k + 1;
+            const uint64_t w_first = st >> 5;
+            const uint64_t* __restrict__ wr = w + w_first;
+            const uint32_t sb = (uint32_t)(st & 31);
+            const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
+            const uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
+            const uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
+            b = bin_of_hash(c, pa) * NCLS + (cls < NCLS ? cls : NCLS - 1);
+            const uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
+            const uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
+#pragma unroll
+            for (int qq = 0; qq < NBW; qq++) {
+                const uint32_t b0 = (uint32_t)qq * 32;
+                const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
+                const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
+                rv[qq] = nb ? v : 0ull;
+            }
+            rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 31u) << 15);
+        }
+        auto store_rec = [&](uint64_t* o) {
+            if (RW % 2 == 0) {
+#pragma unroll
+                for (int qq = 0; qq < RW / 2; qq++) ((ulonglong2*)o)[qq] = make_ulonglong2(rv[2 * qq], rv[2 * qq + 1]);
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < RW; qq++) o[qq] = rv[qq];
+            }
+        };
+        bool to_tmp = act;                        // lanes whose record goes to the read-order buffer
+        if (DIRECT) {
+            uint32_t r = 0;
+            if (act) r = atomicAdd(&cursor[b], 1u);
+            to_tmp = act && r >= slab_cap;
+#ifndef DBG_ABL_NO_STORE
+            if (act && !to_tmp) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
+#else
+            if (act && !to_tmp && rv[0] == 0x123456789ull) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
+#endif
+        }
+        const uint64_t tm = __ballot(to_tmp);
+        if (!tm) return;
+        const uint32_t nt = (uint32_t)__popcll(tm);
+        if (chunk_used + nt > SCAN_CHUNK) {
+            unsigned long long nb = 0;
+            if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
+            chunk_base = __shfl(nb, 0);
+            chunk_used = 0;
+        }
+        const uint64_t idx = chunk_base + chunk_used + (uint32_t)__popcll(tm & lt);
+        chunk_used += nt;
+        if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); return; }
+        if (to_tmp) {
+            atomicAdd(&hist[b], 1u);
+            store_rec(tmp_recs + idx * RW);
+            tmp_bin[idx] = b;
+        }
+    }
+};
+
+// Wave-per-read scan (reads longer than long_min bases: contigs, long reads).
 template <int NBW, bool DIRECT>
 __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
                                                       uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
                                                       unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
                                                       uint32_t* __restrict__ flags, uint64_t* __restrict__ slab,
-                                                      uint32_t slab_cap, uint32_t* __restrict__ cursor) {
-    constexpr int RW = NBW;
+                                                      uint32_t slab_cap, uint32_t* __restrict__ cursor, uint32_t long_min) {
     __shared__ uint32_t s_arr[4][SCAN_ARR];      // ordering hash of the canonical p-mer at each position of the tile
-    constexpr uint32_t PLC = 256;                // per-wave ring of pending pieces (start window, end window, minimizer position, read)
-    __shared__ uint32_t s_pl[4][4 * PLC];
+    __shared__ uint32_t s_pl[4][4 * PLC];        // per-wave ring of pending pieces
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* A = s_arr[wave];
     uint32_t* PL = s_pl[wave];
@@ -146,9 +269,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
     const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lanemask_lt();
-    uint64_t chunk_base = 0;                        // wave-uniform sub-allocator over reserved chunks
-    uint32_t chunk_used = SCAN_CHUNK;
-    uint32_t pl_head = 0, pl_n = 0;                 // pending pieces (wave-uniform)
+    PieceEmitter<NBW, DIRECT> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
 
     // 64 reads per wave iteration: their metadata arrives in three coalesced loads and is broadcast
     // lane by lane, so the per-read critical path holds a single HBM round trip (the packed words).
@@ -162,78 +283,9 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
           if (s.data) v_d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[my] : (s.data_width == 2 ? ((const uint16_t*)s.data)[my] : ((const uint32_t*)s.data)[my]);
       }
       const uint32_t nb_reads = (uint32_t)(s.n - rb < 64 ? s.n - rb : 64);
-      // Record building is long; it runs on full wavefronts: pieces of successive reads wait in the ring and
-      // are turned into records 64 at a time (the read's metadata is fetched back from the owning lane).
-      auto flush = [&](uint32_t cnt) {
-          const uint32_t q = (pl_head + lane) & (PLC - 1);
-          const bool act = lane < cnt;
-          const uint32_t ps = PL[q], pe = PL[PLC + q], pa = PL[2 * PLC + q], pr = act ? PL[3 * PLC + q] : 0u;
-          const uint32_t m = __shfl(v_m, pr);
-          const uint64_t st = __shfl(v_st, pr);
-          const uint32_t sexts = __shfl(v_ex, pr), d1 = __shfl(v_d1, pr);
-          pl_head = (pl_head + cnt) & (PLC - 1);
-          pl_n -= cnt;
-          uint32_t b = 0;
-          uint64_t rv[RW];
-#pragma unroll
-          for (int qq = 0; qq < RW; qq++) rv[qq] = 0;
-          if (act) {
-              const uint32_t nwin = m - (uint32_t)k + 1;
-              const uint64_t w_first = st >> 5;
-              const uint64_t* __restrict__ wr = w + w_first;
-              const uint32_t sb = (uint32_t)(st & 31);
-              const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
-              const uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
-              const uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
-              b = bin_of_hash(c, pa) * NCLS + (cls < NCLS ? cls : NCLS - 1);
-              const uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
-              const uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
-#pragma unroll
-              for (int qq = 0; qq < NBW; qq++) {
-                  const uint32_t b0 = (uint32_t)qq * 32;
-                  const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
-                  const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
-                  rv[qq] = nb ? v : 0ull;
-              }
-              rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 31u) << 15);
-          }
-          auto store_rec = [&](uint64_t* o) {
-              if (RW % 2 == 0) {
-#pragma unroll
-                  for (int qq = 0; qq < RW / 2; qq++) ((ulonglong2*)o)[qq] = make_ulonglong2(rv[2 * qq], rv[2 * qq + 1]);
-              } else {
-#pragma unroll
-                  for (int qq = 0; qq < RW; qq++) o[qq] = rv[qq];
-              }
-          };
-          bool to_tmp = act;                        // lanes whose record goes to the read-order buffer
-          if (DIRECT) {
-              uint32_t r = 0;
-              if (act) r = atomicAdd(&cursor[b], 1u);
-              to_tmp = act && r >= slab_cap;
-              if (act && !to_tmp) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
-          }
-          const uint64_t tm = __ballot(to_tmp);
-          if (!tm) return;
-          const uint32_t nt = (uint32_t)__popcll(tm);
-          if (chunk_used + nt > SCAN_CHUNK) {
-              unsigned long long nb = 0;
-              if (lane == 0) nb = atomicAdd(tmp_cursor, (unsigned long long)SCAN_CHUNK);
-              chunk_base = __shfl(nb, 0);
-              chunk_used = 0;
-          }
-          const uint64_t idx = chunk_base + chunk_used + (uint32_t)__popcll(tm & lt);
-          chunk_used += nt;
-          if (chunk_base + SCAN_CHUNK > tmp_cap) { if (lane == 0) atomicOr(&flags[0], 1u); return; }
-          if (to_tmp) {
-              atomicAdd(&hist[b], 1u);
-              store_rec(tmp_recs + idx * RW);
-              tmp_bin[idx] = b;
-          }
-      };
       for (uint32_t rj = 0; rj < nb_reads; rj++) {
         const uint32_t m = __shfl(v_m, rj);
-        if (m < (uint32_t)k) continue;
+        if (m < (uint32_t)k || m <= long_min) continue;     // shorter reads belong to the lane-per-read kernel
         const uint64_t st = __shfl(v_st, rj);
         const uint32_t nwin = m - (uint32_t)k + 1, npos = m - (uint32_t)p + 1;
         const uint64_t w_first = st >> 5;                                      // word holding the read's first base
@@ -354,23 +406,187 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
                     if (below) ps = t0 + slot * 64 + (63 - __clzll(below));
                     else if (slot == 1 && mask[0]) ps = t0 + (63 - __clzll(mask[0]));
                     else ps = open_start;
-                    const uint32_t q = (pl_head + pl_n + npieces + __popcll(em & lt)) & (PLC - 1);
+                    const uint32_t q = (E.pl_head + E.pl_n + npieces + __popcll(em & lt)) & (PLC - 1);
                     PL[q] = ps; PL[PLC + q] = i; PL[2 * PLC + q] = prev[slot]; PL[3 * PLC + q] = rj;
                 }
                 npieces += __popcll(em);
             }
             if (read_ends) {
-                const uint32_t q = (pl_head + pl_n + npieces) & (PLC - 1);
+                const uint32_t q = (E.pl_head + E.pl_n + npieces) & (PLC - 1);
                 if (lane == 0) { PL[q] = new_open; PL[PLC + q] = nwin; PL[2 * PLC + q] = last_arg; PL[3 * PLC + q] = rj; }
                 npieces++;
             }
-            pl_n += npieces;
-            while (pl_n >= 64) { flush(64u); }
+            E.pl_n += npieces;
+            while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);
             open_start = new_open;
             carry_arg = last_arg;
         }
       }
-      if (pl_n) flush(pl_n);                        // the lanes' read metadata changes with the next batch
+      if (E.pl_n) E.flush(E.pl_n, v_m, v_st, v_ex, v_d1);   // the lanes' read metadata changes with the next batch
+    }
+}
+
+// Lane-per-read scan (the default for reads of up to SCAN_LANE_MAX bases): a wavefront takes 64 reads, one per lane, and
+// every lane walks its own read base by base -- rolling forward and reverse-complement p-mer, ordering hash, sliding-window
+// minimum, piece boundaries -- so that all 64 lanes do useful work at every step (the wave-per-read formulation hashes 136
+// p-mer positions in 3 x 64 lane slots and runs a 5-step log-step minimum over them: about 3x the instructions per read).
+// Control flow stays wave-uniform: the window minimum is the van Herk / Gil-Werman scheme with blocks of W elements held
+// IN PLACE in (W + 1) x 64 LDS words per wave (slot j of every lane in one 256-byte row: conflict-free).  While block B is
+// scanned, slot j still holds the suffix minimum S[j] of block B-1 until element j of block B overwrites it:
+//   window ending at element e = B*W + j  =  min(S_{B-1}[j+1], prefix minimum of block B up to j)      (S[W] = +inf);
+// at the end of a block one backward pass turns the raw values into suffix minima.  4 LDS operations per element, no
+// data-dependent branches (a literal "rescan when the minimizer expires" loop would run on almost every step, because
+// among 64 lanes some minimizer nearly always expires).  Steps run in groups of four between the wave-uniform events
+// (half-word of bases used up, block complete): the four suffix minima are requested before any of the group's stores, so
+// one LDS round trip serves four steps.
+constexpr uint32_t SCAN_LANE_MAX = 1024;        // longer reads go to the wave-per-read kernel (a wave lasts as long as its longest read)
+__host__ __device__ constexpr uint32_t scan_lane_lds_words(uint32_t W) { return (W + 1) * 64 + 2 * PLC_PACKED; }
+template <int NBW, bool DIRECT>
+__global__ void __launch_bounds__(256) sk_scan_lane_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
+                                                           uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
+                                                           unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
+                                                           uint32_t* __restrict__ flags, uint64_t* __restrict__ slab,
+                                                           uint32_t slab_cap, uint32_t* __restrict__ cursor) {
+    extern __shared__ uint32_t s_dyn[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = c.k, p = c.p;
+    const uint32_t W = (uint32_t)(k - p + 1);
+    uint32_t* SV = s_dyn + wave * scan_lane_lds_words(W) + lane;    // slot j of this lane: SV[j * 64]
+    uint32_t* PL = s_dyn + wave * scan_lane_lds_words(W) + (W + 1) * 64;
+    SV[W * 64] = 0xffffffffu;                                       // S[W]: the empty suffix
+    const uint64_t* __restrict__ w = s.words;
+    const uint64_t last_word = s.n_words ? s.n_words - 1 : 0;
+    const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t lt = lanemask_lt();
+    PieceEmitter<NBW, DIRECT, true> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
+    const uint32_t pmask = (1u << (2 * p)) - 1u, top = 2u * (uint32_t)(p - 1);      // p <= 15
+    const bool stranded = c.stranded != 0;
+
+    for (uint64_t rb = gwave * 64; rb < s.n; rb += nwaves * 64) {
+        const uint64_t my = rb + lane;
+        uint32_t v_m = 0, v_ex = 0, v_d1 = 0;
+        uint64_t v_st = 0;
+        if (my < s.n) {
+            v_m = s.length[my]; v_st = s.start[my];
+            if (s.exts) v_ex = s.exts[my];
+            if (s.data) v_d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[my] : (s.data_width == 2 ? ((const uint16_t*)s.data)[my] : ((const uint32_t*)s.data)[my]);
+        }
+        uint32_t m = v_m;
+        if (m > SCAN_LANE_MAX) { atomicOr(&flags[1], 1u); m = 0; }              // left to the wave-per-read kernel
+        if (m < (uint32_t)k) m = 0;
+        const uint32_t nwin = m ? m - (uint32_t)k + 1 : 0u, npos = m ? m - (uint32_t)p + 1 : 0u;
+        uint32_t mmax = m;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mmax, d); mmax = o > mmax ? o : mmax; }
+        mmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)mmax);
+        if (mmax == 0) continue;
+        const uint64_t w_first = v_st >> 5;
+        const uint64_t* __restrict__ wr = w + w_first;
+        const uint32_t sb2 = (uint32_t)(v_st & 31) * 2u;
+        const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
+        uint64_t prev = wr[0];
+        uint32_t widx = 1;
+        uint32_t fw = 0, rc = 0, P = 0xffffffffu, cur_val = 0, ps = 0, cur = 0, lo_half = 0;
+        uint32_t j = 0;                                                           // slot of the next element (wave-uniform)
+
+        // one base: roll both strands' p-mers
+        auto roll = [&]() {
+            const uint32_t b = cur >> 30;
+            cur <<= 2;
+            fw = ((fw << 2) | b) & pmask;
+            rc = (rc >> 2) | ((3u - b) << top);
+        };
+        // element e of this lane (wave-uniform index): ordering hash of the canonical p-mer, +inf past the read's end
+        auto elem = [&](uint32_t e) -> uint32_t {
+            const uint32_t x = mix_pmer(stranded ? fw : (fw < rc ? fw : rc), p);
+            return e < npos ? x : 0xffffffffu;
+        };
+        // window sw (wave-uniform index) has minimum `out`: piece boundaries
+        auto window = [&](uint32_t sw, uint32_t out) {
+            const bool isb = sw < nwin && (sw == 0 || out != cur_val || sw - ps == W);
+            E.push(isb && sw > 0, ps, sw, cur_val, lane);                         // the boundary closes the piece that was open
+            ps = isb ? sw : ps;
+            cur_val = isb ? out : cur_val;
+        };
+
+        for (uint32_t t = 0; t < mmax;) {
+            if ((t & 31u) == 0) {                                                 // the next 32 bases of every lane's read, left-aligned
+                const uint64_t nw = wr[widx < last_rel ? widx : last_rel];
+                widx++;
+                const uint64_t chunk = (prev << sb2) | ((nw >> 1) >> (63u - sb2));
+                prev = nw;
+                cur = (uint32_t)(chunk >> 32);
+                lo_half = (uint32_t)chunk;
+            } else if ((t & 15u) == 0) cur = lo_half;
+            uint32_t n = 16u - (t & 15u);                                         // steps until the next wave-uniform event
+            n = mmax - t < n ? mmax - t : n;
+            if (t + 1 < (uint32_t)p) {                                            // the first p-mer is not complete yet
+                n = (uint32_t)p - 1 - t < n ? (uint32_t)p - 1 - t : n;
+                for (uint32_t u = 0; u < n; u++) roll();
+                t += n;
+                continue;
+            }
+            n = W - j < n ? W - j : n;
+            uint32_t e = t + 1 - (uint32_t)p;                                     // element = p-mer position of the base rolled next
+            if (e + 1 < W) {                                                      // the first window is not complete yet: fill block 0
+                n = W - 1 - e < n ? W - 1 - e : n;
+                for (uint32_t u = 0; u < n; u++) {
+                    roll();
+                    const uint32_t h = elem(e + u);
+                    P = h < P ? h : P;
+                    SV[(j + u) * 64] = h;
+                }
+            } else {
+                uint32_t u = 0;
+                while (u < n) {
+                    if (n - u >= 4) {
+                        uint32_t* q = SV + (j + u) * 64;
+                        const uint32_t s1 = q[64], s2 = q[128], s3 = q[192], s4 = q[256];
+                        uint32_t h, out;
+                        roll(); h = elem(e + u);     P = h < P ? h : P; out = s1 < P ? s1 : P; q[0] = h;   window(e + u + 1 - W, out);
+                        roll(); h = elem(e + u + 1); P = h < P ? h : P; out = s2 < P ? s2 : P; q[64] = h;  window(e + u + 2 - W, out);
+                        roll(); h = elem(e + u + 2); P = h < P ? h : P; out = s3 < P ? s3 : P; q[128] = h; window(e + u + 3 - W, out);
+                        roll(); h = elem(e + u + 3); P = h < P ? h : P; out = s4 < P ? s4 : P; q[192] = h; window(e + u + 4 - W, out);
+                        u += 4;
+                    } else {
+                        uint32_t* q = SV + (j + u) * 64;
+                        const uint32_t s1 = q[64];
+                        roll();
+                        const uint32_t h = elem(e + u);
+                        P = h < P ? h : P;
+                        const uint32_t out = s1 < P ? s1 : P;
+                        q[0] = h;
+                        window(e + u + 1 - W, out);
+                        u++;
+                    }
+                    while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);
+                }
+            }
+            t += n;
+            j += n;
+            if (j == W) {                                                         // block complete: raw values -> suffix minima, in place
+                uint32_t run = 0xffffffffu;
+                uint32_t q = W;
+                for (; q >= 5; q -= 4) {                                          // slots q-1 .. q-4 (slot 0 is never read back)
+                    uint32_t* r = SV + (q - 4) * 64;
+                    uint32_t x3 = r[192], x2 = r[128], x1 = r[64], x0 = r[0];
+                    x3 = x3 < run ? x3 : run; x2 = x2 < x3 ? x2 : x3; x1 = x1 < x2 ? x1 : x2; x0 = x0 < x1 ? x0 : x1;
+                    r[192] = x3; r[128] = x2; r[64] = x1; r[0] = x0;
+                    run = x0;
+                }
+                for (; q >= 2; q--) {
+                    const uint32_t x = SV[(q - 1) * 64];
+                    run = x < run ? x : run;
+                    SV[(q - 1) * 64] = run;
+                }
+                j = 0;
+                P = 0xffffffffu;
+            }
+        }
+        E.push(nwin > 0, ps, nwin, cur_val, lane);                                // every read's last piece
+        while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);
+        if (E.pl_n) E.flush(E.pl_n, v_m, v_st, v_ex, v_d1);                       // the lanes' read metadata changes with the next batch
     }
 }
 
@@ -1086,7 +1302,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     DBuf<unsigned long long> tmp_cursor;
     ALLOC_OR_FAIL(c, st->hist, nbins);
     ALLOC_OR_FAIL(c, tmp_cursor, 1);
-    ALLOC_OR_FAIL(c, sflags, 1);
+    ALLOC_OR_FAIL(c, sflags, 2);
     // expected density of minimizer changes is 2/(W+1) per window plus one piece per read
     uint64_t tmp_cap = (uint64_t)((double)n_kmers * 2.0 / (double)(k - p + 2) * 1.15) + s.n + 1024;
     if (tmp_cap > n_kmers) tmp_cap = n_kmers;
@@ -1112,20 +1328,44 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         ALLOC_OR_FAIL(c, st->tmp_bin, tmp_cap);
         HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)nbins * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(tmp_cursor.p, 0, 8, c->stream));
-        HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 4, c->stream));
+        HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(st->tmp_bin.p, 0xff, tmp_cap * 4, c->stream));
         if (direct) HIP_TRY(c, hipMemsetAsync(st->cursor.p, 0, (size_t)nbins * 4, c->stream));
-        c->t_begin("sk_scan", n_kmers);
-#define SCAN(NBW_, D_) sk_scan_kernel<NBW_, D_><<<scan_blocks, 256, 0, c->stream>>>(sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, \
-            tmp_cursor.p, tmp_cap, sflags.p, st->slab.p, st->slab_cap, st->cursor.p)
-        if (direct) { if (nbw == 2) SCAN(2, true); else if (nbw == 3) SCAN(3, true); else SCAN(4, true); }
-        else { if (nbw == 2) SCAN(2, false); else if (nbw == 3) SCAN(3, false); else SCAN(4, false); }
-#undef SCAN
-        c->t_end();
-        LAUNCH_CHECK(c, "sk_scan");
+        // reads of up to SCAN_LANE_MAX bases: lane-per-read kernel; it flags longer reads, which the wave-per-read kernel then
+        // takes (DBG_SCAN=wave: everything through the wave-per-read kernel)
+        const bool lane_scan = !(c->opt("DBG_SCAN") && !strcmp(c->opt("DBG_SCAN"), "wave"));
         unsigned long long cur = 0;
-        HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t sfl[2] = {0, 0};
+#define SCAN_ARGS sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p, st->slab.p, st->slab_cap, st->cursor.p
+        if (lane_scan) {
+            const uint32_t W = (uint32_t)(k - p + 1);
+            const size_t lds = (size_t)4 * scan_lane_lds_words(W) * sizeof(uint32_t);
+            const uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 255) / 256, 256ull * 12));
+            c->t_begin("sk_scan", n_kmers);
+#define SCANL(NBW_, D_) do { HIP_TRY(c, hipFuncSetAttribute((const void*)sk_scan_lane_kernel<NBW_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            sk_scan_lane_kernel<NBW_, D_><<<lane_blocks, 256, lds, c->stream>>>(SCAN_ARGS); } while (0)
+            if (direct) { if (nbw == 2) SCANL(2, true); else if (nbw == 3) SCANL(3, true); else SCANL(4, true); }
+            else { if (nbw == 2) SCANL(2, false); else if (nbw == 3) SCANL(3, false); else SCANL(4, false); }
+#undef SCANL
+            c->t_end();
+            LAUNCH_CHECK(c, "sk_scan_lane");
+            HIP_TRY(c, hipMemcpyAsync(sfl, sflags.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        if (!lane_scan || sfl[1]) {
+            const uint32_t long_min = lane_scan ? SCAN_LANE_MAX : 0u;
+            c->t_begin(lane_scan ? "sk_scan_long" : "sk_scan", lane_scan ? 0 : n_kmers);
+#define SCAN(NBW_, D_) sk_scan_kernel<NBW_, D_><<<scan_blocks, 256, 0, c->stream>>>(SCAN_ARGS, long_min)
+            if (direct) { if (nbw == 2) SCAN(2, true); else if (nbw == 3) SCAN(3, true); else SCAN(4, true); }
+            else { if (nbw == 2) SCAN(2, false); else if (nbw == 3) SCAN(3, false); else SCAN(4, false); }
+#undef SCAN
+            c->t_end();
+            LAUNCH_CHECK(c, "sk_scan");
+            HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+#undef SCAN_ARGS
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] scan done: nbw=%d rw=%d bins=%u slab_cap=%u tmp used %llu of %llu\n", nbw, rw, nbins, st->slab_cap,
                                          cur, (unsigned long long)tmp_cap);
         if (cur > tmp_cap) {                                  // low-complexity input: more pieces than estimated
