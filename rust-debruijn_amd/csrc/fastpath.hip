@@ -83,6 +83,12 @@ __device__ __forceinline__ uint32_t pmer_rc32(uint32_t pm, int p) {
 // bijection on 2p-bit integers (odd multiply and xorshift are both invertible mod 2^(2p))
 __device__ __forceinline__ uint32_t mix_pmer(uint32_t x, int p) {
     const uint32_t mask = p >= 16 ? 0xffffffffu : ((1u << (2 * p)) - 1);
+#ifdef DBG_MIX_CHEAP
+    x = (x + (x << 3)) & mask; x ^= x >> p;
+    x = (x + (x << 5)) & mask; x ^= x >> 7;
+    x = (x + (x << 2)) & mask; x ^= x >> p;
+    return x;
+#endif
     x = (x * 0x9E3779B1u) & mask;
     x ^= x >> p;
     x = (x * 0x85EBCA6Bu) & mask;
@@ -127,7 +133,7 @@ constexpr uint32_t NCLS = 1;                    // length classes per bin: recor
 // DIRECT: a record goes straight to slot atomicAdd(cursor[bin]) of its bin's fixed-capacity slab (slab_cap records per
 // bin); only the records of bins that outgrow their slab take the read-order temporary buffer and the scatter kernel.
 constexpr uint32_t PLC = 256;                   // ring slots per wave (wave-per-read kernel: 4 words per piece)
-constexpr uint32_t PLC_PACKED = 512;            // lane-per-read kernel: 2 words per piece {start | end << 11 | lane << 22, hash}
+constexpr uint32_t PLC_PACKED = 256;            // lane-per-read kernel: 2 words per piece {start | end << 11 | lane << 22, hash}
 template <int NBW, bool DIRECT, bool PACKED = false>
 struct PieceEmitter {
     static constexpr int RW = NBW;
@@ -168,7 +174,6 @@ struct PieceEmitter {
         pl_head = (pl_head + cnt) & (CAP - 1); pl_n -= cnt; return;
 #endif
         const int k = c.k;
-        const uint32_t W = (uint32_t)(c.k - c.p + 1);
         const uint64_t* __restrict__ w = s.words;
         const uint32_t q = (pl_head + lane) & (CAP - 1);
         const bool act = lane < cnt;
@@ -184,27 +189,40 @@ struct PieceEmitter {
         const uint32_t sexts = __shfl(v_ex, pr), d1 = __shfl(v_d1, pr);
         pl_head = (uint32_t)__builtin_amdgcn_readfirstlane((int)((pl_head + cnt) & (CAP - 1)));
         pl_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pl_n - cnt));
-        uint32_t b = 0;
+        // The slot in the bin's slab comes from a global atomic with return (the longest latency of the flush): it is requested
+        // first and the record is built while it is in flight.
+        static_assert(NCLS == 1, "one bin per minimizer class");
+        uint32_t b = 0, r = 0;
+        if (act) {
+            b = bin_of_hash(c, pa);
+#ifdef DBG_ABL_NO_ATOMIC
+            if (DIRECT) r = (pa * 2654435761u + lane * 40503u) % slab_cap;
+#else
+            if (DIRECT) r = atomicAdd(&cursor[b], 1u);
+#endif
+        }
         uint64_t rv[RW];
 #pragma unroll
         for (int qq = 0; qq < RW; qq++) rv[qq] = 0;
         if (act) {
             const uint32_t nwin = m - (uint32_t)k + 1;
-            const uint64_t w_first = st >> 5;
-            const uint64_t* __restrict__ wr = w + w_first;
-            const uint32_t sb = (uint32_t)(st & 31);
-            const uint32_t last_rel = (uint32_t)(last_word - w_first < 0x7fffffffull ? last_word - w_first : 0x7fffffffull);
             const uint32_t len = (pe == nwin ? m : pe + (uint32_t)k - 1) - ps;
-            const uint32_t cls = ((len - (uint32_t)k) * NCLS) / W;                 // nk - 1 in [0, W) -> class
-            b = bin_of_hash(c, pa) * NCLS + (cls < NCLS ? cls : NCLS - 1);
-            const uint32_t le = ps > 0 ? (1u << rel_base(wr, sb + ps - 1)) : (sexts & 0xfu);
-            const uint32_t re = ps + len < m ? (1u << rel_base(wr, sb + ps + len)) : (sexts >> 4);
+            // bases [ps - 1, ps + len] of the read (the piece and its two neighbours) lie in at most NBW + 1 words (2 * 32 * NBW >=
+            // 2k - p + 20 meta bits, and the piece may start anywhere in a word): they are fetched once, everything else is shifts
+            const uint64_t o = st + ps, wi0 = o >> 5;
+            const uint32_t sh = (uint32_t)(o & 31) * 2u;
+            uint64_t x[NBW + 1];
+#pragma unroll
+            for (int qq = 0; qq <= NBW; qq++) x[qq] = w[wi0 + qq < last_word ? wi0 + qq : last_word];
+            uint32_t le = sexts & 0xfu, re = sexts >> 4;
+            if (ps > 0) le = 1u << (sh ? (uint32_t)(x[0] >> (64u - sh)) & 3u : packed_get(w, o - 1));
 #pragma unroll
             for (int qq = 0; qq < NBW; qq++) {
+                const uint64_t v = (x[qq] << sh) | ((x[qq + 1] >> 1) >> (63u - sh));      // bases [32 qq, 32 qq + 32) of the piece
                 const uint32_t b0 = (uint32_t)qq * 32;
                 const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
-                const uint64_t v = rel_word(wr, sb + ps + (b0 < len ? b0 : 0), last_rel, nb ? nb : 1);
-                rv[qq] = nb ? v : 0ull;
+                rv[qq] = nb ? v & (~0ull << (64 - 2 * nb)) : 0ull;
+                if (ps + len < m && len >= b0 && len < b0 + 32) re = 1u << ((uint32_t)(v >> (62u - 2u * (len - b0))) & 3u);   // base right of the piece
             }
             rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 31u) << 15);
         }
@@ -219,8 +237,6 @@ struct PieceEmitter {
         };
         bool to_tmp = act;                        // lanes whose record goes to the read-order buffer
         if (DIRECT) {
-            uint32_t r = 0;
-            if (act) r = atomicAdd(&cursor[b], 1u);
             to_tmp = act && r >= slab_cap;
 #ifndef DBG_ABL_NO_STORE
             if (act && !to_tmp) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
@@ -442,22 +458,22 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
 constexpr uint32_t SCAN_LANE_MAX = 1024;        // longer reads go to the wave-per-read kernel (a wave lasts as long as its longest read)
 __host__ __device__ constexpr uint32_t scan_lane_lds_words(uint32_t W) { return (W + 1) * 64 + 2 * PLC_PACKED; }
 template <int NBW, bool DIRECT>
-__global__ void __launch_bounds__(256) sk_scan_lane_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
+__global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
                                                            uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
                                                            unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
                                                            uint32_t* __restrict__ flags, uint64_t* __restrict__ slab,
                                                            uint32_t slab_cap, uint32_t* __restrict__ cursor) {
     extern __shared__ uint32_t s_dyn[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // one wave per workgroup: the waves share nothing, and 11 KB granules pack a CU's LDS (14 waves) better than 43 KB ones (12)
+    const uint32_t lane = threadIdx.x;
     const int k = c.k, p = c.p;
     const uint32_t W = (uint32_t)(k - p + 1);
-    uint32_t* SV = s_dyn + wave * scan_lane_lds_words(W) + lane;    // slot j of this lane: SV[j * 64]
-    uint32_t* PL = s_dyn + wave * scan_lane_lds_words(W) + (W + 1) * 64;
+    uint32_t* SV = s_dyn + lane;                                    // slot j of this lane: SV[j * 64]
+    uint32_t* PL = s_dyn + (W + 1) * 64;
     SV[W * 64] = 0xffffffffu;                                       // S[W]: the empty suffix
     const uint64_t* __restrict__ w = s.words;
     const uint64_t last_word = s.n_words ? s.n_words - 1 : 0;
-    const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t gwave = blockIdx.x, nwaves = gridDim.x;
     const uint64_t lt = lanemask_lt();
     PieceEmitter<NBW, DIRECT, true> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
     const uint32_t pmask = (1u << (2 * p)) - 1u, top = 2u * (uint32_t)(p - 1);      // p <= 15
@@ -475,7 +491,7 @@ __global__ void __launch_bounds__(256) sk_scan_lane_kernel(SeqDev s, FastCfg c, 
         uint32_t m = v_m;
         if (m > SCAN_LANE_MAX) { atomicOr(&flags[1], 1u); m = 0; }              // left to the wave-per-read kernel
         if (m < (uint32_t)k) m = 0;
-        const uint32_t nwin = m ? m - (uint32_t)k + 1 : 0u, npos = m ? m - (uint32_t)p + 1 : 0u;
+        const uint32_t nwin = m ? m - (uint32_t)k + 1 : 0u;
         uint32_t mmax = m;
 #pragma unroll
         for (int d = 32; d; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mmax, d); mmax = o > mmax ? o : mmax; }
@@ -497,11 +513,10 @@ __global__ void __launch_bounds__(256) sk_scan_lane_kernel(SeqDev s, FastCfg c, 
             fw = ((fw << 2) | b) & pmask;
             rc = (rc >> 2) | ((3u - b) << top);
         };
-        // element e of this lane (wave-uniform index): ordering hash of the canonical p-mer, +inf past the read's end
-        auto elem = [&](uint32_t e) -> uint32_t {
-            const uint32_t x = mix_pmer(stranded ? fw : (fw < rc ? fw : rc), p);
-            return e < npos ? x : 0xffffffffu;
-        };
+        // element of this lane: ordering hash of the canonical p-mer.  Past the read's end (shorter reads of the batch) the
+        // values are garbage, which is harmless: a window sw < nwin only covers elements sw .. sw + W - 1 <= npos - 1, and both
+        // halves of its minimum (suffix of the previous block, prefix of the current one) lie inside the window.
+        auto elem = [&]() -> uint32_t { return mix_pmer(stranded ? fw : (fw < rc ? fw : rc), p); };
         // window sw (wave-uniform index) has minimum `out`: piece boundaries
         auto window = [&](uint32_t sw, uint32_t out) {
             const bool isb = sw < nwin && (sw == 0 || out != cur_val || sw - ps == W);
@@ -533,7 +548,7 @@ __global__ void __launch_bounds__(256) sk_scan_lane_kernel(SeqDev s, FastCfg c, 
                 n = W - 1 - e < n ? W - 1 - e : n;
                 for (uint32_t u = 0; u < n; u++) {
                     roll();
-                    const uint32_t h = elem(e + u);
+                    const uint32_t h = elem();
                     P = h < P ? h : P;
                     SV[(j + u) * 64] = h;
                 }
@@ -544,16 +559,17 @@ __global__ void __launch_bounds__(256) sk_scan_lane_kernel(SeqDev s, FastCfg c, 
                         uint32_t* q = SV + (j + u) * 64;
                         const uint32_t s1 = q[64], s2 = q[128], s3 = q[192], s4 = q[256];
                         uint32_t h, out;
-                        roll(); h = elem(e + u);     P = h < P ? h : P; out = s1 < P ? s1 : P; q[0] = h;   window(e + u + 1 - W, out);
-                        roll(); h = elem(e + u + 1); P = h < P ? h : P; out = s2 < P ? s2 : P; q[64] = h;  window(e + u + 2 - W, out);
-                        roll(); h = elem(e + u + 2); P = h < P ? h : P; out = s3 < P ? s3 : P; q[128] = h; window(e + u + 3 - W, out);
-                        roll(); h = elem(e + u + 3); P = h < P ? h : P; out = s4 < P ? s4 : P; q[192] = h; window(e + u + 4 - W, out);
+                        roll(); h = elem(); P = h < P ? h : P; out = s1 < P ? s1 : P; q[0] = h;   window(e + u + 1 - W, out);
+                        roll(); h = elem(); P = h < P ? h : P; out = s2 < P ? s2 : P; q[64] = h;  window(e + u + 2 - W, out);
+                        while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);      // the ring holds 64 + 2 x 64 pieces
+                        roll(); h = elem(); P = h < P ? h : P; out = s3 < P ? s3 : P; q[128] = h; window(e + u + 3 - W, out);
+                        roll(); h = elem(); P = h < P ? h : P; out = s4 < P ? s4 : P; q[192] = h; window(e + u + 4 - W, out);
                         u += 4;
                     } else {
                         uint32_t* q = SV + (j + u) * 64;
                         const uint32_t s1 = q[64];
                         roll();
-                        const uint32_t h = elem(e + u);
+                        const uint32_t h = elem();
                         P = h < P ? h : P;
                         const uint32_t out = s1 < P ? s1 : P;
                         q[0] = h;
@@ -1339,11 +1355,14 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
 #define SCAN_ARGS sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p, st->slab.p, st->slab_cap, st->cursor.p
         if (lane_scan) {
             const uint32_t W = (uint32_t)(k - p + 1);
-            const size_t lds = (size_t)4 * scan_lane_lds_words(W) * sizeof(uint32_t);
-            const uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 255) / 256, 256ull * 12));
+#ifndef DBG_SCAN_LDS_PAD
+#define DBG_SCAN_LDS_PAD 0
+#endif
+            const size_t lds = (size_t)scan_lane_lds_words(W) * sizeof(uint32_t) + DBG_SCAN_LDS_PAD;
+            const uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 63) / 64, 256ull * 16 * 4));
             c->t_begin("sk_scan", n_kmers);
 #define SCANL(NBW_, D_) do { HIP_TRY(c, hipFuncSetAttribute((const void*)sk_scan_lane_kernel<NBW_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            sk_scan_lane_kernel<NBW_, D_><<<lane_blocks, 256, lds, c->stream>>>(SCAN_ARGS); } while (0)
+            sk_scan_lane_kernel<NBW_, D_><<<lane_blocks, 64, lds, c->stream>>>(SCAN_ARGS); } while (0)
             if (direct) { if (nbw == 2) SCANL(2, true); else if (nbw == 3) SCANL(3, true); else SCANL(4, true); }
             else { if (nbw == 2) SCANL(2, false); else if (nbw == 3) SCANL(3, false); else SCANL(4, false); }
 #undef SCANL

@@ -18,8 +18,10 @@ eng = D.HipEngine(ctx, dev)
 tot = eng.count_instances(ss, k)
 plan = eng.plan(k, False, 1, 2, tot)
 import time
+ctx.enable_timing(True)
 for rep in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     bin_off, n_recs = eng.scan(ss, plan)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(os.environ.get("DBG_LIB", "default"), "rep", rep, "scan+compact %.2f ms" % (dt * 1e3), "records", n_recs, flush=True)
+    kt = {x["name"]: round(x["ms"], 2) for x in ctx.timings()}
+    print(os.path.basename(os.environ.get("DBG_LIB", "default")), "rep", rep, "scan+compact %.2f ms" % (dt * 1e3), "kernels", kt, "records", n_recs, flush=True)
