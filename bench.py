@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--digest", action="store_true",
                     help="report an order-independent digest of the result table(s): per-rank digests of a sharded run add up to the "
                          "single-GPU digest over the same reads (tools/check_multirank.sh)")
+    ap.add_argument("--no-host-boundary", action="store_true",
+                    help="skip the host-pointer measurement (dbg_filter_kmers: host arrays in, host table out -- the reference's own boundary)")
     ap.add_argument("--compress-reads", type=int, default=-1,
                     help="reads of the stream used for the secondary unitigs/s measurement (0 = skip, -1 = all: BASELINE config 3)")
     args = ap.parse_args()
@@ -280,6 +282,32 @@ def main():
                                     "sample": "%d reads of an equally-parameterised stream (%.0fM k-mer instances), oracle "
                                               "msp_sequence(p=8) -> %d shards -> filter_kmers per shard on %d threads, %.1f s"
                                               % (n_m, n_m * (L - k + 1) / 1e6, 16 * nt, nt, msec)}
+        hostb = None
+        if not args.no_host_boundary and world == 1:
+            # The reference's own boundary (filter.rs:139-148): the caller's reads in (pageable) host memory, the table back in
+            # host memory.  PCIe-inclusive, so it is never `value`; CountFilter is the north-star figure, CountFilterSet = the
+            # bench workload.  First call of each kind warms the ctx's pinned result pool (hipHostMalloc is slow), second is timed.
+            hw, hst, hl, hc = words.cpu().numpy(), start.cpu().numpy(), length.cpu().numpy(), colour.cpu().numpy()
+            hostb = {}
+            for kind, setk in (("CountFilter", 0), ("CountFilterSet", 1)):
+                hss = capi.SeqSet(hw.ctypes.data, nw, hst.ctypes.data, hl.ctypes.data, None, hc.ctypes.data if setk else None, 1 if setk else 0,
+                                  reads_per_gpu)
+                hfp = capi.FilterParams(k, 0, setk, args.min_obs, 0, 4)
+                for rep in range(2):
+                    ht = capi.KmerTable()
+                    torch.cuda.synchronize()
+                    h0 = time.perf_counter()
+                    ctx.check(lib.dbg_filter_kmers(ctx.h, C.byref(hss), C.byref(hfp), C.byref(ht)))
+                    hdt = time.perf_counter() - h0
+                    b_in = hw.nbytes + hst.nbytes + hl.nbytes + (hc.nbytes if setk else 0)
+                    b_out = ht.n * 17 + ((ht.n + 1) * 8 + ht.n_set_val * 4 if setk else ht.n * 2)
+                    n_i = ht.n_kmer_instances
+                    lib.dbg_free_table(ctx.h, C.byref(ht))
+                hostb[kind] = {"value": round(n_i / hdt / 1e9, 3), "unit": "Gkmer/s", "seconds": round(hdt, 4),
+                               "gb_host_to_device": round(b_in / 1e9, 2), "gb_device_to_host": round(b_out / 1e9, 2),
+                               "pcie_gb_per_s": round((b_in + b_out) / hdt / 1e9, 1)}
+            hostb["boundary"] = "dbg_filter_kmers: pageable host arrays in, host table out (pinned result pool of the ctx, warm)"
+            del hw, hst, hl, hc
         comp = None
         if args.compress_reads and world == 1:
             # second half of the metric ("+ unitigs/s compressed"): CountFilter(2) table of a prefix of the same
@@ -319,7 +347,7 @@ def main():
                     "device_resident_index": {"seconds": round(ddt, 4), "unitigs": dev_nodes, "unitigs_per_s": round(dev_nodes / ddt, 1),
                                               "kmers_per_s": round(nk / ddt, 1), "boundary": "index in HBM, host BaseGraph out"}}
             lib.dbg_free_graph(ctx.h, C.byref(g))
-            lib.dbg_free_table(None, C.byref(h2))
+            lib.dbg_free_table(ctx.h, C.byref(h2))
         out = {
             "metric": "Gkmer/s extracted+counted (k=%d, 150 bp synthetic reads)" % k, "value": round(value, 4),
             "unit": "Gkmer/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -338,7 +366,7 @@ def main():
             "exchange": ({"bytes_sent_per_step_all_ranks": xbytes_total // max(args.steps, 1),
                           "exposed_ms_per_step_max_rank": round(exposed_ms / max(args.steps, 1), 3),
                           "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1)} if world > 1 else None),
-            "roofline": roof, "cpu_baseline": cpu, "compress": comp,
+            "roofline": roof, "cpu_baseline": cpu, "host_boundary": hostb, "compress": comp,
         }
     ctx.close()
     if world > 1 or args.force_exchange:

@@ -2,6 +2,7 @@
 #include "dbg_internal.hpp"
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 
 static thread_local std::string g_create_err;
 
@@ -33,6 +34,8 @@ extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->shard_scan.reset(); c->shard_count.reset();          // they hold pool blocks of this ctx
+    c->stager.reset();
+    ctx_hrelease_all(c);
     (void)hipStreamSynchronize(c->stream);
     c->t_clear();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -163,22 +166,32 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     return 0;
 }
 
-static void* xmalloc(size_t n) { return dbg_host_alloc(n); }
-
 extern "C" int dbg_table_to_host(dbg_ctx* c, const dbg_kmer_table* d, dbg_kmer_table* h) {
     *h = *d;
     h->on_device = 0;
     h->key_hi = h->key_lo = h->set_off = h->all_hi = h->all_lo = nullptr;
     h->exts = nullptr; h->count = nullptr; h->set_val = nullptr;
+    // the arrays leave on two streams (both directions of PCIe stay busy with one copy each at most, but a second stream
+    // hides the gaps between copies); destinations are pinned blocks of the ctx pool
+    hipStream_t st[2] = {c->stream, c->get_copy_stream() ? c->get_copy_stream() : c->stream};
+    int which = 0;
+    hipError_t e = hipSuccess;
 #define CP(field, T, cnt)                                                                             \
-    if (d->field) {                                                                                   \
-        h->field = (T*)xmalloc((size_t)(cnt) * sizeof(T));                                            \
-        if ((cnt)) HIP_TRY(c, hipMemcpyAsync(h->field, d->field, (size_t)(cnt) * sizeof(T), hipMemcpyDeviceToHost, c->stream)); \
+    if (d->field && e == hipSuccess) {                                                                \
+        h->field = (T*)ctx_halloc(c, (size_t)(cnt) * sizeof(T));                                      \
+        if (!h->field) e = hipErrorOutOfMemory;                                                       \
+        else if ((cnt)) e = hipMemcpyAsync(h->field, d->field, (size_t)(cnt) * sizeof(T), hipMemcpyDeviceToHost, st[which++ & 1]); \
     }
     CP(key_hi, uint64_t, d->n) CP(key_lo, uint64_t, d->n) CP(exts, uint8_t, d->n) CP(count, uint16_t, d->n)
     CP(set_off, uint64_t, d->n + 1) CP(set_val, uint32_t, d->n_set_val) CP(all_hi, uint64_t, d->n_all) CP(all_lo, uint64_t, d->n_all)
 #undef CP
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(st[0]);
+    if (e == hipSuccess && st[1] != st[0]) e = hipStreamSynchronize(st[1]);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dbg_free_table(c, h);
+        return c->fail(100, std::string("HIP error while copying the table to the host: ") + hipGetErrorString(e));
+    }
     return 0;
 }
 
@@ -187,7 +200,7 @@ extern "C" void dbg_free_table(dbg_ctx* c, dbg_kmer_table* t) {
     void* ptrs[] = {t->key_hi, t->key_lo, t->exts, t->count, t->set_off, t->set_val, t->all_hi, t->all_lo};
     for (void* p : ptrs) {
         if (!p) continue;
-        if (t->on_device) { if (c) c->dfree(p); } else free(p);
+        if (t->on_device) { if (c) c->dfree(p); } else ctx_hfree(c, p);
     }
     memset(t, 0, sizeof(*t));
 }
@@ -205,36 +218,40 @@ int upload_seqset(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d) {
     ALLOC_OR_FAIL(c, d->words, std::max<uint64_t>(hs->n_words, 1));
     ALLOC_OR_FAIL(c, d->start, std::max<uint64_t>(n, 1));
     ALLOC_OR_FAIL(c, d->length, std::max<uint64_t>(n, 1));
-    if (hs->n_words) HIP_TRY(c, hipMemcpyAsync(d->words.p, hs->words, hs->n_words * 8, hipMemcpyHostToDevice, c->stream));
-    if (n) {
-        HIP_TRY(c, hipMemcpyAsync(d->start.p, hs->start, n * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(d->length.p, hs->length, n * 4, hipMemcpyHostToDevice, c->stream));
-    }
+    std::vector<UploadJob> jobs;
+    jobs.push_back({d->words.p, hs->words, (size_t)hs->n_words * 8});
+    jobs.push_back({d->start.p, hs->start, (size_t)n * 8});
+    jobs.push_back({d->length.p, hs->length, (size_t)n * 4});
     d->view = *hs;
     d->view.words = d->words.p; d->view.start = d->start.p; d->view.length = d->length.p;
     d->view.exts = nullptr; d->view.data = nullptr;
     if (hs->exts) {
         ALLOC_OR_FAIL(c, d->exts, std::max<uint64_t>(n, 1));
-        if (n) HIP_TRY(c, hipMemcpyAsync(d->exts.p, hs->exts, n, hipMemcpyHostToDevice, c->stream));
+        jobs.push_back({d->exts.p, hs->exts, (size_t)n});
         d->view.exts = d->exts.p;
     }
     if (hs->data && hs->data_width) {
         ALLOC_OR_FAIL(c, d->data, std::max<uint64_t>(n * hs->data_width, 1));
-        if (n) HIP_TRY(c, hipMemcpyAsync(d->data.p, hs->data, n * hs->data_width, hipMemcpyHostToDevice, c->stream));
+        jobs.push_back({d->data.p, hs->data, (size_t)n * hs->data_width});
         d->view.data = d->data.p;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return staged_upload(c, jobs);
 }
 
 static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs) {
-    // bounds + D1 range checks that would be undefined behaviour on the device
-    for (uint64_t i = 0; i < hs->n_seqs; i++) {
-        uint64_t end = hs->start[i] + hs->length[i];
-        if ((end + 31) / 32 > hs->n_words && hs->length[i]) return c->fail(16, "sequence runs past n_words");
-        if (hs->data && hs->data_width == 4 && ((const uint32_t*)hs->data)[i] >= (1u << 24))
-            return c->fail(17, "D1 values must be < 2^24");
-    }
+    // bounds + D1 range checks that would be undefined behaviour on the device (on the host threads the container is granted)
+    std::atomic<int> bad{0};
+    host_parallel_ranges(hs->n_seqs, [&](uint64_t a, uint64_t b, unsigned) {
+        int f = 0;
+        for (uint64_t i = a; i < b; i++) {
+            const uint64_t end = hs->start[i] + hs->length[i];
+            if ((end + 31) / 32 > hs->n_words && hs->length[i]) f |= 1;
+            if (hs->data && hs->data_width == 4 && ((const uint32_t*)hs->data)[i] >= (1u << 24)) f |= 2;
+        }
+        if (f) bad |= f;
+    });
+    if (bad & 1) return c->fail(16, "sequence runs past n_words");
+    if (bad & 2) return c->fail(17, "D1 values must be < 2^24");
     return 0;
 }
 

@@ -241,15 +241,16 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
         if (has_hi) ALLOC_OR_FAIL(c, d_hi, n);
         ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n); ALLOC_OR_FAIL(c, d_link, 2 * n); ALLOC_OR_FAIL(c, d_flag, 1);
         if (data) ALLOC_OR_FAIL(c, d_data, n);
-        auto upload = [&]() -> int {
+        auto upload = [&]() -> int {                               // pinned staging ring, several host threads (hostio.hip)
+            std::vector<UploadJob> jobs;
             if (has_hi) {
-                if (key_hi) HIP_TRY(c, hipMemcpyAsync(d_hi.p, key_hi, n * 8, hipMemcpyHostToDevice, c->stream));
+                if (key_hi) jobs.push_back({d_hi.p, key_hi, (size_t)n * 8});
                 else HIP_TRY(c, hipMemsetAsync(d_hi.p, 0, n * 8, c->stream));
             }
-            HIP_TRY(c, hipMemcpyAsync(d_lo.p, key_lo, n * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(d_exts.p, exts, n, hipMemcpyHostToDevice, c->stream));
-            if (data) HIP_TRY(c, hipMemcpyAsync(d_data.p, data, n * 4, hipMemcpyHostToDevice, c->stream));
-            return 0;
+            jobs.push_back({d_lo.p, key_lo, (size_t)n * 8});
+            jobs.push_back({d_exts.p, exts, (size_t)n});
+            if (data) jobs.push_back({d_data.p, data, (size_t)n * 4});
+            return staged_upload(c, jobs);
         };
         DBG_TRY(upload());
         KeysDev t{has_hi ? d_hi.p : nullptr, d_lo.p, n};

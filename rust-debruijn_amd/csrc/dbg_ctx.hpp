@@ -40,6 +40,9 @@ struct dbg_ctx {
         return it == opts.end() ? nullptr : it->second.c_str();
     }
     dbg_state_slot shard_scan, shard_count;
+    dbg_state_slot stager;                  // pinned staging ring of the host-boundary uploads (hostio.hip)
+    std::multimap<size_t, void*> hfree_blocks;   // pinned host blocks kept for result arrays
+    std::map<void*, size_t> hlive_blocks;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipStream_t copy_stream = nullptr;     // created on first use: result copies that overlap kernels of `stream`

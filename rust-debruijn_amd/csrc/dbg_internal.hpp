@@ -15,6 +15,17 @@ static inline void* dbg_host_alloc(size_t bytes) {
 }
 
 
+// ---- hostio.hip : fast host <-> device transfers for the host-pointer entry points ----------------
+#include <functional>
+#include <vector>
+struct UploadJob { void* dst; const void* src; size_t bytes; };
+int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs);            // complete on return
+void host_parallel_ranges(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)>& fn);
+unsigned host_parallel_width();
+void* ctx_halloc(dbg_ctx* c, size_t bytes);                                  // result array: pinned block from the ctx pool (malloc when small)
+void ctx_hfree(dbg_ctx* c, void* p);                                         // c may be null
+void ctx_hrelease_all(dbg_ctx* c);
+
 // device view of &[(V, Exts, D1)] in PackedDnaStringSet layout
 struct SeqDev {
     const uint64_t* words;

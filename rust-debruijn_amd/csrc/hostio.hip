@@ -1,0 +1,156 @@
+// The reference's own boundary takes and returns HOST memory (filter_kmers(&[(V, Exts, D1)]) -> BoomHashMap2, src/filter.rs:139-148;
+// compress_kmers_with_hash(&BoomHashMap2) -> BaseGraph, src/compression.rs:588-594), so the unsuffixed entry points move GBs over
+// PCIe around ~0.15 s of kernels.  Two things make that fast:
+//   * uploads of the caller's (pageable) arrays go through a ring of pinned staging buffers filled by several host threads, each
+//     with its own stream: the CPU copies of chunk i+1.. overlap the DMA of chunk i, and PCIe, not one memcpy thread, is the limit
+//     (a plain hipMemcpy from pageable memory stages through one thread: ~12 GB/s measured);
+//   * result arrays are handed out from a per-ctx pool of pinned host blocks (hipHostMalloc is slow, ~GB/s, so blocks are kept
+//     and reused): device-to-host copies then run at PCIe speed straight into the caller-visible arrays, on two streams.
+#include "dbg_internal.hpp"
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace {
+constexpr size_t STAGE_CHUNK = 16u << 20;       // bytes per staging buffer
+constexpr size_t STAGE_MIN = 8u << 20;          // smaller transfers take the plain copy
+
+struct UploadLane {
+    hipStream_t st = nullptr;
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+struct Stager {
+    std::vector<UploadLane> lanes;
+    ~Stager() {
+        for (auto& l : lanes) {
+            for (int b = 0; b < 2; b++) { if (l.buf[b]) (void)hipHostFree(l.buf[b]); if (l.ev[b]) (void)hipEventDestroy(l.ev[b]); }
+            if (l.st) (void)hipStreamDestroy(l.st);
+        }
+    }
+};
+void stager_delete(void* p) { delete static_cast<Stager*>(p); }
+
+unsigned host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n ? n : 64, (unsigned)CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {       // container CPU quota (cgroup v2)
+        char q[32]; long long per = 0;
+        if (fscanf(f, "%31s %lld", q, &per) == 2 && strcmp(q, "max") && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (atoll(q) + per - 1) / per));
+        fclose(f);
+    }
+    return std::max(1u, std::min(n, 8u));
+}
+
+Stager* get_stager(dbg_ctx* c) {
+    if (c->stager.p) return static_cast<Stager*>(c->stager.p);
+    Stager* s = new Stager();
+    const unsigned nt = host_threads();
+    s->lanes.resize(nt);
+    bool ok = true;
+    for (auto& l : s->lanes) {
+        ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; b < 2 && ok; b++)
+            ok = hipHostMalloc(&l.buf[b], STAGE_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { (void)hipGetLastError(); delete s; return nullptr; }
+    c->stager.reset(s, stager_delete);
+    return s;
+}
+}  // namespace
+
+// host -> device copies of several arrays, complete on return
+int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs) {
+    size_t total = 0;
+    for (auto& j : jobs) total += j.bytes;
+    const char* mode = c->opt("DBG_HOST_STAGING");            // "off": plain copies (for A/B measurements)
+    Stager* s = (total >= STAGE_MIN && !(mode && !strcmp(mode, "off"))) ? get_stager(c) : nullptr;
+    if (!s) {
+        for (auto& j : jobs) if (j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    struct Chunk { char* dst; const char* src; size_t n; };
+    std::vector<Chunk> chunks;
+    for (auto& j : jobs)
+        for (size_t o = 0; o < j.bytes; o += STAGE_CHUNK) chunks.push_back({(char*)j.dst + o, (const char*)j.src + o, std::min(STAGE_CHUNK, j.bytes - o)});
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{0};
+    const int device = c->device;
+    auto work = [&](UploadLane* l) {
+        if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
+        for (unsigned it = 0;; it++) {
+            const size_t i = next.fetch_add(1);
+            if (i >= chunks.size() || err) break;
+            const int b = it & 1;
+            if (it >= 2 && hipEventSynchronize(l->ev[b]) != hipSuccess) { err = 1; break; }       // the buffer's previous DMA is done
+            memcpy(l->buf[b], chunks[i].src, chunks[i].n);
+            if (hipMemcpyAsync(chunks[i].dst, l->buf[b], chunks[i].n, hipMemcpyHostToDevice, l->st) != hipSuccess ||
+                hipEventRecord(l->ev[b], l->st) != hipSuccess) { err = 1; break; }
+        }
+        if (hipStreamSynchronize(l->st) != hipSuccess) err = 1;
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < s->lanes.size(); t++) th.emplace_back(work, &s->lanes[t]);
+    work(&s->lanes[0]);
+    for (auto& t : th) t.join();
+    if (err) { (void)hipGetLastError(); return c->fail(100, "HIP error in the staged host-to-device upload"); }
+    return 0;
+}
+
+// parallel for over [0, n) in contiguous ranges on the host threads the container is granted
+void host_parallel_ranges(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)>& fn) {
+    const unsigned nt = n < (1u << 20) ? 1u : host_threads();
+    if (nt == 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt, t);
+    fn(0, n / nt, 0);
+    for (auto& t : th) t.join();
+}
+unsigned host_parallel_width() { return host_threads(); }
+
+// ---- pinned result arrays ----------------------------------------------------------------------------------------------
+void* ctx_halloc(dbg_ctx* c, size_t bytes) {
+    if (bytes < STAGE_MIN) return malloc(bytes ? bytes : 1);
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    auto it = c->hfree_blocks.lower_bound(bytes);
+    if (it != c->hfree_blocks.end() && it->first <= bytes + bytes / 4 + (1u << 20)) {
+        void* p = it->second;
+        c->hlive_blocks[p] = it->first;
+        c->hfree_blocks.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        for (auto& kv : c->hfree_blocks) (void)hipHostFree(kv.second);        // give the kept blocks back and retry once
+        c->hfree_blocks.clear();
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return dbg_host_alloc(bytes); }
+    }
+    c->hlive_blocks[p] = bytes;
+    return p;
+}
+
+void ctx_hfree(dbg_ctx* c, void* p) {
+    if (!p) return;
+    if (c) {
+        auto it = c->hlive_blocks.find(p);
+        if (it != c->hlive_blocks.end()) {
+            c->hfree_blocks.insert({it->second, p});
+            c->hlive_blocks.erase(it);
+            return;
+        }
+    }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) { (void)hipHostFree(p); return; }   // a pinned block released without its ctx
+    (void)hipGetLastError();
+    free(p);
+}
+
+void ctx_hrelease_all(dbg_ctx* c) {
+    for (auto& kv : c->hfree_blocks) (void)hipHostFree(kv.second);
+    for (auto& kv : c->hlive_blocks) (void)hipHostFree(kv.first);
+    c->hfree_blocks.clear(); c->hlive_blocks.clear();
+}

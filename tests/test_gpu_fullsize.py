@@ -187,7 +187,7 @@ def test_fullsize_prefix_bit_exact(env):
     g_hi, g_lo = as_np(h.key_hi, C.c_uint64, n), as_np(h.key_lo, C.c_uint64, n)
     g_ex = as_np(h.exts, C.c_uint8, n)
     g_off, g_val = as_np(h.set_off, C.c_uint64, n + 1), as_np(h.set_val, C.c_uint32, h.n_set_val)
-    lib.dbg_free_table(None, C.byref(h))
+    lib.dbg_free_table(ctx.h, C.byref(h))
     # the same reads from the bit-identical host generator
     hs = dbg.synth_reads_host(n_reads=m, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001, stranded=False, n_colours=4)
     want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1), K, O.COUNT_FILTER_SET, 1, stranded=False)

@@ -37,7 +37,7 @@ def table_to_host(ctx, tab, k):
     h = capi.KmerTable()
     ctx.check(ctx.lib.dbg_table_to_host(ctx.h, C.byref(tab), C.byref(h)))
     out = dbg._table_from_c(h, k)
-    ctx.lib.dbg_free_table(None, C.byref(h))
+    ctx.lib.dbg_free_table(ctx.h, C.byref(h))
     return out
 
 

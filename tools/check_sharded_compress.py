@@ -47,7 +47,7 @@ def main():
         h = capi.KmerTable()
         ctx.check(ctx.lib.dbg_table_to_host(ctx.h, C.byref(tab), C.byref(h)))
         th = dbg._table_from_c(h, k)
-        ctx.lib.dbg_free_table(None, C.byref(h))
+        ctx.lib.dbg_free_table(ctx.h, C.byref(h))
         spec = dbg.ScmapCompress() if kind else dbg.SimpleCompress("saturating_add")
         spec2 = spec if kind else dbg.SimpleCompress("max")
         final, local = D.sharded_compress(eng, tab, k, False, spec, dst=0, second_spec=spec2)
