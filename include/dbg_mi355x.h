@@ -8,7 +8,7 @@
  * (src/compression.rs:588-594) plus the sibling `msp_sequence`
  * (src/msp.rs:279-288).  Traits and closures cannot cross a C ABI, so this
  * header monomorphises over a closed set:
- *   K   : VarIntKmer<u64|u128, K> with run-time k, 1 <= k <= 64; every key
+ *   K   : VarIntKmer<u64|u128, K> with run-time k, 1 <= k <= 64 (filter_kmers: 4 <= k, see dbg_filter_params); every key
  *         crosses the ABI as a (hi, lo) u64 pair, right-aligned in 2k bits,
  *         base 0 most significant (src/kmer.rs:429-437).
  *   V   : any Vmer, flattened to PackedDnaStringSet layout
@@ -71,7 +71,9 @@ typedef struct {
 enum { DBG_COUNT_FILTER = 0, DBG_COUNT_FILTER_SET = 1 };
 
 typedef struct {
-    uint32_t k;                 /* K::k() */
+    uint32_t k;                 /* K::k(); 4 <= k <= 64: filter_kmers' bucket() reads base 3 of every k-mer (filter.rs:18-23), and
+                                   Kmer::get(3) of a shorter k-mer underflows `k - 1 - pos` (kmer.rs:254-257, :515-518) -- a panic in
+                                   the reference's debug builds, reproduced here as an error */
     int32_t  stranded;          /* filter.rs:142 */
     int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min) */
     uint64_t min_kmer_obs;      /* filter.rs:41,69 */
@@ -221,6 +223,18 @@ void dbg_free_edges(dbg_edges* e);
 int  dbg_graph_to_gfa(dbg_ctx* ctx, uint32_t k, const dbg_graph* g, char** text, uint64_t* len);
 int  dbg_graph_write_gfa(dbg_ctx* ctx, uint32_t k, const dbg_graph* g, const char* path);
 void dbg_free_text(char* text);
+
+/* ---- serde forms of BaseGraph<K, D> (derives: src/graph.rs:43-50, src/dna_string.rs:72-76,762-767, src/lib.rs:577-580) ----
+ * DBG_SERDE_JSON = serde_json (a dependency of the crate): {"sequences":{"sequence":{"storage":[..],"len":n},"start":[..],
+ * "length":[..]},"exts":[{"val":v},..],"data":[..],"stranded":b,"phantom":null}.  DBG_SERDE_BINCODE = bincode 1.x default
+ * options: fields in that order, little-endian fixed-width integers, usize as u64, Vec = u64 length + elements.
+ * data_width = size_of::<D>() (0 = unit, 1, 2, 4); JSON ignores it when reading.  Host-side formatting: ctx may be NULL
+ * (then dbg_serde_last_error() holds the message).  Release with dbg_free_bytes / dbg_free_graph. */
+enum { DBG_SERDE_JSON = 0, DBG_SERDE_BINCODE = 1 };
+int  dbg_graph_serialize(dbg_ctx* ctx, const dbg_graph* g, int format, uint32_t data_width, uint8_t** bytes, uint64_t* len);
+int  dbg_graph_deserialize(dbg_ctx* ctx, const uint8_t* bytes, uint64_t len, int format, uint32_t data_width, dbg_graph* out);
+void dbg_free_bytes(uint8_t* bytes);
+const char* dbg_serde_last_error(void);
 
 /* ---- near side of the path: ASCII <-> 2-bit packing -----------------------------------------
  * dbg_pack_acgt = DnaString::from_acgt_bytes (src/dna_string.rs:222-250; AVX2 helpers convert_bases /

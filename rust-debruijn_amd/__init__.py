@@ -539,6 +539,36 @@ def _graph_from_c(ctx, g, k):
         ctx.lib.dbg_free_graph(ctx.h, C.byref(g))
 
 
+SERDE_JSON, SERDE_BINCODE = 0, 1
+
+
+def graph_serialize(graph, fmt=SERDE_BINCODE, data_width=4):
+    """serde form of a BaseGraph<K, D> (src/graph.rs:43-50): serde_json text or bincode bytes.  Needs no GPU."""
+    lib = _capi.load()
+    cg, keep = _graph_to_c(graph)
+    out, ln = C.c_void_p(), C.c_uint64()
+    if lib.dbg_graph_serialize(None, C.byref(cg), fmt, data_width, C.byref(out), C.byref(ln)):
+        raise DbgError(lib.dbg_serde_last_error().decode())
+    b = C.string_at(out, ln.value)
+    lib.dbg_free_bytes(out)
+    return b
+
+
+def graph_deserialize(data, k, fmt=SERDE_BINCODE, data_width=4):
+    """BaseGraph from its serde_json / bincode form"""
+    lib = _capi.load()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    g = _capi.Graph()
+    if lib.dbg_graph_deserialize(None, buf, len(data), fmt, data_width, C.byref(g)):
+        raise DbgError(lib.dbg_serde_last_error().decode())
+    try:
+        seqs = PackedDnaStringSet(_copy(g.seq_words, g.n_seq_words, np.uint64), _copy(g.start, g.n_nodes, np.uint64),
+                                  _copy(g.length, g.n_nodes, np.uint32), g.seq_len_bases)
+        return BaseGraph(k, seqs, _copy(g.exts, g.n_nodes, np.uint8), _copy(g.data, g.n_nodes, np.uint32), bool(g.stranded))
+    finally:
+        lib.dbg_free_graph(None, C.byref(g))
+
+
 def combine_graphs(graphs, ctx=None):
     """BaseGraph::combine (src/graph.rs:71-100)."""
     ctx = ctx or default_context()

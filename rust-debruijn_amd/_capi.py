@@ -78,6 +78,7 @@ EXPORTS = [
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
     "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
+    "dbg_graph_serialize", "dbg_graph_deserialize", "dbg_free_bytes", "dbg_serde_last_error",
     "dbg_pack_acgt", "dbg_pack_acgt_dev", "dbg_pack_acgt_hashn", "dbg_pack_acgt_hashn_dev", "dbg_unpack_acgt", "dbg_unpack_acgt_dev",
 ]
 
@@ -139,6 +140,11 @@ def load():
     lib.dbg_graph_write_gfa.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Graph), C.c_char_p]
     lib.dbg_free_text.argtypes = [C.c_void_p]
     lib.dbg_free_text.restype = None
+    lib.dbg_graph_serialize.argtypes = [C.c_void_p, C.POINTER(Graph), C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.dbg_graph_deserialize.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(Graph)]
+    lib.dbg_free_bytes.argtypes = [C.c_void_p]
+    lib.dbg_free_bytes.restype = None
+    lib.dbg_serde_last_error.restype = C.c_char_p
     lib.dbg_pack_acgt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.dbg_pack_acgt_dev.argtypes = lib.dbg_pack_acgt.argtypes
     lib.dbg_pack_acgt_hashn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
