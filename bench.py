@@ -208,9 +208,6 @@ def main():
         dom = max(ktimes.items(), key=lambda kv: kv[1]["ms"]) if ktimes else None
         roof = None
         if dom:
-            name, a = dom
-            avg_ms = a["ms"] / a["launches"]
-            units_per_launch = a["units"] / a["launches"]
             key = 8 if k <= 32 else 16
             rbytes = key + 4                                   # record = key + 4-byte payload in this build
             pint = 15 if k >= 23 else (13 if k >= 21 else max(4, k - 8))
@@ -218,25 +215,64 @@ def main():
             b_in = (L / 4.0) / (L - k + 1)
             sk_b = n_recs * rec_b / max(n_inst, 1)             # super-k-mer bytes per k-mer instance
             r_alg = key + 1 + (1 if is_set else 0)             # SURVEY 8(d) record R
-            per_unit = {"extract_kmers": b_in + rbytes, "radix_scatter": 2 * rbytes, "radix_hist": 8,
-                        "reduce_groups": rbytes + u_over_n * (key + 3),
-                        "sk_scan": b_in + sk_b, "sk_scatter": 2 * rec_b + 4, "slab_compact": 2 * rec_b,
-                        "bin_count": r_alg + u_over_n * (key + 3)}.get(name, 2 * rbytes)
-            ach = per_unit * units_per_launch / (avg_ms * 1e-3) / 1e9
-            # HBM traffic from the PMC passes (tools/pmc.sh: separate --pmc runs of this same bench at 10M
-            # reads; FETCH_SIZE doubled per the gfx950 correction), scaled per k-mer instance
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic_10Mreads.json")
-            if os.path.exists(tf):
-                tj = json.load(open(tf))
-                ent = tj.get(name + "_kernel") or tj.get(name)
-                if ent:
-                    traffic = round(ent["bytes_per_instance"] * n_inst / (a["launches"] / args.steps), 0)
-            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "alg_bytes_per_unit": round(per_unit, 2), "units_per_launch": units_per_launch,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": a["launches"] / args.steps,
+            # algorithmic bytes per unit of each kernel (unit = k-mer instance for the scan and the
+            # counting kernel, valid k-mer for the order-restoring stages)
+            sort_rec = 16 if 2 * k <= 96 else rbytes
+            alg = {"extract_kmers": b_in + rbytes, "radix_scatter": 2 * sort_rec, "radix_hist": 4 if 2 * k <= 96 else 8,
+                   "reduce_groups": rbytes + u_over_n * (key + 3), "sk_scan": b_in + sk_b, "sk_scan_long": b_in + sk_b,
+                   "sk_scatter": 2 * rec_b + 4, "slab_compact": 2 * rec_b, "bin_count": r_alg + u_over_n * (key + 3),
+                   "span_sort": sort_rec + 16 + 1 + (4 if is_set else 2), "set_csr": 4 + 8 + 4 * 1.5}
+            # HBM traffic per k-mer instance from the PMC passes (tools/pmc.sh: separate --pmc runs of this same bench at
+            # 10M reads; FETCH_SIZE doubled per the gfx950 correction): newest profiles/r*_pmc_traffic*.json
+            import glob
+            tj, tf = {}, sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+            if tf:
+                tj = json.load(open(tf[-1]))
+            pmc_name = {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
+                        "radix_hist": "radix16_hist_kernel" if 2 * k <= 96 else "radix_hist_kernel",
+                        "radix_scatter": "radix16_scatter_kernel" if 2 * k <= 96 else "radix_scatter_kernel",
+                        "span_sort": "span_sort16_kernel" if 2 * k <= 96 else "span_sort_kernel", "set_csr": "csr_apply_kernel",
+                        "sk_scatter": "sk_scatter_kernel", "slab_compact": "slab_compact_kernel"}
+
+            def row(name, a):
+                per_unit = alg.get(name, 2 * rbytes)
+                step_ms = a["ms"] / args.steps
+                units_step = a["units"] / args.steps
+                ach = per_unit * units_step / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+                ent = tj.get(pmc_name.get(name, name))
+                r = {"kernel": name, "ms_per_step": round(step_ms, 3), "launches_per_step": a["launches"] / args.steps,
+                     "alg_bytes_per_unit": round(per_unit, 2), "units_per_step": units_step,
+                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                     "traffic_bytes_per_step": None, "measured_gb_per_s": None, "measured_hbm_frac": None, "bound": "hbm"}
+                if ent and step_ms > 0:
+                    tb = ent["bytes_per_instance"] * n_inst     # the PMC file is normalised per k-mer instance of the profiled run
+                    r["traffic_bytes_per_step"] = round(tb, 0)
+                    r["measured_gb_per_s"] = round(tb / (step_ms * 1e-3) / 1e9, 1)
+                    r["measured_hbm_frac"] = round(tb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    # a kernel that moves < 0.2x its algorithmic bytes through HBM is not bounded by HBM: its work happens in
+                    # LDS / VALU (the counting kernel keeps the records' k-mers on chip)
+                    if tb < 0.2 * per_unit * units_step:
+                        r["bound"] = "lds/valu"
+                    elif r["measured_hbm_frac"] < 0.25:
+                        r["bound"] = "valu/latency"
+                return r
+
+            rows = [row(nm, a) for nm, a in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])]
+            d = rows[0]
+            a = dom[1]
+            roof = {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["frac"], "traffic": (round(d["traffic_bytes_per_step"] / d["launches_per_step"], 0)
+                                                   if d["traffic_bytes_per_step"] is not None else None),
+                    "measured_hbm_frac": d["measured_hbm_frac"],
+                    "alg_bytes_per_unit": d["alg_bytes_per_unit"], "units_per_launch": a["units"] / a["launches"],
+                    "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches_per_step": d["launches_per_step"],
                     "whole_path_alg_frac": round(value * b_alg / HBM_PEAK_GBS, 4),
+                    "whole_path_measured_hbm_frac": (round(sum(r["traffic_bytes_per_step"] or 0 for r in rows) / (ms_per_step * 1e-3) / 1e9
+                                                           / HBM_PEAK_GBS, 4) if any(r["traffic_bytes_per_step"] for r in rows) else None),
+                    "note": "achieved/frac: SURVEY 8(d) algorithmic bytes / HIP-event time (the contract figure); measured_*: HBM bytes "
+                            "from the FETCH_SIZE/WRITE_SIZE counter passes (%s); bound = lds/valu when the measured traffic is "
+                            "below 0.2x the algorithmic bytes" % (os.path.basename(tf[-1]) if tf else "no PMC file"),
+                    "kernels": rows,
                     "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
@@ -366,7 +402,8 @@ def main():
             "exchange": ({"bytes_sent_per_step_all_ranks": xbytes_total // max(args.steps, 1),
                           "exposed_ms_per_step_max_rank": round(exposed_ms / max(args.steps, 1), 3),
                           "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1)} if world > 1 else None),
-            "roofline": roof, "cpu_baseline": cpu, "host_boundary": hostb, "compress": comp,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
+            "host_boundary": hostb, "compress": comp,
         }
     ctx.close()
     if world > 1 or args.force_exchange:
