@@ -665,15 +665,26 @@ __device__ __forceinline__ uint64_t hash_key(uint64_t hi, uint64_t lo) {
 #endif
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and broadcasts: seven VALU instructions, no LDS
+// traffic (the shuffle-based form issues six ds_bpermute through the LDS crossbar, which the probing waves of the other
+// workgroup on the CU are saturating).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    // row_shr:1..3 combine within groups of four, row_shr:4/8 within a row of 16, row_bcast:15/31 across rows
+    const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
+    v = v + a + b + c;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 template <int NT>
 __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s_wsum, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    const uint32_t incl = wave_inclusive_scan_u32(v);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -688,16 +699,12 @@ __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s
     return base + incl;
 }
 
-// the same over four 16-bit counters packed in a u64 (no field may reach 65536 in the block total)
+// the same over four 16-bit counters packed in a u64 (no field may reach 65536 in the block total): the two 32-bit halves hold
+// two fields each and never carry into one another, so they are scanned as two independent words
 template <int NT>
 __device__ __forceinline__ uint64_t block_inclusive_scan64(uint64_t v, uint64_t* s_wsum, uint64_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint64_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
+    const uint64_t incl = (uint64_t)wave_inclusive_scan_u32((uint32_t)v) | ((uint64_t)wave_inclusive_scan_u32((uint32_t)(v >> 32)) << 32);
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
     uint64_t base = 0, tot = 0;
@@ -763,7 +770,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     uint32_t* const s_dd = reinterpret_cast<uint32_t*>(s_cmap);      // duplicate filter of the batch (dead before s_cmap is filled)
     __shared__ uint32_t s_w[NT / 2];            // per staged record: how many identical records of the batch it stands for (u16 halves)
     __shared__ uint32_t s_cmk[IS_SET ? NT : 1]; // ... and the union of their colours (CountFilterSet)
-    __shared__ uint32_t s_m, s_cproc, s_nextq;
+    __shared__ uint32_t s_m, s_cproc, s_nextq, s_nst;
 #ifdef DBG_COUNT_STATS
     __shared__ uint32_t s_stat[16];
     if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
@@ -838,7 +845,11 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 pmeta = (NBW == 2 ? P1 : (NBW == 3 ? P2 : P3)) & ((1ull << META_BITS) - 1);
             }
         };
-        load_rec(tid);                                  // the first batch is on its way while the table is cleared
+        // the first two rounds of incoming records are on their way while the table is cleared (a bin normally holds 512 + ~33)
+        load_rec(NT + tid);
+        uint64_t Q0 = P0, Q1 = P1, Q2 = P2, Q3 = P3, qmeta = pmeta;
+        bool q_valid = true;                            // Q holds record NT + tid
+        load_rec(tid);
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
         __syncthreads();
@@ -852,255 +863,296 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         //      complement per chunk) and then rolls (extend_right on the forward strand, extend_left of the
         //      complement on the reverse strand).  The next batch is prefetched into registers meanwhile. ----
         bool pass_ovf = false;
-
-        for (uint32_t bstart = 0; bstart < total_recs && !pass_ovf;) {
-            // A. stage this batch's records (prefetched) + per-record chunking
-            const bool have = bstart + tid < total_recs;
-            uint32_t nkr = have ? (uint32_t)(pmeta & 0x7f) - (uint32_t)k + 1u : 0u;
-            s_slab[tid] = P0; s_slab[NT + tid] = P1;
-            if (NBW > 2) s_slab[2 * NT + tid] = P2;
-            if (NBW > 3) s_slab[3 * NT + tid] = P3;
-            // A'. identical records of the batch are counted once.  Reads that cover the same stretch of the genome cut
-            //     it into the same super-k-mers (the cut points depend on the sequence alone), so at 30x most records
-            //     that do not touch a read end have a dozen exact copies in their bin.  A record that finds an equal one
-            //     (bases, length, boundary Exts) already entered in the batch's filter adds 1 to that record's weight and
-            //     its colour to that record's colour set and contributes no chunks; the k-mers of the surviving record
-            //     are inserted with count += weight.  The filter (open addressing on DD slots, entry = staged slot + 1
-            //     | 22 hash bits) lives in s_cmap, which is not in use until the chunk map is built.
-            constexpr uint64_t COLOUR_BITS = 31ull << 15;
-            if (tid < NT / 2) s_w[tid] = 0x00010001u;       // weight 1 in both halves (slots past the bin's end are never read)
-            if (IS_SET) s_cmk[tid] = 1u << ((uint32_t)(pmeta >> 15) & 31u);
+        // Staged records persist across rounds of incoming records: DISTINCT records collect in the staging area (identical
+        // ones only add to a staged record's weight and colour set), and their k-mers are inserted once the area is nearly
+        // full or the bin is exhausted.  A bin of ~545 records holds ~230 distinct ones, so it is normally filled in two rounds
+        // (512 + 33 incoming records) and processed ONCE -- the tail batch used to pay for its own staging, chunk map and
+        // insertion round, and its records could not be merged with the first batch's.
+        //   s_dd   duplicate filter (open addressing; entry = staged slot + 1 | 22 hash bits); lives in s_cmap, which is only
+        //          needed once the staged records are cut into chunks -- after that the filter is rebuilt from scratch
+        //   s_nst  staged records; a round accepts min(NT - s_nst, remaining) incoming records, so every one of them finds room
+        constexpr uint64_t COLOUR_BITS = 31ull << 15;
+        constexpr uint32_t MIN_ROOM = NT / 8;           // keep filling while the rest of the bin, or at least this many records, still fit
+        constexpr uint32_t MAX_FILLS = 100;             // weights are 16-bit: at most NT per round, 100 x 512 < 65536
+        uint32_t rnext = 0;                             // next incoming record of the bin (uniform)
+        while (rnext < total_recs && !pass_ovf) {
+            // ---- reset the staging area and the filter ----
+            if (tid < NT / 2) s_w[tid] = 0;
+            if (IS_SET) s_cmk[tid] = 0;
             for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
-            const uint32_t nkr0 = nkr;
+            if (tid == 0) s_nst = 0;
             __syncthreads();
-            if (have) {
-                const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);           // word holding the meta bits
-                const uint64_t lastw = PL0 & ~COLOUR_BITS;
-                uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
-                if (NBW == 3) ha += lastw * 0x9E3779B97F4A7C15ull;
-                if (NBW == 4) { ha += P2 * 0x9E3779B97F4A7C15ull; hb += lastw * 0xC2B2AE3D27D4EB4Full; }
-                const uint64_t h = hash_key(ha, hb);
-                const uint32_t mine = (tid + 1u) | ((uint32_t)(h >> 42) << 10);
-                uint32_t sl = (uint32_t)h & (DD - 1);
-                for (;;) {
-                    asm volatile("" ::: "memory");
-                    uint32_t v = s_dd[sl];
-                    if (v == 0u) { v = atomicCAS(&s_dd[sl], 0u, mine); if (v == 0u) break; }     // first of its kind
-                    if ((v >> 10) == (mine >> 10)) {
-                        const uint32_t r = (v & 1023u) - 1u;
-                        bool same = s_slab[r] == P0;
-                        if (NBW > 2) same = same && s_slab[NT + r] == P1;
-                        if (NBW > 3) same = same && s_slab[2 * NT + r] == P2;
-                        same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
-                        if (same) {
-                            atomicAdd(&s_w[r >> 1], 1u << (16 * (r & 1u)));           // <= NT per half: no carry
-                            if (IS_SET) atomicOr(&s_cmk[r], 1u << ((uint32_t)(pmeta >> 15) & 31u));
-                            nkr = 0;                                                     // no chunks of its own
-                            break;
+            uint32_t nstaged = 0;
+            // ---- fill rounds: thread tid holds incoming record rnext + tid (prefetched) ----
+            for (uint32_t fills = 0;; fills++) {
+                const uint32_t room = NT - nstaged;
+                const uint32_t take = total_recs - rnext < room ? total_recs - rnext : room;
+                if (tid < take) {
+                    const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);           // word holding the meta bits
+                    const uint64_t lastw = PL0 & ~COLOUR_BITS;
+                    uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
+                    if (NBW == 3) ha += lastw * 0x9E3779B97F4A7C15ull;
+                    if (NBW == 4) { ha += P2 * 0x9E3779B97F4A7C15ull; hb += lastw * 0xC2B2AE3D27D4EB4Full; }
+                    const uint64_t h = hash_key(ha, hb);
+                    const uint32_t mytag = (uint32_t)(h >> 42) << 10;
+                    const uint32_t colour = 1u << ((uint32_t)(pmeta >> 15) & 31u);
+                    uint32_t sl = (uint32_t)h & (DD - 1);
+                    // Claim-then-stage: the first record of its kind wins the filter slot with a PENDING entry, takes the next
+                    // staging slot, writes the record and only then publishes the slot number; records that meet a PENDING entry
+                    // with their own hash bits re-read it (the claimer is in another wave, or has finished its stores before this
+                    // wave's next loop iteration -- the same argument as for TAG_BUSY in the k-mer table).  Allocating before the
+                    // claim would hand out a slot to every record of the first round (all of them see an empty filter).
+                    constexpr uint32_t PENDING = 1023u;
+                    for (;;) {
+                        asm volatile("" ::: "memory");
+                        uint32_t v = s_dd[sl];
+                        if (v == 0u) {                                                   // end of the probe chain: first of its kind
+                            v = atomicCAS(&s_dd[sl], 0u, PENDING | mytag);
+                            if (v == 0u) {
+                                const uint32_t mine = atomicAdd(&s_nst, 1u);             // < NT: at most `room` records allocate
+                                s_slab[mine] = P0; s_slab[NT + mine] = P1;
+                                if (NBW > 2) s_slab[2 * NT + mine] = P2;
+                                if (NBW > 3) s_slab[3 * NT + mine] = P3;
+                                atomicAdd(&s_w[mine >> 1], 1u << (16 * (mine & 1u)));
+                                if (IS_SET) atomicOr(&s_cmk[mine], colour);
+                                asm volatile("" ::: "memory");                           // the record is written before it is published
+                                __hip_atomic_store(&s_dd[sl], (mine + 1u) | mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                break;
+                            }
                         }
-                    }
-                    sl = (sl + 1u) & (DD - 1);
-                }
-            }
-            if (tid == 0) { s_m = NT; s_cproc = 0; s_nextq = 0; }
-            // Chunks are entered into the map by length (CH, CH-1, ..., 1): the 64 chunks a wave takes then roll the
-            // same number of k-mers, where record order mixes lengths cb and cb+1 in every wave (11 % idle lanes).
-            // One scan of four packed 16-bit counters gives every record its place in both of its length classes.
-            uint32_t nch = (nkr + CH - 1) / CH;
-            uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;          // chunk c: cb + (c < cr) k-mers
-            const uint32_t cl_hi = CH - cb - 1, cl_lo = CH - cb;             // class of the cr longer / nch-cr shorter chunks
-            uint64_t contrib = 0;
-            if (nch) contrib = (cr ? (uint64_t)cr << (16 * cl_hi) : 0ull) + ((uint64_t)(nch - cr) << (16 * cl_lo));
-            uint64_t tot64;
-            const uint64_t incl64 = block_inclusive_scan64<NT>(contrib, s_wsum64, &tot64);   // barriers inside
-            auto fsum = [](uint64_t x) { return (uint32_t)(x & 0xffff) + (uint32_t)((x >> 16) & 0xffff) + (uint32_t)((x >> 32) & 0xffff) + (uint32_t)(x >> 48); };
-            const uint32_t totc = fsum(tot64);
-            const bool all_fit = totc <= CAPC;                               // uniform
-            if (all_fit) {
-                if (nch) {
-                    const uint64_t excl64 = incl64 - contrib;
-                    // class c starts after the totals of classes 0..c-1
-                    const uint64_t below_lo = tot64 & ((1ull << (16 * cl_lo)) - 1);
-                    const uint32_t pos_lo = fsum(below_lo) + (uint32_t)((excl64 >> (16 * cl_lo)) & 0xffff);
-                    for (uint32_t c = cr; c < nch; c++) s_cmap[pos_lo + c - cr] = (uint16_t)(tid | (c << 10));
-                    if (cr) {
-                        const uint64_t below_hi = tot64 & ((1ull << (16 * cl_hi)) - 1);
-                        const uint32_t pos_hi = fsum(below_hi) + (uint32_t)((excl64 >> (16 * cl_hi)) & 0xffff);
-                        for (uint32_t c = 0; c < cr; c++) s_cmap[pos_hi + c] = (uint16_t)(tid | (c << 10));
+                        if ((v & ~1023u) == mytag) {
+                            if ((v & 1023u) == PENDING) continue;                        // being staged: look again
+                            const uint32_t r = (v & 1023u) - 1u;
+                            bool same = s_slab[r] == P0;
+                            if (NBW > 2) same = same && s_slab[NT + r] == P1;
+                            if (NBW > 3) same = same && s_slab[2 * NT + r] == P2;
+                            same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
+                            if (same) {                                                  // an equal record is staged: it stands for this one too
+                                STAT(fills ? 14 : 15, 1);
+                                atomicAdd(&s_w[r >> 1], 1u << (16 * (r & 1u)));
+                                if (IS_SET) atomicOr(&s_cmk[r], colour);
+                                break;
+                            }
+                        }
+                        sl = (sl + 1u) & (DD - 1);
                     }
                 }
-            } else {
-                // Even the distinct records of the batch need more chunks than the map holds (long records with few
-                // copies): the filter is undone -- every record counts for itself again -- and as many records as fit
-                // are taken in record order; the rest is staged again with the next batch.
-                if (tid == 0) atomicAdd(&gflags[12], 1u);
-                if (tid < NT / 2) s_w[tid] = 0x00010001u;
-                if (IS_SET) s_cmk[tid] = 1u << ((uint32_t)(pmeta >> 15) & 31u);
-                nch = (nkr0 + CH - 1) / CH;
-                uint32_t dummy;
-                const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &dummy);
-                if (incl <= CAPC) {
-                    if (nch) atomicMax(&s_cproc, incl);
-                    for (uint32_t c = 0; c < nch; c++) s_cmap[incl - nch + c] = (uint16_t)(tid | (c << 10));
-                } else if (have) atomicMin(&s_m, tid);
-            }
-            __syncthreads();
-            const uint32_t nrec = total_recs - bstart < (uint32_t)NT ? total_recs - bstart : (uint32_t)NT;
-            const uint32_t m = all_fit ? nrec : (s_m < nrec ? s_m : nrec);  // records of this batch whose chunks fit the map (>= 1)
-            const uint32_t cproc = all_fit ? totc : s_cproc;
-            // B. prefetch the next batch while this one is processed
-            load_rec(bstart + m + tid);
-            PH(7);
-            // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
-            for (;;) {
-                uint32_t q0 = 0;
-                if (lane == 0) q0 = atomicAdd(&s_nextq, 64u);
-                q0 = __shfl(q0, 0);
-                if (q0 >= cproc) break;
-                const uint32_t q = q0 + lane;
-                const bool act = q < cproc;
-                const uint32_t e = act ? (uint32_t)s_cmap[q] : 0u;
-                const uint32_t r = e & 1023u, c = e >> 10;
-                W0 = s_slab[r]; W1 = s_slab[NT + r];
-                if (NBW > 2) W2 = s_slab[2 * NT + r];
-                if (NBW > 3) W3 = s_slab[3 * NT + r];
-                {   // the record's meta bits sit below its bases in the last word
-                    uint64_t& WL = NBW == 2 ? W1 : (NBW == 3 ? W2 : W3);
-                    meta = WL & ((1ull << META_BITS) - 1);
-                    WL &= ~((1ull << META_BITS) - 1);
-                }
-                const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu;
-                const uint32_t wgt = (s_w[r >> 1] >> (16 * (r & 1u))) & 0xffffu, cset = IS_SET ? s_cmk[r] << 8 : 0u;
-                // the record's chunking, as stage A cut it: ceil(nk/4) chunks of cbase (+1 for the first crem) k-mers
-                static_assert(CH == 4, "closed form of nk / ceil(nk / CH)");
-                const uint32_t rnk = rlen - (uint32_t)k + 1u, rnch = (rnk + 3u) >> 2;
-                const uint32_t cbase = rnk < 4u ? rnk : (rnk == 5u ? 2u : ((rnk & 3u) ? 3u : 4u)), crem = rnk - cbase * rnch;
-                uint32_t j = c * cbase + (c < crem ? c : crem);
-                const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
-                // k-mer j of the record: bases [j, j + k) of the 2-bit stream W[0..NBW)
-                K128 fw;
-                {
-                    const uint32_t sft = 2 * j, ws = sft >> 6, bs = sft & 63;
-                    const uint64_t A = ws == 0 ? W0 : W1, B = ws == 0 ? W1 : (NBW > 2 ? W2 : 0ull),
-                                   C = ws == 0 ? (NBW > 2 ? W2 : 0ull) : (NBW > 3 ? W3 : 0ull);
-                    const uint64_t h = bs ? (A << bs) | (B >> (64 - bs)) : A, l = bs ? (B << bs) | (C >> (64 - bs)) : B;
-                    fw = k128_shr(K128{h, l}, 128 - 2 * k);
-                }
-                K128 rcw = kmer_rc(fw, k);
-                uint32_t lb = j ? base_at(j - 1) : 0u;
-                // the (at most CH) bases that follow the chunk's first k-mer, top-aligned; zero beyond the record's end
-                uint32_t nx;
-                {
-                    const uint32_t sft = 2 * (j + (uint32_t)k), ws = sft >> 6, bs = sft & 63;
-                    const uint64_t A = ws == 0 ? W0 : (ws == 1 ? W1 : (NBW > 2 && ws == 2 ? W2 : (NBW > 3 && ws == 3 ? W3 : 0ull)));
-                    const uint64_t B = ws == 0 ? W1 : (NBW > 2 && ws == 1 ? W2 : (NBW > 3 && ws == 2 ? W3 : 0ull));
-                    const uint64_t v = bs ? (A << bs) | (B >> (64 - bs)) : A;
-                    nx = (uint32_t)(v >> 32);
-                }
-                while (__any(j < jend)) {
-                    const bool alive = j < jend;
+                __syncthreads();
+                nstaged = s_nst;
 #ifdef DBG_COUNT_STATS
-            { uint64_t bal = __ballot(alive); if (lane == 0) { atomicAdd(&s_stat[4], 1u); atomicAdd(&s_stat[5], (uint32_t)__popcll(bal)); } }
+                if (tid == 0 && fills == 0) atomicAdd(&s_stat[13], nstaged);
+                if (tid == 0 && fills == 1) atomicAdd(&s_stat[12], take);
 #endif
-            if (alive) {
-                const uint32_t nbase = nx >> 30;                                         // base right of the k-mer (0 past the end)
-                nx <<= 2;
-                {
-                    // Exts of k-mer j inside the piece (lib.rs:820-832 with seq_exts = the piece's boundary Exts)
-                    uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << lb);
-                    uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << nbase);
-                    uint32_t ex = left | right;
-                    K128 km = fw;
-                    if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = __brev(ex) >> 24; }   // ties flip (lib.rs:226-230); Exts::rc = byte bit-reversal
-                    const uint64_t h = hash_key(km.hi, km.lo);
-                    if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
-                        // Bucketised linear probing: 4 tags per 16-byte bucket.  One round = one ds_read_b128 of the
-                        // bucket's tags, then at most one dependent LDS operation per lane: the 16-byte key of the one
-                        // candidate slot whose tag matches, or a CAS on the first free slot.  (Divergent branches run
-                        // one after the other, so every extra dependent LDS access inside a branch costs the whole
-                        // wave a round trip; the candidate is therefore chosen with compares and selects only.)
-                        // A key lives in the first bucket (in probe order) that had a free slot when it was inserted;
-                        // a failed CAS re-reads the bucket, so two lanes can never claim two slots for one key.
-                        const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
-                        uint32_t bkt = (uint32_t)h & (T / 4 - 1);
-                        uint32_t slot = 0, tried = 0, nprobe = 0;
-                        bool hit = false;
-                        for (;;) {
-                            asm volatile("" ::: "memory");                           // re-read the tags every round
-                            const uint4 t4 = *reinterpret_cast<const uint4*>(&s_tag[bkt * 4]);
-                            const uint32_t mm = ((t4.x == mytag ? 1u : 0u) | (t4.y == mytag ? 2u : 0u) | (t4.z == mytag ? 4u : 0u) |
-                                                 (t4.w == mytag ? 8u : 0u)) & ~tried;
-                            const uint32_t bz = mytag | TAG_BUSY;
-                            const bool busy = t4.x == bz || t4.y == bz || t4.z == bz || t4.w == bz;
-                            const uint32_t em = (t4.x == 0u ? 1u : 0u) | (t4.y == 0u ? 2u : 0u) | (t4.z == 0u ? 4u : 0u) | (t4.w == 0u ? 8u : 0u);
-                            STAT(6, 1);
-                            if (mm) {                                                // ready entry with my tag: verify the key
-                                const uint32_t i = (uint32_t)__ffs((int)mm) - 1u, sl = bkt * 4 + i;
-                                bool same;
-                                if (KW == 2) {
-                                    const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s_key[2 * sl]);
-                                    same = kk.x == km.lo && kk.y == km.hi;
-                                } else same = s_key[sl] == km.lo;
-                                if (same) { hit = true; slot = sl; break; }
-                                tried |= 1u << i;                                    // a different key with the same 31-bit tag
-                                STAT(8, 1);
-                                continue;
-                            }
-                            if (busy) { STAT(9, 1); continue; }                      // a claimer is still writing its key: re-read
-                            if (em) {
-                                const uint32_t sl = bkt * 4 + (uint32_t)__ffs((int)em) - 1u;
-                                if (atomicCAS(&s_tag[sl], 0u, bz) == 0u) {
-                                    if (KW == 2) *reinterpret_cast<ulonglong2*>(&s_key[2 * sl]) = make_ulonglong2(km.lo, km.hi);
-                                    else s_key[sl] = km.lo;
-                                    asm volatile("" ::: "memory");                   // the key store is issued before the tag store
-                                    __hip_atomic_store(&s_tag[sl], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    atomicAdd(&s_flag[1], 1u);                       // occupancy, polled between batches
-                                    hit = true; slot = sl;
-                                    STAT(11, 1);
-                                    break;
-                                }
-                                STAT(10, 1);
-                                continue;                                            // lost the race: re-read this bucket
-                            }
-                            bkt = (bkt + 1) & (T / 4 - 1);
-                            tried = 0;
-                            STAT(7, 1);
-                            if (++nprobe >= (uint32_t)(T / 4)) break;                // table full
-                        }
-                        if (hit) {
-                            atomicAdd(&s_cnt[slot], wgt);
-                            atomicOr(&s_aux[slot], ex | cset);
-                        } else {
-                            __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full: the pass is re-split
+                rnext += take;
+                if (q_valid && rnext == (uint32_t)NT) { P0 = Q0; P1 = Q1; P2 = Q2; P3 = Q3; pmeta = qmeta; }   // requested at the start
+                else load_rec(rnext + tid);                                              // the next incoming records are on their way
+                q_valid = false;
+                if (rnext >= total_recs || fills >= MAX_FILLS) break;
+                if (NT - nstaged < MIN_ROOM && NT - nstaged < total_recs - rnext) break;
+            }
+            PH(7);
+            // ---- cut the staged records into chunks and insert their k-mers; the chunk map may take several rounds when the
+            //      records are long and all different ----
+            for (uint32_t base = 0; base < nstaged && !pass_ovf;) {
+                const bool have = tid >= base && tid < nstaged;
+                uint32_t nkr = 0;
+                if (have) {
+                    const uint32_t wg = (s_w[tid >> 1] >> (16 * (tid & 1u))) & 0xffffu;
+                    const uint32_t rl = (uint32_t)(s_slab[(NBW - 1) * NT + tid] & 0x7f);
+                    nkr = wg ? rl - (uint32_t)k + 1u : 0u;
+                }
+                if (tid == 0) { s_m = nstaged; s_cproc = 0; s_nextq = 0; }
+                // Chunks are entered into the map by length (CH, CH-1, ..., 1): the 64 chunks a wave takes then roll the
+                // same number of k-mers, where record order mixes lengths cb and cb+1 in every wave (11 % idle lanes).
+                // One scan of four packed 16-bit counters gives every record its place in both of its length classes.
+                const uint32_t nch = (nkr + CH - 1) / CH;
+                const uint32_t cb = nch ? nkr / nch : 0u, cr = nkr - cb * nch;    // chunk c: cb + (c < cr) k-mers
+                const uint32_t cl_hi = CH - cb - 1, cl_lo = CH - cb;             // class of the cr longer / nch-cr shorter chunks
+                uint64_t contrib = 0;
+                if (nch) contrib = (cr ? (uint64_t)cr << (16 * cl_hi) : 0ull) + ((uint64_t)(nch - cr) << (16 * cl_lo));
+                uint64_t tot64;
+                const uint64_t incl64 = block_inclusive_scan64<NT>(contrib, s_wsum64, &tot64);   // barriers inside
+                auto fsum = [](uint64_t x) { return (uint32_t)(x & 0xffff) + (uint32_t)((x >> 16) & 0xffff) + (uint32_t)((x >> 32) & 0xffff) + (uint32_t)(x >> 48); };
+                const uint32_t totc = fsum(tot64);
+                const bool all_fit = totc <= CAPC;                               // uniform
+                if (all_fit) {
+                    if (nch) {
+                        const uint64_t excl64 = incl64 - contrib;
+                        // class c starts after the totals of classes 0..c-1
+                        const uint64_t below_lo = tot64 & ((1ull << (16 * cl_lo)) - 1);
+                        const uint32_t pos_lo = fsum(below_lo) + (uint32_t)((excl64 >> (16 * cl_lo)) & 0xffff);
+                        for (uint32_t c = cr; c < nch; c++) s_cmap[pos_lo + c - cr] = (uint16_t)(tid | (c << 10));
+                        if (cr) {
+                            const uint64_t below_hi = tot64 & ((1ull << (16 * cl_hi)) - 1);
+                            const uint32_t pos_hi = fsum(below_hi) + (uint32_t)((excl64 >> (16 * cl_hi)) & 0xffff);
+                            for (uint32_t c = 0; c < cr; c++) s_cmap[pos_hi + c] = (uint16_t)(tid | (c << 10));
                         }
                     }
+                } else {
+                    // the chunks of the remaining staged records do not fit the map (long records, few copies): as many records
+                    // as fit are taken in slot order, the rest in the next round
+                    if (tid == 0) atomicAdd(&gflags[12], 1u);
+                    uint32_t dummy;
+                    const uint32_t incl = block_inclusive_scan<NT>(nch, s_wsum, &dummy);
+                    if (incl <= CAPC) {
+                        if (nch) atomicMax(&s_cproc, incl);
+                        for (uint32_t c = 0; c < nch; c++) s_cmap[incl - nch + c] = (uint16_t)(tid | (c << 10));
+                    } else if (have) atomicMin(&s_m, tid);
                 }
-                // roll to k-mer j+1
-                if (KW == 2) {                                       // 33 <= k <= 64: the first base sits in hi
-                    const int sh = 2 * (k - 1) - 64;
-                    lb = (uint32_t)(fw.hi >> sh) & 3u;
-                    fw.hi = ((fw.hi << 2) | (fw.lo >> 62)) & kmask.hi;
-                    fw.lo = (fw.lo << 2) | nbase;
-                    rcw.lo = (rcw.lo >> 2) | (rcw.hi << 62);
-                    rcw.hi = (rcw.hi >> 2) | ((uint64_t)(3u - nbase) << sh);
-                } else {                                             // k <= 32: everything sits in lo
-                    const int sh = 2 * (k - 1);
-                    lb = (uint32_t)(fw.lo >> sh) & 3u;
-                    fw.lo = ((fw.lo << 2) | nbase) & kmask.lo;
-                    rcw.lo = (rcw.lo >> 2) | ((uint64_t)(3u - nbase) << sh);
+                __syncthreads();
+                const uint32_t mend = all_fit ? nstaged : s_m;                   // records [base, mend) are in the map (at least one)
+                const uint32_t cproc = all_fit ? totc : s_cproc;
+                // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
+                for (;;) {
+                    uint32_t q0 = 0;
+                    if (lane == 0) q0 = atomicAdd(&s_nextq, 64u);
+                    q0 = __shfl(q0, 0);
+                    if (q0 >= cproc) break;
+                    const uint32_t q = q0 + lane;
+                    const bool act = q < cproc;
+                    const uint32_t e = act ? (uint32_t)s_cmap[q] : 0u;
+                    const uint32_t r = e & 1023u, c = e >> 10;
+                    W0 = s_slab[r]; W1 = s_slab[NT + r];
+                    if (NBW > 2) W2 = s_slab[2 * NT + r];
+                    if (NBW > 3) W3 = s_slab[3 * NT + r];
+                    {   // the record's meta bits sit below its bases in the last word
+                        uint64_t& WL = NBW == 2 ? W1 : (NBW == 3 ? W2 : W3);
+                        meta = WL & ((1ull << META_BITS) - 1);
+                        WL &= ~((1ull << META_BITS) - 1);
+                    }
+                    const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu;
+                    const uint32_t wgt = (s_w[r >> 1] >> (16 * (r & 1u))) & 0xffffu, cset = IS_SET ? s_cmk[r] << 8 : 0u;
+                    // the record's chunking, as stage A cut it: ceil(nk/4) chunks of cbase (+1 for the first crem) k-mers
+                    static_assert(CH == 4, "closed form of nk / ceil(nk / CH)");
+                    const uint32_t rnk = rlen - (uint32_t)k + 1u, rnch = (rnk + 3u) >> 2;
+                    const uint32_t cbase = rnk < 4u ? rnk : (rnk == 5u ? 2u : ((rnk & 3u) ? 3u : 4u)), crem = rnk - cbase * rnch;
+                    uint32_t j = c * cbase + (c < crem ? c : crem);
+                    const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
+                    // k-mer j of the record: bases [j, j + k) of the 2-bit stream W[0..NBW)
+                    K128 fw;
+                    {
+                        const uint32_t sft = 2 * j, ws = sft >> 6, bs = sft & 63;
+                        const uint64_t A = ws == 0 ? W0 : W1, B = ws == 0 ? W1 : (NBW > 2 ? W2 : 0ull),
+                                       C = ws == 0 ? (NBW > 2 ? W2 : 0ull) : (NBW > 3 ? W3 : 0ull);
+                        const uint64_t h = bs ? (A << bs) | (B >> (64 - bs)) : A, l = bs ? (B << bs) | (C >> (64 - bs)) : B;
+                        fw = k128_shr(K128{h, l}, 128 - 2 * k);
+                    }
+                    K128 rcw = kmer_rc(fw, k);
+                    uint32_t lb = j ? base_at(j - 1) : 0u;
+                    // the (at most CH) bases that follow the chunk's first k-mer, top-aligned; zero beyond the record's end
+                    uint32_t nx;
+                    {
+                        const uint32_t sft = 2 * (j + (uint32_t)k), ws = sft >> 6, bs = sft & 63;
+                        const uint64_t A = ws == 0 ? W0 : (ws == 1 ? W1 : (NBW > 2 && ws == 2 ? W2 : (NBW > 3 && ws == 3 ? W3 : 0ull)));
+                        const uint64_t B = ws == 0 ? W1 : (NBW > 2 && ws == 1 ? W2 : (NBW > 3 && ws == 2 ? W3 : 0ull));
+                        const uint64_t v = bs ? (A << bs) | (B >> (64 - bs)) : A;
+                        nx = (uint32_t)(v >> 32);
+                    }
+                    while (__any(j < jend)) {
+                        const bool alive = j < jend;
+#ifdef DBG_COUNT_STATS
+                { uint64_t bal = __ballot(alive); if (lane == 0) { atomicAdd(&s_stat[4], 1u); atomicAdd(&s_stat[5], (uint32_t)__popcll(bal)); } }
+#endif
+                if (alive) {
+                    const uint32_t nbase = nx >> 30;                                         // base right of the k-mer (0 past the end)
+                    nx <<= 2;
+                    {
+                        // Exts of k-mer j inside the piece (lib.rs:820-832 with seq_exts = the piece's boundary Exts)
+                        uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << lb);
+                        uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << nbase);
+                        uint32_t ex = left | right;
+                        K128 km = fw;
+                        if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = __brev(ex) >> 24; }   // ties flip (lib.rs:226-230); Exts::rc = byte bit-reversal
+                        const uint64_t h = hash_key(km.hi, km.lo);
+                        if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
+                            // Bucketised linear probing: 4 tags per 16-byte bucket.  One round = one ds_read_b128 of the
+                            // bucket's tags, then at most one dependent LDS operation per lane: the 16-byte key of the one
+                            // candidate slot whose tag matches, or a CAS on the first free slot.  (Divergent branches run
+                            // one after the other, so every extra dependent LDS access inside a branch costs the whole
+                            // wave a round trip; the candidate is therefore chosen with compares and selects only.)
+                            // A key lives in the first bucket (in probe order) that had a free slot when it was inserted;
+                            // a failed CAS re-reads the bucket, so two lanes can never claim two slots for one key.
+                            const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
+                            uint32_t bkt = (uint32_t)h & (T / 4 - 1);
+                            uint32_t slot = 0, tried = 0, nprobe = 0;
+                            bool hit = false;
+                            for (;;) {
+                                asm volatile("" ::: "memory");                           // re-read the tags every round
+                                const uint4 t4 = *reinterpret_cast<const uint4*>(&s_tag[bkt * 4]);
+                                const uint32_t mm = ((t4.x == mytag ? 1u : 0u) | (t4.y == mytag ? 2u : 0u) | (t4.z == mytag ? 4u : 0u) |
+                                                     (t4.w == mytag ? 8u : 0u)) & ~tried;
+                                const uint32_t bz = mytag | TAG_BUSY;
+                                const bool busy = t4.x == bz || t4.y == bz || t4.z == bz || t4.w == bz;
+                                const uint32_t em = (t4.x == 0u ? 1u : 0u) | (t4.y == 0u ? 2u : 0u) | (t4.z == 0u ? 4u : 0u) | (t4.w == 0u ? 8u : 0u);
+                                STAT(6, 1);
+                                if (mm) {                                                // ready entry with my tag: verify the key
+                                    const uint32_t i = (uint32_t)__ffs((int)mm) - 1u, sl = bkt * 4 + i;
+                                    bool same;
+                                    if (KW == 2) {
+                                        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s_key[2 * sl]);
+                                        same = kk.x == km.lo && kk.y == km.hi;
+                                    } else same = s_key[sl] == km.lo;
+                                    if (same) { hit = true; slot = sl; break; }
+                                    tried |= 1u << i;                                    // a different key with the same 31-bit tag
+                                    STAT(8, 1);
+                                    continue;
+                                }
+                                if (busy) { STAT(9, 1); continue; }                      // a claimer is still writing its key: re-read
+                                if (em) {
+                                    const uint32_t sl = bkt * 4 + (uint32_t)__ffs((int)em) - 1u;
+                                    if (atomicCAS(&s_tag[sl], 0u, bz) == 0u) {
+                                        if (KW == 2) *reinterpret_cast<ulonglong2*>(&s_key[2 * sl]) = make_ulonglong2(km.lo, km.hi);
+                                        else s_key[sl] = km.lo;
+                                        asm volatile("" ::: "memory");                   // the key store is issued before the tag store
+                                        __hip_atomic_store(&s_tag[sl], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        atomicAdd(&s_flag[1], 1u);                       // occupancy, polled between batches
+                                        hit = true; slot = sl;
+                                        STAT(11, 1);
+                                        break;
+                                    }
+                                    STAT(10, 1);
+                                    continue;                                            // lost the race: re-read this bucket
+                                }
+                                bkt = (bkt + 1) & (T / 4 - 1);
+                                tried = 0;
+                                STAT(7, 1);
+                                if (++nprobe >= (uint32_t)(T / 4)) break;                // table full
+                            }
+                            if (hit) {
+                                atomicAdd(&s_cnt[slot], wgt);
+                                atomicOr(&s_aux[slot], ex | cset);
+                            } else {
+                                __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full: the pass is re-split
+                            }
+                        }
+                    }
+                    // roll to k-mer j+1
+                    if (KW == 2) {                                       // 33 <= k <= 64: the first base sits in hi
+                        const int sh = 2 * (k - 1) - 64;
+                        lb = (uint32_t)(fw.hi >> sh) & 3u;
+                        fw.hi = ((fw.hi << 2) | (fw.lo >> 62)) & kmask.hi;
+                        fw.lo = (fw.lo << 2) | nbase;
+                        rcw.lo = (rcw.lo >> 2) | (rcw.hi << 62);
+                        rcw.hi = (rcw.hi >> 2) | ((uint64_t)(3u - nbase) << sh);
+                    } else {                                             // k <= 32: everything sits in lo
+                        const int sh = 2 * (k - 1);
+                        lb = (uint32_t)(fw.lo >> sh) & 3u;
+                        fw.lo = ((fw.lo << 2) | nbase) & kmask.lo;
+                        rcw.lo = (rcw.lo >> 2) | ((uint64_t)(3u - nbase) << sh);
+                    }
+                    j++;
                 }
-                j++;
+                    }   // rolling loop
+                }       // chunk loop
+                PH(2);
+                __syncthreads();
+                PH(3);
+                base = mend;
+                // a table more than 7/8 full makes the remaining records probe long chains: give up early and re-split the pass
+                if ((base < nstaged || rnext < total_recs) && tid == 0 && s_flag[1] > (uint32_t)(T - T / 8)) s_flag[0] = 1;
+                __syncthreads();
+                pass_ovf = __hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
             }
-                }   // rolling loop
-            }       // chunk loop
-            PH(2);
-            __syncthreads();
-            PH(3);
-            bstart += m;
-            // a table more than 7/8 full makes the remaining batches probe long chains: give up early and re-split the pass
-            if (bstart < total_recs && tid == 0 && s_flag[1] > (uint32_t)(T - T / 8)) s_flag[0] = 1;
-            if (bstart < total_recs) __syncthreads();
-            pass_ovf = __hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
         }
                  // wave 0's own streaming time
         __syncthreads();
@@ -1563,8 +1615,8 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         }
 #endif
 #ifdef DBG_COUNT_STATS
-        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath-stats] wave-iterations=%u active lanes=%u (%.1f/64); lane-rounds=%u next-bucket=%u tag-collision=%u busy=%u cas-lost=%u inserts=%u\n",
-                                         flv[4], flv[5], flv[4] ? (double)flv[5] / flv[4] : 0.0, flv[6], flv[7], flv[8], flv[9], flv[10], flv[11]);
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath-stats] wave-iterations=%u active lanes=%u (%.1f/64); lane-rounds=%u next-bucket=%u tag-collision=%u busy=%u cas-lost=%u inserts=%u; staged after round 1=%u, round-2 incoming=%u, merged in round 1=%u, later=%u\n",
+                                         flv[4], flv[5], flv[4] ? (double)flv[5] / flv[4] : 0.0, flv[6], flv[7], flv[8], flv[9], flv[10], flv[11], flv[13], flv[12], flv[15], flv[14]);
 #endif
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (fl & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
