@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     __shared__ uint64_t s_wsum64[NWV];
     __shared__ uint32_t s_flag[2];              // [0] table overflow, [1] claimed entries
     __shared__ unsigned long long s_base, s_base_all;
-    __shared__ uint32_t s_stP[40], s_stR[40];
+    __shared__ uint32_t s_st[24];               // work stack of passes: P | r << 16 (P <= 4096: at most 13 levels, one pending sibling each)
     __shared__ int s_sp;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -790,11 +790,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     // its overflow in the single-GPU case): segment s spans records [seg_beg[s*stride + bin], seg_end[s*stride + bin])
     // of `recs` (of `recs_alt` for s >= alt_from).
     __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
+    __shared__ uint64_t s_segbeg[64];           // first record of segment s (so that a record fetch is one global round trip, not two)
     if (tid < 64) {                             // n_src <= 64: one lane per segment, prefix sum by shuffles
         uint32_t len = 0;
         if (tid < n_src) {
             const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[tid * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
             len = (uint32_t)(b - a);
+            s_segbeg[tid] = a;
         }
         uint32_t incl = len;
 #pragma unroll
@@ -814,13 +816,13 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     // Work stack of hash-selected passes (P, r): the pass handles the keys with (hash >> 16) % P == r.
     // A pass whose distinct keys overflow the table emits nothing and is replaced by its two children
     // (2P, r) and (2P, r + P), which partition exactly its key set.
-    if (tid == 0) { s_stP[0] = 1; s_stR[0] = 0; s_sp = 1; }
+    if (tid == 0) { s_st[0] = 1u; s_sp = 1; }
     __syncthreads();
     for (uint32_t guard = 0;; guard++) {
         const int sp = s_sp;
         if (sp == 0) break;
         if (guard > 20000u) { if (tid == 0) atomicOr(&gflags[3], 2u); break; }                   // watchdog
-        const uint32_t P = s_stP[sp - 1], pr = s_stR[sp - 1];
+        const uint32_t P = s_st[sp - 1] & 0xffffu, pr = s_st[sp - 1] >> 16;
         __syncthreads();
         if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
         constexpr uint32_t CH = 4;
@@ -831,25 +833,26 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             uint64_t wd = q < 32 ? W0 : (q < 64 ? W1 : (NBW > 2 && q < 96 ? W2 : (NBW > 3 ? W3 : (NBW > 2 ? W2 : W1))));
             return (uint32_t)(wd >> (62 - 2 * (q & 31))) & 3u;
         };
-        auto load_rec = [&](uint32_t ridx) {                         // -> P0..P3, pmeta (zero when past the end)
-            P0 = P1 = P2 = P3 = 0;
-            pmeta = 0;
+        auto load_into = [&](uint32_t ridx, uint64_t& A0, uint64_t& A1, uint64_t& A2, uint64_t& A3, uint64_t& am) {   // zero when past the end
+            A0 = A1 = A2 = A3 = 0;
+            am = 0;
             if (ridx < total_recs) {
                 uint32_t sg = 0;
                 while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
-                const uint64_t sbase = seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS];    // first record of the segment
+                const uint64_t sbase = s_segbeg[sg];                                            // first record of the segment
                 const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + (sbase + (ridx - s_segpre[sg])) * RW;
-                P0 = g[0]; P1 = g[1];
-                if (NBW > 2) P2 = g[2];
-                if (NBW > 3) P3 = g[3];
-                pmeta = (NBW == 2 ? P1 : (NBW == 3 ? P2 : P3)) & ((1ull << META_BITS) - 1);
+                A0 = g[0]; A1 = g[1];
+                if (NBW > 2) A2 = g[2];
+                if (NBW > 3) A3 = g[3];
+                am = (NBW == 2 ? A1 : (NBW == 3 ? A2 : A3)) & ((1ull << META_BITS) - 1);
             }
         };
+        auto load_rec = [&](uint32_t ridx) { load_into(ridx, P0, P1, P2, P3, pmeta); };   // -> P0..P3, pmeta
         // the first two rounds of incoming records are on their way while the table is cleared (a bin normally holds 512 + ~33)
-        load_rec(NT + tid);
-        uint64_t Q0 = P0, Q1 = P1, Q2 = P2, Q3 = P3, qmeta = pmeta;
-        bool q_valid = true;                            // Q holds record NT + tid
+        uint64_t Q0, Q1, Q2, Q3, qmeta;
         load_rec(tid);
+        load_into(NT + tid, Q0, Q1, Q2, Q3, qmeta);     // both requests are in flight together
+        bool q_valid = true;                            // Q holds record NT + tid
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
         __syncthreads();
@@ -1160,59 +1163,73 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         const bool ovf = s_flag[0] != 0;
         // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
         if (!ovf && !DBG_SKIP_EMIT) {
-            uint32_t nvalid = 0, nall = 0;
-            for (int i = tid; i < T; i += NT) {
-                if (!s_tag[i]) continue;
-                uint32_t c = s_cnt[i];
-                bool valid = IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs;
-                nvalid += valid ? 1u : 0u;
-                nall++;
+            // Every wave emits its own T / NWV slots: ballots give the counts and the ranks; the waves' counts meet in LDS, one
+            // thread reserves the bin's output range with ONE global atomic per list (same-address device atomics complete at about
+            // 10^8 per second: one per wave was measured at twice the kernel time), and each wave writes behind its predecessors.
+            constexpr int EMIT_IT = T / NWV / 64;
+            const uint32_t wave = tid >> 6;
+            const uint32_t slot0 = wave * (T / NWV) + lane;
+            uint64_t vb[EMIT_IT], ab[EMIT_IT];
+            uint32_t nv = 0, na = 0;
+#pragma unroll
+            for (int it = 0; it < EMIT_IT; it++) {
+                const uint32_t i = slot0 + it * 64;
+                const bool occ = s_tag[i] != 0u;
+                const uint32_t c = s_cnt[i];
+                const bool valid = occ && (IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs);
+                vb[it] = __ballot(valid); ab[it] = __ballot(occ);
+                nv += (uint32_t)__popcll(vb[it]); na += (uint32_t)__popcll(ab[it]);
             }
-            // one scan for both lists: valid count in the low half, distinct count in the high half (each <= T < 65536)
-            uint32_t tot2;
-            const uint32_t incl2 = block_inclusive_scan<NT>(nvalid | (nall << 16), s_wsum, &tot2);
-            const uint32_t tot_valid = tot2 & 0xffffu, tot_all = tot2 >> 16;
-            const uint32_t incl = incl2 & 0xffffu, incl_all = incl2 >> 16;
+            if (lane == 0) s_wsum[wave] = nv | (na << 16);                   // each <= T / NWV
+            __syncthreads();
             PH(4);
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NWV; w++) { const uint32_t x = s_wsum[w]; before += (uint32_t)w < wave ? x : 0u; total += x; }
+            const uint32_t tot_valid = total & 0xffffu, tot_all = total >> 16;
             if (tid == 0) {
                 s_base = tot_valid ? atomicAdd(out_cursor, (unsigned long long)tot_valid) : 0ull;
                 s_base_all = (out.all_lo && tot_all) ? atomicAdd(out.all_cursor, (unsigned long long)tot_all) : 0ull;
             }
             __syncthreads();
             PH(5);
-            uint64_t o = s_base + (incl - nvalid);
-            uint64_t oa = s_base_all + (incl_all - nall);
-            const bool fit = !(tot_valid && s_base + tot_valid > out_cap);
-            const bool fit_all = !(out.all_lo && tot_all && s_base_all + tot_all > out.all_cap);
-            if (!fit && tid == 0) atomicOr(&gflags[0], 1u);                // output buffer too small: host grows it and retries
+            const unsigned long long base = s_base + (before & 0xffffu), base_all = s_base_all + (before >> 16);
+            nv = tot_valid; na = tot_all;                                     // the fit test is about the whole bin
+            const bool fit = !(nv && s_base + nv > out_cap);
+            const bool fit_all = !(out.all_lo && na && s_base_all + na > out.all_cap);
+            if (!fit && tid == 0) atomicOr(&gflags[0], 1u);                  // output buffer too small: host grows it and retries
             if (!fit_all && tid == 0) atomicOr(&gflags[0], 8u);
             if (fit && fit_all) {
-                for (int i = tid; i < T; i += NT) {
-                    if (!s_tag[i]) continue;
-                    if (out.all_lo) {
-                        if (KW == 2) { out.all_hi[oa] = s_key[2 * i + 1]; out.all_lo[oa] = s_key[2 * i]; }
-                        else out.all_lo[oa] = s_key[i];
-                        oa++;
+                const uint64_t lt_mask = lanemask_lt();
+                uint64_t o = base, oa = base_all;
+#pragma unroll
+                for (int it = 0; it < EMIT_IT; it++) {
+                    const uint32_t i = slot0 + it * 64;
+                    if (out.all_lo && ((ab[it] >> lane) & 1ull)) {
+                        const uint64_t q = oa + (uint32_t)__popcll(ab[it] & lt_mask);
+                        if (KW == 2) { out.all_hi[q] = s_key[2 * i + 1]; out.all_lo[q] = s_key[2 * i]; }
+                        else out.all_lo[q] = s_key[i];
                     }
-                    uint32_t c = s_cnt[i];
-                    uint32_t c16 = c > 65535u ? 65535u : c;
-                    bool valid = IS_SET ? (uint64_t)c >= min_obs : (uint64_t)c16 >= min_obs;
-                    if (!valid) continue;
-                    const uint32_t pay = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
-                    if (out.rec16) {
-                        const uint64_t klo = KW == 2 ? s_key[2 * i] : s_key[i], khi = KW == 2 ? s_key[2 * i + 1] : 0ull;
-                        out.rec16[o] = make_uint4((uint32_t)klo, (uint32_t)(klo >> 32), (uint32_t)khi, pay);
-                    } else {
-                        if (KW == 2) { out.hi[o] = s_key[2 * i + 1]; out.lo[o] = s_key[2 * i]; }
-                        else out.lo[o] = s_key[i];
-                        out.pay[o] = pay;
+                    if ((vb[it] >> lane) & 1ull) {
+                        const uint64_t q = o + (uint32_t)__popcll(vb[it] & lt_mask);
+                        const uint32_t c = s_cnt[i];
+                        const uint32_t c16 = c > 65535u ? 65535u : c;
+                        const uint32_t pay = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
+                        if (out.rec16) {
+                            const uint64_t klo = KW == 2 ? s_key[2 * i] : s_key[i], khi = KW == 2 ? s_key[2 * i + 1] : 0ull;
+                            out.rec16[q] = make_uint4((uint32_t)klo, (uint32_t)(klo >> 32), (uint32_t)khi, pay);
+                        } else {
+                            if (KW == 2) { out.hi[q] = s_key[2 * i + 1]; out.lo[q] = s_key[2 * i]; }
+                            else out.lo[q] = s_key[i];
+                            out.pay[q] = pay;
+                        }
                     }
-                    o++;
+                    o += (uint32_t)__popcll(vb[it]); oa += (uint32_t)__popcll(ab[it]);
                 }
             }
         } else {
-            if (P >= 4096u || sp + 1 >= 40) { if (tid == 0) atomicOr(&gflags[0], 2u); break; }
-            if (tid == 0) { s_stP[sp - 1] = 2 * P; s_stR[sp - 1] = pr; s_stP[sp] = 2 * P; s_stR[sp] = pr + P; s_sp = sp + 1; }
+            if (P >= 4096u || sp + 1 >= 24) { if (tid == 0) atomicOr(&gflags[0], 2u); break; }
+            if (tid == 0) { s_st[sp - 1] = (2 * P) | (pr << 16); s_st[sp] = (2 * P) | ((pr + P) << 16); s_sp = sp + 1; }
         }
         __syncthreads();
         PH(6);
