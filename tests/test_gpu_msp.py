@@ -134,3 +134,35 @@ def test_msp_tie_heavy_short_reads(ctx, k, p, alphabet):
     check_batch(ctx, seqs, k, p, None, True)
     check_batch(ctx, seqs, k, p, None, False)
     check_batch(ctx, seqs, k, p, perm, True, lmer_words=0 if k > 47 else 3)
+
+
+@pytest.mark.parametrize("k,p", [(47, 8), (31, 6), (21, 11), (106, 11)])
+def test_msp_kernel_routes(ctx, k, p):
+    """Three kernels share the reads by length and shape (lane-per-read up to 1024 bases when p <= 11; wave-per-read up to 256
+    p-mer positions; the literal loop beyond): one batch holds reads on every side of those borders, tie-heavy ones included,
+    and the wave route forced for everything (DBG_MSP=wave) must give the same pieces."""
+    rng = np.random.default_rng(k + p)
+    lens = [k, k + 1, 150, 255 + p, 256 + p, 257 + p, 1023, 1024, 1025, 1500, 3000, 40, 0]
+    seqs = [R.random_dna(rng, n) for n in lens if n == 0 or n >= 1]
+    seqs += [np.zeros(1024, np.uint8), np.tile(np.array([0, 3], np.uint8), 512), np.tile(R.random_dna(rng, 5), 205)[:1024],
+             rng.integers(0, 2, size=1024).astype(np.uint8), rng.integers(0, 2, size=1030).astype(np.uint8)]
+    for rc in (True, False):
+        a = check_batch(ctx, seqs, k, p, None, rc, lmer_words=4 if 2 * k - p <= 124 else 0)
+        with ctx.options(DBG_MSP="wave"):
+            b = check_batch(ctx, seqs, k, p, None, rc, lmer_words=4 if 2 * k - p <= 124 else 0)
+        for name in ("piece_off", "bucket", "exts", "start", "len", "minimizer_pos"):
+            assert np.array_equal(a[name], b[name]), name
+
+
+def test_msp_permutation_values_beyond_packing(ctx):
+    """The lane kernel packs (score, position) into 32 bits; a `permutation` table with scores of 2^22 and more (not a
+    permutation of 0..4^p, which the reference does not demand) must take the other kernels and still be exact."""
+    rng = np.random.default_rng(11)
+    p, k = 6, 31
+    perm = (rng.permutation(4 ** p).astype(np.uint64) * np.uint64(1 << 20)).astype(np.uint32)     # scores up to 2^32
+    seqs = [R.random_dna(rng, int(n)) for n in rng.integers(20, 600, size=60)]
+    seqs.append(rng.integers(0, 2, size=500).astype(np.uint8))
+    check_batch(ctx, seqs, k, p, perm, True)
+    small = rng.permutation(4 ** p).astype(np.uint32)
+    check_batch(ctx, seqs, k, p, small, True)
+    check_batch(ctx, seqs, k, p, small, False)
