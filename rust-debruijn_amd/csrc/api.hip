@@ -113,7 +113,11 @@ static void table_from_reduce(const ReduceOut& r, uint64_t n_inst, dbg_kmer_tabl
     t->n_kmer_instances = n_inst; t->n_passes = 1; t->on_device = 1;
 }
 
-// Generic path: extract every k-mer instance -> global radix sort -> segmented reduce.
+__global__ void shift_u64_kernel(const uint64_t* __restrict__ in, uint64_t n, uint64_t add, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+
 extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out) {
     DBG_TRY(validate_filter(c, ds, p));
     HIP_TRY(c, hipSetDevice(c->device));
@@ -143,26 +147,100 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
             if (force && !strcmp(force, "fast") && n_kmers) return c->fail(21, "DBG_PATH=fast but the fast path does not support this call shape");
         }
     }
-    if (n_kmers >= (1ull << 32)) return c->fail(20, "generic path: more than 2^32-1 k-mer instances in one call");
-
-    DBuf<uint64_t> a_hi, a_lo, b_hi, b_lo;
-    DBuf<uint32_t> a_pay, b_pay;
-    size_t nalloc = std::max<uint64_t>(n_kmers, 1);
-    if (has_hi) { ALLOC_OR_FAIL(c, a_hi, nalloc); ALLOC_OR_FAIL(c, b_hi, nalloc); }
-    ALLOC_OR_FAIL(c, a_lo, nalloc); ALLOC_OR_FAIL(c, b_lo, nalloc);
-    ALLOC_OR_FAIL(c, a_pay, nalloc); ALLOC_OR_FAIL(c, b_pay, nalloc);
-    RecArrays A{a_hi.p, a_lo.p, a_pay.p}, B{b_hi.p, b_lo.p, b_pay.p};
-    DBG_TRY(extract_kmers(c, s, koff.p, n_kmers, k, p->stranded != 0, A));
-    bool in_b = false;
-    // CountFilterSet needs (key, D1) order so distinct labels are adjacent; D1 < 2^24
-    int pay_bits = is_set && s.data ? (s.data_width == 1 ? 8 : (s.data_width == 2 ? 16 : 24)) : 0;
-    DBG_TRY(radix_sort_records(c, n_kmers, A, B, 2 * k, 8, pay_bits, &in_b));
+    // ---- generic path: extract every k-mer instance -> global radix sort -> segmented reduce, in as many passes over key
+    //      ranges as the records need (one pass = at most `pass_max` records: 2^32 - 1, less when device memory is short; the
+    //      reference does the same with its bucket ranges, filter.rs:156-168).  Ranges ascend, so the passes' tables simply
+    //      follow one another. ----
+    uint64_t pass_max = (1ull << 32) - 1;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t budget = c->scratch_budget ? c->scratch_budget : (uint64_t)((free_b + c->pooled_bytes) * 0.6);
+            const uint64_t per_rec = 2ull * ((has_hi ? 8 : 0) + 8 + 4) + 24;       // two record buffers + sort/reduce scratch
+            pass_max = std::min<uint64_t>(pass_max, std::max<uint64_t>(budget / per_rec, 1u << 20));
+        } else (void)hipGetLastError();
+        if (const char* e = c->opt("DBG_GENERIC_PASS_MAX")) pass_max = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests: force several passes
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;                             // top-byte ranges [lo, hi)
+    std::vector<uint64_t> range_n;
+    if (n_kmers <= pass_max) { ranges.push_back({0u, 256u}); range_n.push_back(n_kmers); }
+    else {
+        DBuf<unsigned long long> d_hist;
+        ALLOC_OR_FAIL(c, d_hist, 256);
+        DBG_TRY(kmer_top_byte_hist(c, s, k, p->stranded != 0, d_hist.p));
+        unsigned long long hist[256];
+        HIP_TRY(c, hipMemcpyAsync(hist, d_hist.p, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t lo = 0; uint64_t acc = 0;
+        for (uint32_t b = 0; b < 256; b++) {
+            if (hist[b] > pass_max) return c->fail(20, "generic path: one top-byte range of k-mers alone exceeds what a pass can hold");
+            if (acc + hist[b] > pass_max) { ranges.push_back({lo, b}); range_n.push_back(acc); lo = b; acc = 0; }
+            acc += hist[b];
+        }
+        ranges.push_back({lo, 256u}); range_n.push_back(acc);
+    }
+    std::vector<ReduceOut> parts(ranges.size());
+    auto free_parts = [&]() {
+        for (auto& r : parts) for (void* q : {(void*)r.key_hi, (void*)r.key_lo, (void*)r.exts, (void*)r.count, (void*)r.set_off, (void*)r.set_val, (void*)r.all_hi, (void*)r.all_lo}) c->dfree(q);
+    };
+    int rc = 0;
+    for (size_t pi = 0; pi < ranges.size() && !rc; pi++) {
+        const uint64_t np = range_n[pi];
+        DBuf<uint64_t> a_hi, a_lo, b_hi, b_lo;
+        DBuf<uint32_t> a_pay, b_pay;
+        const size_t nalloc = std::max<uint64_t>(np, 1);
+        bool ok = (!has_hi || (a_hi.alloc(c, nalloc) && b_hi.alloc(c, nalloc))) && a_lo.alloc(c, nalloc) && b_lo.alloc(c, nalloc) &&
+                  a_pay.alloc(c, nalloc) && b_pay.alloc(c, nalloc);
+        if (!ok) { rc = c->fail(101, "device allocation failed in the generic path"); break; }
+        RecArrays A{a_hi.p, a_lo.p, a_pay.p}, B{b_hi.p, b_lo.p, b_pay.p};
+        if (ranges.size() == 1) rc = extract_kmers(c, s, koff.p, np, k, p->stranded != 0, A);
+        else {
+            rc = kmer_counts_range(c, s, k, p->stranded != 0, ranges[pi].first, ranges[pi].second, kcount.p);
+            if (!rc) rc = scan_exclusive_u32_u64(c, kcount.p, koff.p, s.n);
+            if (!rc) rc = extract_kmers_range(c, s, koff.p, np, k, p->stranded != 0, ranges[pi].first, ranges[pi].second, A);
+        }
+        bool in_b = false;
+        // CountFilterSet needs (key, D1) order so distinct labels are adjacent; D1 < 2^24
+        const int pay_bits = is_set && s.data ? (s.data_width == 1 ? 8 : (s.data_width == 2 ? 16 : 24)) : 0;
+        if (!rc) rc = radix_sort_records(c, np, A, B, 2 * k, 8, pay_bits, &in_b);
+        if (!rc) rc = reduce_sorted_records(c, np, in_b ? B : A, has_hi, p->summarizer, p->min_kmer_obs, p->report_all_kmers != 0, &parts[pi]);
+    }
+    if (rc) { free_parts(); return rc; }
     ReduceOut r;
-    DBG_TRY(reduce_sorted_records(c, n_kmers, in_b ? B : A, has_hi, p->summarizer, p->min_kmer_obs,
-                                  p->report_all_kmers != 0, &r));
+    if (parts.size() == 1) r = parts[0];
+    else {
+        // the passes' tables, one after the other (set_off entries of later passes are shifted by the labels before them)
+        for (auto& q : parts) { r.n_valid += q.n_valid; r.n_all += q.n_all; r.n_set_val += q.n_set_val; }
+        DBuf<uint64_t> o_hi, o_lo, o_set_off, all_hi, all_lo;
+        DBuf<uint8_t> o_exts; DBuf<uint16_t> o_count; DBuf<uint32_t> o_set_val;
+        bool ok = o_hi.alloc(c, std::max<uint64_t>(r.n_valid, 1)) && o_lo.alloc(c, std::max<uint64_t>(r.n_valid, 1)) && o_exts.alloc(c, std::max<uint64_t>(r.n_valid, 1));
+        if (is_set) ok = ok && o_set_off.alloc(c, r.n_valid + 1) && o_set_val.alloc(c, std::max<uint64_t>(r.n_set_val, 1));
+        else ok = ok && o_count.alloc(c, std::max<uint64_t>(r.n_valid, 1));
+        if (p->report_all_kmers) ok = ok && all_hi.alloc(c, std::max<uint64_t>(r.n_all, 1)) && all_lo.alloc(c, std::max<uint64_t>(r.n_all, 1));
+        if (!ok) { free_parts(); return c->fail(101, "device allocation failed in the generic path"); }
+        uint64_t ov = 0, oa = 0, os = 0;
+        hipError_t e = hipSuccess;
+        auto cp = [&](void* d, const void* sp, size_t bytes) { if (bytes && e == hipSuccess) e = hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, c->stream); };
+        for (auto& q : parts) {
+            cp(o_hi.p + ov, q.key_hi, q.n_valid * 8); cp(o_lo.p + ov, q.key_lo, q.n_valid * 8); cp(o_exts.p + ov, q.exts, q.n_valid);
+            if (is_set) {
+                cp(o_set_val.p + os, q.set_val, q.n_set_val * 4);
+                if (e == hipSuccess && q.n_valid) { shift_u64_kernel<<<cdiv(q.n_valid, 256), 256, 0, c->stream>>>(q.set_off, q.n_valid, os, o_set_off.p + ov); e = hipGetLastError(); }
+            } else cp(o_count.p + ov, q.count, q.n_valid * 2);
+            if (p->report_all_kmers) { cp(all_hi.p + oa, q.all_hi, q.n_all * 8); cp(all_lo.p + oa, q.all_lo, q.n_all * 8); }
+            ov += q.n_valid; oa += q.n_all; os += q.n_set_val;
+        }
+        if (is_set && e == hipSuccess) e = hipMemcpyAsync(o_set_off.p + r.n_valid, &r.n_set_val, 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        free_parts();
+        if (e != hipSuccess) { (void)hipGetLastError(); return c->fail(100, std::string("HIP error while joining the passes: ") + hipGetErrorString(e)); }
+        r.key_hi = o_hi.take(); r.key_lo = o_lo.take(); r.exts = o_exts.take(); r.count = o_count.take();
+        r.set_off = o_set_off.take(); r.set_val = o_set_val.take(); r.all_hi = all_hi.take(); r.all_lo = all_lo.take();
+    }
     if (!has_hi && r.n_valid) HIP_TRY(c, hipMemsetAsync(r.key_hi, 0, r.n_valid * 8, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     table_from_reduce(r, n_kmers, out);
+    out->n_passes = (uint32_t)ranges.size();
     return 0;
 }
 

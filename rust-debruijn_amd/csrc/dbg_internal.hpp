@@ -57,6 +57,13 @@ int kmer_counts(dbg_ctx* ctx, const SeqDev& s, int k, uint32_t* kcount);
 int extract_kmers(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uint64_t n_kmers, int k, bool stranded,
                   RecArrays out);
 
+// passes over key ranges: histogram of the canonical k-mers' top bytes; per-sequence counts and records of the k-mers whose
+// top byte lies in [b_lo, b_hi)
+int kmer_top_byte_hist(dbg_ctx* ctx, const SeqDev& s, int k, bool stranded, unsigned long long* hist_dev);
+int kmer_counts_range(dbg_ctx* ctx, const SeqDev& s, int k, bool stranded, uint32_t b_lo, uint32_t b_hi, uint32_t* kcount);
+int extract_kmers_range(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uint64_t n_kmers, int k, bool stranded, uint32_t b_lo, uint32_t b_hi,
+                        RecArrays out);
+
 // ---- radix.hip : stable LSD radix sort of records by (key, selected payload bits) -----------
 // Sorts n (< 2^32) records.  key_bits = 2k significant key bits; pay_shift/pay_bits select payload
 // bits that act as the least-significant sort digits (CountFilterSet needs (key, D1) order).

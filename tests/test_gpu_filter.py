@@ -164,3 +164,26 @@ def test_reference_would_panic(ctx):
         dbg.filter_kmers(to_host_seqs(ss), dbg.CountFilter(1), False, False, 0, k=31, ctx=ctx)   # memory_size = 0
     with pytest.raises(dbg.DbgError):
         dbg.filter_kmers(to_host_seqs(ss), dbg.CountFilter(1), False, False, 4, k=65, ctx=ctx)
+
+
+@pytest.mark.parametrize("k,kind,stranded", [(31, 0, False), (47, 1, False), (15, 0, True), (64, 1, False), (5, 0, False)])
+def test_generic_path_in_key_range_passes(ctx, path_mode, k, kind, stranded):
+    """The generic path takes as many passes over ranges of the canonical k-mers' top byte as one pass's record limit asks for
+    (2^32 - 1 records, or what device memory holds; here forced down to a few thousand) -- the device analogue of the
+    reference's bucket ranges (filter.rs:156-168).  Same table, same all_kmers list, whatever the number of passes."""
+    if path_mode != "generic":
+        pytest.skip("generic path")
+    rng = np.random.default_rng(k * 7 + kind)
+    seqs = random_reads(rng, 400, 3000, 120, stranded, err=0.01, ragged=True)
+    data = rng.integers(0, 300, size=len(seqs)) if kind else None
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=2) if kind else O.SeqSet.from_byte_seqs(seqs)
+    want = O.filter_kmers(ss, k, kind, 2, stranded=stranded, report_all=True)
+    summ = (dbg.CountFilterSet if kind else dbg.CountFilter)(2)
+    seen = set()
+    for limit in ("1000000000", "9000", "2500"):
+        with ctx.options(DBG_GENERIC_PASS_MAX=limit):
+            got, allk = dbg.filter_kmers(to_host_seqs(ss, 2 if kind else 0), summ, stranded, True, 4, k=k, ctx=ctx)
+        assert_tables_equal(got, want, kind == 1)
+        assert allk == [(int(h) << 64) | int(l) for h, l in zip(want.all_hi, want.all_lo)]
+        seen.add(got.n_passes)
+    assert 1 in seen and max(seen) >= 2
