@@ -128,15 +128,8 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
 
-    DBuf<uint32_t> kcount;
-    DBuf<uint64_t> koff;
-    ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
-    ALLOC_OR_FAIL(c, koff, s.n + 1);
-    DBG_TRY(kmer_counts(c, s, k, kcount.p));
-    DBG_TRY(scan_exclusive_u32_u64(c, kcount.p, koff.p, s.n));
     uint64_t n_kmers = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_kmers, koff.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    DBG_TRY(kmer_total(c, s, k, &n_kmers));                  // the fast path needs the total only
     {   // fast path: super-k-mer bins + LDS hash tables (fastpath.hip); DBG_PATH=generic|fast|auto overrides
         const char* force = c->opt("DBG_PATH");
         bool want_fast = !(force && !strcmp(force, "generic"));
@@ -147,6 +140,12 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
             if (force && !strcmp(force, "fast") && n_kmers) return c->fail(21, "DBG_PATH=fast but the fast path does not support this call shape");
         }
     }
+    DBuf<uint32_t> kcount;                                   // per-sequence counts and offsets: the generic path writes one record per k-mer
+    DBuf<uint64_t> koff;
+    ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
+    ALLOC_OR_FAIL(c, koff, s.n + 1);
+    DBG_TRY(kmer_counts(c, s, k, kcount.p));
+    DBG_TRY(scan_exclusive_u32_u64(c, kcount.p, koff.p, s.n));
     // ---- generic path: extract every k-mer instance -> global radix sort -> segmented reduce, in as many passes over key
     //      ranges as the records need (one pass = at most `pass_max` records: 2^32 - 1, less when device memory is short; the
     //      reference does the same with its bucket ranges, filter.rs:156-168).  Ranges ascend, so the passes' tables simply

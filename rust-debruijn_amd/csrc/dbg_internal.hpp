@@ -53,6 +53,7 @@ int scan_exclusive_u64(dbg_ctx* ctx, const uint64_t* in, uint64_t* out, uint64_t
 // ---- extract.hip : iter_kmer_exts + min_rc_flip + Exts::rc fused (lib.rs:812-841, filter.rs:190-196)
 // kcount[i] = len_i.saturating_sub(k-1) (filter.rs:154)
 int kmer_counts(dbg_ctx* ctx, const SeqDev& s, int k, uint32_t* kcount);
+int kmer_total(dbg_ctx* ctx, const SeqDev& s, int k, uint64_t* n_out);      // their sum alone
 // writes records of sequence i at koff[i] .. koff[i+1]
 int extract_kmers(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uint64_t n_kmers, int k, bool stranded,
                   RecArrays out);

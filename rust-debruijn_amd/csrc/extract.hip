@@ -184,6 +184,32 @@ int extract_kmers_range(dbg_ctx* ctx, const SeqDev& s, const uint64_t* koff, uin
     return 0;
 }
 
+__global__ void __launch_bounds__(256) kmer_total_kernel(const uint32_t* __restrict__ length, uint64_t n, int k, unsigned long long* __restrict__ out) {
+    unsigned long long v = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t len = length[i];
+        v += len >= (uint32_t)(k - 1) ? len - (uint32_t)(k - 1) : 0u;          // saturating_sub (filter.rs:154)
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+// input_kmers (filter.rs:152-155) alone: one pass over the lengths
+int kmer_total(dbg_ctx* ctx, const SeqDev& s, int k, uint64_t* n_out) {
+    *n_out = 0;
+    if (s.n == 0) return 0;
+    DBuf<unsigned long long> d;
+    ALLOC_OR_FAIL(ctx, d, 1);
+    HIP_TRY(ctx, hipMemsetAsync(d.p, 0, 8, ctx->stream));
+    kmer_total_kernel<<<(uint32_t)std::min<uint64_t>(cdiv(s.n, 256), 2048), 256, 0, ctx->stream>>>(s.length, s.n, k, d.p);
+    LAUNCH_CHECK(ctx, "kmer_total");
+    unsigned long long h = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&h, d.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = h;
+    return 0;
+}
+
 int kmer_counts(dbg_ctx* ctx, const SeqDev& s, int k, uint32_t* kcount) {
     if (s.n == 0) return 0;
     kmer_counts_kernel<<<cdiv(s.n, 256), 256, 0, ctx->stream>>>(s.length, s.n, k, kcount);

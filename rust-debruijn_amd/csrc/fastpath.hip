@@ -1829,15 +1829,7 @@ template <class T> static void slot_delete(void* p) { delete static_cast<T*>(p);
 extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t k, uint64_t* n_out) {
     HIP_TRY(c, hipSetDevice(c->device));
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
-    DBuf<uint32_t> kcount;
-    DBuf<uint64_t> koff;
-    ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
-    ALLOC_OR_FAIL(c, koff, s.n + 1);
-    DBG_TRY(kmer_counts(c, s, (int)k, kcount.p));
-    DBG_TRY(scan_exclusive_u32_u64(c, kcount.p, koff.p, s.n));
-    HIP_TRY(c, hipMemcpyAsync(n_out, koff.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return kmer_total(c, s, (int)k, n_out);
 }
 
 static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {

@@ -1,7 +1,8 @@
 """Times dbg_compress_kmers_with_hash (host arrays in, host BaseGraph out) on the valid-k-mer table of a
 synthetic read set: filter (GPU, CountFilter(2)) -> table to host -> compress."""
 import ctypes as C, importlib, sys, time, os
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 dbg = importlib.import_module("rust-debruijn_amd"); capi = importlib.import_module("rust-debruijn_amd._capi")
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000

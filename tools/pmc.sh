@@ -8,7 +8,11 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 run() { # name counters...
   n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python $GRAFT_REPO_ROOT/bench.py "${BENCH_ARGS[@]}" > $OUT/$n.log 2>&1 || tail -5 $OUT/$n.log
+  if [ -n "$PMC_SCRIPT" ]; then   # another driver than bench.py (tools/bench_msp.py, tools/bench_compress.py)
+    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python $GRAFT_REPO_ROOT/$PMC_SCRIPT "${BENCH_ARGS[@]}" > $OUT/$n.log 2>&1 || tail -5 $OUT/$n.log
+  else
+    rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python $GRAFT_REPO_ROOT/bench.py "${BENCH_ARGS[@]}" > $OUT/$n.log 2>&1 || tail -5 $OUT/$n.log
+  fi
 }
 BENCH_ARGS=("$@")
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_ANY
