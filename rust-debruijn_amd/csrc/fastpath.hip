@@ -878,6 +878,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         constexpr uint32_t MIN_ROOM = NT / 8;           // keep filling while the rest of the bin, or at least this many records, still fit
         constexpr uint32_t MAX_FILLS = 100;             // weights are 16-bit: at most NT per round, 100 x 512 < 65536
         uint32_t rnext = 0;                             // next incoming record of the bin (uniform)
+        bool pass_bad = false;
         while (rnext < total_recs && !pass_ovf) {
             // ---- reset the staging area and the filter ----
             if (tid < NT / 2) s_w[tid] = 0;
@@ -891,6 +892,11 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 const uint32_t room = NT - nstaged;
                 const uint32_t take = total_recs - rnext < room ? total_recs - rnext : room;
                 if (tid < take) {
+                    {   // a record whose length cannot come from the scan (a wrong segment table, an incomplete exchange) must not
+                        // be expanded: its k-mer count would be garbage.  The launch is failed instead.
+                        const uint32_t rl = (uint32_t)(pmeta & 0x7f);
+                        if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - META_BITS / 2)) { atomicOr(&gflags[3], 4u); pass_bad = true; }
+                    }
                     const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);           // word holding the meta bits
                     const uint64_t lastw = PL0 & ~COLOUR_BITS;
                     uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
@@ -940,7 +946,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                         sl = (sl + 1u) & (DD - 1);
                     }
                 }
-                __syncthreads();
+                if (__syncthreads_or(pass_bad ? 1 : 0)) { pass_ovf = true; nstaged = 0; rnext = total_recs; break; }     // corrupt input: give up on the bin
                 nstaged = s_nst;
 #ifdef DBG_COUNT_STATS
                 if (tid == 0 && fills == 0) atomicAdd(&s_stat[13], nstaged);
@@ -1635,6 +1641,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath-stats] wave-iterations=%u active lanes=%u (%.1f/64); lane-rounds=%u next-bucket=%u tag-collision=%u busy=%u cas-lost=%u inserts=%u; staged after round 1=%u, round-2 incoming=%u, merged in round 1=%u, later=%u\n",
                                          flv[4], flv[5], flv[4] ? (double)flv[5] / flv[4] : 0.0, flv[6], flv[7], flv[8], flv[9], flv[10], flv[11], flv[13], flv[12], flv[15], flv[14]);
 #endif
+        if (flv[3] & 4u) return c->fail(134, "fast path: corrupt super-k-mer record (record buffer or segment table of the counting stage is wrong)");
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (fl & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
         if (fl & 9u) {                                            // an output buffer is too small: grow (earlier chunks are kept) and redo this launch

@@ -260,16 +260,26 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
     import torch.distributed as dist
     engine.sync()                                  # the reads may still be in flight on torch's current stream
     n_local = engine.count_instances(ss, k)
-    total = n_local
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        t = torch.tensor([n_local], dtype=torch.int64, device="cpu" if dist.get_backend(group) == "gloo" else engine.device)
+    total = n_max = n_local
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        rdev = "cpu" if dist.get_backend(group) == "gloo" else engine.device
+        t = torch.tensor([n_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t, group=group)
         total = int(t.item())
+        t = torch.tensor([n_local], dtype=torch.int64, device=rdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        n_max = int(t.item())
     plan = engine.plan(k, stranded, summarizer_kind, min_obs, total)
     bin_off, n_recs = engine.scan(ss, plan)
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
     layout = None
     force = force_exchange and dist.is_initialized()
+    if n_chunks is None:
+        # One message (one peer, one round) stays under 1 GiB: RCCL transfers of 2 GiB and more were seen to arrive incomplete.
+        # Records are at most ~2.5 bytes per k-mer instance (24-byte records of >= 10 k-mers at k = 47; denser for small k),
+        # and every rank must arrive at the same number of rounds, hence the estimate from the largest rank.
+        est = max(n_max, 1) * 4 // max(world, 1)
+        n_chunks = max(4 if world < 4 else 8, -(-est // (1 << 30)))
     if world > 1 or force:
         bounds, nch, cuts = exchange_geometry(plan.n_bins, world, getattr(plan, "bin_group", 1) or 1, n_chunks, force)
         layout = send_layout(bin_off, bounds, cuts, nch)
