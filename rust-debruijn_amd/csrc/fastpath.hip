@@ -681,6 +681,10 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
     return v;
 }
 
+// Workgroup barrier that waits for this wave's LDS operations only.  __syncthreads() also waits for outstanding global loads
+// (s_waitcnt vmcnt(0)), which would expose the latency of the record prefetch at the first barrier after it is issued.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int NT>
 __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* s_wsum, uint32_t* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -844,7 +848,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 A0 = g[0]; A1 = g[1];
                 if (NBW > 2) A2 = g[2];
                 if (NBW > 3) A3 = g[3];
-                am = (NBW == 2 ? A1 : (NBW == 3 ? A2 : A3)) & ((1ull << META_BITS) - 1);
+                // (the meta bits are taken from the last word where they are used: touching a loaded word here would wait for
+                //  the load and expose the latency the prefetch is meant to hide)
             }
         };
         auto load_rec = [&](uint32_t ridx) { load_into(ridx, P0, P1, P2, P3, pmeta); };   // -> P0..P3, pmeta
@@ -855,7 +860,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         bool q_valid = true;                            // Q holds record NT + tid
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-        __syncthreads();
+        lds_barrier();                                  // the prefetched records stay in flight
         PH(1);
 
         // ---- stream the bin, chunk-parallel.  A super-k-mer record holds 1..W k-mers; handing whole records to
@@ -885,13 +890,14 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (IS_SET) s_cmk[tid] = 0;
             for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
             if (tid == 0) s_nst = 0;
-            __syncthreads();
+            lds_barrier();
             uint32_t nstaged = 0;
             // ---- fill rounds: thread tid holds incoming record rnext + tid (prefetched) ----
             for (uint32_t fills = 0;; fills++) {
                 const uint32_t room = NT - nstaged;
                 const uint32_t take = total_recs - rnext < room ? total_recs - rnext : room;
                 if (tid < take) {
+                    pmeta = (NBW == 2 ? P1 : (NBW == 3 ? P2 : P3)) & ((1ull << META_BITS) - 1);
                     {   // a record whose length cannot come from the scan (a wrong segment table, an incomplete exchange) must not
                         // be expanded: its k-mer count would be garbage.  The launch is failed instead.
                         const uint32_t rl = (uint32_t)(pmeta & 0x7f);
