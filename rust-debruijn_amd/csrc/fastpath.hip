@@ -648,17 +648,17 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
     return x;
 }
 // 64-bit hash of a key: low bits -> bucket, bits 16.. -> pass selection, high word -> tag.
-// (A chain of 32-bit multiplies was measured: cheaper in VALU but no faster -- the kernel is bound by LDS
-// round-trip latency at 4 waves/SIMD, and weaker mixing costs extra probes.)
+// Two 64-bit multiplies (= 2 x three quarter-rate 32-bit multiplies on this hardware).  Round 1 found a third mixing round free
+// because the kernel waited on LDS; since round 2 it is bound by instruction issue, and dropping the third round is worth 1.8 %
+// with the same probe statistics.  DBG_HASH_1MUL (measurement): the high word folded in by rotations, one multiply.
 __device__ __forceinline__ uint64_t hash_key(uint64_t hi, uint64_t lo) {
-#ifdef DBG_HASH_CHEAP
-    uint64_t h = lo ^ (hi * 0x9E3779B97F4A7C15ull);
-    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
+#ifdef DBG_HASH_1MUL
+    uint64_t h = lo ^ ((hi << 21) | (hi >> 43)) ^ (hi >> 7);
+    h ^= h >> 29; h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32;
     return h;
 #else
     uint64_t h = lo ^ (hi * 0x9E3779B97F4A7C15ull);
-    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32;
     return h;
