@@ -1344,6 +1344,7 @@ struct FastPlan {
 static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
     if (k < 16 || k > 64) return false;
     pl->k = k; pl->p = fast_internal_p(k);
+    if (const char* e = c->opt("DBG_FAST_P")) pl->p = std::max(4, std::min(std::min(15, k - 8), atoi(e)));     // measurement: internal minimizer length
     pl->nbw = std::max(2, (2 * (2 * k - pl->p) + META_BITS + 63) / 64);   // words per record: bases + META_BITS
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw;
