@@ -105,6 +105,8 @@ typedef struct {
 
 int  dbg_filter_kmers(dbg_ctx* ctx, const dbg_seqset* host_seqs, const dbg_filter_params* p, dbg_kmer_table* out_host);
 int  dbg_filter_kmers_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, const dbg_filter_params* p, dbg_kmer_table* out_dev);
+/* Host tables hold arrays from the ctx's pool of pinned host blocks (kept and reused: pinning is slow): release them with the
+ * ctx that produced them, before dbg_ctx_destroy. */
 void dbg_free_table(dbg_ctx* ctx, dbg_kmer_table* t);
 /* copy a device table to freshly allocated host arrays */
 int  dbg_table_to_host(dbg_ctx* ctx, const dbg_kmer_table* dev, dbg_kmer_table* out_host);
