@@ -412,9 +412,10 @@ constexpr int R16_WAVES = R16_THREADS / DBG_WAVE;
 constexpr int R16_ITEMS = 8;
 constexpr int R16_TILE = R16_THREADS * R16_ITEMS;       // 4096 records = 64 KB of staging: ~16 records (256 B) per digit
 
-__device__ __forceinline__ uint32_t digit16(const uint4& r, int shift) {        // shift is a multiple of 8 below 96
-    const uint32_t w = shift < 32 ? r.x : (shift < 64 ? r.y : r.z);
-    return (w >> (shift & 31)) & 0xffu;
+__device__ __forceinline__ uint32_t digit16(const uint4& r, int shift) {        // 8 key bits from bit `shift` (< 96) on; a digit may straddle two words
+    const uint32_t w = (uint32_t)shift >> 5, s = (uint32_t)shift & 31u;
+    const uint32_t lo = w == 0 ? r.x : (w == 1 ? r.y : r.z), hi = w == 0 ? r.y : (w == 1 ? r.z : 0u);
+    return (uint32_t)(((((uint64_t)hi << 32) | lo) >> s) & 0xffu);
 }
 
 __global__ void __launch_bounds__(R16_THREADS) radix16_hist_kernel(const uint4* __restrict__ in, uint32_t n, int shift, uint32_t mask,
@@ -424,11 +425,15 @@ __global__ void __launch_bounds__(R16_THREADS) radix16_hist_kernel(const uint4* 
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t base = blockIdx.x * R16_TILE + wave * (R16_ITEMS * 64) + lane;
+    const bool one_word = (shift & 31) <= 24;                     // the digit lies inside one 32-bit word: fetch only that word
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(in) + (shift >> 5);
 #pragma unroll
     for (int r = 0; r < R16_ITEMS; r++) {
         const uint32_t e = base + r * 64;
-        if (e < n) atomicAdd(&h[(w32[(size_t)e * 4] >> (shift & 31)) & mask], 1u);
+        if (e < n) {
+            const uint32_t d = one_word ? (w32[(size_t)e * 4] >> (shift & 31)) & mask : digit16(in[e], shift) & mask;
+            atomicAdd(&h[d], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < 256) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -597,6 +602,135 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_kernel(const uint4* __
     }
 }
 
+// The finisher for prefix groups of a few dozen records (three top-bit passes = 24 prefix bits instead of 30: one pass over HBM
+// less).  Ranking a record by walking its group (span_sort16_kernel) is a chain of dependent LDS reads as long as the group.
+// Here a WAVE takes a group: (1) a counting sort on the next `dbits` key bits -- one LDS counter per digit value, every member
+// takes its rank inside its digit with an LDS atomic, the wave scans the counters -- puts the members in (prefix + digit) order;
+// (2) members that share a digit (on average every second one has a partner) are ranked among themselves by full key from their
+// provisional places.  Groups of up to 128 records are held two per lane; longer ones (heavily repeated prefixes) raise the flag
+// and the caller runs the walking finisher.  Canonical keys are denser at small values (min(k-mer, rc)), so groups of twice
+// the average size are normal.
+constexpr int SG_MAXD = 8;
+template <bool IS_SET>
+__global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const uint4* __restrict__ in, uint32_t n, int key_bits, int top_bits, int dbits,
+                                                                        uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
+                                                                        uint8_t* __restrict__ o_exts, uint16_t* __restrict__ o_count,
+                                                                        uint32_t* __restrict__ o_setn, uint32_t* __restrict__ o_msk,
+                                                                        uint32_t* __restrict__ flags) {
+    __shared__ uint4 s_rec[SS_CAP];                     // 48 KB
+    __shared__ uint32_t s_pre[SS_CAP + 1];              // prefix of every record; afterwards: start of group g
+    __shared__ uint32_t s_cnt[SS_THREADS / 64][1 << SG_MAXD];   // per wave: members per digit value, then exclusive prefix
+    __shared__ uint32_t s_start, s_end, s_ng;
+    __shared__ uint32_t s_wsum[SS_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * SS_WINDOW;
+    const uint32_t avail = n - base < (uint32_t)SS_CAP ? n - base : (uint32_t)SS_CAP;
+    if (tid == 0) { s_start = 0xffffffffu; s_end = 0xffffffffu; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;                   // coalesced load order
+        if (i < avail) { const uint4 q = in[base + i]; s_rec[i] = q; s_pre[i] = prefix16(q, key_bits, top_bits); }
+    }
+    uint32_t prev0 = 0;
+    if (base > 0 && tid == 0) prev0 = prefix16(in[base - 1], key_bits, top_bits);
+    __syncthreads();
+    // thread t looks at records t*ITEMS .. t*ITEMS + ITEMS - 1 (consecutive: the group enumeration is a scan in record order)
+    uint32_t bflags = 0;
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid * SS_ITEMS + r;
+        if (i < avail) {
+            const uint32_t pc = s_pre[i];
+            const bool boundary = i == 0 ? (base == 0 || pc != prev0) : pc != s_pre[i - 1];
+            if (boundary) {
+                bflags |= 1u << r;
+                if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i); else atomicMin(&s_end, i);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t start = s_start;
+    if (start == 0xffffffffu) return;                           // no group starts here
+    uint32_t end = s_end;
+    if (end == 0xffffffffu) {
+        if (avail == (uint32_t)SS_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
+        end = avail;
+    }
+    {   // enumerate the groups that start in [start, end): s_pre[g] <- first record of group g, s_pre[ng] <- end
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) mine++; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();                                           // (every thread is done reading the prefixes in s_pre)
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SS_THREADS / 64; w++) { const uint32_t x = s_wsum[w]; off += (uint32_t)w < wave ? x : 0u; tot += x; }
+        uint32_t g = off + incl - mine;
+#pragma unroll
+        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) s_pre[g++] = i; }
+        if (tid == 0) { s_ng = tot; s_pre[tot] = end; }
+    }
+    __syncthreads();
+    const uint32_t ng = s_ng;
+    const int dshift = key_bits - top_bits - dbits;             // the digit = key bits [dshift, dshift + dbits)
+    const uint32_t nd = 1u << dbits, dmask = nd - 1u;
+    uint32_t* cnt = s_cnt[wave];
+    for (uint32_t gi = wave; gi < ng; gi += SS_THREADS / 64) {
+        const uint32_t gs = s_pre[gi], gn = s_pre[gi + 1] - gs;
+        if (gn > 128) { if (lane == 0) atomicOr(flags, 1u); continue; }
+        if (gn == 1) continue;
+        const bool hasA = lane < gn, hasB = 64 + lane < gn;
+        uint4 qa = make_uint4(0, 0, 0, 0), qb = make_uint4(0, 0, 0, 0);
+        if (hasA) qa = s_rec[gs + lane];
+        if (hasB) qb = s_rec[gs + 64 + lane];
+        for (uint32_t d = lane; d < nd; d += 64) cnt[d] = 0;
+        const uint32_t da = digit16(qa, dshift) & dmask, db = digit16(qb, dshift) & dmask;
+        uint32_t ra = 0, rb = 0;                                   // rank inside the digit (any order: step 2 orders equal digits)
+        if (hasA) ra = atomicAdd(&cnt[da], 1u);
+        if (hasB) rb = atomicAdd(&cnt[db], 1u);
+        // exclusive prefix of the counters: lanes take digit values in turn (nd <= 256: four rounds)
+        uint32_t carry = 0;
+        for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
+            const uint32_t c = d0 + lane < nd ? cnt[d0 + lane] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+            if (d0 + lane < nd) cnt[d0 + lane] = carry + incl - c;
+            carry += __shfl(incl, 63);
+        }
+        // provisional places: (prefix + digit) order
+        const uint32_t ca = hasA ? cnt[da] : 0u, cb = hasB ? cnt[db] : 0u;                 // first place of my digit
+        if (hasA) s_rec[gs + ca + ra] = qa;
+        if (hasB) s_rec[gs + cb + rb] = qb;
+        // members that share a digit: rank by key among the run [c, c_next)
+        const uint32_t ea = hasA ? (da + 1 < nd ? cnt[da + 1] : gn) : 0u, eb = hasB ? (db + 1 < nd ? cnt[db + 1] : gn) : 0u;
+        uint32_t la = 0, lb = 0;
+        if (hasA && ea - ca > 1) for (uint32_t j = ca; j < ea; j++) la += less16(s_rec[gs + j], qa, false) ? 1u : 0u;
+        if (hasB && eb - cb > 1) for (uint32_t j = cb; j < eb; j++) lb += less16(s_rec[gs + j], qb, false) ? 1u : 0u;
+        // (the wave's LDS operations are performed in order: every read above precedes the writes below)
+        if (hasA && ea - ca > 1) s_rec[gs + ca + la] = qa;
+        if (hasB && eb - cb > 1) s_rec[gs + cb + lb] = qb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i >= start && i < end) {
+            const uint32_t g = base + i;
+            const uint4 q = s_rec[i];
+            o_hi[g] = q.z;
+            o_lo[g] = ((uint64_t)q.y << 32) | q.x;
+            o_exts[g] = (uint8_t)(q.w & 0xffu);
+            if (IS_SET) { o_msk[g] = q.w >> 8; if (o_setn) o_setn[g] = __popc(q.w >> 8); }
+            else o_count[g] = (uint16_t)(q.w >> 8);
+        }
+    }
+}
+
 template <bool IS_SET>
 __global__ void decode16_kernel(uint32_t n, const uint4* __restrict__ in, uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
                                 uint8_t* __restrict__ exts, uint16_t* __restrict__ count, uint32_t* __restrict__ setn, uint32_t* __restrict__ msk) {
@@ -637,11 +771,17 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
     uint4 *src = a, *dst = b;
     int sorted_from = key_bits;                              // bits [sorted_from, key_bits) are in order
     if (allow_hybrid) {
+        // Enough top bits that an average prefix group holds ~32 records, in 8-bit passes that start exactly at bit
+        // key_bits - top_bits (a digit may straddle the 32-bit words of a record); the wave-per-group finisher orders such
+        // groups with a counting sort on the next 6 key bits.  DBG_SORT=bytealigned: the round-1 form (digits on byte boundaries,
+        // up to 7 more prefix bits -- a fourth pass at k = 47 -- and the walking finisher), which is also what runs when a
+        // group is too long for a wave.
         int top_bits = 0;
         while (top_bits < key_bits && top_bits < 32 && (n64 >> top_bits) > 32) top_bits += 8;
         if (top_bits > key_bits) top_bits = key_bits;
-        const int s0 = top_bits ? ((key_bits - top_bits) / 8) * 8 : key_bits;
-        top_bits = key_bits - s0;
+        const bool bytealigned = ctx->opt("DBG_SORT") && !strcmp(ctx->opt("DBG_SORT"), "bytealigned");
+        int s0 = key_bits - top_bits;
+        if (bytealigned) { s0 = top_bits ? (s0 / 8) * 8 : key_bits; top_bits = key_bits - s0; }
         for (int s = s0; s < key_bits; s += 8) {
             DBG_TRY(radix16_pass(ctx, src, dst, n, s, std::min(8, key_bits - s), hist.p, hist_scanned.p, nblocks));
             std::swap(src, dst);
@@ -649,17 +789,25 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
         sorted_from = s0;
         DBuf<uint32_t> flags;
         ALLOC_OR_FAIL(ctx, flags, 1);
-        HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
         const uint32_t nwg = cdiv(n, SS_WINDOW);
-        ctx->t_begin("span_sort", n);
-        if (is_set) span_sort16_kernel<true><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
-        else span_sort16_kernel<false><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
-        ctx->t_end();
-        LAUNCH_CHECK(ctx, "span_sort16");
-        uint32_t fl = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (fl == 0) return 0;
+        const int dbits = std::min(6, key_bits - top_bits);
+        for (int form = (bytealigned || dbits <= 0) ? 1 : 0; form < 2; form++) {       // 0: wave per group; 1: walking finisher
+            HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
+            ctx->t_begin("span_sort", n);
+            if (form == 0) {
+                if (is_set) span_sort16_groups_kernel<true><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+                else span_sort16_groups_kernel<false><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+            } else {
+                if (is_set) span_sort16_kernel<true><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+                else span_sort16_kernel<false><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+            }
+            ctx->t_end();
+            LAUNCH_CHECK(ctx, "span_sort16");
+            uint32_t fl = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (fl == 0) return 0;
+        }
     }
     // plain LSD sort over every key bit (stable passes compose, so the top-bit passes above need not be undone: a full
     // LSD from bit 0 re-sorts everything)
