@@ -794,13 +794,16 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     // its overflow in the single-GPU case): segment s spans records [seg_beg[s*stride + bin], seg_end[s*stride + bin])
     // of `recs` (of `recs_alt` for s >= alt_from).
     __shared__ uint32_t s_segpre[66];           // records of this bin before segment s (flat index space)
-    __shared__ uint64_t s_segbeg[64];           // first record of segment s (so that a record fetch is one global round trip, not two)
+    // first record of segment s (so that a record fetch is one global round trip, not two); the one variant whose LDS has no
+    // 512 bytes left for it (k >= 56 with colour sets) reads the segment table again instead
+    constexpr bool HAVE_SEGBEG = !(NBW == 4 && IS_SET && NT == 512);
+    __shared__ uint64_t s_segbeg[HAVE_SEGBEG ? 64 : 1];
     if (tid < 64) {                             // n_src <= 64: one lane per segment, prefix sum by shuffles
         uint32_t len = 0;
         if (tid < n_src) {
             const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[tid * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
             len = (uint32_t)(b - a);
-            s_segbeg[tid] = a;
+            if (HAVE_SEGBEG) s_segbeg[tid] = a;
         }
         uint32_t incl = len;
 #pragma unroll
@@ -843,7 +846,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             if (ridx < total_recs) {
                 uint32_t sg = 0;
                 while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
-                const uint64_t sbase = s_segbeg[sg];                                            // first record of the segment
+                const uint64_t sbase = HAVE_SEGBEG ? s_segbeg[sg] : seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS];   // first record of the segment
                 const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + (sbase + (ridx - s_segpre[sg])) * RW;
                 A0 = g[0]; A1 = g[1];
                 if (NBW > 2) A2 = g[2];

@@ -316,6 +316,138 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_kernel(RecArrays in, uin
     }
 }
 
+// Wave-per-group finisher for the three-array record form (keys longer than 96 bits, or DBG_NO_REC16): the same scheme as
+// span_sort16_groups_kernel below -- counting sort of every prefix group on the next `dbits` key bits with per-wave LDS
+// counters, then members that share a digit ranked by key from their provisional places; groups of up to 128 records,
+// two per lane.
+constexpr int SG3_MAXD = 6;
+template <bool HAS_HI, bool IS_SET>
+__global__ void __launch_bounds__(SS_THREADS) span_sort_groups_kernel(RecArrays in, uint32_t n, int key_bits, int top_bits, int dbits,
+                                                                      uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
+                                                                      uint8_t* __restrict__ o_exts, uint16_t* __restrict__ o_count,
+                                                                      uint32_t* __restrict__ o_setn, uint32_t* __restrict__ o_msk,
+                                                                      uint32_t* __restrict__ flags) {
+    __shared__ uint64_t s_lo[SS_CAP];
+    __shared__ uint64_t s_hi[HAS_HI ? SS_CAP : 1];
+    __shared__ uint32_t s_pay[SS_CAP];
+    __shared__ uint32_t s_pre[SS_CAP + 1];              // prefix of every record; afterwards: start of group g
+    __shared__ uint32_t s_cnt[SS_THREADS / 64][1 << SG3_MAXD];
+    __shared__ uint32_t s_start, s_end, s_ng;
+    __shared__ uint32_t s_wsum[SS_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t base = blockIdx.x * SS_WINDOW;
+    const uint32_t avail = n - base < (uint32_t)SS_CAP ? n - base : (uint32_t)SS_CAP;
+    if (tid == 0) { s_start = 0xffffffffu; s_end = 0xffffffffu; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i < avail) {
+            const uint32_t g = base + i;
+            const uint64_t h = HAS_HI ? in.hi[g] : 0, l = in.lo[g];
+            s_lo[i] = l; if (HAS_HI) s_hi[i] = h; s_pay[i] = in.pay[g];
+            s_pre[i] = key_prefix(h, l, key_bits, top_bits);
+        }
+    }
+    uint32_t prev0 = 0;
+    if (base > 0 && tid == 0) prev0 = key_prefix(HAS_HI ? in.hi[base - 1] : 0, in.lo[base - 1], key_bits, top_bits);
+    __syncthreads();
+    uint32_t bflags = 0;
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid * SS_ITEMS + r;
+        if (i < avail) {
+            const uint32_t pc = s_pre[i];
+            const bool boundary = i == 0 ? (base == 0 || pc != prev0) : pc != s_pre[i - 1];
+            if (boundary) {
+                bflags |= 1u << r;
+                if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i); else atomicMin(&s_end, i);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t start = s_start;
+    if (start == 0xffffffffu) return;
+    uint32_t end = s_end;
+    if (end == 0xffffffffu) {
+        if (avail == (uint32_t)SS_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
+        end = avail;
+    }
+    {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) mine++; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SS_THREADS / 64; w++) { const uint32_t x = s_wsum[w]; off += (uint32_t)w < wave ? x : 0u; tot += x; }
+        uint32_t g = off + incl - mine;
+#pragma unroll
+        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) s_pre[g++] = i; }
+        if (tid == 0) { s_ng = tot; s_pre[tot] = end; }
+    }
+    __syncthreads();
+    const uint32_t ng = s_ng;
+    const int dshift = key_bits - top_bits - dbits;             // the digit = key bits [dshift, dshift + dbits): inside one key word (caller)
+    const uint32_t nd = 1u << dbits, dmask = nd - 1u;
+    uint32_t* cnt = s_cnt[wave];
+    struct R3 { uint64_t hi, lo; uint32_t pay; };
+    auto get = [&](uint32_t i) { return R3{HAS_HI ? s_hi[i] : 0ull, s_lo[i], s_pay[i]}; };
+    auto put = [&](uint32_t i, const R3& q) { s_lo[i] = q.lo; if (HAS_HI) s_hi[i] = q.hi; s_pay[i] = q.pay; };
+    auto dig = [&](const R3& q) { return (uint32_t)((dshift >= 64 ? q.hi >> (dshift - 64) : q.lo >> dshift)) & dmask; };
+    auto lt = [&](uint32_t j, const R3& q) { const uint64_t jl = s_lo[j]; return HAS_HI ? (s_hi[j] < q.hi || (s_hi[j] == q.hi && jl < q.lo)) : jl < q.lo; };
+    for (uint32_t gi = wave; gi < ng; gi += SS_THREADS / 64) {
+        const uint32_t gs = s_pre[gi], gn = s_pre[gi + 1] - gs;
+        if (gn > 128) { if (lane == 0) atomicOr(flags, 1u); continue; }
+        if (gn == 1) continue;
+        const bool hasA = lane < gn, hasB = 64 + lane < gn;
+        R3 qa{0, 0, 0}, qb{0, 0, 0};
+        if (hasA) qa = get(gs + lane);
+        if (hasB) qb = get(gs + 64 + lane);
+        for (uint32_t d = lane; d < nd; d += 64) cnt[d] = 0;
+        const uint32_t da = dig(qa), db = dig(qb);
+        uint32_t ra = 0, rb = 0;
+        if (hasA) ra = atomicAdd(&cnt[da], 1u);
+        if (hasB) rb = atomicAdd(&cnt[db], 1u);
+        uint32_t carry = 0;
+        for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
+            const uint32_t c = d0 + lane < nd ? cnt[d0 + lane] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+            if (d0 + lane < nd) cnt[d0 + lane] = carry + incl - c;
+            carry += __shfl(incl, 63);
+        }
+        const uint32_t ca = hasA ? cnt[da] : 0u, cb = hasB ? cnt[db] : 0u;
+        if (hasA) put(gs + ca + ra, qa);
+        if (hasB) put(gs + cb + rb, qb);
+        const uint32_t ea = hasA ? (da + 1 < nd ? cnt[da + 1] : gn) : 0u, eb = hasB ? (db + 1 < nd ? cnt[db + 1] : gn) : 0u;
+        uint32_t la = 0, lb = 0;
+        if (hasA && ea - ca > 1) for (uint32_t j = ca; j < ea; j++) la += lt(gs + j, qa) ? 1u : 0u;
+        if (hasB && eb - cb > 1) for (uint32_t j = cb; j < eb; j++) lb += lt(gs + j, qb) ? 1u : 0u;
+        if (hasA && ea - ca > 1) put(gs + ca + la, qa);
+        if (hasB && eb - cb > 1) put(gs + cb + lb, qb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; r++) {
+        const uint32_t i = tid + r * SS_THREADS;
+        if (i >= start && i < end) {
+            const uint32_t g = base + i;
+            o_hi[g] = HAS_HI ? s_hi[i] : 0;
+            o_lo[g] = s_lo[i];
+            const uint32_t p = s_pay[i];
+            o_exts[g] = (uint8_t)(p & 0xffu);
+            if (IS_SET) { o_msk[g] = p >> 8; if (o_setn) o_setn[g] = __popc(p >> 8); }
+            else o_count[g] = (uint16_t)(p >> 8);
+        }
+    }
+}
+
 template <bool IS_SET>
 __global__ void decode_payload_kernel(uint32_t n, const uint32_t* __restrict__ pay, uint8_t* __restrict__ exts,
                                       uint16_t* __restrict__ count, uint32_t* __restrict__ setn, uint32_t* __restrict__ msk) {
@@ -343,11 +475,15 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
         int top_bits = 0;
         while (top_bits < key_bits && top_bits < 32 && (n64 >> top_bits) > 32) top_bits += 8;
         if (top_bits > key_bits) top_bits = key_bits;
-        // digit boundaries sit at multiples of 8 from bit 0 so that no digit straddles the two key words; rounding down
-        // adds up to 7 prefix bits (30 at k = 47: a 4th, 6-bit pass).  Measured at 5e8 keys: with exactly 24 prefix bits the
-        // groups hold ~30 records and the finisher's rank-by-comparison takes 31 ms instead of 8 -- more than the pass costs.
-        const int s0 = top_bits ? ((key_bits - top_bits) / 8) * 8 : key_bits;
-        top_bits = key_bits - s0;
+        // Passes start exactly at bit key_bits - top_bits and the wave-per-group finisher orders the groups on the next 6 bits,
+        // when those bits and the pass digits all lie inside one of the two 64-bit key words (always true for k >= 49, whose
+        // top 30 bits sit in the high word).  Otherwise, and with DBG_SORT=bytealigned, digit boundaries sit at multiples of 8
+        // from bit 0 -- up to 7 more prefix bits (30 at k = 51: a 4th, 6-bit pass) -- and the walking finisher runs.
+        const int dbits = std::min(6, key_bits - top_bits);
+        int s0 = key_bits - top_bits;
+        const bool one_word = top_bits > 0 && dbits > 0 && (s0 - dbits >= 64 || key_bits <= 64);
+        const bool groups = one_word && !(ctx->opt("DBG_SORT") && !strcmp(ctx->opt("DBG_SORT"), "bytealigned"));
+        if (!groups) { s0 = top_bits ? (s0 / 8) * 8 : key_bits; top_bits = key_bits - s0; }
         if (top_bits > 0) {
             const uint32_t nblocks = cdiv(n, RS_TILE);
             DBuf<uint32_t> hist, hist_scanned;
@@ -371,20 +507,30 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
         }
         DBuf<uint32_t> flags;
         ALLOC_OR_FAIL(ctx, flags, 1);
-        HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
         const uint32_t nwg = cdiv(n, SS_WINDOW);
-        ctx->t_begin("span_sort", n);
-#define GO(HH, SS) span_sort_kernel<HH, SS><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, \
-            o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p)
-        if (has_hi) { if (is_set) GO(true, true); else GO(true, false); }
-        else        { if (is_set) GO(false, true); else GO(false, false); }
+        for (int form = groups ? 0 : 1; form < 2; form++) {            // 0: wave per group; 1: walking finisher (long groups)
+            HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
+            ctx->t_begin("span_sort", n);
+            if (form == 0) {
+#define GO(HH, SS) span_sort_groups_kernel<HH, SS><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, \
+                o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p)
+                if (has_hi) { if (is_set) GO(true, true); else GO(true, false); }
+                else        { if (is_set) GO(false, true); else GO(false, false); }
 #undef GO
-        ctx->t_end();
-        LAUNCH_CHECK(ctx, "span_sort");
-        uint32_t fl = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (fl == 0) return 0;
+            } else {
+#define GO(HH, SS) span_sort_kernel<HH, SS><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, \
+                o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p)
+                if (has_hi) { if (is_set) GO(true, true); else GO(true, false); }
+                else        { if (is_set) GO(false, true); else GO(false, false); }
+#undef GO
+            }
+            ctx->t_end();
+            LAUNCH_CHECK(ctx, "span_sort");
+            uint32_t fl = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (fl == 0) return 0;
+        }
     }
     // plain LSD sort over every key bit
     bool in_b = false;
@@ -610,7 +756,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_kernel(const uint4* __
 // provisional places.  Groups of up to 128 records are held two per lane; longer ones (heavily repeated prefixes) raise the flag
 // and the caller runs the walking finisher.  Canonical keys are denser at small values (min(k-mer, rc)), so groups of twice
 // the average size are normal.
-constexpr int SG_MAXD = 8;
+constexpr int SG_MAXD = 6;
 template <bool IS_SET>
 __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const uint4* __restrict__ in, uint32_t n, int key_bits, int top_bits, int dbits,
                                                                         uint64_t* __restrict__ o_hi, uint64_t* __restrict__ o_lo,
@@ -692,7 +838,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const ui
         uint32_t ra = 0, rb = 0;                                   // rank inside the digit (any order: step 2 orders equal digits)
         if (hasA) ra = atomicAdd(&cnt[da], 1u);
         if (hasB) rb = atomicAdd(&cnt[db], 1u);
-        // exclusive prefix of the counters: lanes take digit values in turn (nd <= 256: four rounds)
+        // exclusive prefix of the counters: lanes take digit values in turn (nd <= 64: one round)
         uint32_t carry = 0;
         for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
             const uint32_t c = d0 + lane < nd ? cnt[d0 + lane] : 0u;
