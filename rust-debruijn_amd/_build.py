@@ -34,14 +34,41 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _check_bin_count_budget(remarks):
+    """The counting kernel is laid out for two 512-thread workgroups per CU: 160 KB of LDS / 2 and 128 VGPRs.  A variant that
+    slips over either limit silently halves its occupancy (it happened to the k >= 56 colour-set variant), so the build checks
+    the compiler's resource report."""
+    import re
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        if name and "bin_count_kernel" in name and "Li512ELi2048E" in name:
+            m = re.search(r"LDS Size \[bytes/block\]: (\d+)", line)
+            if m and int(m.group(1)) > 81920:
+                raise RuntimeError("bin_count variant %s needs %s bytes of LDS: more than half a CU's 160 KB" % (name, m.group(1)))
+            m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
+            if m and int(m.group(1)) < 4:
+                raise RuntimeError("bin_count variant %s reaches %s waves per SIMD, not the 4 that two workgroups per CU need" % (name, m.group(1)))
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src[:-4] + ".o")
     if _stale(obj, [os.path.join(CSRC, src)] + _headers()):
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ["-Rpass-analysis=kernel-resource-usage"] if src == "fastpath.hip" else []
+        cmd = [HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-        if r.stderr.strip():
+        if extra:
+            try:
+                _check_bin_count_budget(r.stderr)
+            except RuntimeError:
+                os.remove(obj)
+                raise
+        elif r.stderr.strip():
             sys.stderr.write(r.stderr)
     return obj
 
