@@ -482,7 +482,7 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
         const int dbits = std::min(6, key_bits - top_bits);
         int s0 = key_bits - top_bits;
         const bool one_word = top_bits > 0 && dbits > 0 && (s0 - dbits >= 64 || key_bits <= 64);
-        const bool groups = one_word && !(ctx->opt("DBG_SORT") && !strcmp(ctx->opt("DBG_SORT"), "bytealigned"));
+        const bool groups = one_word && !(ctx->opt("DBG_SORT") && !strcmp(ctx->opt("DBG_SORT"), "bytealigned")) && (n64 >> top_bits) >= 16;   // see sort_table_hybrid16
         if (!groups) { s0 = top_bits ? (s0 / 8) * 8 : key_bits; top_bits = key_bits - s0; }
         if (top_bits > 0) {
             const uint32_t nblocks = cdiv(n, RS_TILE);
@@ -925,7 +925,11 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
         int top_bits = 0;
         while (top_bits < key_bits && top_bits < 32 && (n64 >> top_bits) > 32) top_bits += 8;
         if (top_bits > key_bits) top_bits = key_bits;
+        // A wave per group pays ~100 instructions per group: right for groups of dozens of records, wrong for small ones (n well
+        // below 32 x 2^top_bits) -- those keep the round-1 form, whose extra prefix bits leave almost nothing to the finisher.
         const bool bytealigned = ctx->opt("DBG_SORT") && !strcmp(ctx->opt("DBG_SORT"), "bytealigned");
+        const bool small_groups = (n64 >> top_bits) < 16;
+        if (small_groups && (n64 >> top_bits) >= 2 && top_bits + 8 <= std::min(key_bits, 32)) top_bits += 8;   // the walking finisher wants (nearly) nothing left
         int s0 = key_bits - top_bits;
         if (bytealigned) { s0 = top_bits ? (s0 / 8) * 8 : key_bits; top_bits = key_bits - s0; }
         for (int s = s0; s < key_bits; s += 8) {
@@ -937,7 +941,7 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
         ALLOC_OR_FAIL(ctx, flags, 1);
         const uint32_t nwg = cdiv(n, SS_WINDOW);
         const int dbits = std::min(6, key_bits - top_bits);
-        for (int form = (bytealigned || dbits <= 0) ? 1 : 0; form < 2; form++) {       // 0: wave per group; 1: walking finisher
+        for (int form = (bytealigned || dbits <= 0 || small_groups) ? 1 : 0; form < 2; form++) {       // 0: wave per group; 1: walking finisher
             HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
             ctx->t_begin("span_sort", n);
             if (form == 0) {
