@@ -231,7 +231,8 @@ def main():
             pmc_name = {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
                         "radix_hist": "radix16_hist_kernel" if 2 * k <= 96 else "radix_hist_kernel",
                         "radix_scatter": "radix16_scatter_kernel" if 2 * k <= 96 else "radix_scatter_kernel",
-                        "span_sort": "span_sort16_kernel" if 2 * k <= 96 else "span_sort_kernel", "set_csr": "csr_apply_kernel",
+                        "span_sort": (("span_sort16_groups_kernel", "span_sort16_kernel") if 2 * k <= 96
+                                      else ("span_sort_groups_kernel", "span_sort_kernel")), "set_csr": "csr_apply_kernel",
                         "sk_scatter": "sk_scatter_kernel", "slab_compact": "slab_compact_kernel"}
 
             def row(name, a):
@@ -239,13 +240,17 @@ def main():
                 step_ms = a["ms"] / args.steps
                 units_step = a["units"] / args.steps
                 ach = per_unit * units_step / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
-                ent = tj.get(pmc_name.get(name, name))
+                pn = pmc_name.get(name, name)
+                ent = next((tj[c] for c in (pn if isinstance(pn, tuple) else (pn,)) if c in tj), None)
                 r = {"kernel": name, "ms_per_step": round(step_ms, 3), "launches_per_step": a["launches"] / args.steps,
                      "alg_bytes_per_unit": round(per_unit, 2), "units_per_step": units_step,
                      "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
                      "traffic_bytes_per_step": None, "measured_gb_per_s": None, "measured_hbm_frac": None, "bound": "hbm"}
                 if ent and step_ms > 0:
                     tb = ent["bytes_per_instance"] * n_inst     # the PMC file is normalised per k-mer instance of the profiled run
+                    pl = ent.get("dispatches", 0) / max(tj.get("_steps", 0), 1)
+                    if tj.get("_steps") and pl > 0:             # ... and per launch, if the profiled size ran another number of passes
+                        tb *= (a["launches"] / args.steps) / pl
                     r["traffic_bytes_per_step"] = round(tb, 0)
                     r["measured_gb_per_s"] = round(tb / (step_ms * 1e-3) / 1e9, 1)
                     r["measured_hbm_frac"] = round(tb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -754,8 +754,18 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define PH(i) do {} while (0)
 #endif
+// DBG_ABL_COUNT = n (measurement builds, tools/abl_count.sh): the counting kernel stops after phase n of a bin -- 1 segment bounds,
+// 2 table cleared, 3 records staged, 4 chunk map built, 5 chunks set up (no k-mer is rolled or inserted)
+#ifndef DBG_ABL_COUNT
+#define DBG_ABL_COUNT 0
+#endif
+#ifdef DBG_ASM_MARKS     // phase markers in the assembly listing
+#define MARK(t) asm volatile("; ##MARK " t ::: "memory")
+#else
+#define MARK(t) do {} while (0)
+#endif
 template <int KW, int NBW, bool IS_SET, int NT, int T>
-__global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
@@ -774,7 +784,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     uint32_t* const s_dd = reinterpret_cast<uint32_t*>(s_cmap);      // duplicate filter of the batch (dead before s_cmap is filled)
     __shared__ uint32_t s_w[NT / 2];            // per staged record: how many identical records of the batch it stands for (u16 halves)
     __shared__ uint32_t s_cmk[IS_SET ? NT : 1]; // ... and the union of their colours (CountFilterSet)
-    __shared__ uint32_t s_m, s_cproc, s_nextq, s_nst;
+    __shared__ uint32_t s_m, s_cproc, s_nextq, s_nst, s_bad;
 #ifdef DBG_COUNT_STATS
     __shared__ uint32_t s_stat[16];
     if (threadIdx.x < 16) s_stat[threadIdx.x] = 0;
@@ -816,8 +826,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
     }
     __syncthreads();
     const uint32_t total_recs = s_segpre[n_src];
-    PH(0);
-    if (total_recs == 0) return;
+    PH(0); MARK("prologue_done");
+    if (total_recs == 0 || DBG_ABL_COUNT == 1) return;
     const K128 kmask = k128_mask(k);
 
     // Work stack of hash-selected passes (P, r): the pass handles the keys with (hash >> 16) % P == r.
@@ -862,9 +872,10 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
         load_into(NT + tid, Q0, Q1, Q2, Q3, qmeta);     // both requests are in flight together
         bool q_valid = true;                            // Q holds record NT + tid
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_bad = 0; }
         lds_barrier();                                  // the prefetched records stay in flight
-        PH(1);
+        PH(1); MARK("cleared");
+        if (DBG_ABL_COUNT == 2) break;
 
         // ---- stream the bin, chunk-parallel.  A super-k-mer record holds 1..W k-mers; handing whole records to
         //      lanes leaves the waves of the workgroup badly balanced (a bin is only ~1.3 records per lane).  So
@@ -899,63 +910,76 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
             for (uint32_t fills = 0;; fills++) {
                 const uint32_t room = NT - nstaged;
                 const uint32_t take = total_recs - rnext < room ? total_recs - rnext : room;
-                if (tid < take) {
-                    pmeta = (NBW == 2 ? P1 : (NBW == 3 ? P2 : P3)) & ((1ull << META_BITS) - 1);
+                // Claim, barrier, compare -- nobody waits in a loop: the first record of its kind wins its filter slot (CAS), takes
+                // the next staging slot, writes the record and publishes the slot number; the others of its kind stop at that
+                // filter entry (claimed or published, it carries their hash bits), and after the workgroup's barrier compare
+                // themselves with the staged record and add to its weight.  Only a record that met a DIFFERENT record with its
+                // hash bits goes round again from the next filter slot.  (The version that re-read a claimed entry until it was
+                // published spent a third of the staging phase's lane iterations doing that: a bin's ~18 copies of each piece
+                // arrive together.)
+                bool pend = tid < take;
+                uint32_t mytag = 0, sl = 0, colour = 0;
+                const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);               // word holding the meta bits
+                if (pend) {
+                    pmeta = PL0 & ((1ull << META_BITS) - 1);
                     {   // a record whose length cannot come from the scan (a wrong segment table, an incomplete exchange) must not
                         // be expanded: its k-mer count would be garbage.  The launch is failed instead.
                         const uint32_t rl = (uint32_t)(pmeta & 0x7f);
                         if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - META_BITS / 2)) { atomicOr(&gflags[3], 4u); pass_bad = true; }
                     }
-                    const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);           // word holding the meta bits
                     const uint64_t lastw = PL0 & ~COLOUR_BITS;
                     uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
                     if (NBW == 3) ha += lastw * 0x9E3779B97F4A7C15ull;
                     if (NBW == 4) { ha += P2 * 0x9E3779B97F4A7C15ull; hb += lastw * 0xC2B2AE3D27D4EB4Full; }
                     const uint64_t h = hash_key(ha, hb);
-                    const uint32_t mytag = (uint32_t)(h >> 42) << 10;
-                    const uint32_t colour = 1u << ((uint32_t)(pmeta >> 15) & 31u);
-                    uint32_t sl = (uint32_t)h & (DD - 1);
-                    // Claim-then-stage: the first record of its kind wins the filter slot with a PENDING entry, takes the next
-                    // staging slot, writes the record and only then publishes the slot number; records that meet a PENDING entry
-                    // with their own hash bits re-read it (the claimer is in another wave, or has finished its stores before this
-                    // wave's next loop iteration -- the same argument as for TAG_BUSY in the k-mer table).  Allocating before the
-                    // claim would hand out a slot to every record of the first round (all of them see an empty filter).
-                    constexpr uint32_t PENDING = 1023u;
-                    for (;;) {
-                        asm volatile("" ::: "memory");
-                        uint32_t v = s_dd[sl];
-                        if (v == 0u) {                                                   // end of the probe chain: first of its kind
-                            v = atomicCAS(&s_dd[sl], 0u, PENDING | mytag);
-                            if (v == 0u) {
-                                const uint32_t mine = atomicAdd(&s_nst, 1u);             // < NT: at most `room` records allocate
-                                s_slab[mine] = P0; s_slab[NT + mine] = P1;
-                                if (NBW > 2) s_slab[2 * NT + mine] = P2;
-                                if (NBW > 3) s_slab[3 * NT + mine] = P3;
-                                atomicAdd(&s_w[mine >> 1], 1u << (16 * (mine & 1u)));
-                                if (IS_SET) atomicOr(&s_cmk[mine], colour);
-                                asm volatile("" ::: "memory");                           // the record is written before it is published
-                                __hip_atomic_store(&s_dd[sl], (mine + 1u) | mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                break;
-                            }
-                        }
-                        if ((v & ~1023u) == mytag) {
-                            if ((v & 1023u) == PENDING) continue;                        // being staged: look again
-                            const uint32_t r = (v & 1023u) - 1u;
-                            bool same = s_slab[r] == P0;
-                            if (NBW > 2) same = same && s_slab[NT + r] == P1;
-                            if (NBW > 3) same = same && s_slab[2 * NT + r] == P2;
-                            same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
-                            if (same) {                                                  // an equal record is staged: it stands for this one too
-                                STAT(fills ? 14 : 15, 1);
-                                atomicAdd(&s_w[r >> 1], 1u << (16 * (r & 1u)));
-                                if (IS_SET) atomicOr(&s_cmk[r], colour);
-                                break;
-                            }
-                        }
-                        sl = (sl + 1u) & (DD - 1);
-                    }
+                    mytag = (uint32_t)(h >> 42) << 10;
+                    colour = 1u << ((uint32_t)(pmeta >> 15) & 31u);
+                    sl = (uint32_t)h & (DD - 1);
                 }
-                if (__syncthreads_or(pass_bad ? 1 : 0)) { pass_ovf = true; nstaged = 0; rnext = total_recs; break; }     // corrupt input: give up on the bin
+                bool bad_round = false;
+                for (;;) {
+                    if (pend) {
+                        constexpr uint32_t CLAIMED = 1023u;
+                        for (;;) {                                                       // to the first slot that is free or carries my hash bits
+                            uint32_t v = s_dd[sl];
+                            if (v == 0u) {
+                                v = atomicCAS(&s_dd[sl], 0u, CLAIMED | mytag);
+                                if (v == 0u) {                                           // first of its kind: stage it
+                                    const uint32_t mine = atomicAdd(&s_nst, 1u);         // < NT: at most `room` records allocate
+                                    s_slab[mine] = P0; s_slab[NT + mine] = P1;
+                                    if (NBW > 2) s_slab[2 * NT + mine] = P2;
+                                    if (NBW > 3) s_slab[3 * NT + mine] = P3;
+                                    atomicAdd(&s_w[mine >> 1], 1u << (16 * (mine & 1u)));
+                                    if (IS_SET) atomicOr(&s_cmk[mine], colour);
+                                    s_dd[sl] = (mine + 1u) | mytag;
+                                    pend = false;
+                                    break;
+                                }
+                            }
+                            if ((v & ~1023u) == mytag) break;                            // (being) staged here: compared after the barrier
+                            sl = (sl + 1u) & (DD - 1);
+                        }
+                    }
+                    lds_barrier();
+                    if (pend) {
+                        const uint32_t r = (s_dd[sl] & 1023u) - 1u;
+                        bool same = s_slab[r] == P0;
+                        if (NBW > 2) same = same && s_slab[NT + r] == P1;
+                        if (NBW > 3) same = same && s_slab[2 * NT + r] == P2;
+                        same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
+                        if (same) {                                                      // an equal record is staged: it stands for this one too
+                            STAT(fills ? 14 : 15, 1);
+                            atomicAdd(&s_w[r >> 1], 1u << (16 * (r & 1u)));
+                            if (IS_SET) atomicOr(&s_cmk[r], colour);
+                            pend = false;
+                        } else sl = (sl + 1u) & (DD - 1);
+                    }
+                    if (pass_bad) s_bad = 1u;
+                    const int more = __syncthreads_or(pend ? 1 : 0);
+                    if (s_bad) { bad_round = true; break; }
+                    if (!more) break;
+                }
+                if (bad_round) { pass_ovf = true; nstaged = 0; rnext = total_recs; break; }     // corrupt input: give up on the bin
                 nstaged = s_nst;
 #ifdef DBG_COUNT_STATS
                 if (tid == 0 && fills == 0) atomicAdd(&s_stat[13], nstaged);
@@ -968,7 +992,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                 if (rnext >= total_recs || fills >= MAX_FILLS) break;
                 if (NT - nstaged < MIN_ROOM && NT - nstaged < total_recs - rnext) break;
             }
-            PH(7);
+            PH(7); MARK("filled");
+            if (DBG_ABL_COUNT == 3) continue;
             // ---- cut the staged records into chunks and insert their k-mers; the chunk map may take several rounds when the
             //      records are long and all different ----
             for (uint32_t base = 0; base < nstaged && !pass_ovf;) {
@@ -1018,6 +1043,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     } else if (have) atomicMin(&s_m, tid);
                 }
                 __syncthreads();
+                MARK("map_done");
+                if (DBG_ABL_COUNT == 4) { base = nstaged; continue; }
                 const uint32_t mend = all_fit ? nstaged : s_m;                   // records [base, mend) are in the map (at least one)
                 const uint32_t cproc = all_fit ? totc : s_cproc;
                 // C. chunks, 64 at a time to whichever wave is free (a wave's rounds differ in length: probe retries, chunk sizes)
@@ -1066,6 +1093,8 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                         const uint64_t v = bs ? (A << bs) | (B >> (64 - bs)) : A;
                         nx = (uint32_t)(v >> 32);
                     }
+                    MARK("chunk_setup_done");
+                    if (DBG_ABL_COUNT == 5) { if (fw.lo + rcw.hi + lb + nx + wgt + cset + rexts == 0x1234567u) s_flag[1] = 7; continue; }
                     while (__any(j < jend)) {
                         const bool alive = j < jend;
 #ifdef DBG_COUNT_STATS
@@ -1093,6 +1122,7 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                             const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
                             uint32_t bkt = (uint32_t)h & (T / 4 - 1);
                             uint32_t slot = 0, tried = 0, nprobe = 0;
+                            const uint32_t rot = (uint32_t)(h >> 12) & 3u;
                             bool hit = false;
                             for (;;) {
                                 asm volatile("" ::: "memory");                           // re-read the tags every round
@@ -1117,7 +1147,12 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                                 }
                                 if (busy) { STAT(9, 1); continue; }                      // a claimer is still writing its key: re-read
                                 if (em) {
-                                    const uint32_t sl = bkt * 4 + (uint32_t)__ffs((int)em) - 1u;
+                                    // first free slot in a cyclic order that depends on the key: lanes that insert DIFFERENT keys into
+                                    // one bucket at the same moment then mostly try different slots (with "first free" they all meet on
+                                    // the same one and all but one lose a round); two lanes with the SAME key use the same order, so the
+                                    // argument above (a failed CAS re-reads the bucket) still keeps a key from getting two slots.
+                                    const uint32_t emr = ((em >> rot) | (em << (4u - rot))) & 15u;
+                                    const uint32_t sl = bkt * 4 + (((uint32_t)__ffs((int)emr) - 1u + rot) & 3u);
                                     if (atomicCAS(&s_tag[sl], 0u, bz) == 0u) {
                                         if (KW == 2) *reinterpret_cast<ulonglong2*>(&s_key[2 * sl]) = make_ulonglong2(km.lo, km.hi);
                                         else s_key[sl] = km.lo;
@@ -1161,8 +1196,9 @@ __global__ void __launch_bounds__(NT) bin_count_kernel(const uint64_t* __restric
                     j++;
                 }
                     }   // rolling loop
+                    MARK("roll_done");
                 }       // chunk loop
-                PH(2);
+                PH(2); MARK("chunks_done");
                 __syncthreads();
                 PH(3);
                 base = mend;

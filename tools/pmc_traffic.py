@@ -3,6 +3,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coal
 (MI355X_MICROARCH.md, HBM section), so traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes."""
 import csv, glob, json, os, sys, collections
 root, out, n_inst = sys.argv[1], sys.argv[2], float(sys.argv[3])
+n_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2          # bench steps the counter passes ran (tools/pmc_round.sh)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(int)
 def newest_per_pass(root):
@@ -24,7 +25,8 @@ for f in newest_per_pass(root):
         if r["Counter_Name"] == "FETCH_SIZE":
             disp[k] += 1
 res = {"_note": "bytes per k-mer instance of the profiled run = (2*FETCH_SIZE + WRITE_SIZE)*1024 / instances; "
-                "FETCH_SIZE doubled per the gfx950 correction", "_instances": n_inst}
+                "FETCH_SIZE doubled per the gfx950 correction; dispatches = launches seen in the pass (over _steps bench steps)",
+       "_instances": n_inst, "_steps": n_steps}
 for k, v in agg.items():
     b = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
     res[k] = {"fetch_kib": v.get("FETCH_SIZE", 0), "write_kib": v.get("WRITE_SIZE", 0), "dispatches": disp[k],
