@@ -530,6 +530,7 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
             HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (fl == 0) return 0;
+            if (ctx->opt("DBG_DEBUG")) fprintf(stderr, "[sort] finisher form %d met a group of equal prefix that is too long for it (n=%u, top_bits=%d)\n", form, n, top_bits);
         }
     }
     // plain LSD sort over every key bit
@@ -957,6 +958,7 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
             HIP_TRY(ctx, hipMemcpyAsync(&fl, flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (fl == 0) return 0;
+            if (ctx->opt("DBG_DEBUG")) fprintf(stderr, "[sort] finisher form %d met a group of equal prefix that is too long for it (n=%u, top_bits=%d)\n", form, n, top_bits);
         }
     }
     // plain LSD sort over every key bit (stable passes compose, so the top-bit passes above need not be undone: a full

@@ -223,3 +223,26 @@ def test_fast_large_bins_high_coverage(ctx):
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 2, stranded=False)
     got = _with_env(ctx, {"DBG_FAST_TARGET": "40000"}, lambda: dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=47, ctx=ctx)[0])
     assert_tables_equal(got, want, True)
+
+
+@pytest.mark.parametrize("k,kind", [(31, 0), (47, 1), (47, 0), (63, 1), (63, 0)])
+@pytest.mark.parametrize("shape", ["uniform", "groups_200", "groups_1000"])
+def test_fast_sort_group_finisher_regimes(ctx, k, kind, shape, capfd):
+    """The order-restoring sort picks its finisher from the table size: between 16 and 32 k-mers per group of equal prefix
+    (4096 .. 8192 valid k-mers for an 8-bit prefix -- and 2.7e8 .. 5.4e8 for the 24 bits of the benchmark) a wave sorts each
+    group; a group of more than 128 sends the call back to the walking finisher, one of more than 512 to the plain LSD sort.
+    Reads made of 'AAAA' + four random bases put every eighth k-mer into the prefix group of AAAA."""
+    rng = np.random.default_rng(900 + k + kind + len(shape))
+    n_skew = {"uniform": 0, "groups_200": 12, "groups_1000": 60}[shape]
+    seqs = [R.random_dna(rng, 150) for _ in range(52 - min(n_skew, 40))]
+    for _ in range(n_skew):
+        blocks = [np.concatenate([np.zeros(4, np.uint8), R.random_dna(rng, 4)]) for _ in range(19)]
+        seqs.append(np.concatenate(blocks)[:150])
+    data = rng.integers(0, 6, size=len(seqs)) if kind else None
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1) if kind else O.SeqSet.from_byte_seqs(seqs)
+    with ctx.options(DBG_DEBUG="1"):
+        got = run_fast(ctx, ss, k, O.COUNT_FILTER_SET if kind else O.COUNT_FILTER, 1, False, data_width=1 if kind else 0)
+    err = capfd.readouterr().err
+    gave_up = [int(l.split("form ")[1][0]) for l in err.splitlines() if l.startswith("[sort] finisher form")]
+    if 4096 <= len(got) <= 8192:                              # the size range in which a wave sorts each group
+        assert gave_up in {"uniform": ([],), "groups_200": ([0],), "groups_1000": ([0], [0, 1])}[shape], err
