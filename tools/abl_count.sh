@@ -5,7 +5,7 @@ NR=${1:-10000000}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/abl_count
 rm -rf $OUT; mkdir -p $OUT
-for v in 3 full; do
+for v in 2 3 4 5 full; do
   L=$GRAFT_REPO_ROOT/rust-debruijn_amd/_exp/libabl$v.so
   [ $v = full ] && L=$GRAFT_REPO_ROOT/rust-debruijn_amd/libdbg_mi355x.so
   DBG_LIB=$L timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/$v -- \
@@ -14,7 +14,7 @@ done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, glob, collections
-for v in ["3", "full"]:
+for v in ["2", "3", "4", "5", "full"]:
     agg = collections.defaultdict(float)
     for f in glob.glob("gpurun_out/abl_count/%s/*/*counter_collection.csv" % v):
         for r in csv.DictReader(open(f)):
