@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction counts and duration of the counting kernel per phase: runs the DBG_ABL_COUNT builds (tools/build_variant.py ablN
-# fastpath.hip -DDBG_ABL_COUNT=N, N = 1..6, and the regular build) under one counter pass each.  usage: tools/abl_count.sh [reads]
+# fastpath.hip -DDBG_ABL_COUNT=N, N = 2..5, and the regular build) under one counter pass each.  usage: tools/abl_count.sh [reads]
 NR=${1:-10000000}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/abl_count
