@@ -794,7 +794,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
     __shared__ uint32_t s_flag[2];              // [0] table overflow, [1] claimed entries
     __shared__ unsigned long long s_base, s_base_all;
     __shared__ uint32_t s_st[24];               // work stack of passes: P | r << 16 (P <= 4096: at most 13 levels, one pending sibling each)
-    __shared__ int s_sp;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
 #ifdef DBG_PHASE_TIMES
@@ -833,15 +832,17 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
     // Work stack of hash-selected passes (P, r): the pass handles the keys with (hash >> 16) % P == r.
     // A pass whose distinct keys overflow the table emits nothing and is replaced by its two children
     // (2P, r) and (2P, r + P), which partition exactly its key set.
-    if (tid == 0) { s_st[0] = 1u; s_sp = 1; }
-    __syncthreads();
+    // The stack pointer is kept by every thread (all see the same overflow decisions); only the entries live in LDS, written by
+    // one thread when a pass is split and read after the barrier that ends the pass.  A bin spends its time in a sequence of
+    // barrier-separated phases: every barrier saved counts (the first pass needs no stack access at all).
+    int sp = 1;
     for (uint32_t guard = 0;; guard++) {
-        const int sp = s_sp;
         if (sp == 0) break;
         if (guard > 20000u) { if (tid == 0) atomicOr(&gflags[3], 2u); break; }                   // watchdog
-        const uint32_t P = s_st[sp - 1] & 0xffffu, pr = s_st[sp - 1] >> 16;
-        __syncthreads();
-        if (tid == 0) { s_sp = sp - 1; if (P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); } }
+        const uint32_t ent = guard == 0 ? 1u : s_st[sp - 1];
+        const uint32_t P = ent & 0xffffu, pr = ent >> 16;
+        sp--;
+        if (tid == 0 && P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); }
         constexpr uint32_t CH = 4;
         // (scalars, not arrays: an indexed private array is placed in scratch memory by the compiler)
         uint64_t W0 = 0, W1 = 0, W2 = 0, W3 = 0, P0 = 0, P1 = 0, P2 = 0, P3 = 0;
@@ -872,7 +873,11 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
         load_into(NT + tid, Q0, Q1, Q2, Q3, qmeta);     // both requests are in flight together
         bool q_valid = true;                            // Q holds record NT + tid
         for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
-        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_bad = 0; }
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_bad = 0; s_nst = 0; }
+        // (the staging area and the filter of the first fill are reset here too: one barrier for both)
+        if (tid < NT / 2) s_w[tid] = 0;
+        if (IS_SET) s_cmk[tid] = 0;
+        for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
         lds_barrier();                                  // the prefetched records stay in flight
         PH(1); MARK("cleared");
         if (DBG_ABL_COUNT == 2) break;
@@ -897,14 +902,16 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
         constexpr uint32_t MIN_ROOM = NT / 8;           // keep filling while the rest of the bin, or at least this many records, still fit
         constexpr uint32_t MAX_FILLS = 100;             // weights are 16-bit: at most NT per round, 100 x 512 < 65536
         uint32_t rnext = 0;                             // next incoming record of the bin (uniform)
-        bool pass_bad = false;
+        bool pass_bad = false, bad_bin = false;
         while (rnext < total_recs && !pass_ovf) {
-            // ---- reset the staging area and the filter ----
-            if (tid < NT / 2) s_w[tid] = 0;
-            if (IS_SET) s_cmk[tid] = 0;
-            for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
-            if (tid == 0) s_nst = 0;
-            lds_barrier();
+            // ---- reset the staging area and the filter (the first fill's were reset with the table) ----
+            if (rnext != 0) {
+                if (tid < NT / 2) s_w[tid] = 0;
+                if (IS_SET) s_cmk[tid] = 0;
+                for (uint32_t i = tid; i < DD; i += NT) s_dd[i] = 0;
+                if (tid == 0) s_nst = 0;
+                lds_barrier();
+            }
             uint32_t nstaged = 0;
             // ---- fill rounds: thread tid holds incoming record rnext + tid (prefetched) ----
             for (uint32_t fills = 0;; fills++) {
@@ -979,7 +986,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                     if (s_bad) { bad_round = true; break; }
                     if (!more) break;
                 }
-                if (bad_round) { pass_ovf = true; nstaged = 0; rnext = total_recs; break; }     // corrupt input: give up on the bin
+                if (bad_round) { pass_ovf = true; bad_bin = true; nstaged = 0; rnext = total_recs; break; }     // corrupt input: give up on the bin
                 nstaged = s_nst;
 #ifdef DBG_COUNT_STATS
                 if (tid == 0 && fills == 0) atomicAdd(&s_stat[13], nstaged);
@@ -1200,18 +1207,19 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                 }       // chunk loop
                 PH(2); MARK("chunks_done");
                 __syncthreads();
-                PH(3);
+                PH(3);                 // waiting for the slowest wave
                 base = mend;
                 // a table more than 7/8 full makes the remaining records probe long chains: give up early and re-split the pass
-                if ((base < nstaged || rnext < total_recs) && tid == 0 && s_flag[1] > (uint32_t)(T - T / 8)) s_flag[0] = 1;
-                __syncthreads();
+                // (only when records remain: the last round of a bin needs no second barrier)
+                if (base < nstaged || rnext < total_recs) {
+                    if (tid == 0 && s_flag[1] > (uint32_t)(T - T / 8)) s_flag[0] = 1;
+                    __syncthreads();
+                }
                 pass_ovf = __hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
             }
         }
-                 // wave 0's own streaming time
-        __syncthreads();
-        PH(3);                 // waiting for the slowest wave
-        const bool ovf = s_flag[0] != 0;
+        if (bad_bin) break;                              // corrupt input: the launch fails (gflags), nothing is emitted
+        const bool ovf = pass_ovf;                       // (every thread read the flag after the last barrier above)
         // ---- emit the valid entries of this pass (a pass that overflowed emits nothing) ----
         if (!ovf && !DBG_SKIP_EMIT) {
             // Every wave emits its own T / NWV slots: ballots give the counts and the ranks; the waves' counts meet in LDS, one
@@ -1279,10 +1287,11 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                 }
             }
         } else {
-            if (P >= 4096u || sp + 1 >= 24) { if (tid == 0) atomicOr(&gflags[0], 2u); break; }
-            if (tid == 0) { s_st[sp - 1] = (2 * P) | (pr << 16); s_st[sp] = (2 * P) | ((pr + P) << 16); s_sp = sp + 1; }
+            if (P >= 4096u || sp + 2 >= 24) { if (tid == 0) atomicOr(&gflags[0], 2u); break; }
+            if (tid == 0) { s_st[sp] = (2 * P) | (pr << 16); s_st[sp + 1] = (2 * P) | ((pr + P) << 16); }
+            sp += 2;
         }
-        __syncthreads();
+        if (sp != 0) __syncthreads();                    // another pass follows: it clears the table and reads the stack
         PH(6);
     }
 #ifdef DBG_COUNT_STATS
