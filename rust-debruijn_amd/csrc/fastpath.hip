@@ -1659,7 +1659,8 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
             c->t_begin("bin_count", n_kmers_units);
             const int nt_env = c->opt("DBG_FAST_NT") ? atoi(c->opt("DBG_FAST_NT")) : 512;
             const int tb_env = c->opt("DBG_FAST_TABLE") ? atoi(c->opt("DBG_FAST_TABLE")) : 2048;
-#define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, 0, c->stream>>>( \
+            const size_t dyn_lds = c->opt("DBG_DYN_LDS") ? (size_t)atoi(c->opt("DBG_DYN_LDS")) : 0;   // measurement: extra LDS per workgroup (8192 leaves room for only one per CU)
+#define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, dyn_lds, c->stream>>>( \
             recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
 #define GO(KW, NBW, SET) do { \
             if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
