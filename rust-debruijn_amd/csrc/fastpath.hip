@@ -28,10 +28,12 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // internal minimizer order + bin hash
 // ------------------------------------------------------------------------------------------------
+struct LabelInv { uint32_t v[24]; uint32_t on; };       // colour index -> D1 label (sparse label alphabets)
 struct FastCfg {
     int k, p;
     int stranded;
     uint32_t nbins;
+    const uint8_t* lmap;        // D1 label -> dense colour index (sparse label alphabets), or null: the label is the index
 };
 
 // p-mer (p <= 16) at absolute base offset o: two funnel-shifted words, right-aligned
@@ -297,6 +299,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
           v_m = s.length[my]; v_st = s.start[my];
           if (s.exts) v_ex = s.exts[my];
           if (s.data) v_d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[my] : (s.data_width == 2 ? ((const uint16_t*)s.data)[my] : ((const uint32_t*)s.data)[my]);
+          if (c.lmap) v_d1 = c.lmap[v_d1];
       }
       const uint32_t nb_reads = (uint32_t)(s.n - rb < 64 ? s.n - rb : 64);
       for (uint32_t rj = 0; rj < nb_reads; rj++) {
@@ -487,6 +490,7 @@ __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, u
             v_m = s.length[my]; v_st = s.start[my];
             if (s.exts) v_ex = s.exts[my];
             if (s.data) v_d1 = s.data_width == 1 ? ((const uint8_t*)s.data)[my] : (s.data_width == 2 ? ((const uint16_t*)s.data)[my] : ((const uint32_t*)s.data)[my]);
+            if (c.lmap) v_d1 = c.lmap[v_d1];
         }
         uint32_t m = v_m;
         if (m > SCAN_LANE_MAX) { atomicOr(&flags[1], 1u); m = 0; }              // left to the wave-per-read kernel
@@ -1318,8 +1322,10 @@ __global__ void __launch_bounds__(CSR_THREADS) csr_partials_kernel(const uint32_
     if (threadIdx.x == 0) partial[blockIdx.x] = (uint64_t)s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 __global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const uint32_t* __restrict__ msk, uint32_t n, const uint64_t* __restrict__ partial_scanned,
-                                                                uint64_t* __restrict__ set_off, uint32_t* __restrict__ set_val) {
+                                                                uint64_t* __restrict__ set_off, uint32_t* __restrict__ set_val, LabelInv inv) {
     __shared__ uint32_t s_w[CSR_THREADS / 64];
+    __shared__ uint32_t s_inv[24];
+    if (threadIdx.x < 24) s_inv[threadIdx.x] = inv.on ? inv.v[threadIdx.x] : threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wbase = blockIdx.x * CSR_TILE + wave * (64 * CSR_ITEMS);
     uint32_t m[CSR_ITEMS], s = 0;
@@ -1342,7 +1348,7 @@ __global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const uint32_t* 
         if (e < n) {
             set_off[e] = o;
             uint32_t x = m[r];
-            while (x) { set_val[o++] = (uint32_t)__ffs((int)x) - 1u; x &= x - 1; }   // ascending = sort(); dedup()
+            while (x) { set_val[o++] = s_inv[(uint32_t)__ffs((int)x) - 1u]; x &= x - 1; }   // ascending = sort(); dedup() (the map keeps the labels' order)
         }
         run += __shfl(incl, 63);
     }
@@ -1387,6 +1393,8 @@ struct FastPlan {
     int k, p, nbw, rw;
     bool stranded, is_set, has_hi;
     uint32_t nbins;
+    LabelInv linv = {};
+    const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
 };
 
 static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
@@ -1421,9 +1429,27 @@ struct FastScan {
     uint32_t slab_cap = 0;
 };
 
-// labels must be < 24 for the LDS colour bitmask
-static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
+// which D1 labels (< 65536) occur: one bit each; bitmap[2048] != 0 when a label >= 65536 was seen
+__global__ void __launch_bounds__(256) label_presence_kernel(const void* data, uint32_t width, uint64_t n, uint32_t* __restrict__ bitmap) {
+    __shared__ uint32_t s_b[2049];
+    for (int i = threadIdx.x; i < 2049; i += 256) s_b[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = width == 1 ? ((const uint8_t*)data)[i] : (width == 2 ? ((const uint16_t*)data)[i] : ((const uint32_t*)data)[i]);
+        if (v < 65536u) { const uint32_t bit = 1u << (v & 31u); if (!(s_b[v >> 5] & bit)) atomicOr(&s_b[v >> 5], bit); }
+        else s_b[2048] = 1u;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2049; i += 256) if (s_b[i]) atomicOr(&bitmap[i], s_b[i]);
+}
+
+// The LDS colour bitmask holds 24 colours: labels < 24 are their own colour; a sparse alphabet of at most 24 distinct labels
+// (all < 65536) is mapped to colour indices in increasing label order and mapped back when the label sets are written.
+// lmap_buf receives the device table (it must outlive the scan).
+static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<uint8_t>* lmap_buf, bool* ok) {
     *ok = false;
+    pl->linv.on = 0; pl->lmap = nullptr;
     if (!s.data) return 0;
     DBuf<uint32_t> mx;
     ALLOC_OR_FAIL(c, mx, 1);
@@ -1432,7 +1458,39 @@ static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
     uint32_t h = 0;
     HIP_TRY(c, hipMemcpyAsync(&h, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *ok = h < 24;
+    if (h < 24) { *ok = true; return 0; }
+    if (h >= 65536u) return 0;
+    DBuf<uint32_t> bm;
+    ALLOC_OR_FAIL(c, bm, 2049);
+    HIP_TRY(c, hipMemsetAsync(bm.p, 0, 2049 * 4, c->stream));
+    label_presence_kernel<<<(uint32_t)std::min<uint64_t>(cdiv(s.n, 256), 1024), 256, 0, c->stream>>>(s.data, s.data_width, s.n, bm.p);
+    LAUNCH_CHECK(c, "label_presence");
+    std::vector<uint32_t> hb(2049);
+    HIP_TRY(c, hipMemcpyAsync(hb.data(), bm.p, 2049 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hb[2048]) return 0;
+    std::vector<uint8_t> map((size_t)h + 1, 0);
+    uint32_t nd = 0;
+    for (uint32_t v = 0; v <= h; v++) {
+        if (hb[v >> 5] & (1u << (v & 31))) {
+            if (nd == 24) return 0;                         // more than 24 distinct labels: the generic path
+            pl->linv.v[nd] = v;
+            map[v] = (uint8_t)nd++;
+        }
+    }
+    ALLOC_OR_FAIL(c, *lmap_buf, map.size());
+    HIP_TRY(c, hipMemcpyAsync(lmap_buf->p, map.data(), map.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));            // `map` leaves scope
+    pl->linv.on = 1; pl->lmap = lmap_buf->p;
+    *ok = true;
+    return 0;
+}
+// the sharded entry points keep the plain rule (every rank must use the same colours)
+static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
+    FastPlan tmp;
+    DBuf<uint8_t> unused;
+    DBG_TRY(fast_labels_prepare(c, s, &tmp, &unused, ok));
+    if (tmp.linv.on) *ok = false;
     return 0;
 }
 
@@ -1441,7 +1499,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     st->pl = pl; st->n_kmers = n_kmers;
     const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
     const uint32_t nbins = pl.nbins * NCLS;                      // sub-bins (bin, length class)
-    FastCfg cfg{k, p, pl.stranded, pl.nbins};
+    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap};
     SeqDev sd = s;
     if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
     DBuf<uint32_t> sflags;
@@ -1756,7 +1814,7 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         ALLOC_OR_FAIL(c, o_set_val, std::max<uint64_t>(n_setval, 1));
         c->t_begin("set_csr", n_out);
-        csr_apply_kernel<<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part_sc.p, o_set_off.p, o_set_val.p);
+        csr_apply_kernel<<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part_sc.p, o_set_off.p, o_set_val.p, pl.linv);
         c->t_end();
         LAUNCH_CHECK(c, "csr_apply");
     }
@@ -1845,7 +1903,8 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     if (n_kmers == 0) return 0;
     FastPlan pl;
     if (!fast_make_plan(c, (int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
-    if (is_set) { bool ok; DBG_TRY(fast_labels_ok(c, s, &ok)); if (!ok) return 0; }
+    DBuf<uint8_t> lmap_buf;
+    if (is_set) { bool ok; DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok)); if (!ok) return 0; }
     FastScan st;
     DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
     const uint32_t nb = pl.nbins * NCLS;

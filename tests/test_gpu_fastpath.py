@@ -246,3 +246,17 @@ def test_fast_sort_group_finisher_regimes(ctx, k, kind, shape, capfd):
     gave_up = [int(l.split("form ")[1][0]) for l in err.splitlines() if l.startswith("[sort] finisher form")]
     if 4096 <= len(got) <= 8192:                              # the size range in which a wave sorts each group
         assert gave_up in {"uniform": ([],), "groups_200": ([0],), "groups_1000": ([0], [0, 1])}[shape], err
+
+
+@pytest.mark.parametrize("k,width,labels", [(47, 1, [31, 40, 77, 200, 255]), (31, 2, list(range(1000, 60000, 2600))), (63, 4, [24, 25, 26, 65535]),
+                                            (47, 1, list(range(100, 124)))])
+def test_fast_sparse_label_alphabet(ctx, k, width, labels):
+    """CountFilterSet labels >= 24: the LDS colour mask has 24 bits, so an alphabet of at most 24 distinct labels (< 65536) is
+    mapped to colour indices in label order and mapped back when the label sets are written (filter.rs:85-100 sorts and
+    de-duplicates the labels, so order is all that has to survive)."""
+    assert len(labels) <= 24
+    rng = np.random.default_rng(k + width)
+    seqs = random_reads(rng, 600, 3000, 150, False)
+    data = np.asarray(labels)[rng.integers(0, len(labels), size=len(seqs))]
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=width)
+    run_fast(ctx, ss, k, O.COUNT_FILTER_SET, 2, False, data_width=width)
