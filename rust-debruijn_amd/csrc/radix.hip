@@ -202,6 +202,15 @@ constexpr int SS_THREADS = 512;
 constexpr int SS_ITEMS = 6;
 constexpr int SS_CAP = SS_THREADS * SS_ITEMS;       // 3072 records per workgroup
 constexpr int SS_WINDOW = 2560;                      // C: a prefix group must be <= CAP - C = 512 records
+// Geometry of the wave-per-group finishers: a group holds at most 128 records, so the window only needs that much overlap with the
+// next one (the walking finisher's 512 would re-read a fifth of the table), and a smaller staging area lets more workgroups
+// share a CU -- the kernel is a streaming pass with a sort in the middle, and what it lacks is loads in flight.
+#ifndef DBG_SG_ITEMS
+#define DBG_SG_ITEMS 3
+#endif
+constexpr int SG_ITEMS = DBG_SG_ITEMS;
+constexpr int SG_CAP = SS_THREADS * SG_ITEMS;
+constexpr int SG_WINDOW = SG_CAP - 128;
 
 __device__ __forceinline__ uint32_t key_prefix(uint64_t hi, uint64_t lo, int key_bits, int top_bits) {
     int sh = key_bits - top_bits;                    // drop the low bits
@@ -327,20 +336,20 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_groups_kernel(RecArrays 
                                                                       uint8_t* __restrict__ o_exts, uint16_t* __restrict__ o_count,
                                                                       uint32_t* __restrict__ o_setn, uint32_t* __restrict__ o_msk,
                                                                       uint32_t* __restrict__ flags) {
-    __shared__ uint64_t s_lo[SS_CAP];
-    __shared__ uint64_t s_hi[HAS_HI ? SS_CAP : 1];
-    __shared__ uint32_t s_pay[SS_CAP];
-    __shared__ uint32_t s_pre[SS_CAP + 1];              // prefix of every record; afterwards: start of group g
+    __shared__ uint64_t s_lo[SG_CAP];
+    __shared__ uint64_t s_hi[HAS_HI ? SG_CAP : 1];
+    __shared__ uint32_t s_pay[SG_CAP];
+    __shared__ uint32_t s_pre[SG_CAP + 1];              // prefix of every record; afterwards: start of group g
     __shared__ uint32_t s_cnt[SS_THREADS / 64][1 << SG3_MAXD];
     __shared__ uint32_t s_start, s_end, s_ng;
     __shared__ uint32_t s_wsum[SS_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t base = blockIdx.x * SS_WINDOW;
-    const uint32_t avail = n - base < (uint32_t)SS_CAP ? n - base : (uint32_t)SS_CAP;
+    const uint32_t base = blockIdx.x * SG_WINDOW;
+    const uint32_t avail = n - base < (uint32_t)SG_CAP ? n - base : (uint32_t)SG_CAP;
     if (tid == 0) { s_start = 0xffffffffu; s_end = 0xffffffffu; }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SS_ITEMS; r++) {
+    for (int r = 0; r < SG_ITEMS; r++) {
         const uint32_t i = tid + r * SS_THREADS;
         if (i < avail) {
             const uint32_t g = base + i;
@@ -354,14 +363,14 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_groups_kernel(RecArrays 
     __syncthreads();
     uint32_t bflags = 0;
 #pragma unroll
-    for (int r = 0; r < SS_ITEMS; r++) {
-        const uint32_t i = tid * SS_ITEMS + r;
+    for (int r = 0; r < SG_ITEMS; r++) {
+        const uint32_t i = tid * SG_ITEMS + r;
         if (i < avail) {
             const uint32_t pc = s_pre[i];
             const bool boundary = i == 0 ? (base == 0 || pc != prev0) : pc != s_pre[i - 1];
             if (boundary) {
                 bflags |= 1u << r;
-                if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i); else atomicMin(&s_end, i);
+                if (i < (uint32_t)SG_WINDOW) atomicMin(&s_start, i); else atomicMin(&s_end, i);
             }
         }
     }
@@ -370,13 +379,13 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_groups_kernel(RecArrays 
     if (start == 0xffffffffu) return;
     uint32_t end = s_end;
     if (end == 0xffffffffu) {
-        if (avail == (uint32_t)SS_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
+        if (avail == (uint32_t)SG_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
         end = avail;
     }
     {
         uint32_t mine = 0;
 #pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) mine++; }
+        for (int r = 0; r < SG_ITEMS; r++) { const uint32_t i = tid * SG_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) mine++; }
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
@@ -387,7 +396,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_groups_kernel(RecArrays 
         for (int w = 0; w < SS_THREADS / 64; w++) { const uint32_t x = s_wsum[w]; off += (uint32_t)w < wave ? x : 0u; tot += x; }
         uint32_t g = off + incl - mine;
 #pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) s_pre[g++] = i; }
+        for (int r = 0; r < SG_ITEMS; r++) { const uint32_t i = tid * SG_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) s_pre[g++] = i; }
         if (tid == 0) { s_ng = tot; s_pre[tot] = end; }
     }
     __syncthreads();
@@ -434,7 +443,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort_groups_kernel(RecArrays 
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SS_ITEMS; r++) {
+    for (int r = 0; r < SG_ITEMS; r++) {
         const uint32_t i = tid + r * SS_THREADS;
         if (i >= start && i < end) {
             const uint32_t g = base + i;
@@ -512,7 +521,7 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
             HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
             ctx->t_begin("span_sort", n);
             if (form == 0) {
-#define GO(HH, SS) span_sort_groups_kernel<HH, SS><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, \
+#define GO(HH, SS) span_sort_groups_kernel<HH, SS><<<cdiv(n, SG_WINDOW), SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, \
                 o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p)
                 if (has_hi) { if (is_set) GO(true, true); else GO(true, false); }
                 else        { if (is_set) GO(false, true); else GO(false, false); }
@@ -556,7 +565,10 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
 namespace {
 constexpr int R16_THREADS = 512;
 constexpr int R16_WAVES = R16_THREADS / DBG_WAVE;
-constexpr int R16_ITEMS = 8;
+#ifndef DBG_R16_ITEMS
+#define DBG_R16_ITEMS 8
+#endif
+constexpr int R16_ITEMS = DBG_R16_ITEMS;
 constexpr int R16_TILE = R16_THREADS * R16_ITEMS;       // 4096 records = 64 KB of staging: ~16 records (256 B) per digit
 
 __device__ __forceinline__ uint32_t digit16(const uint4& r, int shift) {        // 8 key bits from bit `shift` (< 96) on; a digit may straddle two words
@@ -764,18 +776,18 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const ui
                                                                         uint8_t* __restrict__ o_exts, uint16_t* __restrict__ o_count,
                                                                         uint32_t* __restrict__ o_setn, uint32_t* __restrict__ o_msk,
                                                                         uint32_t* __restrict__ flags) {
-    __shared__ uint4 s_rec[SS_CAP];                     // 48 KB
-    __shared__ uint32_t s_pre[SS_CAP + 1];              // prefix of every record; afterwards: start of group g
+    __shared__ uint4 s_rec[SG_CAP];                     // 48 KB
+    __shared__ uint32_t s_pre[SG_CAP + 1];              // prefix of every record; afterwards: start of group g
     __shared__ uint32_t s_cnt[SS_THREADS / 64][1 << SG_MAXD];   // per wave: members per digit value, then exclusive prefix
     __shared__ uint32_t s_start, s_end, s_ng;
     __shared__ uint32_t s_wsum[SS_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t base = blockIdx.x * SS_WINDOW;
-    const uint32_t avail = n - base < (uint32_t)SS_CAP ? n - base : (uint32_t)SS_CAP;
+    const uint32_t base = blockIdx.x * SG_WINDOW;
+    const uint32_t avail = n - base < (uint32_t)SG_CAP ? n - base : (uint32_t)SG_CAP;
     if (tid == 0) { s_start = 0xffffffffu; s_end = 0xffffffffu; }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SS_ITEMS; r++) {
+    for (int r = 0; r < SG_ITEMS; r++) {
         const uint32_t i = tid + r * SS_THREADS;                   // coalesced load order
         if (i < avail) { const uint4 q = in[base + i]; s_rec[i] = q; s_pre[i] = prefix16(q, key_bits, top_bits); }
     }
@@ -785,14 +797,14 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const ui
     // thread t looks at records t*ITEMS .. t*ITEMS + ITEMS - 1 (consecutive: the group enumeration is a scan in record order)
     uint32_t bflags = 0;
 #pragma unroll
-    for (int r = 0; r < SS_ITEMS; r++) {
-        const uint32_t i = tid * SS_ITEMS + r;
+    for (int r = 0; r < SG_ITEMS; r++) {
+        const uint32_t i = tid * SG_ITEMS + r;
         if (i < avail) {
             const uint32_t pc = s_pre[i];
             const bool boundary = i == 0 ? (base == 0 || pc != prev0) : pc != s_pre[i - 1];
             if (boundary) {
                 bflags |= 1u << r;
-                if (i < (uint32_t)SS_WINDOW) atomicMin(&s_start, i); else atomicMin(&s_end, i);
+                if (i < (uint32_t)SG_WINDOW) atomicMin(&s_start, i); else atomicMin(&s_end, i);
             }
         }
     }
@@ -801,13 +813,13 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const ui
     if (start == 0xffffffffu) return;                           // no group starts here
     uint32_t end = s_end;
     if (end == 0xffffffffu) {
-        if (avail == (uint32_t)SS_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
+        if (avail == (uint32_t)SG_CAP && base + avail < n) { if (tid == 0) atomicOr(flags, 1u); return; }
         end = avail;
     }
     {   // enumerate the groups that start in [start, end): s_pre[g] <- first record of group g, s_pre[ng] <- end
         uint32_t mine = 0;
 #pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) mine++; }
+        for (int r = 0; r < SG_ITEMS; r++) { const uint32_t i = tid * SG_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) mine++; }
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
@@ -818,7 +830,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const ui
         for (int w = 0; w < SS_THREADS / 64; w++) { const uint32_t x = s_wsum[w]; off += (uint32_t)w < wave ? x : 0u; tot += x; }
         uint32_t g = off + incl - mine;
 #pragma unroll
-        for (int r = 0; r < SS_ITEMS; r++) { const uint32_t i = tid * SS_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) s_pre[g++] = i; }
+        for (int r = 0; r < SG_ITEMS; r++) { const uint32_t i = tid * SG_ITEMS + r; if (((bflags >> r) & 1u) && i >= start && i < end) s_pre[g++] = i; }
         if (tid == 0) { s_ng = tot; s_pre[tot] = end; }
     }
     __syncthreads();
@@ -864,7 +876,7 @@ __global__ void __launch_bounds__(SS_THREADS) span_sort16_groups_kernel(const ui
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < SS_ITEMS; r++) {
+    for (int r = 0; r < SG_ITEMS; r++) {
         const uint32_t i = tid + r * SS_THREADS;
         if (i >= start && i < end) {
             const uint32_t g = base + i;
@@ -946,8 +958,8 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
             HIP_TRY(ctx, hipMemsetAsync(flags.p, 0, 4, ctx->stream));
             ctx->t_begin("span_sort", n);
             if (form == 0) {
-                if (is_set) span_sort16_groups_kernel<true><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
-                else span_sort16_groups_kernel<false><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+                if (is_set) span_sort16_groups_kernel<true><<<cdiv(n, SG_WINDOW), SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
+                else span_sort16_groups_kernel<false><<<cdiv(n, SG_WINDOW), SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, dbits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
             } else {
                 if (is_set) span_sort16_kernel<true><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
                 else span_sort16_kernel<false><<<nwg, SS_THREADS, 0, ctx->stream>>>(src, n, key_bits, top_bits, o_hi, o_lo, o_exts, o_count, o_setn, o_msk, flags.p);
