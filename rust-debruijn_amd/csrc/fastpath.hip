@@ -1341,9 +1341,7 @@ __global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const uint32_t* 
     for (int r = 0; r < CSR_ITEMS; r++) {
         const uint32_t e = wbase + r * 64 + lane;
         const uint32_t c = __popc(m[r]);
-        uint32_t incl = c;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        const uint32_t incl = wave_inclusive_scan_u32(c);            // DPP: no traffic through the LDS crossbar
         uint64_t o = run + incl - c;
         if (e < n) {
             set_off[e] = o;
