@@ -135,7 +135,7 @@ constexpr uint32_t NCLS = 1;                    // length classes per bin: recor
 // DIRECT: a record goes straight to slot atomicAdd(cursor[bin]) of its bin's fixed-capacity slab (slab_cap records per
 // bin); only the records of bins that outgrow their slab take the read-order temporary buffer and the scatter kernel.
 constexpr uint32_t PLC = 256;                   // ring slots per wave (wave-per-read kernel: 4 words per piece)
-constexpr uint32_t PLC_PACKED = 256;            // lane-per-read kernel: 2 words per piece {start | end << 11 | lane << 22, hash}
+constexpr uint32_t PLC_PACKED = 128;            // lane-per-read kernel: 2 words per piece {start | end << 11 | lane << 22, hash}
 template <int NBW, bool DIRECT, bool PACKED = false>
 struct PieceEmitter {
     static constexpr int RW = NBW;
@@ -563,10 +563,13 @@ __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, u
                         uint32_t* q = SV + (j + u) * 64;
                         const uint32_t s1 = q[64], s2 = q[128], s3 = q[192], s4 = q[256];
                         uint32_t h, out;
+                        // (the ring holds 63 + 64 pieces: it is emptied after every window, which lets 16 waves instead of 14 share a CU's LDS)
                         roll(); h = elem(); P = h < P ? h : P; out = s1 < P ? s1 : P; q[0] = h;   window(e + u + 1 - W, out);
+                        while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);
                         roll(); h = elem(); P = h < P ? h : P; out = s2 < P ? s2 : P; q[64] = h;  window(e + u + 2 - W, out);
-                        while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);      // the ring holds 64 + 2 x 64 pieces
+                        while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);
                         roll(); h = elem(); P = h < P ? h : P; out = s3 < P ? s3 : P; q[128] = h; window(e + u + 3 - W, out);
+                        while (E.pl_n >= 64) E.flush(64u, v_m, v_st, v_ex, v_d1);
                         roll(); h = elem(); P = h < P ? h : P; out = s4 < P ? s4 : P; q[192] = h; window(e + u + 4 - W, out);
                         u += 4;
                     } else {
