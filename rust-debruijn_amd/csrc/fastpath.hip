@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, u
                                                            uint32_t* __restrict__ flags, uint64_t* __restrict__ slab,
                                                            uint32_t slab_cap, uint32_t* __restrict__ cursor) {
     extern __shared__ uint32_t s_dyn[];
-    // one wave per workgroup: the waves share nothing, and 11 KB granules pack a CU's LDS (14 waves) better than 43 KB ones (12)
+    // one wave per workgroup: the waves share nothing, and 9.5 KB granules pack a CU's LDS (16 waves) better than 38 KB ones (12)
     const uint32_t lane = threadIdx.x;
     const int k = c.k, p = c.p;
     const uint32_t W = (uint32_t)(k - p + 1);
