@@ -199,9 +199,18 @@ int radix_sort_records(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int SS_THREADS = 512;
-constexpr int SS_ITEMS = 6;
-constexpr int SS_CAP = SS_THREADS * SS_ITEMS;       // 3072 records per workgroup
-constexpr int SS_WINDOW = 2560;                      // C: a prefix group must be <= CAP - C = 512 records
+// Geometry of the walking finishers: 1536 records staged per workgroup, 256 of them shared with the next window (a group of equal
+// prefix longer than that sends the call to the plain LSD sort).  Measured at 2.5e8 reads: 3072 / 512 -> 21.5 ms, 1536 / 512 -> 15.3,
+// 1536 / 256 -> 11.3: like the wave-per-group finisher, the pass wants more workgroups per CU (loads in flight), not bigger tiles.
+#ifndef DBG_SS_ITEMS
+#define DBG_SS_ITEMS 3
+#endif
+constexpr int SS_ITEMS = DBG_SS_ITEMS;
+constexpr int SS_CAP = SS_THREADS * SS_ITEMS;       // records per workgroup
+#ifndef DBG_SS_OVERLAP
+#define DBG_SS_OVERLAP 256
+#endif
+constexpr int SS_WINDOW = SS_CAP - DBG_SS_OVERLAP;   // C: a prefix group must be <= CAP - C records
 // Geometry of the wave-per-group finishers: a group holds at most 128 records, so the window only needs that much overlap with the
 // next one (the walking finisher's 512 would re-read a fifth of the table), and a smaller staging area lets more workgroups
 // share a CU -- the kernel is a streaming pass with a sort in the middle, and what it lacks is loads in flight.
