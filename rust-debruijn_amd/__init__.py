@@ -231,14 +231,15 @@ class Context:
             raise DbgError(self.lib.dbg_last_error(None).decode())
         self.h = h
         self.device = device
-        self._opts = {}
+        import os
+        # the knobs as the library saw them in dbg_ctx_create (it never reads the environment again): what set_option restores to
+        self._opts = {n: v for n, v in os.environ.items() if n.startswith("DBG_")}
 
     def set_option(self, name, value):
         """dbg_ctx_set_option: one diagnostic knob of this ctx (the library reads the environment only in dbg_ctx_create).
         value None = unset.  Returns the value the knob had (as far as this wrapper knows: the environment at creation or
         an earlier set_option)."""
-        import os
-        old = self._opts.get(name, os.environ.get(name))
+        old = self._opts.get(name)
         self.check(self.lib.dbg_ctx_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
         self._opts[name] = value
         return old
@@ -495,7 +496,11 @@ def compress_table_dev(stranded, spec, table_dev, k, ctx=None):
     g = _capi.Graph()
     cl = _capi.LabelClasses()
     ctx.check(ctx.lib.dbg_compress_table_dev(ctx.h, k, int(bool(stranded)), spec.kind, C.byref(table_dev), C.byref(g), C.byref(cl)))
-    out = _graph_from_c(ctx, g, k)
+    try:
+        out = _graph_from_c(ctx, g, k)
+    except BaseException:
+        ctx.lib.dbg_free_label_classes(C.byref(cl))
+        raise
     out.classes = _classes_from_c(cl) if table_dev.set_off else None
     return out
 

@@ -40,6 +40,7 @@ def _check_bin_count_budget(remarks):
     the compiler's resource report."""
     import re
     name = None
+    matched = set()
     for line in remarks.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
@@ -52,6 +53,29 @@ def _check_bin_count_budget(remarks):
             m = re.search(r"Occupancy \[waves/SIMD\]: (\d+)", line)
             if m and int(m.group(1)) < 4:
                 raise RuntimeError("bin_count variant %s reaches %s waves per SIMD, not the 4 that two workgroups per CU need" % (name, m.group(1)))
+            if m:
+                matched.add(name)
+    if not matched:
+        raise RuntimeError("the resource check saw no bin_count_kernel<..,512,2048> variant in hipcc's remarks: the remark format or the "
+                           "kernel's template signature changed -- update _check_bin_count_budget")
+
+
+def _without_remarks(stderr):
+    """hipcc's stderr minus the -Rpass-analysis resource report (remark lines and their source-line echo + caret), so that
+    warnings for fastpath.hip are still shown"""
+    out, skip = [], 0
+    for line in stderr.splitlines(True):
+        if "remark:" in line:
+            skip = 2
+            continue
+        if skip and (line.lstrip().startswith("|") or "^" in line or "__global__" in line or line[:1] in " \t" or line.strip().split(" ")[0].isdigit()):
+            skip -= 1
+            continue
+        skip = 0
+        if "remarks generated" in line or "remark generated" in line:
+            continue
+        out.append(line)
+    return "".join(out)
 
 
 def _compile(src):
@@ -68,8 +92,9 @@ def _compile(src):
             except RuntimeError:
                 os.remove(obj)
                 raise
-        elif r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        rest = _without_remarks(r.stderr) if extra else r.stderr
+        if rest.strip():
+            sys.stderr.write(rest)
     return obj
 
 

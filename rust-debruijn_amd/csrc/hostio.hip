@@ -9,10 +9,17 @@
 #include "dbg_internal.hpp"
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
+// every pinned result block -> the ctx whose pool it belongs to, so that a table released without its ctx (dbg_free_table(NULL, ..))
+// still finds its way back, and a ctx that is destroyed while tables are alive can disown them instead of freeing them
+std::mutex g_pin_mu;
+std::unordered_map<void*, dbg_ctx*> g_pin_owner;
+
 constexpr size_t STAGE_CHUNK = 16u << 20;       // bytes per staging buffer
 constexpr size_t STAGE_MIN = 8u << 20;          // smaller transfers take the plain copy
 
@@ -76,6 +83,9 @@ int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs) {
     std::vector<Chunk> chunks;
     for (auto& j : jobs)
         for (size_t o = 0; o < j.bytes; o += STAGE_CHUNK) chunks.push_back({(char*)j.dst + o, (const char*)j.src + o, std::min(STAGE_CHUNK, j.bytes - o)});
+    // the destinations are pool blocks that c->stream may still be using under their previous owner (the pool hands blocks out
+    // assuming same-stream ordering): nothing is written from the lanes' streams before c->stream has drained
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::atomic<size_t> next{0};
     std::atomic<int> err{0};
     const int device = c->device;
@@ -125,16 +135,19 @@ void* ctx_halloc(dbg_ctx* c, size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
+        { std::lock_guard<std::mutex> g(g_pin_mu); for (auto& kv : c->hfree_blocks) g_pin_owner.erase(kv.second); }
         for (auto& kv : c->hfree_blocks) (void)hipHostFree(kv.second);        // give the kept blocks back and retry once
         c->hfree_blocks.clear();
         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return dbg_host_alloc(bytes); }
     }
     c->hlive_blocks[p] = bytes;
+    { std::lock_guard<std::mutex> g(g_pin_mu); g_pin_owner[p] = c; }
     return p;
 }
 
 void ctx_hfree(dbg_ctx* c, void* p) {
     if (!p) return;
+    if (!c) { std::lock_guard<std::mutex> g(g_pin_mu); auto o = g_pin_owner.find(p); if (o != g_pin_owner.end()) c = o->second; }
     if (c) {
         auto it = c->hlive_blocks.find(p);
         if (it != c->hlive_blocks.end()) {
@@ -149,8 +162,11 @@ void ctx_hfree(dbg_ctx* c, void* p) {
     free(p);
 }
 
+// ctx teardown: pooled blocks are freed; blocks still in a caller's hands are disowned, not freed -- a host table may outlive its
+// ctx (as plain malloc'ed tables always could) and is then released by dbg_free_table(NULL, ..) through the pointer-attribute route
 void ctx_hrelease_all(dbg_ctx* c) {
-    for (auto& kv : c->hfree_blocks) (void)hipHostFree(kv.second);
-    for (auto& kv : c->hlive_blocks) (void)hipHostFree(kv.first);
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    for (auto& kv : c->hfree_blocks) { g_pin_owner.erase(kv.second); (void)hipHostFree(kv.second); }
+    for (auto& kv : c->hlive_blocks) g_pin_owner.erase(kv.first);
     c->hfree_blocks.clear(); c->hlive_blocks.clear();
 }

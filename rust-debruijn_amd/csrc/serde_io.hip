@@ -41,9 +41,15 @@ struct Js {
         ws();
         if (i >= n || p[i] < '0' || p[i] > '9') { bad = true; return 0; }
         uint64_t v = 0;
-        while (i < n && p[i] >= '0' && p[i] <= '9') v = v * 10 + (uint64_t)(p[i++] - '0');
+        while (i < n && p[i] >= '0' && p[i] <= '9') {           // serde_json rejects integers beyond the target type: so does this
+            const uint64_t d = (uint64_t)(p[i++] - '0');
+            if (v > (UINT64_MAX - d) / 10) { bad = true; return 0; }
+            v = v * 10 + d;
+        }
+        if (i < n && (p[i] == '.' || p[i] == 'e' || p[i] == 'E')) { bad = true; return 0; }     // a float is not a u64 for serde either
         return v;
     }
+    uint64_t num_max(uint64_t mx) { const uint64_t v = num(); if (v > mx) { bad = true; return 0; } return v; }
     bool lit(const char* s) { ws(); const size_t l = strlen(s); if (i + l <= n && !memcmp(p + i, s, l)) { i += l; return true; } return false; }
     template <class F> void array(F f) {
         if (!eat('[')) return;
@@ -116,9 +122,20 @@ extern "C" int dbg_graph_serialize(dbg_ctx* c, const dbg_graph* g, int format, u
     return 0;
 }
 
+static int graph_deserialize_impl(dbg_ctx* c, const uint8_t* bytes, uint64_t len, int format, uint32_t data_width, dbg_graph* out);
+
 extern "C" int dbg_graph_deserialize(dbg_ctx* c, const uint8_t* bytes, uint64_t len, int format, uint32_t data_width, dbg_graph* out) {
     if (!bytes || !out) return sfail(c, 10, "null argument");
     memset(out, 0, sizeof(*out));
+    try {                                                           // untrusted input: nothing may unwind through the C ABI
+        return graph_deserialize_impl(c, bytes, len, format, data_width, out);
+    } catch (const std::exception& e) {
+        dbg_free_graph(c, out); memset(out, 0, sizeof(*out));
+        return sfail(c, 101, std::string("out of host memory while reading a BaseGraph: ") + e.what());
+    }
+}
+
+static int graph_deserialize_impl(dbg_ctx* c, const uint8_t* bytes, uint64_t len, int format, uint32_t data_width, dbg_graph* out) {
     std::vector<uint64_t> words, start; std::vector<uint32_t> length, data; std::vector<uint8_t> exts;
     uint64_t n_bases = 0; bool stranded = false;
     if (format == DBG_SERDE_BINCODE) {
@@ -130,7 +147,7 @@ extern "C" int dbg_graph_deserialize(dbg_ctx* c, const uint8_t* bytes, uint64_t 
         m = vec_len(8); start.resize(m); for (auto& x : start) x = r.le(8);
         m = vec_len(4); length.resize(m); for (auto& x : length) x = (uint32_t)r.le(4);
         m = vec_len(1); exts.resize(m); for (auto& x : exts) x = (uint8_t)r.le(1);
-        m = vec_len((int)data_width); if (!data_width && m > (1ull << 40)) r.bad = true;
+        m = vec_len((int)data_width); if (!data_width && m != start.size()) r.bad = true;       // Vec<()> has no bytes to bound its length: it must be one unit per node
         if (!r.bad) { data.resize(m); for (auto& x : data) x = data_width ? (uint32_t)r.le((int)data_width) : 0u; }
         stranded = r.le(1) != 0;
         if (r.bad || r.i != len) return sfail(c, 174, "malformed bincode BaseGraph");
@@ -140,11 +157,11 @@ extern "C" int dbg_graph_deserialize(dbg_ctx* c, const uint8_t* bytes, uint64_t 
         j.array([&] { words.push_back(j.num()); });
         j.eat(','); j.key("len"); n_bases = j.num(); j.eat('}');
         j.eat(','); j.key("start"); j.array([&] { start.push_back(j.num()); });
-        j.eat(','); j.key("length"); j.array([&] { length.push_back((uint32_t)j.num()); });
+        j.eat(','); j.key("length"); j.array([&] { length.push_back((uint32_t)j.num_max(UINT32_MAX)); });
         j.eat('}'); j.eat(','); j.key("exts");
-        j.array([&] { j.eat('{'); j.key("val"); exts.push_back((uint8_t)j.num()); j.eat('}'); });
+        j.array([&] { j.eat('{'); j.key("val"); exts.push_back((uint8_t)j.num_max(255)); j.eat('}'); });
         j.eat(','); j.key("data");
-        j.array([&] { if (j.lit("null")) data.push_back(0u); else data.push_back((uint32_t)j.num()); });
+        j.array([&] { if (j.lit("null")) data.push_back(0u); else data.push_back((uint32_t)j.num_max(data_width == 1 ? 255u : data_width == 2 ? 65535u : UINT32_MAX)); });
         j.eat(','); j.key("stranded");
         if (j.lit("true")) stranded = true; else if (!j.lit("false")) j.bad = true;
         j.eat(','); j.key("phantom"); if (!j.lit("null")) j.bad = true;
@@ -153,7 +170,7 @@ extern "C" int dbg_graph_deserialize(dbg_ctx* c, const uint8_t* bytes, uint64_t 
     } else return sfail(c, 173, "unknown serde format");
     const uint64_t n = start.size();
     if (length.size() != n || exts.size() != n || data.size() != n || words.size() != (n_bases + 31) / 32) return sfail(c, 176, "inconsistent BaseGraph lengths");
-    for (uint64_t i = 0; i < n; i++) if (start[i] + length[i] > n_bases) return sfail(c, 177, "node runs past the sequence");
+    for (uint64_t i = 0; i < n; i++) if (start[i] > n_bases || length[i] > n_bases - start[i]) return sfail(c, 177, "node runs past the sequence");
     out->n_nodes = n; out->n_seq_words = words.size(); out->seq_len_bases = n_bases; out->stranded = stranded ? 1 : 0;
     out->seq_words = (uint64_t*)malloc((words.size() + 2) * 8);     // two words of tail padding, like every graph this library returns
     out->start = (uint64_t*)malloc(std::max<uint64_t>(n, 1) * 8);

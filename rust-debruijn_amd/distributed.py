@@ -361,9 +361,15 @@ def second_stage(engine, graphs, stranded, spec):
     to one global numbering.  -> the final graph (classes attached when the data are label-list classes)."""
     glob = None
     if graphs and graphs[0].classes is not None:
+        from . import BaseGraph
         glob, remaps = unify_classes([g.classes for g in graphs])
+        renumbered = []                                # the callers' graphs keep their rank-local ids and class tables
         for g, m in zip(graphs, remaps):
-            g.data = m[np.asarray(g.data, dtype=np.int64)] if len(g.data) else np.zeros(0, np.uint32)
+            h = BaseGraph(g.k, g.sequences, g.exts, m[np.asarray(g.data, dtype=np.int64)] if len(g.data) else np.zeros(0, np.uint32),
+                          g.stranded)
+            h.classes = glob
+            renumbered.append(h)
+        graphs = renumbered
     out = engine.compress_graph(stranded, spec, engine.combine(graphs))
     out.classes = glob
     return out

@@ -140,3 +140,34 @@ def test_sharded_compress_gloo_world2(tmp_path, kind):
     if kind == 1:
         assert got["classes"] == glob and len(glob) > 1
     assert len(got["start"]) < sum(len(p["local"]["start"]) for p in parts)     # the second stage joined unitigs across shards
+
+
+def test_second_stage_leaves_the_shard_graphs_alone():
+    """world size 1 hands `local` itself to second_stage and returns it: data and classes of the shard graph must still
+    belong together afterwards (rank-local ids into the rank-local table), whatever numbering the second stage uses."""
+    import importlib
+    import oracle_lib as O
+    from oracle_engine import OracleEngine
+    O.build()
+    dbg = importlib.import_module("rust-debruijn_amd")
+    D = importlib.import_module("rust-debruijn_amd.distributed")
+    hs = dbg.synth_reads_host(n_reads=N_READS, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005, stranded=False, n_colours=3)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
+    eng = OracleEngine()
+    tab, _, _, _ = D.sharded_filter_kmers(eng, ss, 51, False, 1, 2)
+    ref = eng.compress_table(tab, 51, False, dbg.ScmapCompress())
+    # a table whose rank-local numbering is NOT the sorted-tuple numbering, as the HIP engine's (ordered by mask) is not
+    perm = np.arange(len(ref.classes))[::-1].copy()
+    shuffled = [ref.classes[i] for i in np.argsort(perm)]
+    before = [ref.classes[int(c)] for c in ref.data]
+
+    class Eng(OracleEngine):
+        def compress_table(self, tab, k, stranded, spec):
+            g = OracleEngine.compress_table(self, tab, k, stranded, spec)
+            g.data = perm[np.asarray(g.data, dtype=np.int64)].astype(np.uint32)
+            g.classes = shuffled
+            return g
+    final, local = D.sharded_compress(Eng(), tab, 51, False, dbg.ScmapCompress())
+    assert local.classes == shuffled
+    assert [local.classes[int(c)] for c in local.data] == before
+    assert final.classes == sorted(set(before)) and len(final) <= len(local)

@@ -68,3 +68,31 @@ def test_malformed_input_is_an_error():
             dbg.graph_deserialize(bad, 3, dbg.SERDE_JSON)
     with pytest.raises(dbg.DbgError):                                  # 65535 does not fit a u8 data column
         dbg.graph_serialize(g, dbg.SERDE_BINCODE, data_width=1)
+
+
+def test_hostile_input_is_rejected_not_trusted():
+    """Cases a reviewer fed to the reader: u64 wrap in the node bounds check, integers beyond the field's
+    type in JSON (serde_json rejects them), and a Vec<()> length with no bytes behind it."""
+    # bincode: start = 2^64 - 2, length = 3 wraps to 1 <= n_bases
+    blob = struct.pack("<Q1Q", 1, 0) + struct.pack("<Q", 8)
+    blob += struct.pack("<Q1Q", 1, (1 << 64) - 2) + struct.pack("<Q1I", 1, 3)
+    blob += struct.pack("<Q1B", 1, 0) + struct.pack("<Q1I", 1, 0) + b"\x00"
+    with pytest.raises(dbg.DbgError):
+        dbg.graph_deserialize(blob, 3, dbg.SERDE_BINCODE, data_width=4)
+    g = small_graph()
+    t = dbg.graph_serialize(g, dbg.SERDE_JSON)
+    for bad in (t.replace(b'"length":[6,', b'"length":[4294967302,'),          # > u32
+                t.replace(b'{"val":128}', b'{"val":256}'),                     # > u8
+                t.replace(b'"data":[7,', b'"data":[4294967303,'),              # > u32
+                t.replace(b'"len":49', b'"len":99999999999999999999999'),      # > u64
+                t.replace(b'"len":49', b'"len":49.0')):
+        assert bad != t
+        with pytest.raises(dbg.DbgError):
+            dbg.graph_deserialize(bad, 3, dbg.SERDE_JSON)
+    with pytest.raises(dbg.DbgError):                                          # u16 data column: 70000 does not fit
+        dbg.graph_deserialize(t.replace(b'"data":[7,', b'"data":[70000,'), 3, dbg.SERDE_JSON, data_width=2)
+    # bincode Vec<()>: a length of 2^39 units with nothing behind it must not be allocated
+    unit = dbg.graph_serialize(g, dbg.SERDE_BINCODE, data_width=0)
+    assert unit[-9:-1] == struct.pack("<Q", 3)
+    with pytest.raises(dbg.DbgError):
+        dbg.graph_deserialize(unit[:-9] + struct.pack("<Q", 1 << 39) + unit[-1:], 3, dbg.SERDE_BINCODE, data_width=0)
