@@ -54,6 +54,11 @@ int         dbg_ctx_set_scratch_budget(dbg_ctx* ctx, uint64_t bytes);
  * in dbg_ctx_create, into the ctx; this call changes one knob of one ctx afterwards (value NULL = unset).  Knobs select
  * among device routes that all produce the same result; unknown names are rejected. */
 int         dbg_ctx_set_option(dbg_ctx* ctx, const char* name, const char* value);
+/* The ctx keeps the device scratch blocks (and pinned host result blocks) of finished calls for reuse -- tens of GB after a
+ * full-size call.  dbg_ctx_trim returns every block that is not in a caller's hands to the driver (after draining the
+ * stream), so that another allocator sharing the GPU (torch, a second ctx) can have the memory; *freed_bytes (may be NULL)
+ * receives the device bytes released.  The library also trims by itself when one of its own allocations fails. */
+int         dbg_ctx_trim(dbg_ctx* ctx, uint64_t* freed_bytes);
 
 /* ---- input: &[(V, Exts, D1)]  (src/filter.rs:140) flattened -------------- */
 typedef struct {

@@ -258,6 +258,12 @@ class Context:
                     self.set_option(n, v)
         return cm()
 
+    def trim(self):
+        """dbg_ctx_trim: give the pooled scratch of finished calls back to the driver -> device bytes released"""
+        n = C.c_uint64()
+        self.check(self.lib.dbg_ctx_trim(self.h, C.byref(n)))
+        return n.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.dbg_ctx_destroy(self.h)

@@ -69,6 +69,15 @@ extern "C" int dbg_ctx_set_option(dbg_ctx* c, const char* name, const char* valu
     return 0;
 }
 
+extern "C" int dbg_ctx_trim(dbg_ctx* c, uint64_t* freed_bytes) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t before = c->pooled_bytes;
+    c->trim();                                       // drains the stream, frees the pooled device blocks
+    ctx_hrelease_free(c);                            // pinned result blocks not in a caller's hands
+    if (freed_bytes) *freed_bytes = before - c->pooled_bytes;
+    return 0;
+}
+
 extern "C" int dbg_ctx_set_scratch_budget(dbg_ctx* c, uint64_t bytes) { c->scratch_budget = bytes; return 0; }
 
 extern "C" int dbg_ctx_enable_timing(dbg_ctx* c, int on) { c->timing = on != 0; c->t_clear(); return 0; }

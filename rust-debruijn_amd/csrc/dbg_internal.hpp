@@ -25,6 +25,7 @@ unsigned host_parallel_width();
 void* ctx_halloc(dbg_ctx* c, size_t bytes);                                  // result array: pinned block from the ctx pool (malloc when small)
 void ctx_hfree(dbg_ctx* c, void* p);                                         // c may be null
 void ctx_hrelease_all(dbg_ctx* c);
+void ctx_hrelease_free(dbg_ctx* c);                                         // pooled pinned blocks only (dbg_ctx_trim)
 
 // device view of &[(V, Exts, D1)] in PackedDnaStringSet layout
 struct SeqDev {

@@ -162,6 +162,12 @@ void ctx_hfree(dbg_ctx* c, void* p) {
     free(p);
 }
 
+void ctx_hrelease_free(dbg_ctx* c) {
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    for (auto& kv : c->hfree_blocks) { g_pin_owner.erase(kv.second); (void)hipHostFree(kv.second); }
+    c->hfree_blocks.clear();
+}
+
 // ctx teardown: pooled blocks are freed; blocks still in a caller's hands are disowned, not freed -- a host table may outlive its
 // ctx (as plain malloc'ed tables always could) and is then released by dbg_free_table(NULL, ..) through the pointer-attribute route
 void ctx_hrelease_all(dbg_ctx* c) {

@@ -21,11 +21,15 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True)
-def force_fast(ctx):
+@pytest.fixture(autouse=True, params=["wave", "wg"])
+def force_fast(ctx, request):
+    """every test runs with both counting kernels: the wave-per-bin kernel (default: small bins, private 256-entry tables,
+    fast_wavecount.hpp) and the workgroup-per-bin kernel (DBG_COUNT=wg: 2048-entry tables)"""
     old = ctx.set_option("DBG_PATH", "fast")
+    old_c = ctx.set_option("DBG_COUNT", request.param)
     yield
     ctx.set_option("DBG_PATH", old)
+    ctx.set_option("DBG_COUNT", old_c)
 
 
 def run_fast(ctx, ss, k, summarizer, min_obs, stranded, data_width=0):
