@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--min-obs", type=int, default=2)
     ap.add_argument("--error-rate", type=float, default=0.001, help="substitution error rate of the synthetic reads (SURVEY 8d: 0.001, also 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-json", default=None,
+                    help="HBM traffic per kernel from a counter pass of this same tree (tools/pmc_round.sh -> tools/pmc_traffic.py); default: "
+                         "the newest profiles/r*_pmc_traffic*.json.  A file measured on other kernel sources is flagged traffic_stale")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device: several ranks on ONE GPU, payload staged through the host (a functional check of the "
                          "N > 1 orchestration on a single-GPU box; its timings mean nothing)")
@@ -225,9 +228,21 @@ def main():
             # HBM traffic per k-mer instance from the PMC passes (tools/pmc.sh: separate --pmc runs of this same bench at
             # 10M reads; FETCH_SIZE doubled per the gfx950 correction): newest profiles/r*_pmc_traffic*.json
             import glob
+            import hashlib
             tj, tf = {}, sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+            if args.pmc_json:
+                tf = [args.pmc_json]
             if tf:
                 tj = json.load(open(tf[-1]))
+            # the counter passes cannot run inside the timed bench (rocprofv3 wraps the process): the traffic file carries the hash
+            # of the kernel sources it was measured on, and a file from other sources is reported as stale
+            hsrc = hashlib.sha256()
+            cdir = os.path.join(ROOT, "rust-debruijn_amd", "csrc")
+            for f_ in sorted(os.listdir(cdir)):
+                if f_.endswith((".hip", ".hpp")):
+                    hsrc.update(f_.encode()); hsrc.update(open(os.path.join(cdir, f_), "rb").read())
+            src_sha = hsrc.hexdigest()[:16]
+            traffic_stale = bool(tj) and tj.get("_kernel_source_sha16") != src_sha
             pmc_name = {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
                         "radix_hist": "radix16_hist_kernel" if 2 * k <= 96 else "radix_hist_kernel",
                         "radix_scatter": "radix16_scatter_kernel" if 2 * k <= 96 else "radix_scatter_kernel",
@@ -277,12 +292,14 @@ def main():
                     "note": "achieved/frac: SURVEY 8(d) algorithmic bytes / HIP-event time (the contract figure); measured_*: HBM bytes "
                             "from the FETCH_SIZE/WRITE_SIZE counter passes (%s); bound = lds/valu when the measured traffic is "
                             "below 0.2x the algorithmic bytes" % (os.path.basename(tf[-1]) if tf else "no PMC file"),
+                    "traffic_source": os.path.basename(tf[-1]) if tf else None, "traffic_stale": traffic_stale if tf else None,
+                    "kernel_source_sha16": src_sha,
                     "kernels": rows,
                     "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
             import oracle_lib as O
-            n_s = 1500000                                      # ~156M k-mer instances: 10-30 s of single-thread CPU work
+            n_s = 500000                                       # ~52M k-mer instances: ~8 s of single-thread CPU work (the rate does not depend on the sample size)
             hs = dbg.synth_reads_host(n_reads=n_s, read_len=L, genome_len=n_s * L // 30, error_rate=args.error_rate,
                                       stranded=False, n_colours=4)
             so = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if is_set else None, 1 if is_set else 0)

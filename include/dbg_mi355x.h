@@ -184,6 +184,14 @@ int  dbg_compress_kmers_with_hash(dbg_ctx* ctx, uint32_t k, int stranded, int sp
 int  dbg_compress_kmers_with_hash_dev(dbg_ctx* ctx, uint32_t k, int stranded, int spec, uint64_t n,
                                       const uint64_t* key_hi_dev, const uint64_t* key_lo_dev, const uint8_t* exts_dev,
                                       const uint32_t* data_dev, const uint16_t* count16_dev, dbg_graph* out);
+/* compress_kmers_no_exts (src/compression.rs:619-659): a bare k-mer set (any key order; the keys as the caller holds them) ->
+ * Exts from eight neighbour probes each (the neighbour is canonicalised with min_rc whether or not the graph is stranded,
+ * as the reference does) -> compress_kmers.  A duplicate key is the reference's assert_eq!(kmer_set.len(), keys.len()).
+ * dbg_kmer_set_exts returns the Exts alone (exts_out: [n] host bytes). */
+int  dbg_kmer_set_exts(dbg_ctx* ctx, uint32_t k, uint64_t n, const uint64_t* key_hi, const uint64_t* key_lo, uint8_t* exts_out);
+int  dbg_compress_kmers_no_exts(dbg_ctx* ctx, uint32_t k, int stranded, int spec, uint64_t n,
+                                const uint64_t* key_hi, const uint64_t* key_lo, const uint32_t* data,
+                                const uint64_t* seed_order, dbg_graph* out);
 void dbg_free_graph(dbg_ctx* ctx, dbg_graph* g);
 
 /* ---- CountFilterSet payload as ScmapCompress data (BASELINE config 5) ------------------------

@@ -237,6 +237,19 @@ BaseGraph<K, uint16_t> compress_kmers_with_hash(Context& ctx, bool stranded, con
     return out;
 }
 
+// compress_kmers_no_exts::<K, u16, S> (compression.rs:619-659): kmer_exts = &[(K, D)]
+template <class K, class S>
+BaseGraph<K, uint16_t> compress_kmers_no_exts(Context& ctx, bool stranded, const S& spec, const std::vector<std::pair<K, uint16_t>>& kmer_exts) {
+    std::vector<uint64_t> hi, lo; std::vector<uint32_t> da;
+    for (auto& kd : kmer_exts) { hi.push_back(kd.first.hi()); lo.push_back(kd.first.lo()); da.push_back(kd.second); }
+    dbg_graph g{};
+    ctx.check(dbg_compress_kmers_no_exts(ctx.raw(), (uint32_t)K::k(), stranded, spec.kind(), kmer_exts.size(), hi.data(), lo.data(), da.data(), nullptr, &g));
+    BaseGraph<K, uint16_t> out;
+    detail::graph_from_c(g, &out);
+    dbg_free_graph(ctx.raw(), &g);
+    return out;
+}
+
 // BaseGraph::combine (graph.rs:71-100)
 template <class K, class D>
 BaseGraph<K, D> combine(Context& ctx, const std::vector<BaseGraph<K, D>>& graphs) {

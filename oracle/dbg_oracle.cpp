@@ -4,6 +4,7 @@
 // reference file:line (relative to /root/reference/src) it follows.
 // =============================================================================
 #include "dbg_oracle.hpp"
+#include <set>
 #include <algorithm>
 #include <cstring>
 #include <cassert>
@@ -686,6 +687,30 @@ struct CompressFromHash {
     }
 };
 }  // namespace
+
+// compress_kmers_no_exts (compression.rs:619-659)
+int compress_kmers_no_exts(int k, bool stranded, Spec spec, const std::vector<Kmer>& keys_in, const std::vector<uint32_t>& data_in,
+                           const uint64_t* seed_order, BaseGraph& out, std::vector<Exts>* exts_out, std::string& err) {
+    KmerSpec ks(k);
+    std::set<Kmer> kmer_set(keys_in.begin(), keys_in.end());        // :624
+    std::vector<Kmer> keys; std::vector<Exts> exts; std::vector<uint32_t> data;
+    for (size_t i = 0; i < keys_in.size(); i++) {                    // :631
+        const Kmer kmer = keys_in[i];
+        Exts e;                                                      // Exts::empty() :632
+        for (uint8_t l = 0; l < 4; l++) {                            // :634-640
+            Kmer nw = kmer_min_rc(ks, kmer_extend_left(ks, kmer, l));       // `can` is min_rc whatever `stranded` is (:626)
+            if (kmer_set.count(nw)) e = e.set(Left, l);
+        }
+        for (uint8_t r = 0; r < 4; r++) {                            // :642-648
+            Kmer nw = kmer_min_rc(ks, kmer_extend_right(ks, kmer, r));
+            if (kmer_set.count(nw)) e = e.set(Right, r);
+        }
+        keys.push_back(kmer); data.push_back(data_in[i]); exts.push_back(e);   // :650-652
+    }
+    if (kmer_set.size() != keys.size()) { err = "assertion failed: kmer_set.len() == keys.len() (compression.rs:655)"; return 1; }
+    if (exts_out) *exts_out = exts;
+    return compress_kmers_with_hash(k, stranded, spec, keys, exts, data, seed_order, out, err);   // :657-658
+}
 
 int compress_kmers_with_hash(int k, bool stranded, Spec spec,
                              const std::vector<Kmer>& keys, const std::vector<Exts>& exts,

@@ -288,6 +288,11 @@ int compress_kmers_with_hash(int k, bool stranded, Spec spec,
                              const std::vector<uint32_t>& data, const uint64_t* seed_order,
                              BaseGraph& out, std::string& err);
 
+// compress_kmers_no_exts (compression.rs:619-659): Exts from neighbour look-ups in the k-mer set, then compress_kmers.
+// exts_out (optional) receives the derived Exts.
+int compress_kmers_no_exts(int k, bool stranded, Spec spec, const std::vector<Kmer>& keys, const std::vector<uint32_t>& data,
+                           const uint64_t* seed_order, BaseGraph& out, std::vector<Exts>* exts_out, std::string& err);
+
 // ---------------------------------------------------------------------------
 // DebruijnGraph pieces used by the sharded second stage and by the ported
 // reference tests: finish (graph.rs:116-170), find_link (:252-291),

@@ -151,6 +151,15 @@ void* orc_compress_kmers(int k, int stranded, int spec, uint64_t n, const uint64
     if (compress_kmers_with_hash(k, stranded != 0, (Spec)spec, keys, e, d, seed_order, h->g, g_err)) { delete h; return nullptr; }
     return h;
 }
+void* orc_compress_kmers_no_exts(int k, int stranded, int spec, uint64_t n, const uint64_t* key_hi, const uint64_t* key_lo,
+                                 const uint32_t* data, const uint64_t* seed_order, uint8_t* exts_out) {
+    std::vector<Kmer> keys(n); std::vector<uint32_t> d(n); std::vector<Exts> e;
+    for (uint64_t i = 0; i < n; i++) { keys[i] = mk(key_hi ? key_hi[i] : 0, key_lo[i]); d[i] = data ? data[i] : 0; }
+    OrcGraph* h = new OrcGraph(); h->k = k;
+    if (compress_kmers_no_exts(k, stranded != 0, (Spec)spec, keys, d, seed_order, h->g, &e, g_err)) { delete h; return nullptr; }
+    if (exts_out) for (uint64_t i = 0; i < n; i++) exts_out[i] = e[i].val;
+    return h;
+}
 static BaseGraph& bg(void* h) { OrcGraph* g = (OrcGraph*)h; return g->finished ? g->dbg.base : g->g; }
 uint64_t orc_graph_len(void* h) { return bg(h).len(); }
 uint64_t orc_graph_n_words(void* h) { return bg(h).sequences.sequence.storage.size(); }

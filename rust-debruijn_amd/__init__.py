@@ -459,6 +459,31 @@ def compress_kmers_with_hash(stranded, spec, index, k=None, seed_order=None, dat
     return out
 
 
+def kmer_set_exts(k, key_hi, key_lo, ctx=None):
+    """the Exts compress_kmers_no_exts derives for a bare k-mer set (src/compression.rs:626-652): one bit per neighbour whose
+    min_rc is in the set"""
+    ctx = ctx or default_context()
+    key_lo = np.ascontiguousarray(key_lo, np.uint64)
+    key_hi = np.ascontiguousarray(key_hi if key_hi is not None else np.zeros(len(key_lo), np.uint64), np.uint64)
+    out = np.zeros(max(len(key_lo), 1), np.uint8)
+    ctx.check(ctx.lib.dbg_kmer_set_exts(ctx.h, k, len(key_lo), _np_ptr(key_hi), _np_ptr(key_lo), _np_ptr(out)))
+    return out[:len(key_lo)]
+
+
+def compress_kmers_no_exts(stranded, spec, k, key_hi, key_lo, data=None, seed_order=None, ctx=None):
+    """compress_kmers_no_exts::<K, D, S> (src/compression.rs:619-659): kmer_exts = [(K, D)] as key columns + data."""
+    ctx = ctx or default_context()
+    key_lo = np.ascontiguousarray(key_lo, np.uint64)
+    n = len(key_lo)
+    key_hi = np.ascontiguousarray(key_hi if key_hi is not None else np.zeros(n, np.uint64), np.uint64)
+    data = np.ascontiguousarray(data if data is not None else np.zeros(n, np.uint32), np.uint32)
+    so = None if seed_order is None else np.ascontiguousarray(seed_order, np.uint64)
+    g = _capi.Graph()
+    ctx.check(ctx.lib.dbg_compress_kmers_no_exts(ctx.h, k, int(bool(stranded)), spec.kind, n, _np_ptr(key_hi), _np_ptr(key_lo),
+                                                 _np_ptr(data), _np_ptr(so), C.byref(g)))
+    return _graph_from_c(ctx, g, k)
+
+
 def upload_seqs(hs, device=0):
     """HostSeqs -> (dbg_seqset of device pointers, tensors that must stay alive)"""
     import torch

@@ -73,7 +73,7 @@ EXPORTS = [
     "dbg_ctx_create", "dbg_ctx_destroy", "dbg_last_error", "dbg_version", "dbg_ctx_set_stream",
     "dbg_ctx_set_scratch_budget", "dbg_ctx_set_option", "dbg_ctx_trim", "dbg_filter_kmers", "dbg_filter_kmers_dev", "dbg_free_table", "dbg_table_to_host",
     "dbg_remove_censored_exts", "dbg_msp_sequence", "dbg_msp_sequence_dev", "dbg_free_pieces",
-    "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_free_graph", "dbg_label_classes_dev", "dbg_free_label_classes", "dbg_compress_table_dev", "dbg_synth_words", "dbg_synth_reads_dev",
+    "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_kmer_set_exts", "dbg_compress_kmers_no_exts", "dbg_free_graph", "dbg_label_classes_dev", "dbg_free_label_classes", "dbg_compress_table_dev", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
@@ -124,6 +124,9 @@ def load():
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Graph)]
     lib.dbg_compress_kmers_with_hash_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Graph)]
+    lib.dbg_kmer_set_exts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dbg_compress_kmers_no_exts.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.POINTER(Graph)]
     lib.dbg_free_graph.argtypes = [C.c_void_p, C.POINTER(Graph)]
     lib.dbg_free_graph.restype = None
     lib.dbg_label_classes_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(LabelClasses)]

@@ -157,6 +157,24 @@ __global__ void censor_kernel(KeysDev valid, KeysDev all, uint8_t* __restrict__ 
     exts[i] = (uint8_t)ne;
 }
 
+// compress_kmers_no_exts (compression.rs:619-659): Exts of every k-mer from eight neighbour probes into the k-mer set.  The
+// reference canonicalises the neighbour with min_rc whether or not the graph is stranded (`let can = |k: K| k.min_rc()`).
+__global__ void neighbour_exts_kernel(KeysDev probe, KeysDev set, uint8_t* __restrict__ exts, int k) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= probe.n) return;
+    const K128 kmer = key_at(probe, i);
+    uint32_t e = 0;
+    for (int dir = 0; dir < 2; dir++) {
+        for (uint32_t b = 0; b < 4; b++) {
+            K128 x = dir == 0 ? kmer_extend_left(kmer, k, b) : kmer_extend_right(kmer, k, b);
+            const K128 rc = kmer_rc(x, k);
+            if (!k128_lt(x, rc)) x = rc;                                               // min_rc (lib.rs:234-241)
+            if (find_key(set, x) >= 0) e |= 1u << (4 * dir + b);                       // Exts::set(dir, base) (lib.rs:640-652)
+        }
+    }
+    exts[i] = (uint8_t)e;
+}
+
 // ---- host side -----------------------------------------------------------------------------
 inline uint32_t spec_reduce(int spec, uint32_t a, uint32_t b, bool* panic) {
     switch (spec) {
@@ -446,6 +464,66 @@ extern "C" int dbg_compress_kmers_with_hash_dev(dbg_ctx* c, uint32_t k_, int str
     d_link.release(); d_wide.release();
     return dbg_compress_kmers_with_hash(c, k_, stranded, spec, n, has_hi ? h_hi.data() : nullptr, h_lo.data(), h_ex.data(),
                                         d_data ? h_da.data() : nullptr, nullptr, out);
+}
+
+// compress_kmers_no_exts (compression.rs:619-659): the Exts come from neighbour probes into the k-mer set, then compress_kmers.
+extern "C" int dbg_kmer_set_exts(dbg_ctx* c, uint32_t k_, uint64_t n, const uint64_t* key_hi, const uint64_t* key_lo, uint8_t* exts_out) {
+    const int k = (int)k_;
+    if (k < 1 || k > 64) return c->fail(40, "k must be in 1..=64");
+    if (n >= (1ull << 32)) return c->fail(42, "at most 2^32-1 k-mers per call in this build");
+    if (n && (!key_lo || !exts_out)) return c->fail(10, "null argument");
+    if (n == 0) return 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool has_hi = k > 32;
+    auto key_of = [&](uint64_t i) { return K128{has_hi && key_hi ? key_hi[i] : 0ull, key_lo[i]}; };
+    DBuf<uint64_t> d_hi, d_lo, s_hi, s_lo; DBuf<uint8_t> d_exts; DBuf<uint32_t> d_flag, d_pidx;
+    if (has_hi) ALLOC_OR_FAIL(c, d_hi, n);
+    ALLOC_OR_FAIL(c, d_lo, n); ALLOC_OR_FAIL(c, d_exts, n); ALLOC_OR_FAIL(c, d_flag, 1);
+    {
+        std::vector<UploadJob> jobs;
+        if (has_hi) { if (key_hi) jobs.push_back({d_hi.p, key_hi, (size_t)n * 8}); else HIP_TRY(c, hipMemsetAsync(d_hi.p, 0, n * 8, c->stream)); }
+        jobs.push_back({d_lo.p, key_lo, (size_t)n * 8});
+        DBG_TRY(staged_upload(c, jobs));
+    }
+    KeysDev probe{has_hi ? d_hi.p : nullptr, d_lo.p, n}, set = probe;
+    uint32_t fl = 0;
+    HIP_TRY(c, hipMemsetAsync(d_flag.p, 0, 4, c->stream));
+    sorted_check_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(probe, d_flag.p);
+    LAUNCH_CHECK(c, "sorted_check");
+    HIP_TRY(c, hipMemcpyAsync(&fl, d_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (fl) {                                                       // any key order is allowed: the probes need an ascending copy
+        std::vector<uint32_t> order(n);
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return k128_lt(key_of(a), key_of(b)); });
+        for (uint64_t i = 1; i < n; i++)                            // assert_eq!(kmer_set.len(), keys.len()) (compression.rs:655)
+            if (k128_eq(key_of(order[i - 1]), key_of(order[i]))) return c->fail(43, "duplicate k-mer in the k-mer set (compression.rs:655)");
+        std::vector<uint64_t> h_hi(has_hi ? n : 0), h_lo(n);
+        for (uint64_t i = 0; i < n; i++) { h_lo[i] = key_lo[order[i]]; if (has_hi) h_hi[i] = key_hi ? key_hi[order[i]] : 0; }
+        ALLOC_OR_FAIL(c, s_lo, n);
+        if (has_hi) ALLOC_OR_FAIL(c, s_hi, n);
+        std::vector<UploadJob> jobs{{s_lo.p, h_lo.data(), (size_t)n * 8}};
+        if (has_hi) jobs.push_back({s_hi.p, h_hi.data(), (size_t)n * 8});
+        DBG_TRY(staged_upload(c, jobs));
+        set = KeysDev{has_hi ? s_hi.p : nullptr, s_lo.p, n};
+    }
+    DBG_TRY(attach_prefix_index(c, &set, k, &d_pidx));
+    c->t_begin("neighbour_exts", n);
+    neighbour_exts_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(probe, set, d_exts.p, k);
+    c->t_end();
+    LAUNCH_CHECK(c, "neighbour_exts");
+    HIP_TRY(c, hipMemcpyAsync(exts_out, d_exts.p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int dbg_compress_kmers_no_exts(dbg_ctx* c, uint32_t k, int stranded, int spec, uint64_t n, const uint64_t* key_hi, const uint64_t* key_lo,
+                                          const uint32_t* data, const uint64_t* seed_order, dbg_graph* out) {
+    if (!out) return c->fail(10, "null argument");
+    memset(out, 0, sizeof(*out));
+    std::vector<uint8_t> exts((size_t)std::max<uint64_t>(n, 1));
+    DBG_TRY(dbg_kmer_set_exts(c, k, n, key_hi, key_lo, exts.data()));
+    return dbg_compress_kmers_with_hash(c, k, stranded, spec, n, key_hi, key_lo, exts.data(), data, seed_order, out);
 }
 
 extern "C" void dbg_free_graph(dbg_ctx*, dbg_graph* g) {

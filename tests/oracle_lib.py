@@ -36,7 +36,7 @@ def lib():
         build()
         _lib = C.CDLL(LIB_PATH)
         _lib.orc_last_error.restype = C.c_char_p
-        for f in ("orc_filter_kmers", "orc_compress_kmers", "orc_graph_from_arrays", "orc_graph_combine",
+        for f in ("orc_filter_kmers", "orc_compress_kmers", "orc_compress_kmers_no_exts", "orc_graph_from_arrays", "orc_graph_combine",
                   "orc_compress_graph"):
             getattr(_lib, f).restype = C.c_void_p
         for f in ("orc_table_len", "orc_table_all_len", "orc_table_setval_len", "orc_graph_len",
@@ -352,6 +352,19 @@ def compress_kmers(k, stranded, spec, key_hi, key_lo, exts, data=None, seed_orde
     if not h:
         raise _err()
     return Graph(h, k)
+
+
+def compress_kmers_no_exts(k, stranded, spec, key_hi, key_lo, data=None, seed_order=None):
+    """compress_kmers_no_exts (compression.rs:619-659) -> (Graph, the Exts it derived)"""
+    key_lo = np.ascontiguousarray(key_lo, dtype=np.uint64)
+    key_hi = np.zeros_like(key_lo) if key_hi is None else np.ascontiguousarray(key_hi, dtype=np.uint64)
+    d = None if data is None else np.ascontiguousarray(data, dtype=np.uint32)
+    so = None if seed_order is None else np.ascontiguousarray(seed_order, dtype=np.uint64)
+    ex = np.zeros(max(len(key_lo), 1), np.uint8)
+    h = lib().orc_compress_kmers_no_exts(k, int(stranded), spec, C.c_uint64(len(key_lo)), _p(key_hi), _p(key_lo), _p(d), _p(so), _p(ex))
+    if not h:
+        raise _err()
+    return Graph(h, k), ex[:len(key_lo)]
 
 
 def graph_from_arrays(k, stranded, words, start, length, exts, data=None):

@@ -246,3 +246,23 @@ def test_compress_routes(ctx, compress_mode, env, k, stranded):
         compare(ctx, t, k, stranded, SPECS[0])
         order = rng.permutation(len(t)).astype(np.uint64)
         compare(ctx, t, k, stranded, SPECS[2], seed_order=order)
+
+
+@pytest.mark.parametrize("k,stranded", [(31, False), (32, True), (47, False), (63, False), (64, True)])
+def test_compress_kmers_no_exts_parity(ctx, k, stranded):
+    """compress_kmers_no_exts (compression.rs:619-659): Exts from eight neighbour probes into the k-mer set (canonicalised with
+    min_rc whether stranded or not), then compress_kmers -- literal BaseGraph and Exts equality with the oracle, keys in a
+    shuffled order, random seed order; a duplicate key is the reference's assertion."""
+    rng = np.random.default_rng(300 + k)
+    t = gpu_table(ctx, R.random_contigs(rng), k, 1, False)
+    perm = rng.permutation(len(t))
+    hi, lo, cnt = t.key_hi[perm], t.key_lo[perm], t.count[perm].astype(np.uint32)
+    for seed_order in (None, rng.permutation(len(t)).astype(np.uint64)):
+        want, wex = O.compress_kmers_no_exts(k, stranded, O.SPEC_SAT_ADD, hi, lo, cnt, seed_order)
+        assert np.array_equal(dbg.kmer_set_exts(k, hi, lo, ctx=ctx), wex)
+        got = dbg.compress_kmers_no_exts(stranded, dbg.SimpleCompress("saturating_add"), k, hi, lo, cnt, seed_order=seed_order, ctx=ctx)
+        assert graphs_equal(got.arrays(), want.arrays())
+    # the ascending table itself (no host sort inside the call) gives the same Exts
+    assert np.array_equal(dbg.kmer_set_exts(k, t.key_hi, t.key_lo, ctx=ctx)[perm], wex)
+    with pytest.raises(dbg.DbgError):
+        dbg.compress_kmers_no_exts(stranded, dbg.SimpleCompress("saturating_add"), k, np.concatenate([hi, hi[:1]]), np.concatenate([lo, lo[:1]]), ctx=ctx)

@@ -122,3 +122,42 @@ def test_gfa_uncompressed_and_empty(ctx):
     empty = dbg.BaseGraph(k, dbg.PackedDnaStringSet(np.zeros(2, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint32), 0),
                           np.zeros(0, np.uint8), np.zeros(0, np.uint32), False)
     assert empty.write_gfa(ctx) == b"H\tVN:Z:debruijn-rs\n"
+
+
+@pytest.mark.parametrize("k,stranded,dw", [(31, False, 2), (47, False, 4), (63, True, 2)])
+def test_serde_of_a_gpu_built_graph(ctx, k, stranded, dw):
+    """serde forms (graph.rs:43-50 derives) of a graph built by the GPU path: serialise, deserialise, literal equality; the
+    JSON text is also read by Python's json module -- an independent reader -- and must describe the same BaseGraph, field
+    by field (sequences.sequence.storage/len, start, length, exts[].val, data, stranded, phantom = null)."""
+    import json
+    rng = np.random.default_rng(700 + k)
+    contigs = R.random_contigs(rng)
+    t, _ = dbg.filter_kmers([(c, 0, None) for c in contigs], dbg.CountFilter(1), stranded, False, 4, k=k, ctx=ctx)
+    g = dbg.compress_kmers_with_hash(stranded, dbg.SimpleCompress("saturating_add"), t, k=k, ctx=ctx)
+    a = g.arrays()
+    nw = (a["n_bases"] + 31) // 32
+    for fmt in (dbg.SERDE_BINCODE, dbg.SERDE_JSON):
+        blob = dbg.graph_serialize(g, fmt, data_width=dw)
+        h = dbg.graph_deserialize(blob, k, fmt, data_width=dw)
+        b = h.arrays()
+        assert a["n_bases"] == b["n_bases"] and g.stranded == h.stranded
+        assert np.array_equal(a["words"][:nw], b["words"][:nw])
+        for name in ("start", "length", "exts", "data"):
+            assert np.array_equal(a[name], b[name]), name
+        assert dbg.graph_serialize(h, fmt, data_width=dw) == blob
+        # the deserialised graph is the same graph to the rest of the library
+        assert h.write_gfa(ctx) == g.write_gfa(ctx)
+    j = json.loads(dbg.graph_serialize(g, dbg.SERDE_JSON, data_width=dw).decode())
+    assert list(j) == ["sequences", "exts", "data", "stranded", "phantom"] and j["phantom"] is None and j["stranded"] is stranded
+    assert list(j["sequences"]) == ["sequence", "start", "length"] and list(j["sequences"]["sequence"]) == ["storage", "len"]
+    assert j["sequences"]["sequence"]["len"] == a["n_bases"]
+    assert j["sequences"]["sequence"]["storage"] == [int(x) for x in a["words"][:nw]]
+    assert j["sequences"]["start"] == [int(x) for x in a["start"]] and j["sequences"]["length"] == [int(x) for x in a["length"]]
+    assert [e["val"] for e in j["exts"]] == [int(x) for x in a["exts"]] and j["data"] == [int(x) for x in a["data"]]
+    # every node sequence read back through the independent reader spells k-mers of the index
+    words = np.array(j["sequences"]["sequence"]["storage"], dtype=np.uint64)
+    truth = set(t.keys())
+    for s0, ln in list(zip(j["sequences"]["start"], j["sequences"]["length"]))[:50]:
+        bases = O.unpack_bases(np.concatenate([words, np.zeros(2, np.uint64)]), s0, ln)
+        for v in R.kmers_of(bases, k):
+            assert (v if stranded else R.canon(k, v)) in truth

@@ -508,3 +508,33 @@ def test_scmap_compress_breaks_on_colour():
     ga = g.arrays()
     assert sorted(int(x) for x in ga["length"]) == sorted([20 + k - 1, len(path) - 20 + k - 1])
     assert g.is_compressed(O.SPEC_SCMAP_EQ) is None
+
+
+# ------------------------------------------------------------------ compress_kmers_no_exts (compression.rs:619-659)
+@pytest.mark.parametrize("k,stranded", [(31, False), (32, True), (47, False), (63, False)])
+def test_compress_kmers_no_exts_against_a_set_model(k, stranded):
+    """The Exts the restatement derives are those of an independent Python set model (one bit per neighbour whose min_rc is in
+    the set, whatever `stranded` says: compression.rs:626), the result equals compress_kmers on those Exts (:657-658), and on
+    the complete k-mer set of error-free contigs the derived Exts contain the Exts the reads themselves showed."""
+    rng = np.random.default_rng(k)
+    contigs = R.random_contigs(rng)
+    t = O.filter_kmers(O.SeqSet.from_byte_seqs(contigs), k, O.COUNT_FILTER, 1, stranded=False)
+    keys = t.keys()
+    kset = set(keys)
+    perm = rng.permutation(len(keys))                                   # any key order (a slice of (K, D) pairs)
+    hi, lo, cnt = t.key_hi[perm], t.key_lo[perm], t.count[perm]
+    g, ex = O.compress_kmers_no_exts(k, stranded, O.SPEC_SAT_ADD, hi, lo, cnt)
+    for i, p in enumerate(perm):
+        v, e = keys[p], 0
+        for b in range(4):
+            if R.canon(k, O.kmer_extend(k, v, b, O.LEFT)) in kset:
+                e |= 1 << b
+            if R.canon(k, O.kmer_extend(k, v, b, O.RIGHT)) in kset:
+                e |= 16 << b
+        assert e == int(ex[i])
+        assert int(t.exts[p]) & ~e == 0                                  # what the reads showed is a subset
+    want = O.compress_kmers(k, stranded, O.SPEC_SAT_ADD, hi, lo, ex, cnt)
+    from graph_canon import graphs_equal
+    assert graphs_equal(g.arrays(), want.arrays())
+    with pytest.raises(RuntimeError):                                    # assert_eq!(kmer_set.len(), keys.len())
+        O.compress_kmers_no_exts(k, stranded, O.SPEC_SAT_ADD, np.concatenate([hi, hi[:1]]), np.concatenate([lo, lo[:1]]), None)

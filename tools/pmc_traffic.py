@@ -1,8 +1,20 @@
 """Turns a tools/pmc.sh output directory into profiles/<name>: per-kernel HBM traffic per unit.
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
 (MI355X_MICROARCH.md, HBM section), so traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes."""
-import csv, glob, json, os, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 root, out, n_inst = sys.argv[1], sys.argv[2], float(sys.argv[3])
+
+
+def kernel_source_sha():
+    """sha-256 (16 hex digits) over the kernel sources: bench.py compares it with the tree it runs from and flags a traffic file
+    measured on other kernels as stale (.git does not travel to the GPU box, so a commit id is not available there)"""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-debruijn_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
 n_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2          # bench steps the counter passes ran (tools/pmc_round.sh)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(int)
@@ -26,7 +38,7 @@ for f in newest_per_pass(root):
             disp[k] += 1
 res = {"_note": "bytes per k-mer instance of the profiled run = (2*FETCH_SIZE + WRITE_SIZE)*1024 / instances; "
                 "FETCH_SIZE doubled per the gfx950 correction; dispatches = launches seen in the pass (over _steps bench steps)",
-       "_instances": n_inst, "_steps": n_steps}
+       "_instances": n_inst, "_steps": n_steps, "_kernel_source_sha16": kernel_source_sha()}
 for k, v in agg.items():
     b = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
     res[k] = {"fetch_kib": v.get("FETCH_SIZE", 0), "write_kib": v.get("WRITE_SIZE", 0), "dispatches": disp[k],
