@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("DBG_BENCH_READS", 0)))
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 (default): BASELINE configs[1], 10^8 reads PER GPU, k = 47 -- weak scaling.  c4 / c5: the BASELINE shapes that "
+                         "name a TOTAL size, strong-scaled over the ranks: c4 = 10^9 reads, k = 63; c5 = 6*10^8 reads (3 Gbp x 30), k = 51, "
+                         "CountFilterSet (the index ScmapCompress works on).  --reads then means total reads")
     ap.add_argument("--k", type=int, default=47)
     ap.add_argument("--summarizer", default="set", choices=["set", "count"])
     ap.add_argument("--min-obs", type=int, default=2)
@@ -112,9 +116,15 @@ def main():
     lib = ctx.lib
 
     k, L = args.k, 150
-    reads_per_gpu = args.reads or 100_000_000          # BASELINE configs[1]: 100M x 150 bp, k=47, CountFilterSet
+    strong = args.config != "c2"
+    if strong:                                          # a BASELINE shape with a total size: split over the ranks
+        k = {"c4": 63, "c5": 51}[args.config] if args.k == 47 else args.k
+        total_reads = args.reads or {"c4": 1_000_000_000, "c5": 600_000_000}[args.config]
+        reads_per_gpu = total_reads // world
+    else:
+        reads_per_gpu = args.reads or 100_000_000      # BASELINE configs[1]: 100M x 150 bp, k=47, CountFilterSet
     is_set = args.summarizer == "set"
-    n_reads_total = reads_per_gpu * world               # weak scaling: fixed reads per GPU
+    n_reads_total = reads_per_gpu * world               # weak scaling: fixed reads per GPU (strong: the total split evenly)
     genome_len = n_reads_total * L // 30
 
     # ---- synthetic input, generated directly in HBM ----
@@ -148,7 +158,11 @@ def main():
         tab, total, n_local, n_recs = D.sharded_filter_kmers(engine, ss, k, False, 1 if is_set else 0, args.min_obs, stats=st,
                                                                  force_exchange=args.force_exchange)
         for kk, v in st.items():
-            xstats[kk] = xstats.get(kk, 0) + v
+            if isinstance(v, list):
+                old = xstats.get(kk, [0.0] * len(v))
+                xstats[kk] = [a_ + b_ for a_, b_ in zip(old, v)] if len(old) == len(v) else list(v)
+            else:
+                xstats[kk] = xstats.get(kk, 0) + v
         res = (tab.n, n_local, D.table_digest(tab, dev) if args.digest else 0)
         engine.free_table(tab)
         return res
@@ -190,6 +204,22 @@ def main():
         xe = torch.tensor([xstats.get("exchange_exposed_ms", 0.0)], dtype=torch.float64, device=rdev)
         dist.all_reduce(xe, op=dist.ReduceOp.MAX)
         exposed_ms = float(xe.item())
+        # per-rank balance: what a 1 -> 8 curve needs to be diagnosed from the record alone
+        kms = lambda *names: sum(ktimes.get(n_, {}).get("ms", 0.0) for n_ in names) / max(args.steps, 1)
+        mine = torch.tensor([xstats.get("records_owned", 0) / max(args.steps, 1), kms("bin_count"), kms("sk_scan", "sk_scan_long"),
+                             kms("slab_compact", "sk_scatter"), kms("radix_hist", "radix_scatter", "span_sort", "set_csr"),
+                             xstats.get("exchange_exposed_ms", 0.0) / max(args.steps, 1), float(n_valid)], dtype=torch.float64, device=rdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        bal_names = ["records_owned", "bin_count_ms", "sk_scan_ms", "compact_ms", "sort_ms", "exchange_exposed_ms", "valid_kmers"]
+        balance = {nm: {"max": round(float(allr[:, i].max()), 3), "mean": round(float(allr[:, i].mean()), 3),
+                        "min": round(float(allr[:, i].min()), 3)} for i, nm in enumerate(bal_names)}
+        rounds = xstats.get("exchange_exposed_ms_by_round", [])
+        if rounds:
+            rr = torch.tensor(rounds, dtype=torch.float64, device=rdev) / max(args.steps, 1)
+            dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+            balance["exchange_exposed_ms_by_round_max_rank"] = [round(float(x), 3) for x in rr.cpu()]
         if args.digest:                                    # sum of the per-rank digests mod 2^64 (two 32-bit halves: no overflow)
             dg = torch.tensor([digest & 0xFFFFFFFF, digest >> 32], dtype=torch.int64, device=rdev)
             dist.all_reduce(dg)
@@ -198,6 +228,7 @@ def main():
         n_inst_total = n_inst
         n_valid_total = n_valid
         ranks_seen, xbytes_total, exposed_ms = 1, 0, 0.0
+        balance = None
     ms_per_step = dt / args.steps * 1e3
     value = n_inst_total * args.steps / dt / 1e9
 
@@ -409,10 +440,11 @@ def main():
         out = {
             "metric": "Gkmer/s extracted+counted (k=%d, 150 bp synthetic reads)" % k, "value": round(value, 4),
             "unit": "Gkmer/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=%g"
-                                   % (reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs, args.error_rate),
+            "config": {"workload": ("%s%dx150bp synthetic reads per GPU, k=%d, non-stranded, %s(min=%d), 30x, e=%g"
+                                    % ("BASELINE config %s strong-scaled: %d reads in all = " % (args.config[1], n_reads_total) if strong else "",
+                                       reads_per_gpu, k, "CountFilterSet<u8>" if is_set else "CountFilter", args.min_obs, args.error_rate)),
                        "kmer_instances_per_step": n_inst_total, "valid_kmers_rank0": n_valid, "valid_kmers_all_ranks": n_valid_total,
                        "path": ("fast (minimizer scan -> super-k-mer slabs per bin -> per-bin LDS hash tables -> order-restoring hybrid sort)" if fast
                                 else "generic (extract -> global LSD radix sort -> segmented reduce)"),
@@ -424,6 +456,7 @@ def main():
             "exchange": ({"bytes_sent_per_step_all_ranks": xbytes_total // max(args.steps, 1),
                           "exposed_ms_per_step_max_rank": round(exposed_ms / max(args.steps, 1), 3),
                           "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1)} if world > 1 else None),
+            "balance": balance,
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
             "host_boundary": hostb, "compress": comp,
         }

@@ -198,8 +198,11 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
     hint = max(n_local_kmers, 1)
     hist = (bin_off[1:] - bin_off[:-1]).contiguous()                         # records per bin (local reads)
     if stats is not None:
-        stats.update(exchange_bytes_sent=0, exchange_exposed_ms=0.0, exchange_rounds=n_chunks if (world > 1 or force) else 0)
+        stats.update(exchange_bytes_sent=0, exchange_exposed_ms=0.0, exchange_rounds=n_chunks if (world > 1 or force) else 0,
+                     records_owned=0, exchange_exposed_ms_by_round=[0.0] * (n_chunks if (world > 1 or force) else 0))
     if world == 1 and not force:
+        if stats is not None:
+            stats["records_owned"] = int(recs.numel() // max(rw, 1))
         seg_off = torch.zeros(1, nb_local + 1, dtype=torch.int64, device=hist.device)
         seg_off[0, 1:] = torch.cumsum(hist.to(torch.int64), 0)
         engine.sync()
@@ -238,7 +241,10 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
         work.wait()
         engine.sync()                                                        # chunk c is complete in device memory
         if stats is not None:
-            stats["exchange_exposed_ms"] += (time.perf_counter() - t0) * 1e3  # time the counting kernels could not hide
+            ex_ms = (time.perf_counter() - t0) * 1e3                          # time the counting kernels could not hide
+            stats["exchange_exposed_ms"] += ex_ms
+            stats["exchange_exposed_ms_by_round"][c] += ex_ms
+            stats["records_owned"] += sum(cnt)
         if c + 1 < n_chunks:
             pending = launch(c + 1)                                          # goes on the wire while chunk c is counted
         lo, hi = my[c], my[c + 1]
@@ -349,7 +355,7 @@ def _gather_payloads(payload, dst, group):
             if ln:
                 t = torch.empty(ln * dt.itemsize, dtype=torch.uint8, device=dev)
                 dist.recv(t, dist.get_global_rank(group, src) if group is not None else src, group=group)
-                p[n] = t.cpu().numpy().view(dt).copy()
+                p[n] = t.cpu().numpy().view(dt)
             else:
                 p[n] = np.zeros(0, dt)
         out.append(p)

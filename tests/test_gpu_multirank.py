@@ -31,6 +31,36 @@ def test_collective_route_world1_nccl():
     assert b["config"]["path"].startswith("fast")
 
 
+def test_collective_route_full_size_nccl():
+    """The same route at BASELINE configs[1]'s full per-GPU size (10^8 reads): slabs + the compacted copy + the receive buffers
+    of the pipelined rounds must fit next to one another, and no single message may reach the sizes at which RCCL transfers were
+    seen to arrive incomplete -- what the first contact with a real 8-GPU node would otherwise find out."""
+    import json
+    r = subprocess.run(["python", "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-boundary", "--compress-reads", "0",
+                        "--digest", "--force-exchange", "--backend", "nccl"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["kmer_instances_per_step"] == 10_400_000_000
+    assert d["config"]["valid_kmers_all_ranks"] == 501537896            # the single-call count of this stream (BENCH_r02)
+
+
+def test_strong_scaled_baseline_shapes_two_ranks_one_gpu():
+    """bench.py --config c4 / c5: BASELINE shapes that name a TOTAL size, split over the ranks (strong scaling).  Two ranks share
+    cuda:0 (gloo); a scaled-down total; the tables add up to the single-call table of the same reads and k."""
+    import json
+    def run(extra):
+        r = subprocess.run(["python", "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-boundary", "--compress-reads", "0",
+                            "--digest"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for cfg, k in (("c4", 63), ("c5", 51)):
+        a = run(["--reads", "400000", "--k", str(k)])
+        b = run(["--config", cfg, "--reads", "400000", "--gpus", "2", "--backend", "gloo", "--one-device"])
+        assert b["scaling"] == "strong" and b["n_gpus"] == 2 and ("k=%d" % k) in b["config"]["workload"]
+        assert a["table_digest"] == b["table_digest"] and a["config"]["valid_kmers_all_ranks"] == b["config"]["valid_kmers_all_ranks"]
+        assert b["balance"]["records_owned"]["min"] > 0
+
+
 def test_two_gpus_nccl():
     """Real multi-GPU run (skips on a one-GPU box): 2 ranks, nccl = RCCL over xGMI; per-rank tables add up to the single-GPU
     table, and the rank-spanning compress stage gives the single-process result."""
