@@ -46,7 +46,8 @@ def _check_bin_count_budget(remarks):
         if m:
             name = m.group(1)
             continue
-        if name and "bin_count_kernel" in name and "Li512ELi2048E" in name:
+        # (the WIDE colour-set variants -- two more mask words per entry -- use 1024-entry tables: ...Li512ELi1024ELb1E)
+        if name and "bin_count_kernel" in name and ("Li512ELi2048ELb0E" in name or "Li512ELi1024ELb1E" in name):
             m = re.search(r"LDS Size \[bytes/block\]: (\d+)", line)
             if m and int(m.group(1)) > 81920:
                 raise RuntimeError("bin_count variant %s needs %s bytes of LDS: more than half a CU's 160 KB" % (name, m.group(1)))

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64) bin_count_wave_kernel(const uint64_t* __re
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = lanemask_lt();
     const K128 kmask = k128_mask(k);
-    constexpr uint64_t COLOUR_BITS = 31ull << 15;
+    constexpr uint64_t COLOUR_BITS = 63ull << 15;
     unsigned long long o_pos = 0, o_end = 0;                            // this wave's output chunk (uniform)
     const uint64_t alt_delta = (uint64_t)((uintptr_t)recs_alt - (uintptr_t)recs);       // bytes from the first record buffer to the second
     uint32_t fl_bad = 0;

@@ -29,7 +29,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // internal minimizer order + bin hash
 // ------------------------------------------------------------------------------------------------
-struct LabelInv { uint32_t v[24]; uint32_t on; };       // colour index -> D1 label (sparse label alphabets)
+struct LabelInv { uint32_t v[64]; uint32_t on; };       // colour index -> D1 label (sparse label alphabets)
 struct FastCfg {
     int k, p;
     int stranded;
@@ -121,13 +121,13 @@ __device__ __forceinline__ uint32_t bin_of_hash(const FastCfg& c, uint32_t mh) {
 // read order to a temporary buffer (wave-level allocation, one atomic per tile) together with their
 // bin id; a second, purely bandwidth-bound kernel moves them into bin order.
 // record = NBW words: bases left-aligned, MSB first; the low META_BITS bits of the last word (always free: NBW is
-// chosen that way) hold len (7) | exts << 7 (8) | D1 << 15 (5: the fast path needs labels < 24).  24 bytes at k = 47.
+// chosen that way) hold len (7) | exts << 7 (8) | D1 << 15 (6: the fast path handles up to 64 colours).  24 bytes at k = 47.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCAN_TILE_W = 128;                // window starts per tile
 constexpr int SCAN_ARR = 192 + 64;              // positions per tile + padding for the shifted reads
 constexpr uint32_t SCAN_CHUNK = 1024;           // records a wave reserves per global atomic (one hot address otherwise)
 constexpr uint32_t BIN_INVALID = 0xffffffffu;   // unused slot of a reserved chunk
-constexpr int META_BITS = 20;
+constexpr int META_BITS = 21;
 constexpr uint32_t NCLS = 1;                    // length classes per bin: records of similar k-mer count sit together
                                                 // so that the 64 records a wave processes finish at about the same time
 
@@ -227,7 +227,7 @@ struct PieceEmitter {
                 rv[qq] = nb ? v & (~0ull << (64 - 2 * nb)) : 0ull;
                 if (ps + len < m && len >= b0 && len < b0 + 32) re = 1u << ((uint32_t)(v >> (62u - 2u * (len - b0))) & 3u);   // base right of the piece
             }
-            rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 31u) << 15);
+            rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 63u) << 15);
         }
         auto store_rec = [&](uint64_t* o) {
             if (RW % 2 == 0) {
@@ -643,6 +643,9 @@ struct FastOut {
     uint64_t* lo;
     uint32_t* pay;      // CountFilter: exts | min(count, 65535) << 8;  CountFilterSet: exts | colour mask << 8 (labels < 24)
     uint4* rec16;       // k <= 48: the same as one 16-byte record {key 0..31, 32..63, 64..95, pay} (hi/lo/pay unused)
+    // colour sets of more than 24 colours (WIDE): the payload is the record's own output position, Exts and the 64-bit colour
+    // mask wait in these side arrays at that position and are gathered after the sort
+    uint4* w_rec;       // {colours 0..31, colours 32..63, Exts, 0}
     // report_all_kmers (filter.rs:208-212): every distinct k-mer, valid or not; null = not requested
     uint64_t* all_hi;
     uint64_t* all_lo;
@@ -772,7 +775,7 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define MARK(t) do {} while (0)
 #endif
-template <int KW, int NBW, bool IS_SET, int NT, int T>
+template <int KW, int NBW, bool IS_SET, int NT, int T, bool WIDE = false>
 __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
@@ -783,15 +786,19 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
     __shared__ __attribute__((aligned(16))) uint32_t s_tag[T];
     __shared__ __attribute__((aligned(16))) uint64_t s_key[KW * T];   // KW == 2: {lo, hi} pairs, one ds_read_b128 per entry
     __shared__ uint32_t s_cnt[T];
-    __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24)
-    constexpr uint32_t CAPC = (NBW == 4 ? 4 : 6) * NT;      // chunk-map capacity per batch
+    __shared__ uint32_t s_aux[T];               // Exts | colour mask << 8 (CountFilterSet labels < 24); WIDE: colours 0..31
+    static_assert(!WIDE || IS_SET, "WIDE is a colour-set layout");
+    __shared__ uint32_t s_aux2[WIDE ? T : 1];   // WIDE: colours 32..63
+    __shared__ uint32_t s_ex4[WIDE ? T / 4 : 1];   // WIDE: Exts, one byte per entry
+    typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type cmask_t;
+    constexpr uint32_t CAPC = (NBW == 4 || WIDE ? 4 : 6) * NT;      // chunk-map capacity per batch
     __shared__ uint64_t s_slab[RW * NT];        // staged batch of records, word-major
     __shared__ __attribute__((aligned(4))) uint16_t s_cmap[CAPC];   // chunk -> record slot | chunk index << 10
     constexpr uint32_t DD = NT >= 512 ? 1024 : 512;                 // slots of the duplicate filter (>= 2 per staged record)
     static_assert(CAPC * 2 >= DD * 4 && DD >= 2 * NT && NT <= 1023, "the duplicate filter borrows s_cmap");
     uint32_t* const s_dd = reinterpret_cast<uint32_t*>(s_cmap);      // duplicate filter of the batch (dead before s_cmap is filled)
     __shared__ uint32_t s_w[NT / 2];            // per staged record: how many identical records of the batch it stands for (u16 halves)
-    __shared__ uint32_t s_cmk[IS_SET ? NT : 1]; // ... and the union of their colours (CountFilterSet)
+    __shared__ cmask_t s_cmk[IS_SET ? NT : 1];  // ... and the union of their colours (CountFilterSet)
     __shared__ uint32_t s_m, s_cproc, s_nextq, s_nst, s_bad;
 #ifdef DBG_COUNT_STATS
     __shared__ uint32_t s_stat[16];
@@ -880,7 +887,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
         load_rec(tid);
         load_into(NT + tid, Q0, Q1, Q2, Q3, qmeta);     // both requests are in flight together
         bool q_valid = true;                            // Q holds record NT + tid
-        for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; }
+        for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_aux[i] = 0; if (WIDE) s_aux2[i] = 0; }
+        if (WIDE) for (int i = tid; i < T / 4; i += NT) s_ex4[i] = 0;
         if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; s_bad = 0; s_nst = 0; }
         // (the staging area and the filter of the first fill are reset here too: one barrier for both)
         if (tid < NT / 2) s_w[tid] = 0;
@@ -906,7 +914,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
         //   s_dd   duplicate filter (open addressing; entry = staged slot + 1 | 22 hash bits); lives in s_cmap, which is only
         //          needed once the staged records are cut into chunks -- after that the filter is rebuilt from scratch
         //   s_nst  staged records; a round accepts min(NT - s_nst, remaining) incoming records, so every one of them finds room
-        constexpr uint64_t COLOUR_BITS = 31ull << 15;
+        constexpr uint64_t COLOUR_BITS = 63ull << 15;
         constexpr uint32_t MIN_ROOM = NT / 8;           // keep filling while the rest of the bin, or at least this many records, still fit
         constexpr uint32_t MAX_FILLS = 100;             // weights are 16-bit: at most NT per round, 100 x 512 < 65536
         uint32_t rnext = 0;                             // next incoming record of the bin (uniform)
@@ -933,7 +941,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                 // published spent a third of the staging phase's lane iterations doing that: a bin's ~18 copies of each piece
                 // arrive together.)
                 bool pend = tid < take;
-                uint32_t mytag = 0, sl = 0, colour = 0;
+                uint32_t mytag = 0, sl = 0;
+                cmask_t colour = 0;
                 const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);               // word holding the meta bits
                 if (pend) {
                     pmeta = PL0 & ((1ull << META_BITS) - 1);
@@ -948,7 +957,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                     if (NBW == 4) { ha += P2 * 0x9E3779B97F4A7C15ull; hb += lastw * 0xC2B2AE3D27D4EB4Full; }
                     const uint64_t h = hash_key(ha, hb);
                     mytag = (uint32_t)(h >> 42) << 10;
-                    colour = 1u << ((uint32_t)(pmeta >> 15) & 31u);
+                    colour = (cmask_t)1 << ((uint32_t)(pmeta >> 15) & (WIDE ? 63u : 31u));
                     sl = (uint32_t)h & (DD - 1);
                 }
                 bool bad_round = false;
@@ -1081,7 +1090,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                         WL &= ~((1ull << META_BITS) - 1);
                     }
                     const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu;
-                    const uint32_t wgt = (s_w[r >> 1] >> (16 * (r & 1u))) & 0xffffu, cset = IS_SET ? s_cmk[r] << 8 : 0u;
+                    const uint32_t wgt = (s_w[r >> 1] >> (16 * (r & 1u))) & 0xffffu;
+                    const cmask_t cmr = IS_SET ? s_cmk[r] : (cmask_t)0;
+                    const uint32_t cset = WIDE ? (uint32_t)cmr : (uint32_t)cmr << 8, cset2 = WIDE ? (uint32_t)((unsigned long long)cmr >> 32) : 0u;
                     // the record's chunking, as stage A cut it: ceil(nk/4) chunks of cbase (+1 for the first crem) k-mers
                     static_assert(CH == 4, "closed form of nk / ceil(nk / CH)");
                     const uint32_t rnk = rlen - (uint32_t)k + 1u, rnch = (rnk + 3u) >> 2;
@@ -1109,7 +1120,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                         nx = (uint32_t)(v >> 32);
                     }
                     MARK("chunk_setup_done");
-                    if (DBG_ABL_COUNT == 5) { if (fw.lo + rcw.hi + lb + nx + wgt + cset + rexts == 0x1234567u) s_flag[1] = 7; continue; }
+                    if (DBG_ABL_COUNT == 5) { if (fw.lo + rcw.hi + lb + nx + wgt + cset + cset2 + rexts == 0x1234567u) s_flag[1] = 7; continue; }
                     while (__any(j < jend)) {
                         const bool alive = j < jend;
 #ifdef DBG_COUNT_STATS
@@ -1188,7 +1199,11 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                             }
                             if (hit) {
                                 atomicAdd(&s_cnt[slot], wgt);
-                                atomicOr(&s_aux[slot], ex | cset);
+                                if (WIDE) {
+                                    atomicOr(&s_aux[slot], cset);
+                                    if (cset2) atomicOr(&s_aux2[slot], cset2);
+                                    atomicOr(&s_ex4[slot >> 2], ex << (8u * (slot & 3u)));
+                                } else atomicOr(&s_aux[slot], ex | cset);
                             } else {
                                 __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // table full: the pass is re-split
                             }
@@ -1281,7 +1296,11 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                         const uint64_t q = o + (uint32_t)__popcll(vb[it] & lt_mask);
                         const uint32_t c = s_cnt[i];
                         const uint32_t c16 = c > 65535u ? 65535u : c;
-                        const uint32_t pay = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
+                        uint32_t pay = IS_SET ? s_aux[i] : ((s_aux[i] & 0xffu) | (c16 << 8));
+                        if (WIDE) {                                          // the payload names the record; Exts and colours wait at that position
+                            out.w_rec[q] = make_uint4(s_aux[i], s_aux2[i], (s_ex4[i >> 2] >> (8u * (i & 3u))) & 0xffu, 0u);
+                            pay = (uint32_t)q;
+                        }
                         if (out.rec16) {
                             const uint64_t klo = KW == 2 ? s_key[2 * i] : s_key[i], khi = KW == 2 ? s_key[2 * i + 1] : 0ull;
                             out.rec16[q] = make_uint4((uint32_t)klo, (uint32_t)(klo >> 32), (uint32_t)khi, pay);
@@ -1314,27 +1333,41 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
 // lanes round-robin inside a wave (entry = wave base + r*64 + lane), so loads, set_off stores and -- because neighbouring
 // lanes own neighbouring output ranges -- set_val stores are all coalesced.
 constexpr int CSR_THREADS = 256, CSR_ITEMS = 8, CSR_TILE = CSR_THREADS * CSR_ITEMS;
-__global__ void __launch_bounds__(CSR_THREADS) csr_partials_kernel(const uint32_t* __restrict__ msk, uint32_t n, uint64_t* __restrict__ partial) {
+__device__ __forceinline__ uint32_t popc_mask(uint32_t m) { return (uint32_t)__popc(m); }
+__device__ __forceinline__ uint32_t popc_mask(unsigned long long m) { return (uint32_t)__popcll(m); }
+__device__ __forceinline__ uint32_t ffs_mask(uint32_t m) { return (uint32_t)__ffs((int)m) - 1u; }
+__device__ __forceinline__ uint32_t ffs_mask(unsigned long long m) { return (uint32_t)__ffsll((long long)m) - 1u; }
+template <class M>
+__global__ void __launch_bounds__(CSR_THREADS) csr_partials_kernel(const M* __restrict__ msk, uint32_t n, uint64_t* __restrict__ partial) {
     __shared__ uint32_t s_w[CSR_THREADS / 64];
     const uint32_t base = blockIdx.x * CSR_TILE + threadIdx.x;
     uint32_t s = 0;
 #pragma unroll
-    for (int i = 0; i < CSR_ITEMS; i++) { const uint32_t e = base + i * CSR_THREADS; if (e < n) s += __popc(msk[e]); }
+    for (int i = 0; i < CSR_ITEMS; i++) { const uint32_t e = base + i * CSR_THREADS; if (e < n) s += popc_mask(msk[e]); }
     for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (uint64_t)s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const uint32_t* __restrict__ msk, uint32_t n, const uint64_t* __restrict__ partial_scanned,
+template <class M>
+__global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const M* __restrict__ msk, uint32_t n, const uint64_t* __restrict__ partial_scanned,
                                                                 uint64_t* __restrict__ set_off, uint32_t* __restrict__ set_val, LabelInv inv) {
+    // A wave takes 64 entries per round.  Their labels -- up to 64 x 64 -- are first laid out in entry order in the wave's LDS
+    // staging area as colour indices (one byte each: every lane walks the bits of its own mask, scattered LDS byte stores), then
+    // leave as coalesced stores (consecutive lanes, consecutive labels).  (Storing straight from the bit walk makes every store
+    // instruction touch 64 different cache lines: 26 ms for 6.7e9 labels at 24 colours, against 4 ms at 4.)
+    constexpr uint32_t STAGE = sizeof(M) * 8 * 64;
     __shared__ uint32_t s_w[CSR_THREADS / 64];
-    __shared__ uint32_t s_inv[24];
-    if (threadIdx.x < 24) s_inv[threadIdx.x] = inv.on ? inv.v[threadIdx.x] : threadIdx.x;
+    __shared__ uint32_t s_inv[64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[CSR_THREADS / 64][STAGE + 16];
+    if (threadIdx.x < 64) s_inv[threadIdx.x] = inv.on ? inv.v[threadIdx.x] : threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wbase = blockIdx.x * CSR_TILE + wave * (64 * CSR_ITEMS);
-    uint32_t m[CSR_ITEMS], s = 0;
+    uint8_t* st = s_stage[wave];
+    M m[CSR_ITEMS];
+    uint32_t s = 0;
 #pragma unroll
-    for (int r = 0; r < CSR_ITEMS; r++) { const uint32_t e = wbase + r * 64 + lane; m[r] = e < n ? msk[e] : 0u; s += __popc(m[r]); }
+    for (int r = 0; r < CSR_ITEMS; r++) { const uint32_t e = wbase + r * 64 + lane; m[r] = e < n ? msk[e] : (M)0; s += popc_mask(m[r]); }
     uint32_t wtot = s;
     for (int d = 32; d; d >>= 1) wtot += __shfl_xor(wtot, d);
     if (lane == 0) s_w[wave] = wtot;
@@ -1344,17 +1377,35 @@ __global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const uint32_t* 
 #pragma unroll
     for (int r = 0; r < CSR_ITEMS; r++) {
         const uint32_t e = wbase + r * 64 + lane;
-        const uint32_t c = __popc(m[r]);
+        const uint32_t c = popc_mask(m[r]);
         const uint32_t incl = wave_inclusive_scan_u32(c);            // DPP: no traffic through the LDS crossbar
-        uint64_t o = run + incl - c;
-        if (e < n) {
-            set_off[e] = o;
-            uint32_t x = m[r];
-            while (x) { set_val[o++] = s_inv[(uint32_t)__ffs((int)x) - 1u]; x &= x - 1; }   // ascending = sort(); dedup() (the map keeps the labels' order)
+        const uint32_t P = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (e < n) set_off[e] = run + incl - c;
+        uint32_t o = incl - c;
+        M x = m[r];
+        while (x) { st[o++] = (uint8_t)ffs_mask(x); x &= x - 1; }    // ascending = sort(); dedup() (the map keeps the labels' order)
+        // (one wave: its LDS operations are performed in order, the stores above precede the loads below)
+        for (uint32_t jb = 0; jb < P; jb += 256) {
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) {                       // every store instruction covers 256 contiguous bytes
+                const uint32_t j = jb + t * 64 + lane;
+                if (j < P) set_val[run + j] = s_inv[st[j]];
+            }
         }
-        run += __shfl(incl, 63);
+        run += P;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) set_off[n] = partial_scanned[gridDim.x];      // total = the scan's last entry
+}
+// WIDE colour sets: after the sort the payload columns spell the record's position in the unsorted output (Exts column = low byte,
+// mask column = the other 24 bits); Exts and the 64-bit colour mask are fetched from there
+__global__ void __launch_bounds__(256) wide_gather_kernel(uint32_t n, uint8_t* __restrict__ exts_io, const uint32_t* __restrict__ q_hi24,
+                                                          const uint4* __restrict__ w_rec, unsigned long long* __restrict__ mask_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t q = (uint32_t)exts_io[i] | (q_hi24[i] << 8);
+    const uint4 r = w_rec[q];                                       // one line per entry
+    exts_io[i] = (uint8_t)r.z;
+    mask_out[i] = (unsigned long long)r.x | ((unsigned long long)r.y << 32);
 }
 __global__ void __launch_bounds__(256) max_label_kernel(const void* data, uint32_t width, uint64_t n, uint32_t* out) {
     // grid-stride maximum of the D1 labels; one atomic per workgroup
@@ -1396,6 +1447,7 @@ struct FastPlan {
     int k, p, nbw, rw;
     bool stranded, is_set, has_hi;
     bool wave = false;                                  // bins sized for the wave-per-bin counting kernel (256-entry tables)
+    bool wide = false;                                  // colour sets of 25..64 colours: two mask words per table entry, payload gathered after the sort
     uint32_t nbins;
     LabelInv linv = {};
     const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
@@ -1455,12 +1507,13 @@ __global__ void __launch_bounds__(256) label_presence_kernel(const void* data, u
     for (int i = threadIdx.x; i < 2049; i += 256) if (s_b[i]) atomicOr(&bitmap[i], s_b[i]);
 }
 
-// The LDS colour bitmask holds 24 colours: labels < 24 are their own colour; a sparse alphabet of at most 24 distinct labels
-// (all < 65536) is mapped to colour indices in increasing label order and mapped back when the label sets are written.
+// The LDS colour bitmask holds 24 colours next to the Exts, or 64 in the WIDE layout of the counting kernel: labels below that are
+// their own colour; a sparse alphabet of at most 64 distinct labels (all < 65536) is mapped to colour indices in increasing label
+// order and mapped back when the label sets are written.
 // lmap_buf receives the device table (it must outlive the scan).
 static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<uint8_t>* lmap_buf, bool* ok) {
     *ok = false;
-    pl->linv.on = 0; pl->lmap = nullptr;
+    pl->linv.on = 0; pl->lmap = nullptr; pl->wide = false;
     if (!s.data) return 0;
     DBuf<uint32_t> mx;
     ALLOC_OR_FAIL(c, mx, 1);
@@ -1470,6 +1523,7 @@ static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<u
     HIP_TRY(c, hipMemcpyAsync(&h, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (h < 24) { *ok = true; return 0; }
+    if (h < 64) { pl->wide = true; *ok = true; return 0; }
     if (h >= 65536u) return 0;
     DBuf<uint32_t> bm;
     ALLOC_OR_FAIL(c, bm, 2049);
@@ -1484,7 +1538,7 @@ static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<u
     uint32_t nd = 0;
     for (uint32_t v = 0; v <= h; v++) {
         if (hb[v >> 5] & (1u << (v & 31))) {
-            if (nd == 24) return 0;                         // more than 24 distinct labels: the generic path
+            if (nd == 64) return 0;                         // more than 64 distinct labels: the generic path
             pl->linv.v[nd] = v;
             map[v] = (uint8_t)nd++;
         }
@@ -1493,6 +1547,7 @@ static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<u
     HIP_TRY(c, hipMemcpyAsync(lmap_buf->p, map.data(), map.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));            // `map` leaves scope
     pl->linv.on = 1; pl->lmap = lmap_buf->p;
+    pl->wide = nd > 24;
     *ok = true;
     return 0;
 }
@@ -1501,7 +1556,7 @@ static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
     FastPlan tmp;
     DBuf<uint8_t> unused;
     DBG_TRY(fast_labels_prepare(c, s, &tmp, &unused, ok));
-    if (tmp.linv.on) *ok = false;
+    if (tmp.linv.on || tmp.wide) *ok = false;
     return 0;
 }
 
@@ -1638,6 +1693,7 @@ struct FastCountState {
     DBuf<uint32_t> u_pay, gflags;
     DBuf<uint4> u16;                       // k <= 48: 16-byte records instead of the three arrays
     bool use16 = false;
+    DBuf<uint4> w_rec;                     // WIDE colour sets: 64-bit colour mask + Exts by output position
     DBuf<unsigned long long> out_cursor;
     // report_all_kmers: every distinct key
     bool report_all = false;
@@ -1663,6 +1719,15 @@ static int fast_count_alloc_all(dbg_ctx* c, FastCountState* st, uint64_t cap) {
 
 static int fast_count_alloc(dbg_ctx* c, FastCountState* st, uint64_t cap) {
     if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+    if (st->pl.wide) {
+        DBuf<uint4> nr;
+        ALLOC_OR_FAIL(c, nr, cap);
+        if (st->n_out) {
+            HIP_TRY(c, hipMemcpyAsync(nr.p, st->w_rec.p, st->n_out * 16, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        std::swap(st->w_rec, nr);
+    }
     if (st->use16) {
         DBuf<uint4> n16;
         ALLOC_OR_FAIL(c, n16, cap);
@@ -1729,7 +1794,7 @@ static int fast_close_holes(dbg_ctx* c, FastCountState* st, const WaveHole* hole
     holes_dest_scan_kernel<<<1, 1024, 0, c->stream>>>(holes_dev, nh, V, dpre.p);
     LAUNCH_CHECK(c, "holes_dest_scan");
     DBG_TRY(scan_exclusive_u32(c, marks.p, mpre.p, tail));
-    FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, nullptr, nullptr, nullptr, 0};
+    FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (st->use16) holes_move_kernel<true><<<cdiv(tail, 256), 256, 0, c->stream>>>(holes_dev, nh, V, (uint32_t)tail, marks.p, mpre.p, dpre.p, fo, st->pl.has_hi ? 1 : 0);
     else holes_move_kernel<false><<<cdiv(tail, 256), 256, 0, c->stream>>>(holes_dev, nh, V, (uint32_t)tail, marks.p, mpre.p, dpre.p, fo, st->pl.has_hi ? 1 : 0);
     c->t_end();
@@ -1753,11 +1818,12 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         HIP_TRY(c, hipMemcpyAsync(st->out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
         if (st->report_all) HIP_TRY(c, hipMemcpyAsync(st->all_cursor.p, &start_all, 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(st->gflags.p, 0, 64, c->stream));
-        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, st->report_all ? st->a_hi.p : nullptr, st->report_all ? st->a_lo.p : nullptr,
+        FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, st->w_rec.p,
+                   st->report_all ? st->a_hi.p : nullptr, st->report_all ? st->a_lo.p : nullptr,
                    st->report_all ? st->all_cursor.p : nullptr, st->all_cap};
         unsigned long long* out_cursor_p = st->out_cursor.p;
         uint32_t* gflags_p = st->gflags.p;
-        const bool wave_mode = pl.wave && !st->report_all;      // (the all-k-mers list leaves through the workgroup kernel)
+        const bool wave_mode = pl.wave && !st->report_all && !pl.wide;   // (the all-k-mers list and the wide colour sets leave through the workgroup kernel)
         uint32_t n_waves = 0;
         DBuf<WaveHole> holes;
         if (nbins_local && wave_mode) {
@@ -1796,14 +1862,18 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
             const size_t dyn_lds = c->opt("DBG_DYN_LDS") ? (size_t)atoi(c->opt("DBG_DYN_LDS")) : 0;   // measurement: extra LDS per workgroup (8192 leaves room for only one per CU)
 #define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, dyn_lds, c->stream>>>( \
             recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
+#define LW(KW, NBW) bin_count_kernel<KW, NBW, true, 512, 1024, true><<<nbins_local, 512, dyn_lds, c->stream>>>( \
+            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
 #define GO(KW, NBW, SET) do { \
-            if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
+            if (SET && pl.wide) LW(KW, NBW); \
+            else if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
             else L(KW, NBW, SET, 512, TABLE); } while (0)
             if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
             else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
             else if (nbw == 3) { if (is_set) GO(2, 3, true); else GO(2, 3, false); }
             else { if (is_set) GO(2, 4, true); else GO(2, 4, false); }
 #undef GO
+#undef LW
 #undef L
             c->t_end();
             LAUNCH_CHECK(c, "bin_count");
@@ -1880,18 +1950,28 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
     } else
     DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, is_set, !c->opt("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, o_count.p,
                               nullptr, msk_sorted.p));
+    DBuf<unsigned long long> msk64;
+    if (is_set && pl.wide) {
+        ALLOC_OR_FAIL(c, msk64, na);
+        c->t_begin("wide_gather", n_out);
+        wide_gather_kernel<<<cdiv(na, 256), 256, 0, c->stream>>>((uint32_t)n_out, o_exts.p, msk_sorted.p, st->w_rec.p, msk64.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "wide_gather");
+    }
     if (is_set) {
         const uint32_t nb = cdiv(std::max<uint64_t>(n_out, 1), CSR_TILE);
         DBuf<uint64_t> part, part_sc;
         ALLOC_OR_FAIL(c, part, nb); ALLOC_OR_FAIL(c, part_sc, (size_t)nb + 1);
-        csr_partials_kernel<<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part.p);
+        if (pl.wide) csr_partials_kernel<unsigned long long><<<nb, CSR_THREADS, 0, c->stream>>>(msk64.p, (uint32_t)n_out, part.p);
+        else csr_partials_kernel<uint32_t><<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part.p);
         LAUNCH_CHECK(c, "csr_partials");
         DBG_TRY(scan_exclusive_u64(c, part.p, part_sc.p, nb));
         HIP_TRY(c, hipMemcpyAsync(&n_setval, part_sc.p + nb, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         ALLOC_OR_FAIL(c, o_set_val, std::max<uint64_t>(n_setval, 1));
         c->t_begin("set_csr", n_out);
-        csr_apply_kernel<<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part_sc.p, o_set_off.p, o_set_val.p, pl.linv);
+        if (pl.wide) csr_apply_kernel<unsigned long long><<<nb, CSR_THREADS, 0, c->stream>>>(msk64.p, (uint32_t)n_out, part_sc.p, o_set_off.p, o_set_val.p, pl.linv);
+        else csr_apply_kernel<uint32_t><<<nb, CSR_THREADS, 0, c->stream>>>(msk_sorted.p, (uint32_t)n_out, part_sc.p, o_set_off.p, o_set_val.p, pl.linv);
         c->t_end();
         LAUNCH_CHECK(c, "csr_apply");
     }
@@ -1982,6 +2062,9 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     if (!fast_make_plan(c, (int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
     DBuf<uint8_t> lmap_buf;
     if (is_set) { bool ok; DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok)); if (!ok) return 0; }
+    // the WIDE colour-set layout keeps two more words per table entry: with 1024-entry tables two workgroups still share a CU's
+    // LDS, so its bins are half the size
+    if (pl.wide && !c->opt("DBG_FAST_TARGET")) pl.nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl.nbins * 2, (1ull << 23) - 1);
     FastScan st;
     DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
     const uint32_t nb = pl.nbins * NCLS;

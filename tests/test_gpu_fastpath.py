@@ -114,9 +114,9 @@ def test_fast_equals_generic_on_synthetic_stream(ctx):
 
 def test_fast_path_refuses_unsupported_shapes(ctx):
     rng = np.random.default_rng(1)
-    seqs = random_reads(rng, 50, 1000, 150, False)
-    ss = O.SeqSet.from_byte_seqs(seqs, data=rng.integers(40, 300, size=50), sizeof_d1=2)
-    with pytest.raises(dbg.DbgError):           # labels >= 24 need the generic (sort-based) CountFilterSet
+    seqs = random_reads(rng, 200, 1000, 150, False)
+    ss = O.SeqSet.from_byte_seqs(seqs, data=np.arange(200) * 7 + 40, sizeof_d1=2)
+    with pytest.raises(dbg.DbgError):           # more than 64 distinct labels need the generic (sort-based) CountFilterSet
         dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     ctx.set_option("DBG_PATH", "auto")
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
@@ -264,3 +264,35 @@ def test_fast_sparse_label_alphabet(ctx, k, width, labels):
     data = np.asarray(labels)[rng.integers(0, len(labels), size=len(seqs))]
     ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=width)
     run_fast(ctx, ss, k, O.COUNT_FILTER_SET, 2, False, data_width=width)
+
+
+@pytest.mark.parametrize("k,width,labels", [(47, 1, list(range(40))), (31, 1, list(range(64))), (63, 2, list(range(500, 30000, 470))),
+                                            (51, 1, [0, 23, 24, 31, 32, 33, 62, 63]), (33, 4, list(range(7, 70, 1)))])
+def test_fast_wide_colour_sets(ctx, k, width, labels):
+    """CountFilterSet with 25..64 colours (labels < 64, or a sparse alphabet of at most 64 distinct labels < 65536): the WIDE
+    layout of the counting kernel -- two colour words + an Exts byte per table entry, the sort carries the record's position and
+    Exts / colours are gathered afterwards -- must give the reference's sorted, de-duplicated label lists (filter.rs:85-100).
+    Several copies of every read in different colours make multi-label sets the rule."""
+    rng = np.random.default_rng(k + width + len(labels))
+    base = random_reads(rng, 250, 2500, 150, False)
+    seqs = [b for b in base for _ in range(4)]
+    data = np.asarray(labels)[rng.integers(0, len(labels), size=len(seqs))]
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=width)
+    got = run_fast(ctx, ss, k, O.COUNT_FILTER_SET, 2, False, data_width=width)
+    sizes = np.diff(got.set_off)
+    assert int(sizes.max()) >= 3 and int(got.set_val.max()) == max(labels)
+    if len(labels) > 24:
+        assert int(got.set_val.max()) >= 24                                   # the wide layout was needed
+
+
+def test_more_than_64_labels_take_the_generic_path(ctx):
+    rng = np.random.default_rng(3)
+    seqs = random_reads(rng, 300, 2000, 150, False)
+    data = rng.integers(0, 200, size=len(seqs))
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1)
+    want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
+    with ctx.options(DBG_PATH="auto"):
+        got, _ = dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+    assert_tables_equal(got, want, True)
+    with pytest.raises(dbg.DbgError):                                           # DBG_PATH=fast must not fall back silently
+        dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
