@@ -291,7 +291,12 @@ typedef struct {
                                    same value); out of dbg_shard_plan_make: bins */
     uint32_t rec_words;         /* out: u64 words per super-k-mer record */
     uint32_t bin_group;         /* out: ownership boundaries must be multiples of this many bins */
+    uint32_t max_label;         /* CountFilterSet: largest D1 label over ALL ranks (dbg_seqset_max_label_dev + a max-reduction);
+                                   labels must be < 64 here -- 24..63 select the two-word colour layout on every rank.
+                                   0 = "below 24" (what callers of the earlier ABI passed) */
 } dbg_shard_plan;
+/* largest D1 label of a device-resident sequence set (0 when it carries no data) */
+int  dbg_seqset_max_label_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t* max_label_out);
 
 int  dbg_count_kmer_instances_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t k, uint64_t* n_out);
 int  dbg_shard_plan_make(dbg_ctx* ctx, dbg_shard_plan* plan);

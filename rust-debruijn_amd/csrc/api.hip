@@ -139,9 +139,19 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
 
     uint64_t n_kmers = 0;
     DBG_TRY(kmer_total(c, s, k, &n_kmers));                  // the fast path needs the total only
+    {   // short k-mers: directly addressed tables (densepath.hip); DBG_PATH=dense insists on it
+        const char* force = c->opt("DBG_PATH");
+        const bool want_dense = !force || !strcmp(force, "auto") || !strcmp(force, "dense");
+        if (want_dense) {
+            bool used = false;
+            DBG_TRY(filter_kmers_dense(c, s, p, n_kmers, out, &used));
+            if (used) return 0;
+            if (force && !strcmp(force, "dense")) return c->fail(21, "DBG_PATH=dense but the dense path does not support this call shape (4 <= k <= 15, labels < 64)");
+        }
+    }
     {   // fast path: super-k-mer bins + LDS hash tables (fastpath.hip); DBG_PATH=generic|fast|auto overrides
         const char* force = c->opt("DBG_PATH");
-        bool want_fast = !(force && !strcmp(force, "generic"));
+        bool want_fast = !(force && (!strcmp(force, "generic") || !strcmp(force, "dense")));
         if (want_fast) {
             bool used = false;
             DBG_TRY(filter_kmers_fast(c, s, p, n_kmers, out, &used));

@@ -99,6 +99,10 @@ int reduce_sorted_records(dbg_ctx* ctx, uint64_t n, RecArrays sorted, bool has_h
 int filter_kmers_fast(dbg_ctx* ctx, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
                       bool* used);
 
+// ---- densepath.hip : directly addressed tables for 4 <= k <= 15 ------------------------------------
+int filter_kmers_dense(dbg_ctx* ctx, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
+                       bool* used);
+
 // ---- classes.hip : label lists of a CountFilterSet table -> dense class ids ---------------------
 int label_classes_device(dbg_ctx* ctx, uint64_t n, const uint64_t* set_off_dev, const uint32_t* set_val_dev, uint64_t n_set_val,
                          uint32_t* class_dev, dbg_label_classes* classes);

@@ -1,0 +1,218 @@
+// Dense path of filter_kmers (src/filter.rs:139-231) for short k-mers, 4 <= k <= 15.
+//
+// The super-k-mer fast path needs k >= 16 (its internal minimizers are 15 bases), and the generic sort-based path moves one
+// 12-byte record per k-mer instance through several radix passes (measured 3 Gkmer/s).  For k <= 15 the whole key space --
+// 4^k <= 2^30 canonical values -- fits in HBM as a directly addressed table: count (u32), Exts (one byte) and, for
+// CountFilterSet, a 64-bit label mask per possible k-mer (14 GB at k = 15).  One wavefront walks a read 64 k-mers at a time
+// (iter_kmer_exts + min_rc_flip + Exts::rc, lib.rs:812-841, :224-231, :729-748, exactly as the generic extractor) and does
+// count += 1 / Exts |= e / mask |= 1 << label (CountFilter / CountFilterSet::summarize, filter.rs:53-62, :85-100) with global
+// atomics; Exts and label bits are only sent when a plain load shows them missing, which after the first few reads is almost
+// never.  The table index IS the key, so one compaction pass over the table emits the valid entries in ascending key order
+// (filter.rs:205-230) -- no sort.  Very short k-mers (k <= 7: at most 16384 entries) are counted in per-workgroup LDS tables
+// first, because a few thousand hot addresses would serialise the device's atomic units.
+#include "dbg_internal.hpp"
+#include <algorithm>
+
+int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out);      // fastpath.hip
+
+namespace {
+constexpr int DENSE_LDS_K = 7;                  // k <= 7: 4^k x u32 fits a workgroup's LDS
+
+__device__ __forceinline__ uint32_t load_label(const void* data, uint32_t width, uint64_t i) {
+    if (width == 1) return ((const uint8_t*)data)[i];
+    if (width == 2) return ((const uint16_t*)data)[i];
+    return ((const uint32_t*)data)[i];
+}
+
+template <bool STRANDED, bool IS_SET, bool LDS_COUNT>
+__global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, uint32_t* __restrict__ cnt, uint32_t* __restrict__ ex4,
+                                                          unsigned long long* __restrict__ mask) {
+    extern __shared__ uint32_t s_cnt[];                              // LDS_COUNT: 4^k counters of this workgroup
+    const uint32_t nkeys = 1u << (2 * k);
+    if (LDS_COUNT) {
+        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t si = wave; si < s.n; si += n_waves) {
+        const uint32_t len = s.length[si];
+        if (len < (uint32_t)k) continue;                                       // lib.rs:813
+        const uint64_t st = s.start[si];
+        const uint32_t nk = len - (uint32_t)k + 1;
+        const uint32_t sexts = s.exts ? s.exts[si] : 0u;
+        unsigned long long lbit = 0;
+        if (IS_SET) lbit = 1ull << (s.data ? load_label(s.data, s.data_width, si) & 63u : 0u);
+        for (uint32_t j = lane; j < nk; j += 64) {
+            K128 km = packed_get_kmer(s.words, st + j, k);
+            // lib.rs:820-832: interior exts from the neighbouring bases, boundary exts from seq_exts
+            const uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << packed_get(s.words, st + j - 1));
+            const uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << packed_get(s.words, st + j + k));
+            uint32_t ex = left | right;
+            if (!STRANDED) {
+                const K128 rc = kmer_rc(km, k);
+                if (!k128_lt(km, rc)) { km = rc; ex = exts_rc(ex); }             // ties flip (lib.rs:226-230)
+            }
+            const uint32_t key = (uint32_t)km.lo;
+            if (LDS_COUNT) atomicAdd(&s_cnt[key], 1u); else atomicAdd(&cnt[key], 1u);
+            const uint32_t sh = 8u * (key & 3u), eb = ex << sh;
+            // (a stale cached value can only lack bits that are set by now: the atomic is then sent needlessly, never skipped wrongly)
+            if ((ex4[key >> 2] & eb) != eb) atomicOr(&ex4[key >> 2], eb);
+            if (IS_SET && (mask[key] & lbit) == 0) atomicOr(&mask[key], lbit);
+        }
+    }
+    if (LDS_COUNT) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) { const uint32_t v = s_cnt[i]; if (v) atomicAdd(&cnt[i], v); }
+    }
+}
+
+// valid / occupied entries per tile of 1024 table slots
+constexpr uint32_t DT = 1024;
+template <bool IS_SET>
+__global__ void __launch_bounds__(256) dense_tile_counts_kernel(const uint32_t* __restrict__ cnt, const unsigned long long* __restrict__ mask,
+                                                                uint32_t nkeys, uint64_t min_obs, uint32_t* __restrict__ n_valid,
+                                                                uint32_t* __restrict__ n_all, uint32_t* __restrict__ n_lab) {
+    __shared__ uint32_t s_v[4], s_a[4], s_l[4];
+    uint32_t v = 0, a = 0, l = 0;
+    for (uint32_t t = 0; t < DT / 256; t++) {
+        const uint32_t i = blockIdx.x * DT + t * 256 + threadIdx.x;
+        if (i < nkeys) {
+            const uint32_t c = cnt[i];
+            const bool ok = c && (IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs);
+            a += c ? 1u : 0u; v += ok ? 1u : 0u;
+            if (IS_SET && ok) l += (uint32_t)__popcll(mask[i]);
+        }
+    }
+    for (int d = 32; d; d >>= 1) { v += __shfl_xor(v, d); a += __shfl_xor(a, d); l += __shfl_xor(l, d); }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = v; s_a[threadIdx.x >> 6] = a; s_l[threadIdx.x >> 6] = l; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n_valid[blockIdx.x] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        n_all[blockIdx.x] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        n_lab[blockIdx.x] = s_l[0] + s_l[1] + s_l[2] + s_l[3];
+    }
+}
+
+// one wavefront per tile walks its 1024 slots in order, 64 at a time: ranks by ballot, output ascending by key
+template <bool IS_SET>
+__global__ void __launch_bounds__(64) dense_emit_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ex4,
+                                                        const unsigned long long* __restrict__ mask, uint32_t nkeys, uint64_t min_obs,
+                                                        const uint64_t* __restrict__ off_valid, const uint64_t* __restrict__ off_all,
+                                                        const uint64_t* __restrict__ off_lab, uint32_t n_tiles,
+                                                        uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo, uint8_t* __restrict__ exts,
+                                                        uint16_t* __restrict__ count, uint64_t* __restrict__ set_off, uint32_t* __restrict__ set_val,
+                                                        uint64_t* __restrict__ all_hi, uint64_t* __restrict__ all_lo) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lt = lanemask_lt();
+    uint64_t ov = off_valid[blockIdx.x], oa = off_all[blockIdx.x], ol = IS_SET ? off_lab[blockIdx.x] : 0;
+    for (uint32_t t = 0; t < DT / 64; t++) {
+        const uint32_t i = blockIdx.x * DT + t * 64 + lane;
+        uint32_t c = 0;
+        if (i < nkeys) c = cnt[i];
+        const bool occ = c != 0;
+        const bool ok = occ && (IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs);
+        const uint64_t bo = __ballot(occ), bv = __ballot(ok);
+        if (all_lo && occ) { const uint64_t q = oa + (uint32_t)__popcll(bo & lt); all_lo[q] = i; if (all_hi) all_hi[q] = 0; }
+        unsigned long long m = 0;
+        uint32_t nl = 0;
+        if (IS_SET && ok) { m = mask[i]; nl = (uint32_t)__popcll(m); }
+        uint32_t incl = nl;
+        if (IS_SET) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        }
+        if (ok) {
+            const uint64_t q = ov + (uint32_t)__popcll(bv & lt);
+            key_lo[q] = i;
+            if (key_hi) key_hi[q] = 0;
+            exts[q] = (uint8_t)(ex4[i >> 2] >> (8u * (i & 3u)));
+            if (IS_SET) {
+                uint64_t o = ol + incl - nl;
+                set_off[q] = o;
+                while (m) { set_val[o++] = (uint32_t)__ffsll((long long)m) - 1u; m &= m - 1; }   // ascending = sort(); dedup() (filter.rs:97-98)
+            } else count[q] = (uint16_t)(c > 65535u ? 65535u : c);                                  // saturating count (filter.rs:57)
+        }
+        ov += (uint32_t)__popcll(bv); oa += (uint32_t)__popcll(bo);
+        if (IS_SET) ol += (uint32_t)__shfl((int)incl, 63);
+    }
+    if (IS_SET && blockIdx.x == n_tiles - 1 && lane == 0) set_off[ov] = ol;
+}
+}  // namespace
+
+// returns 0 and sets *used when the dense path produced the table (4 <= k <= 15, labels < 64)
+int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out, bool* used) {
+    *used = false;
+    const int k = (int)prm->k;
+    if (k < 4 || k > 15) return 0;
+    const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET, stranded = prm->stranded != 0, report_all = prm->report_all_kmers != 0;
+    if (is_set && s.data) {
+        uint32_t mx = 0;
+        DBG_TRY(seq_max_label(c, s, &mx));
+        if (mx >= 64) return 0;                                      // the label mask holds 64 labels: larger alphabets take the generic path
+    }
+    const uint32_t nkeys = 1u << (2 * k);
+    const uint32_t n_tiles = cdiv(nkeys, DT);
+    DBuf<uint32_t> cnt, ex4, t_valid, t_all, t_lab;
+    DBuf<unsigned long long> mask;
+    DBuf<uint64_t> o_valid, o_all, o_lab;
+    ALLOC_OR_FAIL(c, cnt, nkeys); ALLOC_OR_FAIL(c, ex4, std::max(nkeys / 4, 1u));
+    if (is_set) ALLOC_OR_FAIL(c, mask, nkeys);
+    ALLOC_OR_FAIL(c, t_valid, n_tiles); ALLOC_OR_FAIL(c, t_all, n_tiles); ALLOC_OR_FAIL(c, t_lab, n_tiles);
+    ALLOC_OR_FAIL(c, o_valid, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_all, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_lab, (size_t)n_tiles + 1);
+    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, (size_t)nkeys * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ex4.p, 0, (size_t)std::max(nkeys / 4, 1u) * 4, c->stream));
+    if (is_set) HIP_TRY(c, hipMemsetAsync(mask.p, 0, (size_t)nkeys * 8, c->stream));
+    if (s.n && n_kmers) {
+        const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 3) / 4, 256ull * 16));
+        const bool lds = k <= DENSE_LDS_K;
+        const size_t shm = lds ? (size_t)nkeys * 4 : 0;
+        c->t_begin("dense_count", n_kmers);
+#define DL(ST, SET, LD) do { if (shm) HIP_TRY(c, hipFuncSetAttribute((const void*)dense_count_kernel<ST, SET, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+        dense_count_kernel<ST, SET, LD><<<blocks, 256, shm, c->stream>>>(s, k, cnt.p, ex4.p, mask.p); } while (0)
+#define DGO(ST, SET) do { if (lds) DL(ST, SET, true); else DL(ST, SET, false); } while (0)
+        if (stranded) { if (is_set) DGO(true, true); else DGO(true, false); }
+        else { if (is_set) DGO(false, true); else DGO(false, false); }
+#undef DGO
+#undef DL
+        c->t_end();
+        LAUNCH_CHECK(c, "dense_count");
+    }
+    c->t_begin("dense_compact", nkeys);
+    if (is_set) dense_tile_counts_kernel<true><<<n_tiles, 256, 0, c->stream>>>(cnt.p, mask.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);
+    else dense_tile_counts_kernel<false><<<n_tiles, 256, 0, c->stream>>>(cnt.p, mask.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);
+    LAUNCH_CHECK(c, "dense_tile_counts");
+    DBG_TRY(scan_exclusive_u32_u64(c, t_valid.p, o_valid.p, n_tiles));
+    DBG_TRY(scan_exclusive_u32_u64(c, t_all.p, o_all.p, n_tiles));
+    DBG_TRY(scan_exclusive_u32_u64(c, t_lab.p, o_lab.p, n_tiles));
+    uint64_t n_valid = 0, n_all = 0, n_lab = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_valid, o_valid.p + n_tiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&n_all, o_all.p + n_tiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&n_lab, o_lab.p + n_tiles, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    DBuf<uint64_t> k_hi, k_lo, a_hi, a_lo, set_off;
+    DBuf<uint8_t> exts;
+    DBuf<uint16_t> count;
+    DBuf<uint32_t> set_val;
+    const size_t nv = std::max<uint64_t>(n_valid, 1), na = std::max<uint64_t>(n_all, 1);
+    ALLOC_OR_FAIL(c, k_hi, nv); ALLOC_OR_FAIL(c, k_lo, nv); ALLOC_OR_FAIL(c, exts, nv);
+    if (is_set) { ALLOC_OR_FAIL(c, set_off, nv + 1); ALLOC_OR_FAIL(c, set_val, std::max<uint64_t>(n_lab, 1)); HIP_TRY(c, hipMemsetAsync(set_off.p, 0, 8, c->stream)); }
+    else ALLOC_OR_FAIL(c, count, nv);
+    if (report_all) { ALLOC_OR_FAIL(c, a_hi, na); ALLOC_OR_FAIL(c, a_lo, na); }
+    if (is_set) dense_emit_kernel<true><<<n_tiles, 64, 0, c->stream>>>(cnt.p, ex4.p, mask.p, nkeys, prm->min_kmer_obs, o_valid.p, o_all.p, o_lab.p, n_tiles,
+                                                                      k_hi.p, k_lo.p, exts.p, count.p, set_off.p, set_val.p, a_hi.p, a_lo.p);
+    else dense_emit_kernel<false><<<n_tiles, 64, 0, c->stream>>>(cnt.p, ex4.p, mask.p, nkeys, prm->min_kmer_obs, o_valid.p, o_all.p, o_lab.p, n_tiles,
+                                                                 k_hi.p, k_lo.p, exts.p, count.p, set_off.p, set_val.p, a_hi.p, a_lo.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "dense_emit");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memset(out, 0, sizeof(*out));
+    out->n = n_valid;
+    out->key_hi = k_hi.take(); out->key_lo = k_lo.take(); out->exts = exts.take(); out->count = count.take();
+    out->set_off = set_off.take(); out->set_val = set_val.take(); out->n_set_val = is_set ? n_lab : 0;
+    if (report_all) { out->n_all = n_all; out->all_hi = a_hi.take(); out->all_lo = a_lo.take(); }
+    out->n_kmer_instances = n_kmers; out->n_passes = 1; out->on_device = 1;
+    *used = true;
+    return 0;
+}

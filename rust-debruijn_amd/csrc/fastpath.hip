@@ -1551,12 +1551,16 @@ static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<u
     *ok = true;
     return 0;
 }
-// the sharded entry points keep the plain rule (every rank must use the same colours)
-static int fast_labels_ok(dbg_ctx* c, const SeqDev& s, bool* ok) {
-    FastPlan tmp;
-    DBuf<uint8_t> unused;
-    DBG_TRY(fast_labels_prepare(c, s, &tmp, &unused, ok));
-    if (tmp.linv.on || tmp.wide) *ok = false;
+int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out) {
+    *out = 0;
+    if (!s.data || !s.n) return 0;
+    DBuf<uint32_t> mx;
+    ALLOC_OR_FAIL(c, mx, 1);
+    HIP_TRY(c, hipMemsetAsync(mx.p, 0, 4, c->stream));
+    max_label_kernel<<<(uint32_t)std::min<uint64_t>(cdiv(s.n, 256), 2048), 256, 0, c->stream>>>(s.data, s.data_width, s.n, mx.p);
+    LAUNCH_CHECK(c, "max_label");
+    HIP_TRY(c, hipMemcpyAsync(out, mx.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -2118,7 +2122,18 @@ static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
     if (sp->n_bins % NCLS) return c->fail(144, "n_bins must be a multiple of bin_group");
     if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
         return c->fail(140, "sharded counting supports 16 <= k <= 64");
+    // every rank must use the same colour layout: it follows from the plan's global max_label (no per-rank label map here)
+    if (pl->is_set && sp->max_label >= 64) return c->fail(141, "sharded CountFilterSet needs labels < 64 (dbg_shard_plan.max_label)");
+    pl->wide = pl->is_set && sp->max_label >= 24;
+    if (pl->wide && !sp->n_bins && !c->opt("DBG_FAST_TARGET")) pl->nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl->nbins * 2, (1ull << 23) - 1);
     return 0;
+}
+
+extern "C" int dbg_seqset_max_label_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t* out) {
+    if (!ds || !out) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
+    return seq_max_label(c, s, out);
 }
 
 extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
@@ -2138,9 +2153,10 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     DBG_TRY(plan_from(c, sp, &pl));
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     if (pl.is_set) {
-        bool ok;
-        DBG_TRY(fast_labels_ok(c, s, &ok));
-        if (!ok) return c->fail(141, "sharded CountFilterSet needs u8/u16/u32 labels < 24");
+        uint32_t mx = 0;
+        DBG_TRY(seq_max_label(c, s, &mx));
+        if (mx >= 64 || mx > std::max(sp->max_label, 23u))
+            return c->fail(141, "sharded CountFilterSet: a label of this rank exceeds dbg_shard_plan.max_label (labels must be < 64, and max_label the maximum over all ranks)");
     }
     uint64_t n_kmers = 0;
     DBG_TRY(dbg_count_kmer_instances_dev(c, ds, sp->k, &n_kmers));

@@ -41,8 +41,13 @@ class HipEngine:
         self.ctx.check(self.lib.dbg_count_kmer_instances_dev(self.ctx.h, C.byref(ss), k, C.byref(n)))
         return n.value
 
-    def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers):
-        p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0, 0)
+    def max_label(self, ss):
+        m = C.c_uint32()
+        self.ctx.check(self.lib.dbg_seqset_max_label_dev(self.ctx.h, C.byref(ss), C.byref(m)))
+        return m.value
+
+    def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers, max_label=0):
+        p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0, 0, max_label)
         self.ctx.check(self.lib.dbg_shard_plan_make(self.ctx.h, C.byref(p)))
         return p
 
@@ -276,7 +281,14 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
         t = torch.tensor([n_local], dtype=torch.int64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         n_max = int(t.item())
-    plan = engine.plan(k, stranded, summarizer_kind, min_obs, total)
+    max_label = 0
+    if summarizer_kind == 1:                       # CountFilterSet: every rank must pick the same colour layout
+        max_label = engine.max_label(ss)
+        if world > 1:
+            t = torch.tensor([max_label], dtype=torch.int64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            max_label = int(t.item())
+    plan = engine.plan(k, stranded, summarizer_kind, min_obs, total, max_label)
     bin_off, n_recs = engine.scan(ss, plan)
     layout = None
     force = force_exchange and dist.is_initialized()

@@ -26,7 +26,10 @@ class OracleEngine:
     def count_instances(self, ss, k):
         return int(sum(max(0, int(l) - k + 1) for l in ss.length))
 
-    def plan(self, k, stranded, kind, min_obs, total):
+    def max_label(self, ss):
+        return int(ss.data.max()) if getattr(ss, "data", None) is not None and len(ss.data) else 0
+
+    def plan(self, k, stranded, kind, min_obs, total, max_label=0):
         return Plan(k, stranded, kind, min_obs, total, self.n_bins)
 
     def scan(self, ss, plan):

@@ -41,19 +41,22 @@ def table_to_host(ctx, tab, k):
     return out
 
 
-@pytest.mark.parametrize("kind,k,world", [(0, 47, 2), (1, 47, 2), (0, 31, 3), (0, 63, 2)])
-def test_virtual_ranks_multi_segment(ctx, kind, k, world):
+@pytest.mark.parametrize("kind,k,world,colours", [(0, 47, 2, 4), (1, 47, 2, 4), (0, 31, 3, 4), (0, 63, 2, 4), (1, 51, 2, 40), (1, 31, 3, 64)])
+def test_virtual_ranks_multi_segment(ctx, kind, k, world, colours):
+    """colours > 24: the two-word colour layout, selected on every rank by the plan's global max_label"""
     eng = D.HipEngine(ctx, torch.device("cuda", 0))
     n_reads, per = 6000, 6000 // world
     shards, keep = [], []
     for r in range(world):
         hs = dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.003,
-                                  stranded=False, n_colours=4, first_read=r * per)
+                                  stranded=False, n_colours=colours, first_read=r * per)
         ss, kp = dev_seqset(eng, hs, kind == 1)
         shards.append(ss)
         keep.append(kp)
     total = sum(eng.count_instances(s, k) for s in shards)
-    plan = eng.plan(k, False, kind, 2, total)
+    max_label = max(eng.max_label(s) for s in shards) if kind == 1 else 0      # (an all-reduce MAX in the real flow)
+    assert max_label == (colours - 1 if kind == 1 else 0)
+    plan = eng.plan(k, False, kind, 2, total, max_label)
     rw, nb = plan.rec_words, plan.n_bins
     bounds = D.owner_bounds(nb, world, plan.bin_group)
     scanned = []
@@ -61,6 +64,9 @@ def test_virtual_ranks_multi_segment(ctx, kind, k, world):
         bin_off, n = eng.scan(s, plan)
         recs = eng.scatter(plan, bin_off, n)
         scanned.append((bin_off, recs))
+    if kind == 1 and colours > 24:                              # a plan that understates the labels is refused, not miscounted
+        with pytest.raises(dbg.DbgError):
+            eng.scan(shards[0], eng.plan(k, False, kind, 2, total, 0))
     merged = {}
     for owner in range(world):
         lo, hi = bounds[owner], bounds[owner + 1]
@@ -104,7 +110,7 @@ def test_virtual_ranks_multi_segment(ctx, kind, k, world):
             assert key not in merged
             merged[key] = (int(t.exts[i]), t.data(i))
     hs_all = dbg.synth_reads_host(n_reads=n_reads, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.003,
-                                  stranded=False, n_colours=4)
+                                  stranded=False, n_colours=colours)
     want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data, 1), k, kind, 2, stranded=False)
     assert sorted(merged) == want.keys()
     for i, key in enumerate(want.keys()):

@@ -30,7 +30,7 @@ def owner_tables(eng, host_shards, k, stranded, kind, min_obs):
         shards.append(ss)
         keep.append(kp)
     total = sum(eng.count_instances(s, k) for s in shards)
-    plan = eng.plan(k, stranded, kind, min_obs, total)
+    plan = eng.plan(k, stranded, kind, min_obs, total, max(eng.max_label(s) for s in shards) if kind == 1 else 0)
     rw, nb = plan.rec_words, plan.n_bins
     bounds = D.owner_bounds(nb, world, plan.bin_group)
     scanned = []
