@@ -2,16 +2,18 @@
 //
 // The super-k-mer fast path needs k >= 16 (its internal minimizers are 15 bases), and the generic sort-based path moves one
 // 12-byte record per k-mer instance through several radix passes (measured 3 Gkmer/s).  For k <= 15 the whole key space --
-// 4^k <= 2^30 canonical values -- fits in HBM as a directly addressed table: count (u32), Exts (one byte) and, for
-// CountFilterSet, a 64-bit label mask per possible k-mer (14 GB at k = 15).  One wavefront walks a read 64 k-mers at a time
+// 4^k <= 2^30 canonical values -- fits in HBM as a directly addressed table: one 64-bit word per possible k-mer holding the count
+// (40 bits) and the Exts byte, followed for CountFilterSet by a 64-bit label mask in the same 16-byte entry (17 GB at k = 15), so
+// that a k-mer instance touches ONE cache line.  One wavefront walks a read 64 k-mers at a time
 // (iter_kmer_exts + min_rc_flip + Exts::rc, lib.rs:812-841, :224-231, :729-748, exactly as the generic extractor) and does
 // count += 1 / Exts |= e / mask |= 1 << label (CountFilter / CountFilterSet::summarize, filter.rs:53-62, :85-100) with global
-// atomics; Exts and label bits are only sent when a plain load shows them missing, which after the first few reads is almost
-// never.  The table index IS the key, so one compaction pass over the table emits the valid entries in ascending key order
+// atomics: the returning add of the count brings the entry's Exts back, and an OR is only sent for Exts (or label) bits that are
+// still missing, which after the first few reads is almost never.  The table index IS the key, so one compaction pass over the table emits the valid entries in ascending key order
 // (filter.rs:205-230) -- no sort.  Very short k-mers (k <= 7: at most 16384 entries) are counted in per-workgroup LDS tables
 // first, because a few thousand hot addresses would serialise the device's atomic units.
 #include "dbg_internal.hpp"
 #include <algorithm>
+#include <vector>
 
 int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out);      // fastpath.hip
 
@@ -25,8 +27,8 @@ __device__ __forceinline__ uint32_t load_label(const void* data, uint32_t width,
 }
 
 template <bool STRANDED, bool IS_SET, bool LDS_COUNT>
-__global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, uint32_t* __restrict__ cnt, uint32_t* __restrict__ ex4,
-                                                          unsigned long long* __restrict__ mask) {
+__global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, unsigned long long* __restrict__ tab) {
+    constexpr uint32_t ES = IS_SET ? 2 : 1;                          // 64-bit words per entry: {count | Exts << 40} [, label mask]
     extern __shared__ uint32_t s_cnt[];                              // LDS_COUNT: 4^k counters of this workgroup
     const uint32_t nkeys = 1u << (2 * k);
     if (LDS_COUNT) {
@@ -45,7 +47,15 @@ __global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, uint3
         unsigned long long lbit = 0;
         if (IS_SET) lbit = 1ull << (s.data ? load_label(s.data, s.data_width, si) & 63u : 0u);
         for (uint32_t j = lane; j < nk; j += 64) {
-            K128 km = packed_get_kmer(s.words, st + j, k);
+            // the k-mer (at most 30 bits) lies in two consecutive words; both are fetched unconditionally (index clamped to the buffer)
+            K128 km;
+            {
+                const uint64_t o = st + j, wi = o >> 5;
+                const int sft = (int)(o & 31) * 2;
+                const uint64_t w0 = s.words[wi], w1 = s.words[wi + 1 < s.n_words ? wi + 1 : wi];
+                const uint64_t top = sft ? (w0 << sft) | (w1 >> (64 - sft)) : w0;
+                km = K128{0ull, top >> (64 - 2 * k)};
+            }
             // lib.rs:820-832: interior exts from the neighbouring bases, boundary exts from seq_exts
             const uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << packed_get(s.words, st + j - 1));
             const uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << packed_get(s.words, st + j + k));
@@ -55,34 +65,41 @@ __global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, uint3
                 if (!k128_lt(km, rc)) { km = rc; ex = exts_rc(ex); }             // ties flip (lib.rs:226-230)
             }
             const uint32_t key = (uint32_t)km.lo;
-            if (LDS_COUNT) atomicAdd(&s_cnt[key], 1u); else atomicAdd(&cnt[key], 1u);
-            const uint32_t sh = 8u * (key & 3u), eb = ex << sh;
-            // (a stale cached value can only lack bits that are set by now: the atomic is then sent needlessly, never skipped wrongly)
-            if ((ex4[key >> 2] & eb) != eb) atomicOr(&ex4[key >> 2], eb);
-            if (IS_SET && (mask[key] & lbit) == 0) atomicOr(&mask[key], lbit);
+            unsigned long long* e = tab + (uint64_t)key * ES;
+            unsigned long long old;
+            if (LDS_COUNT) { atomicAdd(&s_cnt[key], 1u); old = e[0]; }
+            else old = atomicAdd(&e[0], 1ull);
+            // (a stale value can only lack bits that are set by now: the OR is then sent needlessly, never skipped wrongly)
+            if (((uint32_t)(old >> 40) & ex) != ex) atomicOr(&e[0], (unsigned long long)ex << 40);
+            if (IS_SET && (e[1] & lbit) == 0) atomicOr(&e[1], lbit);
         }
     }
     if (LDS_COUNT) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) { const uint32_t v = s_cnt[i]; if (v) atomicAdd(&cnt[i], v); }
+        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) { const uint32_t v = s_cnt[i]; if (v) atomicAdd(&tab[(uint64_t)i * ES], (unsigned long long)v); }
     }
 }
 
 // valid / occupied entries per tile of 1024 table slots
 constexpr uint32_t DT = 1024;
+constexpr unsigned long long DCNT = (1ull << 40) - 1;            // count field of an entry
+__device__ __forceinline__ bool dense_valid(bool is_set, unsigned long long c, uint64_t min_obs) {
+    return c && (is_set ? c >= min_obs : (c > 65535ull ? 65535ull : c) >= min_obs);     // CountFilter compares its saturated u16 count (filter.rs:57-61)
+}
 template <bool IS_SET>
-__global__ void __launch_bounds__(256) dense_tile_counts_kernel(const uint32_t* __restrict__ cnt, const unsigned long long* __restrict__ mask,
+__global__ void __launch_bounds__(256) dense_tile_counts_kernel(const unsigned long long* __restrict__ tab,
                                                                 uint32_t nkeys, uint64_t min_obs, uint32_t* __restrict__ n_valid,
                                                                 uint32_t* __restrict__ n_all, uint32_t* __restrict__ n_lab) {
+    constexpr uint32_t ES = IS_SET ? 2 : 1;
     __shared__ uint32_t s_v[4], s_a[4], s_l[4];
     uint32_t v = 0, a = 0, l = 0;
     for (uint32_t t = 0; t < DT / 256; t++) {
         const uint32_t i = blockIdx.x * DT + t * 256 + threadIdx.x;
         if (i < nkeys) {
-            const uint32_t c = cnt[i];
-            const bool ok = c && (IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs);
+            const unsigned long long c = tab[(uint64_t)i * ES] & DCNT;
+            const bool ok = dense_valid(IS_SET, c, min_obs);
             a += c ? 1u : 0u; v += ok ? 1u : 0u;
-            if (IS_SET && ok) l += (uint32_t)__popcll(mask[i]);
+            if (IS_SET && ok) l += (uint32_t)__popcll(tab[(uint64_t)i * ES + 1]);
         }
     }
     for (int d = 32; d; d >>= 1) { v += __shfl_xor(v, d); a += __shfl_xor(a, d); l += __shfl_xor(l, d); }
@@ -97,27 +114,28 @@ __global__ void __launch_bounds__(256) dense_tile_counts_kernel(const uint32_t* 
 
 // one wavefront per tile walks its 1024 slots in order, 64 at a time: ranks by ballot, output ascending by key
 template <bool IS_SET>
-__global__ void __launch_bounds__(64) dense_emit_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ ex4,
-                                                        const unsigned long long* __restrict__ mask, uint32_t nkeys, uint64_t min_obs,
+__global__ void __launch_bounds__(64) dense_emit_kernel(const unsigned long long* __restrict__ tab, uint32_t nkeys, uint64_t min_obs,
                                                         const uint64_t* __restrict__ off_valid, const uint64_t* __restrict__ off_all,
                                                         const uint64_t* __restrict__ off_lab, uint32_t n_tiles,
                                                         uint64_t* __restrict__ key_hi, uint64_t* __restrict__ key_lo, uint8_t* __restrict__ exts,
                                                         uint16_t* __restrict__ count, uint64_t* __restrict__ set_off, uint32_t* __restrict__ set_val,
                                                         uint64_t* __restrict__ all_hi, uint64_t* __restrict__ all_lo) {
+    constexpr uint32_t ES = IS_SET ? 2 : 1;
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = lanemask_lt();
     uint64_t ov = off_valid[blockIdx.x], oa = off_all[blockIdx.x], ol = IS_SET ? off_lab[blockIdx.x] : 0;
     for (uint32_t t = 0; t < DT / 64; t++) {
         const uint32_t i = blockIdx.x * DT + t * 64 + lane;
-        uint32_t c = 0;
-        if (i < nkeys) c = cnt[i];
+        unsigned long long w = 0;
+        if (i < nkeys) w = tab[(uint64_t)i * ES];
+        const unsigned long long c = w & DCNT;
         const bool occ = c != 0;
-        const bool ok = occ && (IS_SET ? (uint64_t)c >= min_obs : (uint64_t)(c > 65535u ? 65535u : c) >= min_obs);
+        const bool ok = dense_valid(IS_SET, c, min_obs);
         const uint64_t bo = __ballot(occ), bv = __ballot(ok);
         if (all_lo && occ) { const uint64_t q = oa + (uint32_t)__popcll(bo & lt); all_lo[q] = i; if (all_hi) all_hi[q] = 0; }
         unsigned long long m = 0;
         uint32_t nl = 0;
-        if (IS_SET && ok) { m = mask[i]; nl = (uint32_t)__popcll(m); }
+        if (IS_SET && ok) { m = tab[(uint64_t)i * ES + 1]; nl = (uint32_t)__popcll(m); }
         uint32_t incl = nl;
         if (IS_SET) {
 #pragma unroll
@@ -127,12 +145,12 @@ __global__ void __launch_bounds__(64) dense_emit_kernel(const uint32_t* __restri
             const uint64_t q = ov + (uint32_t)__popcll(bv & lt);
             key_lo[q] = i;
             if (key_hi) key_hi[q] = 0;
-            exts[q] = (uint8_t)(ex4[i >> 2] >> (8u * (i & 3u)));
+            exts[q] = (uint8_t)(w >> 40);
             if (IS_SET) {
                 uint64_t o = ol + incl - nl;
                 set_off[q] = o;
                 while (m) { set_val[o++] = (uint32_t)__ffsll((long long)m) - 1u; m &= m - 1; }   // ascending = sort(); dedup() (filter.rs:97-98)
-            } else count[q] = (uint16_t)(c > 65535u ? 65535u : c);                                  // saturating count (filter.rs:57)
+            } else count[q] = (uint16_t)(c > 65535ull ? 65535ull : c);                                  // saturating count (filter.rs:57)
         }
         ov += (uint32_t)__popcll(bv); oa += (uint32_t)__popcll(bo);
         if (IS_SET) ol += (uint32_t)__shfl((int)incl, 63);
@@ -154,23 +172,21 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     }
     const uint32_t nkeys = 1u << (2 * k);
     const uint32_t n_tiles = cdiv(nkeys, DT);
-    DBuf<uint32_t> cnt, ex4, t_valid, t_all, t_lab;
-    DBuf<unsigned long long> mask;
+    DBuf<uint32_t> t_valid, t_all, t_lab;
+    DBuf<unsigned long long> tab;
     DBuf<uint64_t> o_valid, o_all, o_lab;
-    ALLOC_OR_FAIL(c, cnt, nkeys); ALLOC_OR_FAIL(c, ex4, std::max(nkeys / 4, 1u));
-    if (is_set) ALLOC_OR_FAIL(c, mask, nkeys);
+    const size_t tab_words = (size_t)nkeys * (is_set ? 2 : 1);
+    ALLOC_OR_FAIL(c, tab, tab_words);
     ALLOC_OR_FAIL(c, t_valid, n_tiles); ALLOC_OR_FAIL(c, t_all, n_tiles); ALLOC_OR_FAIL(c, t_lab, n_tiles);
     ALLOC_OR_FAIL(c, o_valid, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_all, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_lab, (size_t)n_tiles + 1);
-    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, (size_t)nkeys * 4, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ex4.p, 0, (size_t)std::max(nkeys / 4, 1u) * 4, c->stream));
-    if (is_set) HIP_TRY(c, hipMemsetAsync(mask.p, 0, (size_t)nkeys * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(tab.p, 0, tab_words * 8, c->stream));
     if (s.n && n_kmers) {
         const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 3) / 4, 256ull * 16));
         const bool lds = k <= DENSE_LDS_K;
         const size_t shm = lds ? (size_t)nkeys * 4 : 0;
         c->t_begin("dense_count", n_kmers);
 #define DL(ST, SET, LD) do { if (shm) HIP_TRY(c, hipFuncSetAttribute((const void*)dense_count_kernel<ST, SET, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        dense_count_kernel<ST, SET, LD><<<blocks, 256, shm, c->stream>>>(s, k, cnt.p, ex4.p, mask.p); } while (0)
+        dense_count_kernel<ST, SET, LD><<<blocks, 256, shm, c->stream>>>(s, k, tab.p); } while (0)
 #define DGO(ST, SET) do { if (lds) DL(ST, SET, true); else DL(ST, SET, false); } while (0)
         if (stranded) { if (is_set) DGO(true, true); else DGO(true, false); }
         else { if (is_set) DGO(false, true); else DGO(false, false); }
@@ -180,8 +196,8 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
         LAUNCH_CHECK(c, "dense_count");
     }
     c->t_begin("dense_compact", nkeys);
-    if (is_set) dense_tile_counts_kernel<true><<<n_tiles, 256, 0, c->stream>>>(cnt.p, mask.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);
-    else dense_tile_counts_kernel<false><<<n_tiles, 256, 0, c->stream>>>(cnt.p, mask.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);
+    if (is_set) dense_tile_counts_kernel<true><<<n_tiles, 256, 0, c->stream>>>(tab.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);
+    else dense_tile_counts_kernel<false><<<n_tiles, 256, 0, c->stream>>>(tab.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);
     LAUNCH_CHECK(c, "dense_tile_counts");
     DBG_TRY(scan_exclusive_u32_u64(c, t_valid.p, o_valid.p, n_tiles));
     DBG_TRY(scan_exclusive_u32_u64(c, t_all.p, o_all.p, n_tiles));
@@ -200,9 +216,9 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     if (is_set) { ALLOC_OR_FAIL(c, set_off, nv + 1); ALLOC_OR_FAIL(c, set_val, std::max<uint64_t>(n_lab, 1)); HIP_TRY(c, hipMemsetAsync(set_off.p, 0, 8, c->stream)); }
     else ALLOC_OR_FAIL(c, count, nv);
     if (report_all) { ALLOC_OR_FAIL(c, a_hi, na); ALLOC_OR_FAIL(c, a_lo, na); }
-    if (is_set) dense_emit_kernel<true><<<n_tiles, 64, 0, c->stream>>>(cnt.p, ex4.p, mask.p, nkeys, prm->min_kmer_obs, o_valid.p, o_all.p, o_lab.p, n_tiles,
+    if (is_set) dense_emit_kernel<true><<<n_tiles, 64, 0, c->stream>>>(tab.p, nkeys, prm->min_kmer_obs, o_valid.p, o_all.p, o_lab.p, n_tiles,
                                                                       k_hi.p, k_lo.p, exts.p, count.p, set_off.p, set_val.p, a_hi.p, a_lo.p);
-    else dense_emit_kernel<false><<<n_tiles, 64, 0, c->stream>>>(cnt.p, ex4.p, mask.p, nkeys, prm->min_kmer_obs, o_valid.p, o_all.p, o_lab.p, n_tiles,
+    else dense_emit_kernel<false><<<n_tiles, 64, 0, c->stream>>>(tab.p, nkeys, prm->min_kmer_obs, o_valid.p, o_all.p, o_lab.p, n_tiles,
                                                                  k_hi.p, k_lo.p, exts.p, count.p, set_off.p, set_val.p, a_hi.p, a_lo.p);
     c->t_end();
     LAUNCH_CHECK(c, "dense_emit");
