@@ -83,6 +83,13 @@ template <class K> static int reassemble(Context& ctx, const std::vector<std::ve
     CHECK(std::is_sorted(res.first.keys.begin(), res.first.keys.end()));
     auto graph = compress_kmers_with_hash<K>(ctx, stranded, SimpleCompress(Reduce::SaturatingAdd), res.first);
     if (check_graph<K>(graph, truth)) return 1;
+    {   // compress_kmers_no_exts (compression.rs:619-659) on the bare k-mer set: the Exts found by neighbour look-ups make the
+        // same unitigs' k-mers (every contig k-mer is in the set, so the look-ups see at least what the reads showed)
+        std::vector<std::pair<K, uint16_t>> bare;
+        for (size_t i = 0; i < res.first.len(); i++) bare.emplace_back(res.first.keys[i], res.first.data[i]);
+        auto g2 = compress_kmers_no_exts<K>(ctx, stranded, SimpleCompress(Reduce::SaturatingAdd), bare);
+        if (check_graph<K>(g2, truth)) return 1;
+    }
     // sharded: per-shard filter + compress, combine, compress_graph (test.rs:446-503)
     std::vector<BaseGraph<K, uint16_t>> shard_asms;
     for (auto& kv : shards) {
