@@ -1585,6 +1585,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         // bin; what does not fit (heavy minimizers of low-complexity sequence) goes through the read-order buffer
         const double mean = (double)tmp_cap / (double)nbins;
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
+        if (const char* e = c->opt("DBG_SLAB_CAP")) st->slab_cap = (uint32_t)std::max(4, atoi(e)) & ~3u;      // measurement: records per slab
         ALLOC_OR_FAIL(c, st->cursor, nbins);
         if (!c->opt("DBG_FAST_NO_SLAB") && st->slab.alloc(c, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
         else {
@@ -1643,8 +1644,8 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
 #undef SCAN_ARGS
-        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] scan done: nbw=%d rw=%d bins=%u slab_cap=%u tmp used %llu of %llu\n", nbw, rw, nbins, st->slab_cap,
-                                         cur, (unsigned long long)tmp_cap);
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] scan done: nbw=%d rw=%d bins=%u slab_cap=%u tmp used %llu of %llu slab=%p cursor=%p words=%p\n", nbw, rw, nbins, st->slab_cap,
+                                         cur, (unsigned long long)tmp_cap, (void*)st->slab.p, (void*)st->cursor.p, (const void*)s.words);
         if (cur > tmp_cap) {                                  // low-complexity input: more pieces than estimated
             if (attempt >= 2) return c->fail(133, "fast path: super-k-mer buffer estimate failed");
             tmp_cap = std::min<uint64_t>(n_kmers, cur) + chunk_slack;
