@@ -223,6 +223,7 @@ constexpr int SG_WINDOW = SG_CAP - 128;
 
 __device__ __forceinline__ uint32_t key_prefix(uint64_t hi, uint64_t lo, int key_bits, int top_bits) {
     int sh = key_bits - top_bits;                    // drop the low bits
+    if (sh >= 128) return 0u;                        // no prefix bits at all (a table of <= 32 records at k = 64): `hi >> 64` is not a shift
     if (sh >= 64) return (uint32_t)(hi >> (sh - 64));
     if (sh == 0) return (uint32_t)lo;
     return (uint32_t)((lo >> sh) | (hi << (64 - sh)));

@@ -296,3 +296,17 @@ def test_more_than_64_labels_take_the_generic_path(ctx):
     assert_tables_equal(got, want, True)
     with pytest.raises(dbg.DbgError):                                           # DBG_PATH=fast must not fall back silently
         dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+
+
+@pytest.mark.parametrize("k", [64, 63, 48, 32])
+@pytest.mark.parametrize("n_valid_target", [1, 5, 25, 40])
+def test_fast_tiny_tables_are_sorted(ctx, k, n_valid_target):
+    """A table of at most 32 valid k-mers takes no prefix pass at all: the finisher sees one group whose prefix has zero bits.  At
+    k = 64 that prefix was computed as `hi >> 64` -- not a shift -- and the table came back unsorted (found by tests/test_gpu_fuzz.py,
+    seed 2066).  Few valid k-mers out of many: a handful of reads repeated three times among singletons, CountFilter(3)."""
+    rng = np.random.default_rng(k * 100 + n_valid_target)
+    rep = R.random_dna(rng, k + n_valid_target - 1)
+    seqs = [rep] * 3 + random_reads(rng, 25, 400000, 150, False, err=0.0)      # (a genome that sparse: no other k-mer is seen three times)
+    ss = O.SeqSet.from_byte_seqs(seqs)
+    got = run_fast(ctx, ss, k, O.COUNT_FILTER, 3, False)
+    assert len(got) == n_valid_target
