@@ -92,3 +92,84 @@ def test_fuzz_filter_and_compress(ctx, seed):
         return
     g = dbg.compress_kmers_with_hash(stranded, spec, got, k=k, data=d, ctx=ctx)
     assert graphs_equal(g.arrays(), og.arrays())
+
+
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 4, 8)))
+def test_fuzz_msp_sequence(ctx, seed):
+    """msp_sequence / Scanner::scan (src/msp.rs:207-324): random k, p (1 <= p <= min(16, k)), permutation or none, rc on / off, reads
+    of every length around k, repeats and homopolymers for the tie rule; pieces, boundary Exts, buckets and minimizer positions
+    bit-exact (the comparison is tests/test_gpu_msp.py's)."""
+    from test_gpu_msp import check_batch
+    rng = np.random.default_rng(70000 + seed)
+    k = int(rng.integers(8, 65))
+    p = int(rng.integers(1, min(16, k) + 1))
+    perm = rng.permutation(1 << (2 * p)).astype(np.uint32) if p <= 8 and rng.random() < 0.4 else None
+    seqs = []
+    for _ in range(int(rng.integers(5, 120))):
+        mode = rng.random()
+        ln = int(rng.integers(0, k + 2)) if mode < 0.15 else (int(rng.integers(1025, 1400)) if mode < 0.22 else int(rng.integers(k, 300)))
+        if rng.random() < 0.2:
+            unit = R.random_dna(rng, int(rng.integers(1, 6)))
+            s = np.tile(unit, ln // len(unit) + 1)[:ln].astype(np.uint8)
+        else:
+            s = R.random_dna(rng, ln)
+        seqs.append(s)
+    lw = 0
+    if rng.random() < 0.3:
+        need = 2 * k - p
+        lw = next((w for w in (1, 2, 3, 4) if 32 * w - 4 >= need), 0)     # Lmer<N>: 8 length bits in the last word (vmer.rs:32-47)
+    check_batch(ctx, seqs, k, p, perm, bool(rng.integers(0, 2)), lmer_words=lw)
+
+
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 8, 6)))
+def test_fuzz_sharded_flow(ctx, seed):
+    """The sharded flow of test.rs:433-487 on random shapes: 2-4 virtual ranks scan into one global plan, every owner counts its
+    bins from one segment per source; union of the owners' tables == filter_kmers over all reads; then per-owner
+    compress_kmers_with_hash -> BaseGraph::combine -> compress_graph against the oracle's same flow, literally."""
+    import importlib
+    import torch
+    from virtual_ranks import owner_tables
+    from test_gpu_sharded import table_to_host
+    D = importlib.import_module("rust-debruijn_amd.distributed")
+    rng = np.random.default_rng(50000 + seed)
+    k = int(rng.integers(16, 65))
+    world = int(rng.integers(2, 5))
+    kind = int(rng.integers(0, 2))
+    colours = int(rng.choice([3, 20, 40, 64])) if kind else 1
+    per = int(rng.choice([40, 400]))
+    n_reads = per * world
+    glen = max(n_reads * 150 // int(rng.choice([3, 30])), 400)
+    err = float(rng.choice([0.0, 0.004]))
+    shards = [dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=glen, error_rate=err, stranded=False, n_colours=max(colours, 1), first_read=r * per)
+              for r in range(world)]
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    tabs, total = owner_tables(eng, shards, k, False, kind, 1)
+    host = [table_to_host(ctx, t, k) for t in tabs]
+    for t in tabs:
+        eng.free_table(t)
+    hs_all = dbg.synth_reads_host(n_reads=n_reads, read_len=150, genome_len=glen, error_rate=err, stranded=False, n_colours=max(colours, 1))
+    want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data if kind else None, 1 if kind else 0), k, kind, 1, stranded=False)
+    merged = {}
+    for t in host:
+        assert t.keys() == sorted(t.keys())
+        for i, key in enumerate(t.keys()):
+            assert key not in merged
+            merged[key] = (int(t.exts[i]), t.data(i))
+    assert sorted(merged) == want.keys()
+    for i, key in enumerate(want.keys()):
+        e, v = merged[key]
+        assert e == int(want.exts[i])
+        assert v == ([int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]] if kind else int(want.count[i]))
+    # second stage (counts as data; label sets stand in as their sizes)
+    gs, ogs = [], []
+    for t in host:
+        if len(t) == 0:
+            continue
+        d = t.count.astype(np.uint32) if not kind else np.diff(t.set_off).astype(np.uint32)
+        gs.append(dbg.compress_kmers_with_hash(False, dbg.SimpleCompress("max"), t, k=k, data=d, ctx=ctx))
+        ogs.append(O.compress_kmers(k, False, O.SPEC_MAX, t.key_hi, t.key_lo, t.exts, d))
+        assert graphs_equal(gs[-1].arrays(), ogs[-1].arrays())
+    if gs:
+        got = dbg.compress_graph(False, dbg.SimpleCompress("max"), dbg.combine_graphs(gs, ctx=ctx), ctx=ctx)
+        wantg = O.graph_combine(ogs).finish().compress_graph(False, O.SPEC_MAX)
+        assert graphs_equal(got.arrays(), wantg.arrays())
