@@ -58,7 +58,13 @@ def draw_case(rng):
         data = alphabet[rng.integers(0, len(alphabet), size=n_reads)]
     min_obs = int(rng.choice([1, 1, 2, 3]))
     report_all = bool(rng.integers(0, 2))
-    return dict(k=k, stranded=stranded, is_set=is_set, seqs=seqs, exts=exts, data=data, width=width, min_obs=min_obs, report_all=report_all)
+    # a route knob now and then (all routes must give the same table): the wave-per-bin counting kernel, tiny and huge bins (multi-pass
+    # tables, slab overflow), no slabs, the three-array sort form, the plain LSD sort, the wave-per-read scanner
+    knobs = [{}, {}, {}, {"DBG_COUNT": "wave"}, {"DBG_FAST_TARGET": "600"}, {"DBG_FAST_TARGET": "50000"}, {"DBG_FAST_NO_SLAB": "1"},
+             {"DBG_NO_REC16": "1"}, {"DBG_NO_HYBRID_SORT": "1"}, {"DBG_SCAN": "wave"}, {"DBG_COUNT": "wave", "DBG_FAST_TARGET": "300"},
+             {"DBG_SORT": "bytealigned"}][int(rng.integers(0, 12))]
+    return dict(k=k, stranded=stranded, is_set=is_set, seqs=seqs, exts=exts, data=data, width=width, min_obs=min_obs, report_all=report_all,
+                knobs=knobs)
 
 
 import os
@@ -77,7 +83,8 @@ def test_fuzz_filter_and_compress(ctx, seed):
     kind = O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER
     want = O.filter_kmers(ss, k, kind, c["min_obs"], stranded=stranded, report_all=c["report_all"])
     summ = (dbg.CountFilterSet if is_set else dbg.CountFilter)(c["min_obs"])
-    got, _ = dbg.filter_kmers(to_host_seqs(ss, c["width"]), summ, stranded, c["report_all"], 4, k=k, ctx=ctx)
+    with ctx.options(**c["knobs"]):
+        got, _ = dbg.filter_kmers(to_host_seqs(ss, c["width"]), summ, stranded, c["report_all"], 4, k=k, ctx=ctx)
     assert_tables_equal(got, want, is_set)
     if len(got) == 0 or c["exts"] is not None:               # (random seq_exts point at k-mers that do not exist: the reference panics there)
         return
@@ -173,3 +180,62 @@ def test_fuzz_sharded_flow(ctx, seed):
         got = dbg.compress_graph(False, dbg.SimpleCompress("max"), dbg.combine_graphs(gs, ctx=ctx), ctx=ctx)
         wantg = O.graph_combine(ogs).finish().compress_graph(False, O.SPEC_MAX)
         assert graphs_equal(got.arrays(), wantg.arrays())
+
+
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 4, 8)))
+def test_fuzz_censor_compress_gfa_serde(ctx, seed):
+    """Downstream of the table, on random shapes: remove_censored_exts / _sharded (filter.rs:238-306) vs the oracle; compress on the
+    censored index (literal BaseGraph, is_compressed == None as test.rs:248-254); GFA text byte-identical (graph.rs:537-616); serde
+    forms round-trip; compress_kmers_no_exts (compression.rs:619-659) on the bare key set in a shuffled order."""
+    import copy
+    rng = np.random.default_rng(30000 + seed)
+    k = int(rng.integers(8, 65))
+    stranded = bool(rng.integers(0, 2))
+    glen = int(rng.choice([400, 3000]))
+    genome = R.random_dna(rng, glen)
+    reads = []
+    for _ in range(int(rng.choice([40, 250]))):
+        ln = int(rng.integers(k, 200))
+        ln = min(ln, glen)
+        st = int(rng.integers(0, glen - ln + 1))
+        s = genome[st:st + ln].copy()
+        m = rng.random(ln) < float(rng.choice([0.0, 0.01]))
+        s[m] = (s[m] + rng.integers(1, 4, size=int(m.sum()))) % 4
+        if not stranded and rng.random() < 0.5:
+            s = R.revcomp_bytes(s)
+        reads.append(s.astype(np.uint8))
+    min_obs = int(rng.choice([1, 2, 2, 3]))
+    t, allk = dbg.filter_kmers([(r, 0, None) for r in reads], dbg.CountFilter(min_obs), stranded, True, 4, k=k, ctx=ctx)
+    if len(t) == 0:
+        return
+    ah = np.array([v >> 64 for v in allk], np.uint64)
+    al = np.array([v & O.M64 for v in allk], np.uint64)
+    want_s = O.remove_censored_exts(k, stranded, t.key_hi, t.key_lo, t.exts, ah, al, sharded=True)
+    want_n = O.remove_censored_exts(k, stranded, t.key_hi, t.key_lo, t.exts)
+    ts = dbg.remove_censored_exts_sharded(stranded, copy.copy(t), allk, ctx=ctx)
+    tn = dbg.remove_censored_exts(stranded, copy.copy(t), ctx=ctx)
+    assert np.array_equal(ts.exts, want_s) and np.array_equal(tn.exts, want_n)
+    spec, ospec = [(dbg.SimpleCompress("saturating_add"), O.SPEC_SAT_ADD), (dbg.SimpleCompress("max"), O.SPEC_MAX),
+                   (dbg.SimpleCompress("add_mod_65535"), O.SPEC_ADD_MOD)][int(rng.integers(0, 3))]
+    seed_order = rng.permutation(len(tn)).astype(np.uint64) if rng.random() < 0.5 else None
+    g = dbg.compress_kmers_with_hash(stranded, spec, tn, k=k, seed_order=seed_order, ctx=ctx)
+    og = O.compress_kmers(k, stranded, ospec, tn.key_hi, tn.key_lo, tn.exts, tn.count, seed_order)
+    ga = g.arrays()
+    assert graphs_equal(ga, og.arrays())
+    assert og.is_compressed(ospec) is None
+    assert g.write_gfa(ctx) == og.write_gfa()
+    for fmt, dw in ((dbg.SERDE_BINCODE, 2), (dbg.SERDE_JSON, 4)):
+        h = dbg.graph_deserialize(dbg.graph_serialize(g, fmt, data_width=dw), k, fmt, data_width=dw)
+        assert graphs_equal(h.arrays(), ga) and h.stranded == g.stranded
+    perm = rng.permutation(len(t))
+    try:
+        wg, wex = O.compress_kmers_no_exts(k, stranded, ospec, t.key_hi[perm], t.key_lo[perm], t.count[perm].astype(np.uint32))
+    except RuntimeError:
+        # stranded keys are not canonical but the neighbour look-ups are (compression.rs:626): the Exts they find can contradict each
+        # other and the reference's walk panics -- here the same, as an error; the Exts themselves are still comparable
+        with pytest.raises(dbg.DbgError):
+            dbg.compress_kmers_no_exts(stranded, spec, k, t.key_hi[perm], t.key_lo[perm], t.count[perm].astype(np.uint32), ctx=ctx)
+        return
+    assert np.array_equal(dbg.kmer_set_exts(k, t.key_hi[perm], t.key_lo[perm], ctx=ctx), wex)
+    ng = dbg.compress_kmers_no_exts(stranded, spec, k, t.key_hi[perm], t.key_lo[perm], t.count[perm].astype(np.uint32), ctx=ctx)
+    assert graphs_equal(ng.arrays(), wg.arrays())
