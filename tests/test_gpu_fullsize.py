@@ -388,3 +388,68 @@ def test_fullsize_sharded_two_virtual_ranks(env, kind):
     if kind == 0:
         assert got["sum_count"] == want["sum_count"] == total
     assert got["digest"] == want["digest"]
+
+
+@only_c2
+def test_fullsize_wide_colour_sets(env):
+    """The WIDE colour layout (25..64 colours: two mask words per table entry, the sort carries the record's position, Exts and
+    colours gathered afterwards) at full size: 64 colours, label = read index mod 64.  Same valid key set as CountFilter(2);
+    every label set sorted, de-duplicated, non-empty, within 0..63; a 10^5-read prefix bit-exact against the oracle."""
+    e = env
+    torch, capi, lib, ctx = e["torch"], e["capi"], e["lib"], e["ctx"]
+    K, N_READS = e["k"], e["n_reads"]
+    torch.cuda.empty_cache()
+    ctx.trim()
+    colour64 = (torch.arange(N_READS, device="cuda", dtype=torch.int64) % 64).to(torch.uint8)
+
+    def run(first, n, summarizer, min_obs):
+        ss = capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"][first:].data_ptr(), e["length"][first:].data_ptr(), None,
+                         colour64[first:].data_ptr() if summarizer else None, 1 if summarizer else 0, n)
+        fp = capi.FilterParams(K, 0, summarizer, min_obs, 0, 4)
+        t = capi.KmerTable()
+        ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+        return t
+    tc = run(0, N_READS, 0, 2)
+    sc = table_stats(e, tc)
+    lib.dbg_free_table(ctx.h, C.byref(tc))
+    ts = run(0, N_READS, 1, 2)
+    ss_ = table_stats(e, ts)
+    ctx.trim()
+    off = dev_view(ts.set_off, ts.n + 1)
+    nsv = int(ts.n_set_val)
+    sizes = off[1:] - off[:-1]
+    assert int(off[0].item()) == 0 and int(off[-1].item()) == nsv
+    assert int(sizes.min().item()) >= 1 and int(sizes.max().item()) <= 64
+    is_boundary = torch.zeros(nsv + 1, dtype=torch.bool, device="cuda")
+    is_boundary[off] = True
+    vmin, vmax, step = 1 << 30, -1, 1 << 27
+    val_all = dev_view(ts.set_val, nsv, "<u4")
+    for a in range(0, nsv, step):                                   # in slices (see test_fullsize_filter_set_vs_count)
+        b = min(a + step, nsv)
+        v = val_all[a:b].to(torch.int64)
+        vmin, vmax = min(vmin, int(v.min().item())), max(vmax, int(v.max().item()))
+        if a == 0:
+            nonasc = (v[1:] <= v[:-1]).nonzero().flatten() + 1
+        else:
+            prev = val_all[a - 1:b - 1].to(torch.int64)
+            nonasc = (v <= prev).nonzero().flatten() + a
+        assert bool(is_boundary[nonasc].all().item())
+    del is_boundary, val_all
+    lib.dbg_free_table(ctx.h, C.byref(ts))
+    assert vmin == 0 and vmax == 63                                  # the wide layout was exercised
+    assert sc["ascending"] and ss_["ascending"] and sc["n"] == ss_["n"] and sc["keysum"] == ss_["keysum"]
+    # prefix of the stream, bit-exact
+    m = min(100_000, N_READS)
+    t = run(0, m, 1, 1)
+    h = capi.KmerTable()
+    ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))
+    lib.dbg_free_table(ctx.h, C.byref(t))
+    n = h.n
+    as_np = lambda p, ct, cnt: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(max(cnt, 1),))[:cnt].copy()
+    g_hi, g_lo, g_ex = as_np(h.key_hi, C.c_uint64, n), as_np(h.key_lo, C.c_uint64, n), as_np(h.exts, C.c_uint8, n)
+    g_off, g_val = as_np(h.set_off, C.c_uint64, n + 1), as_np(h.set_val, C.c_uint32, h.n_set_val)
+    lib.dbg_free_table(ctx.h, C.byref(h))
+    hs = dbg.synth_reads_host(n_reads=m, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001, stranded=False, n_colours=64)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1), K, O.COUNT_FILTER_SET, 1, stranded=False)
+    assert n == want.n and np.array_equal(g_hi, want.key_hi) and np.array_equal(g_lo, want.key_lo) and np.array_equal(g_ex, want.exts)
+    assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)
