@@ -176,7 +176,7 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     DBuf<unsigned long long> tab;
     DBuf<uint64_t> o_valid, o_all, o_lab;
     const size_t tab_words = (size_t)nkeys * (is_set ? 2 : 1);
-    ALLOC_OR_FAIL(c, tab, tab_words);
+    if (!tab.alloc(c, tab_words)) return 0;                          // no room for the table (17 GB at k = 15 with label masks): the generic path takes the call
     ALLOC_OR_FAIL(c, t_valid, n_tiles); ALLOC_OR_FAIL(c, t_all, n_tiles); ALLOC_OR_FAIL(c, t_lab, n_tiles);
     ALLOC_OR_FAIL(c, o_valid, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_all, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_lab, (size_t)n_tiles + 1);
     HIP_TRY(c, hipMemsetAsync(tab.p, 0, tab_words * 8, c->stream));

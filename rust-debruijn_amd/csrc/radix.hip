@@ -912,6 +912,150 @@ __global__ void decode16_kernel(uint32_t n, const uint4* __restrict__ in, uint64
     else count[i] = (uint16_t)(q.w >> 8);
 }
 
+// ---- single-pass-per-digit scatter with decoupled look-back (round 3, DBG_ONESWEEP=1) ----------------------------------------
+// The classic pass reads the records twice: radix16_hist (per-tile digit counts) -> scan -> radix16_scatter.  The global digit
+// totals of ALL prefix passes do not depend on the order of the records, so one pass over the input gives them up front
+// (radix16_global_hist_kernel); what a tile still lacks is the number of records with its digit in EARLIER tiles, and that it
+// can get from its predecessors while it works (Merrill & Garland's decoupled look-back): a tile publishes its digit counts
+// (AGGREGATE), walks back over the published counts of earlier tiles until it meets one that already knows its inclusive
+// prefix, and publishes its own (INCLUSIVE).  Tile ids come from an atomic counter in start order, so every predecessor has
+// started; waits are bounded (a tile that gives up raises the abort flag and the host repeats the pass the classic way).
+constexpr int OS_MAXP = 4;
+// status word = tag (4 bits) | count (60 bits); pass p uses the tags 2p + 1 (AGGREGATE) and 2p + 2 (INCLUSIVE), so that the words
+// of an earlier pass read as "not published yet" and the array is cleared once per sort, not once per pass
+constexpr unsigned long long OS_VAL = (1ull << 60) - 1;
+__global__ void __launch_bounds__(512) radix16_global_hist_kernel(const uint4* __restrict__ in, uint32_t n, int s0, int npass, int key_bits,
+                                                                   unsigned int* __restrict__ ghist) {
+    __shared__ uint32_t h[OS_MAXP][256];
+    for (int i = threadIdx.x; i < OS_MAXP * 256; i += blockDim.x) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const uint4 r = in[e];
+        for (int p = 0; p < npass; p++) {
+            const int sft = s0 + 8 * p;
+            const uint32_t mask = (1u << (key_bits - sft < 8 ? key_bits - sft : 8)) - 1u;
+            atomicAdd(&h[p][digit16(r, sft) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npass * 256; i += blockDim.x) { const uint32_t v = (&h[0][0])[i]; if (v) atomicAdd(&ghist[i], v); }
+}
+// exclusive scan of each pass's 256 totals (one wave per pass)
+__global__ void __launch_bounds__(256) radix16_global_scan_kernel(const unsigned int* __restrict__ ghist, unsigned int* __restrict__ gexcl, int npass) {
+    const uint32_t p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)p >= npass) return;
+    uint32_t run = 0;
+    for (int c = 0; c < 4; c++) {
+        const uint32_t v = ghist[p * 256 + c * 64 + lane];
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        gexcl[p * 256 + c * 64 + lane] = run + incl - v;
+        run += __shfl(incl, 63);
+    }
+}
+
+__global__ void __launch_bounds__(R16_THREADS) radix16_onesweep_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
+                                                                       uint32_t mask, const unsigned int* __restrict__ gexcl,
+                                                                       unsigned long long* __restrict__ status, unsigned int* __restrict__ tile_counter,
+                                                                       unsigned int* __restrict__ abort_flag, uint32_t pass) {
+    const unsigned long long OS_AGG = (unsigned long long)(2 * pass + 1) << 60, OS_INC = (unsigned long long)(2 * pass + 2) << 60;
+    __shared__ uint4 stage[R16_TILE];                   // 64 KB; the per-wave counters alias its first 8 KB
+    __shared__ uint8_t s_dig[R16_TILE];
+    __shared__ uint32_t s_gbase[256];
+    __shared__ uint32_t s_ws[4];
+    __shared__ uint32_t s_tile;
+    uint32_t (*wc)[256] = reinterpret_cast<uint32_t (*)[256]>(stage);
+    for (int i = threadIdx.x; i < R16_WAVES * 256; i += R16_THREADS) (&wc[0][0])[i] = 0;
+    if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u);          // tiles are numbered in the order they start
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile0 = tile * R16_TILE;
+    const uint32_t base = tile0 + wave * (R16_ITEMS * 64) + lane;
+    const uint32_t tile_n = n - tile0 < (uint32_t)R16_TILE ? n - tile0 : (uint32_t)R16_TILE;
+    const uint64_t lt = lanemask_lt();
+    uint4 rec[R16_ITEMS];
+    uint32_t rank[R16_ITEMS];
+    volatile uint32_t* mywc = &wc[wave][0];
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        const uint32_t e = base + r * 64;
+        rec[r] = e < n ? in[e] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        const bool valid = base + r * 64 < n;
+        const uint32_t d = digit16(rec[r], shift) & mask;
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const uint32_t before = __popcll(same & lt), cnt = __popcll(same);
+        uint32_t wbase = 0;
+        if (valid) wbase = mywc[d];
+        if (valid && before == 0) mywc[d] = wbase + cnt;
+        rank[r] = (d << 24) | (wbase + before);
+    }
+    __syncthreads();
+    uint32_t tot = 0, run0 = 0;
+    {
+        if (tid < 256) {
+#pragma unroll
+            for (int w = 0; w < R16_WAVES; w++) tot += wc[w][tid];
+            // publish this tile's count of digit `tid` right away: successors can look back past this tile while it works
+            __hip_atomic_store(&status[(size_t)tile * 256 + tid], OS_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the word is the whole message: no other memory to order)
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { uint32_t o = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += o; }
+        if (tid < 256 && lane == 63) s_ws[wave] = incl;
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < wave; w++) off += s_ws[w];
+            uint32_t run = off + incl - tot;
+            run0 = run;
+#pragma unroll
+            for (int w = 0; w < R16_WAVES; w++) { uint32_t t = wc[w][tid]; wc[w][tid] = run; run += t; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) rank[r] = wc[wave][rank[r] >> 24] + (rank[r] & 0xffffffu);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R16_ITEMS; r++) {
+        if (base + r * 64 < n) { stage[rank[r]] = rec[r]; s_dig[rank[r]] = (uint8_t)(digit16(rec[r], shift) & mask); }
+    }
+    // ---- look back: records with my digit in earlier tiles ----
+    int failed = 0;
+    if (tid < 256) {
+        unsigned long long excl = 0;
+        for (int64_t p = (int64_t)tile - 1; p >= 0; p--) {
+            unsigned long long v = 0;
+            uint32_t spins = 0;
+            for (;;) {
+                v = __hip_atomic_load(&status[(size_t)p * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 60) == (OS_AGG >> 60) || (v >> 60) == (OS_INC >> 60)) break;
+                if (++spins > (1u << 22) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { failed = 1; break; }
+            }
+            if (failed) break;
+            excl += v & OS_VAL;
+            if ((v >> 60) == (OS_INC >> 60)) break;
+        }
+        if (!failed) {
+            __hip_atomic_store(&status[(size_t)tile * 256 + tid], OS_INC | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_gbase[tid] = gexcl[tid] + (uint32_t)excl - run0;
+        }
+    }
+    if (__syncthreads_or(failed)) { if (tid == 0) atomicOr(abort_flag, 1u); return; }
+    for (uint32_t i = tid; i < tile_n; i += R16_THREADS) out[s_gbase[s_dig[i]] + i] = stage[i];
+}
+
 static int radix16_pass(dbg_ctx* ctx, const uint4* src, uint4* dst, uint32_t n, int shift, int bits, uint32_t* hist, uint32_t* hist_scanned, uint32_t nblocks) {
     const uint32_t mask = (1u << bits) - 1;
     ctx->t_begin("radix_hist", n);
@@ -955,8 +1099,42 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
         if (small_groups && (n64 >> top_bits) >= 2 && top_bits + 8 <= std::min(key_bits, 32)) top_bits += 8;   // the walking finisher wants (nearly) nothing left
         int s0 = key_bits - top_bits;
         if (bytealigned) { s0 = top_bits ? (s0 / 8) * 8 : key_bits; top_bits = key_bits - s0; }
-        for (int s = s0; s < key_bits; s += 8) {
-            DBG_TRY(radix16_pass(ctx, src, dst, n, s, std::min(8, key_bits - s), hist.p, hist_scanned.p, nblocks));
+        const int npass = (key_bits - s0 + 7) / 8;
+        // look-back passes (default; DBG_ONESWEEP=0: the classic histogram + scatter passes): -2.1 ms per step at C2
+        const bool onesweep = !(ctx->opt("DBG_ONESWEEP") && !strcmp(ctx->opt("DBG_ONESWEEP"), "0")) && npass >= 1 && npass <= OS_MAXP;
+        DBuf<unsigned int> ghist, gexcl, os_ctl;
+        DBuf<unsigned long long> os_status;
+        if (onesweep) {
+            ALLOC_OR_FAIL(ctx, ghist, OS_MAXP * 256); ALLOC_OR_FAIL(ctx, gexcl, OS_MAXP * 256); ALLOC_OR_FAIL(ctx, os_ctl, 2 * OS_MAXP);
+            ALLOC_OR_FAIL(ctx, os_status, (size_t)nblocks * 256);
+            HIP_TRY(ctx, hipMemsetAsync(ghist.p, 0, OS_MAXP * 256 * 4, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(os_status.p, 0, (size_t)nblocks * 256 * 8, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(os_ctl.p, 0, 2 * OS_MAXP * 4, ctx->stream));
+            ctx->t_begin("radix_hist", n);
+            radix16_global_hist_kernel<<<std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n, 512 * 16), 2048)), 512, 0, ctx->stream>>>(src, n, s0, npass, key_bits, ghist.p);
+            radix16_global_scan_kernel<<<1, 256, 0, ctx->stream>>>(ghist.p, gexcl.p, npass);
+            ctx->t_end();
+            LAUNCH_CHECK(ctx, "radix16_global_hist");
+        }
+        int pi = 0;
+        bool onesweep_broken = false;                        // after a pass gave up the status words are no longer trusted
+        for (int s = s0; s < key_bits; s += 8, pi++) {
+            bool done = false;
+            if (onesweep && !onesweep_broken) {
+                ctx->t_begin("radix_scatter", n);
+                radix16_onesweep_kernel<<<nblocks, R16_THREADS, 0, ctx->stream>>>(src, dst, n, s, (1u << std::min(8, key_bits - s)) - 1u, gexcl.p + pi * 256,
+                                                                                 os_status.p, os_ctl.p + 2 * pi, os_ctl.p + 2 * pi + 1, (uint32_t)pi);
+                ctx->t_end();
+                LAUNCH_CHECK(ctx, "radix16_onesweep");
+                // the pass's input is only intact until the next pass writes over it: a pass that gave up is repeated now
+                unsigned int ctl[2] = {0, 0};
+                HIP_TRY(ctx, hipMemcpyAsync(ctl, os_ctl.p + 2 * pi, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                done = ctl[1] == 0;
+                if (!done) onesweep_broken = true;
+                if (!done && ctx->opt("DBG_DEBUG")) fprintf(stderr, "[sort] look-back pass gave up (shift %d): classic pass instead\n", s);
+            }
+            if (!done) DBG_TRY(radix16_pass(ctx, src, dst, n, s, std::min(8, key_bits - s), hist.p, hist_scanned.p, nblocks));
             std::swap(src, dst);
         }
         sorted_from = s0;

@@ -167,7 +167,7 @@ def test_fast_k_sweep(ctx, k):
 
 
 @pytest.mark.parametrize("env", [{"DBG_NO_HYBRID_SORT": "1"}, {"DBG_NO_REC16": "1"}, {"DBG_NO_REC16": "1", "DBG_NO_HYBRID_SORT": "1"},
-                                 {"DBG_FAST_NO_SLAB": "1"}, {"DBG_SORT": "bytealigned"}])
+                                 {"DBG_FAST_NO_SLAB": "1"}, {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}])
 @pytest.mark.parametrize("k,kind", [(47, 1), (31, 0), (63, 0)])
 def test_fast_sort_variants(ctx, env, k, kind):
     """DBG_FAST_NO_SLAB: what happens when the slabs do not fit in memory (every record through the read-order buffer and
