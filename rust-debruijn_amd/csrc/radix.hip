@@ -48,19 +48,60 @@ __global__ void __launch_bounds__(RS_THREADS) radix_hist_kernel(RecArrays in, ui
 // One tile: rank every element inside the tile (wave-level ballot multisplit + per-wave digit counters), bring
 // the tile into digit order in LDS one array at a time, and write it out linearly: consecutive lanes then hit
 // consecutive addresses of a digit's run (8192/256 = 32 elements on average) instead of 64 scattered slots.
-template <bool HAS_HI>
+// exclusive scan of each pass's 256 totals (one wave per pass)
+__global__ void __launch_bounds__(256) radix_global_scan_kernel(const unsigned int* __restrict__ ghist, unsigned int* __restrict__ gexcl, int npass) {
+    const uint32_t p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)p >= npass) return;
+    uint32_t run = 0;
+    for (int c = 0; c < 4; c++) {
+        const uint32_t v = ghist[p * 256 + c * 64 + lane];
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        gexcl[p * 256 + c * 64 + lane] = run + incl - v;
+        run += __shfl(incl, 63);
+    }
+}
+
+// LOOKBACK: the tile's global digit offsets come from the published counts of earlier tiles instead of a per-tile histogram pass
+// (see radix16_onesweep_kernel below for the scheme; status word = tag (4 bits) | count, tags 2p + 1 / 2p + 2 in pass p).
+struct LookBack {
+    const unsigned int* gexcl;              // exclusive global digit totals of this pass [256]
+    unsigned long long* status;             // [tiles][256]
+    unsigned int* tile_counter;
+    unsigned int* abort_flag;
+    uint32_t pass;
+};
+struct DigitSel4 { DigitSel d[4]; int n; };
+__global__ void __launch_bounds__(512) radix_global_hist_kernel(RecArrays in, uint32_t n, DigitSel4 dsel, unsigned int* __restrict__ ghist) {
+    __shared__ uint32_t h[4][256];
+    for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const uint64_t lo = in.lo[e], hi = in.hi ? in.hi[e] : 0ull;
+        for (int p = 0; p < dsel.n; p++) atomicAdd(&h[p][digit_of(dsel.d[p], hi, lo, 0u)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < dsel.n * 256; i += blockDim.x) { const uint32_t v = (&h[0][0])[i]; if (v) atomicAdd(&ghist[i], v); }
+}
+
+template <bool HAS_HI, bool LOOKBACK = false>
 __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in, RecArrays out, uint32_t n, DigitSel ds,
                                                                    const uint32_t* __restrict__ hist_scanned,
-                                                                   uint32_t nblocks) {
+                                                                   uint32_t nblocks, LookBack lb = LookBack{}) {
     __shared__ uint64_t stage[RS_TILE];                 // 64 KB; the per-wave counters alias its first 8 KB
     __shared__ uint8_t s_dig[RS_TILE];                  // digit of the element at each tile-sorted position
     __shared__ uint32_t s_gbase[256];                   // global position of tile-sorted position 0 of digit d, minus its tile offset
     __shared__ uint32_t s_ws[4];
+    __shared__ uint32_t s_tile;
     uint32_t (*wc)[256] = reinterpret_cast<uint32_t (*)[256]>(stage);
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&wc[0][0])[i] = 0;
+    if (LOOKBACK && threadIdx.x == 0) s_tile = atomicAdd(lb.tile_counter, 1u);       // tiles are numbered in the order they start
     __syncthreads();
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tile0 = blockIdx.x * RS_TILE;
+    const uint32_t tile = LOOKBACK ? s_tile : blockIdx.x;
+    const uint32_t tile0 = tile * RS_TILE;
     const uint32_t base = tile0 + wave * RS_WAVE_CHUNK + lane;
     const uint32_t tile_n = n - tile0 < (uint32_t)RS_TILE ? n - tile0 : (uint32_t)RS_TILE;
     const uint64_t lt = lanemask_lt();
@@ -97,11 +138,13 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in,
         rank[r] = (d << 24) | (wbase + before);
     }
     __syncthreads();
+    const unsigned long long LB_AGG = (unsigned long long)(2 * lb.pass + 1) << 60, LB_INC = (unsigned long long)(2 * lb.pass + 2) << 60;
+    uint32_t tot = 0, run0 = 0;
     {   // digit totals of the tile -> exclusive scan over the 256 digits -> per-wave bases inside the tile
-        uint32_t tot = 0;
         if (tid < 256) {
 #pragma unroll
             for (int w = 0; w < RS_WAVES; w++) tot += wc[w][tid];
+            if (LOOKBACK) __hip_atomic_store(&lb.status[(size_t)tile * 256 + tid], LB_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         uint32_t incl = tot;
 #pragma unroll
@@ -112,7 +155,8 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in,
             uint32_t off = 0;
             for (uint32_t w = 0; w < wave; w++) off += s_ws[w];
             uint32_t run = off + incl - tot;                      // tile position of the first element with digit tid
-            s_gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - run;
+            run0 = run;
+            if (!LOOKBACK) s_gbase[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] - run;
 #pragma unroll
             for (int w = 0; w < RS_WAVES; w++) { uint32_t t = wc[w][tid]; wc[w][tid] = run; run += t; }
         }
@@ -131,7 +175,29 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(RecArrays in,
             s_dig[rank[r]] = (uint8_t)digit_of(ds, hi[r], lo[r], pay[r]);
         }
     }
-    __syncthreads();
+    if (LOOKBACK) {
+        int failed = 0;
+        if (tid < 256) {
+            unsigned long long excl = 0;
+            for (int64_t p = (int64_t)tile - 1; p >= 0; p--) {
+                unsigned long long v = 0;
+                uint32_t spins = 0;
+                for (;;) {
+                    v = __hip_atomic_load(&lb.status[(size_t)p * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 60) == (LB_AGG >> 60) || (v >> 60) == (LB_INC >> 60)) break;
+                    if (++spins > (1u << 22) || __hip_atomic_load(lb.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { failed = 1; break; }
+                }
+                if (failed) break;
+                excl += v & ((1ull << 60) - 1);
+                if ((v >> 60) == (LB_INC >> 60)) break;
+            }
+            if (!failed) {
+                __hip_atomic_store(&lb.status[(size_t)tile * 256 + tid], LB_INC | (excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_gbase[tid] = lb.gexcl[tid] + (uint32_t)excl - run0;
+            }
+        }
+        if (__syncthreads_or(failed)) { if (tid == 0) atomicOr(lb.abort_flag, 1u); return; }
+    } else __syncthreads();
     for (uint32_t i = tid; i < tile_n; i += RS_THREADS) out.lo[s_gbase[s_dig[i]] + i] = stage[i];
     if (HAS_HI) {
         __syncthreads();
@@ -508,19 +574,59 @@ int sort_table_hybrid(dbg_ctx* ctx, uint64_t n64, RecArrays a, RecArrays b, int 
             DBuf<uint32_t> hist, hist_scanned;
             ALLOC_OR_FAIL(ctx, hist, (size_t)256 * nblocks);
             ALLOC_OR_FAIL(ctx, hist_scanned, (size_t)256 * nblocks + 1);
-            for (int s = s0; s < key_bits; s += 8) {
-                DigitSel ds = s < 64 ? DigitSel{1, s, (uint32_t)((1u << std::min(8, std::min(64, key_bits) - s)) - 1)}
-                                     : DigitSel{2, s - 64, (uint32_t)((1u << std::min(8, key_bits - s)) - 1)};
+            auto sel_of = [&](int s) {
+                return s < 64 ? DigitSel{1, s, (uint32_t)((1u << std::min(8, std::min(64, key_bits) - s)) - 1)}
+                              : DigitSel{2, s - 64, (uint32_t)((1u << std::min(8, key_bits - s)) - 1)};
+            };
+            // look-back passes (default; DBG_ONESWEEP=0: per-tile histogram + scan + scatter), as in sort_table_hybrid16
+            const int npass = (key_bits - s0 + 7) / 8;
+            bool lookback = !(ctx->opt("DBG_ONESWEEP") && !strcmp(ctx->opt("DBG_ONESWEEP"), "0")) && npass >= 1 && npass <= 4;
+            DBuf<unsigned int> ghist, gexcl, lb_ctl;
+            DBuf<unsigned long long> lb_status;
+            if (lookback) {
+                ALLOC_OR_FAIL(ctx, ghist, 4 * 256); ALLOC_OR_FAIL(ctx, gexcl, 4 * 256); ALLOC_OR_FAIL(ctx, lb_ctl, 8);
+                ALLOC_OR_FAIL(ctx, lb_status, (size_t)nblocks * 256);
+                HIP_TRY(ctx, hipMemsetAsync(ghist.p, 0, 4 * 256 * 4, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(lb_status.p, 0, (size_t)nblocks * 256 * 8, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(lb_ctl.p, 0, 8 * 4, ctx->stream));
+                DigitSel4 d4{};
+                d4.n = npass;
+                for (int pi = 0; pi < npass; pi++) d4.d[pi] = sel_of(s0 + 8 * pi);
                 ctx->t_begin("radix_hist", n);
-                radix_hist_kernel<<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, n, ds, hist.p, nblocks);
+                radix_global_hist_kernel<<<std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n, 512 * 16), 2048)), 512, 0, ctx->stream>>>(src, n, d4, ghist.p);
+                radix_global_scan_kernel<<<1, 256, 0, ctx->stream>>>(ghist.p, gexcl.p, npass);
                 ctx->t_end();
-                LAUNCH_CHECK(ctx, "radix_hist");
-                DBG_TRY(scan_exclusive_u32(ctx, hist.p, hist_scanned.p, (uint64_t)256 * nblocks));
-                ctx->t_begin("radix_scatter", n);
-                if (has_hi) radix_scatter_kernel<true><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
-                else        radix_scatter_kernel<false><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
-                ctx->t_end();
-                LAUNCH_CHECK(ctx, "radix_scatter");
+                LAUNCH_CHECK(ctx, "radix_global_hist");
+            }
+            int pi = 0;
+            for (int s = s0; s < key_bits; s += 8, pi++) {
+                const DigitSel ds = sel_of(s);
+                bool done = false;
+                if (lookback) {
+                    LookBack lb{gexcl.p + pi * 256, lb_status.p, lb_ctl.p + 2 * pi, lb_ctl.p + 2 * pi + 1, (uint32_t)pi};
+                    ctx->t_begin("radix_scatter", n);
+                    if (has_hi) radix_scatter_kernel<true, true><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, nullptr, nblocks, lb);
+                    else        radix_scatter_kernel<false, true><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, nullptr, nblocks, lb);
+                    ctx->t_end();
+                    LAUNCH_CHECK(ctx, "radix_scatter_lookback");
+                    unsigned int ctl[2] = {0, 0};                      // (the pass's input is only intact until the next pass writes over it)
+                    HIP_TRY(ctx, hipMemcpyAsync(ctl, lb_ctl.p + 2 * pi, 8, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    done = ctl[1] == 0;
+                    if (!done) { lookback = false; if (ctx->opt("DBG_DEBUG")) fprintf(stderr, "[sort] look-back pass gave up (shift %d): classic pass instead\n", s); }
+                }
+                if (!done) {
+                    ctx->t_begin("radix_hist", n);
+                    radix_hist_kernel<<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, n, ds, hist.p, nblocks);
+                    ctx->t_end();
+                    LAUNCH_CHECK(ctx, "radix_hist");
+                    DBG_TRY(scan_exclusive_u32(ctx, hist.p, hist_scanned.p, (uint64_t)256 * nblocks));
+                    ctx->t_begin("radix_scatter", n);
+                    if (has_hi) radix_scatter_kernel<true><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
+                    else        radix_scatter_kernel<false><<<nblocks, RS_THREADS, 0, ctx->stream>>>(src, dst, n, ds, hist_scanned.p, nblocks);
+                    ctx->t_end();
+                    LAUNCH_CHECK(ctx, "radix_scatter");
+                }
                 std::swap(src, dst);
             }
         }
@@ -941,21 +1047,6 @@ __global__ void __launch_bounds__(512) radix16_global_hist_kernel(const uint4* _
     __syncthreads();
     for (int i = threadIdx.x; i < npass * 256; i += blockDim.x) { const uint32_t v = (&h[0][0])[i]; if (v) atomicAdd(&ghist[i], v); }
 }
-// exclusive scan of each pass's 256 totals (one wave per pass)
-__global__ void __launch_bounds__(256) radix16_global_scan_kernel(const unsigned int* __restrict__ ghist, unsigned int* __restrict__ gexcl, int npass) {
-    const uint32_t p = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if ((int)p >= npass) return;
-    uint32_t run = 0;
-    for (int c = 0; c < 4; c++) {
-        const uint32_t v = ghist[p * 256 + c * 64 + lane];
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
-        gexcl[p * 256 + c * 64 + lane] = run + incl - v;
-        run += __shfl(incl, 63);
-    }
-}
-
 __global__ void __launch_bounds__(R16_THREADS) radix16_onesweep_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, uint32_t n, int shift,
                                                                        uint32_t mask, const unsigned int* __restrict__ gexcl,
                                                                        unsigned long long* __restrict__ status, unsigned int* __restrict__ tile_counter,
@@ -1112,7 +1203,7 @@ int sort_table_hybrid16(dbg_ctx* ctx, uint64_t n64, uint4* a, uint4* b, int key_
             HIP_TRY(ctx, hipMemsetAsync(os_ctl.p, 0, 2 * OS_MAXP * 4, ctx->stream));
             ctx->t_begin("radix_hist", n);
             radix16_global_hist_kernel<<<std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n, 512 * 16), 2048)), 512, 0, ctx->stream>>>(src, n, s0, npass, key_bits, ghist.p);
-            radix16_global_scan_kernel<<<1, 256, 0, ctx->stream>>>(ghist.p, gexcl.p, npass);
+            radix_global_scan_kernel<<<1, 256, 0, ctx->stream>>>(ghist.p, gexcl.p, npass);
             ctx->t_end();
             LAUNCH_CHECK(ctx, "radix16_global_hist");
         }
