@@ -275,8 +275,11 @@ def main():
             src_sha = hsrc.hexdigest()[:16]
             traffic_stale = bool(tj) and tj.get("_kernel_source_sha16") != src_sha
             pmc_name = {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
-                        "radix_hist": "radix16_hist_kernel" if 2 * k <= 96 else "radix_hist_kernel",
-                        "radix_scatter": "radix16_scatter_kernel" if 2 * k <= 96 else "radix_scatter_kernel",
+                        # (round 3: look-back passes -- one up-front histogram kernel, the scatter kernel does its own offsets; the classic
+                        #  kernels remain as DBG_ONESWEEP=0 and as the fall-back)
+                        "radix_hist": (("radix16_global_hist_kernel", "radix16_hist_kernel") if 2 * k <= 96
+                                       else ("radix_global_hist_kernel", "radix_hist_kernel")),
+                        "radix_scatter": (("radix16_onesweep_kernel", "radix16_scatter_kernel") if 2 * k <= 96 else ("radix_scatter_kernel",)),
                         "span_sort": (("span_sort16_groups_kernel", "span_sort16_kernel") if 2 * k <= 96
                                       else ("span_sort_groups_kernel", "span_sort_kernel")), "set_csr": "csr_apply_kernel",
                         "sk_scatter": "sk_scatter_kernel", "slab_compact": "slab_compact_kernel"}
