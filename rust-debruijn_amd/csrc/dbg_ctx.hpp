@@ -30,7 +30,7 @@ struct dbg_state_slot {
 static const char* const DBG_OPTION_NAMES[] = {
     "DBG_PATH", "DBG_COMPRESS", "DBG_FAST_TARGET", "DBG_FAST_NT", "DBG_FAST_TABLE", "DBG_NO_HYBRID_SORT", "DBG_NO_REC16",
     "DBG_FAST_NO_SLAB", "DBG_DEBUG", "DBG_UNITIG_NO_WALK", "DBG_UNITIG_NO_CHAINS", "DBG_NO_KEY_RECORDS", "DBG_NO_NODE_RECORDS",
-    "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_COUNT", "DBG_WAVE_GRID", "DBG_SLAB_CAP", "DBG_ONESWEEP"};
+    "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_COUNT", "DBG_WAVE_GRID", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_SLAB_PROBE"};
 
 struct dbg_ctx {
     int device = 0;
@@ -89,6 +89,15 @@ struct dbg_ctx {
         if (it == live_blocks.end()) { (void)hipFree(p); return; }
         free_blocks.insert({it->second, p});
         live_blocks.erase(it);
+    }
+    // blocks that lost the placement probe of the slab allocation (fastpath.hip): they serve the rest of the call from the pool and
+    // go back to the driver when it ends -- hoarding them is what makes the next allocator on the GPU run out
+    std::vector<void*> spare_blocks;
+    void drop_spares() {
+        for (void* q : spare_blocks)
+            for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it)
+                if (it->second == q) { (void)hipFree(q); pooled_bytes -= it->first; free_blocks.erase(it); break; }
+        spare_blocks.clear();
     }
     void trim() {
         (void)hipStreamSynchronize(stream);
