@@ -458,7 +458,8 @@ def main():
             "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
             "exchange": ({"bytes_sent_per_step_all_ranks": xbytes_total // max(args.steps, 1),
                           "exposed_ms_per_step_max_rank": round(exposed_ms / max(args.steps, 1), 3),
-                          "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1)} if world > 1 else None),
+                          "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1),
+                          "sender_merge": bool(xstats.get("merge_dups", 0))} if world > 1 else None),
             "balance": balance,
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
             "host_boundary": hostb, "compress": comp,

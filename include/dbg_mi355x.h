@@ -294,6 +294,10 @@ typedef struct {
     uint32_t max_label;         /* CountFilterSet: largest D1 label over ALL ranks (dbg_seqset_max_label_dev + a max-reduction);
                                    labels must be < 64 here -- 24..63 select the two-word colour layout on every rank.
                                    0 = "below 24" (what callers of the earlier ABI passed) */
+    uint32_t merge_dups;        /* dbg_shard_scan_dev: merge this rank's identical super-k-mer records before the exchange (a
+                                   merged record carries its multiplicity; the counting side reads it either way, so ranks may
+                                   choose independently).  Fewer bytes on the wire: a rank with 1/W of 18x reads still holds
+                                   18/W copies of most records */
 } dbg_shard_plan;
 /* largest D1 label of a device-resident sequence set (0 when it carries no data) */
 int  dbg_seqset_max_label_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t* max_label_out);

@@ -62,7 +62,7 @@ class SynthParams(C.Structure):
 class ShardPlan(C.Structure):
     _fields_ = [("k", C.c_uint32), ("stranded", C.c_int32), ("summarizer", C.c_int32), ("min_kmer_obs", C.c_uint64),
                 ("total_kmers", C.c_uint64), ("n_bins", C.c_uint32), ("rec_words", C.c_uint32), ("bin_group", C.c_uint32),
-                ("max_label", C.c_uint32)]
+                ("max_label", C.c_uint32), ("merge_dups", C.c_uint32)]
 
 
 class KernelTime(C.Structure):

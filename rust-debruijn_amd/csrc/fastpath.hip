@@ -128,6 +128,7 @@ constexpr int SCAN_ARR = 192 + 64;              // positions per tile + padding 
 constexpr uint32_t SCAN_CHUNK = 1024;           // records a wave reserves per global atomic (one hot address otherwise)
 constexpr uint32_t BIN_INVALID = 0xffffffffu;   // unused slot of a reserved chunk
 constexpr int META_BITS = 21;
+constexpr int WEIGHT_BITS = 4;                  // sharded flow: (copies - 1) of a record merged on the sending rank, directly above the meta bits
 constexpr uint32_t NCLS = 1;                    // length classes per bin: records of similar k-mer count sit together
                                                 // so that the 64 records a wave processes finish at about the same time
 
@@ -775,12 +776,14 @@ __device__ unsigned long long g_phase_cycles[8];
 #else
 #define MARK(t) do {} while (0)
 #endif
-template <int KW, int NBW, bool IS_SET, int NT, int T, bool WIDE = false>
+template <int KW, int NBW, bool IS_SET, int NT, int T, bool WIDE = false, bool WEIGHTED = false>
 __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
                                                        unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags) {
+    // WEIGHTED (sharded flow): a record may stand for several copies, merged on the sending rank (slab_merge_kernel)
+    constexpr uint32_t wmask = WEIGHTED ? (1u << WEIGHT_BITS) - 1u : 0u;
     constexpr int RW = NBW;
     constexpr int NWV = NT / 64;
     __shared__ __attribute__((aligned(16))) uint32_t s_tag[T];
@@ -916,7 +919,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
         //   s_nst  staged records; a round accepts min(NT - s_nst, remaining) incoming records, so every one of them finds room
         constexpr uint64_t COLOUR_BITS = 63ull << 15;
         constexpr uint32_t MIN_ROOM = NT / 8;           // keep filling while the rest of the bin, or at least this many records, still fit
-        constexpr uint32_t MAX_FILLS = 100;             // weights are 16-bit: at most NT per round, 100 x 512 < 65536
+        // weights are 16-bit: a round adds at most NT x (the largest weight a record carries): 101 x 512 and 7 x 512 x 16 < 65536
+        constexpr uint32_t MAX_FILLS = wmask ? 6u : 100u;
         uint32_t rnext = 0;                             // next incoming record of the bin (uniform)
         bool pass_bad = false, bad_bin = false;
         while (rnext < total_recs && !pass_ovf) {
@@ -943,7 +947,12 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                 bool pend = tid < take;
                 uint32_t mytag = 0, sl = 0;
                 cmask_t colour = 0;
-                const uint64_t PL0 = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);               // word holding the meta bits
+                // a record merged on the sending rank stands for 1 + (its weight field) copies; the field is cleared before the record
+                // is hashed, compared and staged (wmask = 0: the records carry no weights, the bits may be base bits)
+                uint64_t& PLr = NBW == 2 ? P1 : (NBW == 3 ? P2 : P3);                    // word holding the meta bits
+                const uint32_t wt = 1u + ((uint32_t)(PLr >> META_BITS) & wmask);
+                PLr &= ~((uint64_t)wmask << META_BITS);
+                const uint64_t PL0 = PLr;
                 if (pend) {
                     pmeta = PL0 & ((1ull << META_BITS) - 1);
                     {   // a record whose length cannot come from the scan (a wrong segment table, an incomplete exchange) must not
@@ -973,7 +982,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                                     s_slab[mine] = P0; s_slab[NT + mine] = P1;
                                     if (NBW > 2) s_slab[2 * NT + mine] = P2;
                                     if (NBW > 3) s_slab[3 * NT + mine] = P3;
-                                    atomicAdd(&s_w[mine >> 1], 1u << (16 * (mine & 1u)));
+                                    atomicAdd(&s_w[mine >> 1], wt << (16 * (mine & 1u)));
                                     if (IS_SET) atomicOr(&s_cmk[mine], colour);
                                     s_dd[sl] = (mine + 1u) | mytag;
                                     pend = false;
@@ -993,7 +1002,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                         same = same && ((s_slab[(NBW - 1) * NT + r] ^ PL0) & ~COLOUR_BITS) == 0;
                         if (same) {                                                      // an equal record is staged: it stands for this one too
                             STAT(fills ? 14 : 15, 1);
-                            atomicAdd(&s_w[r >> 1], 1u << (16 * (r & 1u)));
+                            atomicAdd(&s_w[r >> 1], wt << (16 * (r & 1u)));
                             if (IS_SET) atomicOr(&s_cmk[r], colour);
                             pend = false;
                         } else sl = (sl + 1u) & (DD - 1);
@@ -1461,6 +1470,7 @@ struct FastPlan {
     bool stranded, is_set, has_hi;
     bool wave = false;                                  // bins sized for the wave-per-bin counting kernel (256-entry tables)
     bool wide = false;                                  // colour sets of 25..64 colours: two mask words per table entry, payload gathered after the sort
+    bool weighted = false;                              // sharded flow: records may carry a weight (sender-side duplicate merge) in the WEIGHT_BITS above the meta bits
     uint32_t nbins;
     LabelInv linv = {};
     const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
@@ -1474,6 +1484,7 @@ static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw;
     pl->stranded = stranded; pl->is_set = is_set; pl->has_hi = k > 32;
+    pl->weighted = false;
     // k-mer instances per bin.  The table holds T = 2048 distinct k-mers and works best about half full; the share of
     // distinct k-mers among the instances grows with k (every sequencing error spoils k k-mers), so the bins shrink
     // with k: measured optima on 30x reads with e = 0.1 %: k=31 8-12k, k=47 8k, k=51 7-8k, k=63 6k (a bin that
@@ -1932,13 +1943,14 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
             const int nt_env = c->opt("DBG_FAST_NT") ? atoi(c->opt("DBG_FAST_NT")) : 512;
             const int tb_env = c->opt("DBG_FAST_TABLE") ? atoi(c->opt("DBG_FAST_TABLE")) : 2048;
             const size_t dyn_lds = c->opt("DBG_DYN_LDS") ? (size_t)atoi(c->opt("DBG_DYN_LDS")) : 0;   // measurement: extra LDS per workgroup (8192 leaves room for only one per CU)
-#define L(KW, NBW, SET, NTT, TT) bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, dyn_lds, c->stream>>>( \
-            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
-#define LW(KW, NBW) bin_count_kernel<KW, NBW, true, 512, 1024, true><<<nbins_local, 512, dyn_lds, c->stream>>>( \
-            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p)
+#define ARGS_ recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p
+#define L(KW, NBW, SET, NTT, TT) do { if (pl.weighted && NTT == 512) bin_count_kernel<KW, NBW, SET, 512, TT, false, true><<<nbins_local, 512, dyn_lds, c->stream>>>(ARGS_); \
+            else bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, dyn_lds, c->stream>>>(ARGS_); } while (0)
+#define LW(KW, NBW) do { if (pl.weighted) bin_count_kernel<KW, NBW, true, 512, 1024, true, true><<<nbins_local, 512, dyn_lds, c->stream>>>(ARGS_); \
+            else bin_count_kernel<KW, NBW, true, 512, 1024, true><<<nbins_local, 512, dyn_lds, c->stream>>>(ARGS_); } while (0)
 #define GO(KW, NBW, SET) do { \
             if (SET && pl.wide) LW(KW, NBW); \
-            else if (tb_env == 1024 && nt_env == 256) L(KW, NBW, SET, 256, 1024); \
+            else if (tb_env == 1024 && nt_env == 256 && !pl.weighted) L(KW, NBW, SET, 256, 1024); \
             else L(KW, NBW, SET, 512, TABLE); } while (0)
             if (!has_hi) { if (is_set) GO(1, 2, true); else GO(1, 2, false); }
             else if (nbw == 2) { if (is_set) GO(2, 2, true); else GO(2, 2, false); }
@@ -1947,6 +1959,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
 #undef GO
 #undef LW
 #undef L
+#undef ARGS_
             c->t_end();
             LAUNCH_CHECK(c, "bin_count");
         }
@@ -2123,6 +2136,122 @@ __global__ void __launch_bounds__(256) slab_compact_kernel(const uint64_t* __res
     }
 }
 
+// Sender-side duplicate merge of the sharded flow (round 3).  Reads that cover the same stretch of the genome produce
+// identical records (the cut points depend on the sequence alone), and a rank that holds 1/W of the reads still holds
+// coverage/W copies of each: before the exchange every bin's identical records are merged IN PLACE in its slab into one record
+// that carries (copies - 1) in the WEIGHT_BITS above its meta bits (more than 16 copies: several records), and the bin's fill
+// count shrinks.  One wave per bin: distinct records collect in a per-wave LDS staging area behind a small hash filter (the
+// same claim / compare scheme as bin_count's staging, without barriers: a wave's LDS operations are performed in order) and
+// are written back behind the wave's read position when the area fills up or the bin ends.  Any grouping of equal records is
+// correct -- duplicates that meet in different fills just stay separate.  Bins that overflowed their slab are left alone.
+// MG_S staged records per wave: 256 merge a two-rank job's bins (270 records, 130 distinct) as well as can be done; bins of
+// under ~130 records (eight ranks) take the 128-slot instantiation, whose smaller LDS footprint keeps 28 waves per CU resident
+// instead of 12 (1.85 ms against 2.87 per 2*10^7 reads).
+constexpr uint32_t MG_WAVES = 4, MG_COUNTERS = 4096;
+template <int RW, uint32_t MG_S>
+__global__ void __launch_bounds__(64 * MG_WAVES) slab_merge_kernel(uint64_t* __restrict__ slab, uint32_t slab_cap, uint32_t* __restrict__ cursor, uint32_t nb,
+                                                                   unsigned long long* __restrict__ merged_away) {
+    constexpr uint32_t MG_F = 2 * MG_S;                      // the filter stays at most half full; its entries hold a 10-bit slot number
+    static_assert(MG_S < 1023, "slot field");
+    __shared__ uint64_t s_rec[MG_WAVES][RW * MG_S];          // staged records, word-major
+    __shared__ uint32_t s_wt[MG_WAVES][MG_S];
+    __shared__ uint32_t s_f[MG_WAVES][MG_F];                 // filter: (staged slot + 1, or 1023 = being staged) | hash bits << 10
+    __shared__ uint32_t s_n[MG_WAVES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * MG_WAVES + wave;
+    if (b >= nb) return;
+    const uint32_t cnt = cursor[b];
+    if (cnt < 2 || cnt > slab_cap) return;
+    uint64_t* const rec = slab + (uint64_t)b * slab_cap * RW;
+    uint64_t* const R = s_rec[wave];
+    uint32_t* const WT = s_wt[wave];
+    uint32_t* const F = s_f[wave];
+    constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
+    uint32_t m = 0, nst = 0;                                 // records written back / staged (wave-uniform)
+    for (uint32_t i = lane; i < MG_F; i += 64) F[i] = 0;
+    if (lane == 0) s_n[wave] = 0;
+    __builtin_amdgcn_wave_barrier();
+    auto flush = [&]() {
+        for (uint32_t i0 = 0; i0 < nst; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool on = i < nst;
+            uint32_t w = on ? WT[i] : 0u;
+            const uint32_t ne = (w + WCAP - 1u) / WCAP;      // output records of this staged record
+            uint32_t incl = ne;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+            const uint32_t tot = __shfl(incl, 63);
+            if (on) {
+                uint64_t a[RW];
+#pragma unroll
+                for (int j = 0; j < RW; j++) a[j] = R[j * MG_S + i];
+                uint64_t* dst = rec + (uint64_t)(m + incl - ne) * RW;
+                for (uint32_t e = 0; e < ne; e++, dst += RW) {
+                    const uint32_t part = w < WCAP ? w : WCAP;
+                    w -= part;
+#pragma unroll
+                    for (int j = 0; j < RW - 1; j++) dst[j] = a[j];
+                    dst[RW - 1] = a[RW - 1] | ((uint64_t)(part - 1u) << META_BITS);
+                }
+            }
+            m += tot;
+        }
+        nst = 0;
+        for (uint32_t i = lane; i < MG_F; i += 64) F[i] = 0;
+        if (lane == 0) s_n[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
+        // everything written back so far lies below r0 (one output record stands for at least one consumed record)
+        if (nst + 64 > MG_S) flush();
+        bool pend = r0 + lane < cnt;
+        uint64_t a[RW];
+#pragma unroll
+        for (int j = 0; j < RW; j++) a[j] = pend ? rec[(uint64_t)(r0 + lane) * RW + j] : 0ull;
+        uint64_t ha = a[0], hb = a[1];
+        if (RW > 2) ha += a[2] * 0x9E3779B97F4A7C15ull;
+        if (RW > 3) hb += a[3] * 0xC2B2AE3D27D4EB4Full;
+        const uint64_t h = hash_key(ha, hb);
+        const uint32_t tag = (uint32_t)(h >> 42) << 10;
+        uint32_t sl = (uint32_t)h & (MG_F - 1);
+        while (__ballot(pend) != 0ull) {
+            if (pend) {
+                for (;;) {                                   // to the first filter slot that is free or carries my hash bits
+                    uint32_t v = F[sl];
+                    if (v == 0u) {
+                        v = atomicCAS(&F[sl], 0u, 1023u | tag);
+                        if (v == 0u) {                       // first of its kind: stage it
+                            const uint32_t mine = atomicAdd(&s_n[wave], 1u);
+#pragma unroll
+                            for (int j = 0; j < RW; j++) R[j * MG_S + mine] = a[j];
+                            WT[mine] = 1u;
+                            F[sl] = (mine + 1u) | tag;
+                            pend = false;
+                            break;
+                        }
+                    }
+                    if ((v & ~1023u) == tag) break;
+                    sl = (sl + 1u) & (MG_F - 1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                 // (every lane is out of the loop: what was claimed is now staged)
+            if (pend) {
+                const uint32_t r = (F[sl] & 1023u) - 1u;
+                bool same = true;
+#pragma unroll
+                for (int j = 0; j < RW; j++) same = same && R[j * MG_S + r] == a[j];
+                if (same) { atomicAdd(&WT[r], 1u); pend = false; }
+                else sl = (sl + 1u) & (MG_F - 1);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        nst = s_n[wave];
+    }
+    flush();
+    // (one counter would be a single hot address: same-address atomics complete at ~1e8/s, and there are millions of bins)
+    if (lane == 0) { cursor[b] = m; if (cnt != m) atomicAdd(&merged_away[b & (MG_COUNTERS - 1)], (unsigned long long)(cnt - m)); }
+}
+
 // returns 0 and sets *used = true when the fast path produced the table; *used = false means the
 // caller must take the generic path (unsupported shape), nothing was written.
 int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
@@ -2195,6 +2324,8 @@ static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
     // every rank must use the same colour layout: it follows from the plan's global max_label (no per-rank label map here)
     if (pl->is_set && sp->max_label >= 64) return c->fail(141, "sharded CountFilterSet needs labels < 64 (dbg_shard_plan.max_label)");
     pl->wide = pl->is_set && sp->max_label >= 24;
+    // records of the sharded flow may carry weights when the record has the spare bits (every rank derives the same answer)
+    pl->weighted = !pl->wave && 64 * pl->nbw - 2 * (2 * pl->k - pl->p) - META_BITS >= WEIGHT_BITS;
     if (pl->wide && !sp->n_bins && !c->opt("DBG_FAST_TARGET")) pl->nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl->nbins * 2, (1ull << 23) - 1);
     return 0;
 }
@@ -2238,6 +2369,27 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
         ALLOC_OR_FAIL(c, st->hist, nb); ALLOC_OR_FAIL(c, st->cursor, nb); ALLOC_OR_FAIL(c, st->slab, 4);
         HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)nb * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(st->cursor.p, 0, (size_t)nb * 4, c->stream));
+    }
+    if (n_kmers && sp->merge_dups && pl.weighted && st->slab_cap) {
+        DBuf<unsigned long long> away;
+        ALLOC_OR_FAIL(c, away, MG_COUNTERS);
+        HIP_TRY(c, hipMemsetAsync(away.p, 0, 8 * MG_COUNTERS, c->stream));
+        c->t_begin("slab_merge", 0);
+        const uint32_t blocks = cdiv(nb, MG_WAVES);
+        const bool small = st->slab_cap <= 176;            // slab_cap = 1.3 x the mean bin + 48: bins of up to ~100 records on average
+#define MERGE(RW_) do { if (small) slab_merge_kernel<RW_, 128><<<blocks, 64 * MG_WAVES, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, nb, away.p); \
+                        else slab_merge_kernel<RW_, 256><<<blocks, 64 * MG_WAVES, 0, c->stream>>>(st->slab.p, st->slab_cap, st->cursor.p, nb, away.p); } while (0)
+        if (pl.rw == 2) MERGE(2); else if (pl.rw == 3) MERGE(3); else MERGE(4);
+#undef MERGE
+        c->t_end();
+        LAUNCH_CHECK(c, "slab_merge");
+        std::vector<unsigned long long> h_away(MG_COUNTERS);
+        HIP_TRY(c, hipMemcpyAsync(h_away.data(), away.p, 8 * MG_COUNTERS, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        unsigned long long n_away = 0;
+        for (unsigned long long v : h_away) n_away += v;
+        c->t_begin("sk_merged_away", n_away);  // bookkeeping entry: units = records the merge removed (no kernel)
+        c->t_end();
     }
     // per-bin record counts (slab + overflow) -> exclusive offsets of the bin-ordered layout
     DBG_TRY(scan_exclusive_u32_u64(c, st->cursor.p, bin_off_dev, nb));

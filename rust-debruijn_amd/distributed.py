@@ -46,8 +46,10 @@ class HipEngine:
         self.ctx.check(self.lib.dbg_seqset_max_label_dev(self.ctx.h, C.byref(ss), C.byref(m)))
         return m.value
 
-    def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers, max_label=0):
-        p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0, 0, max_label)
+    def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers, max_label=0, merge_dups=True):
+        """merge_dups: this rank merges its identical super-k-mer records before the exchange (dbg_shard_plan.merge_dups)"""
+        p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0, 0, max_label,
+                            int(bool(merge_dups)))
         self.ctx.check(self.lib.dbg_shard_plan_make(self.ctx.h, C.byref(p)))
         return p
 
@@ -263,10 +265,14 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
     return engine.count_finish(plan)
 
 
-def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None, n_chunks=None, stats=None, force_exchange=False):
+def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None, n_chunks=None, stats=None, force_exchange=False,
+                         merge_dups=None):
     """Distributed filter_kmers: returns this rank's table (the valid k-mers of the bins it owns,
     ascending by key) and the global k-mer instance count.  stats (a dict, optional) receives the exchange volume and the
-    exchange time the counting kernels could not hide."""
+    exchange time the counting kernels could not hide.  merge_dups: merge identical records on the sending rank before the
+    exchange (default: at 2..4 ranks, where a rank holds enough copies of each record for the merge to remove more wire time
+    than it costs -- DESIGN.md section 5; DBG_SHARD_MERGE=0 / 1 forces it off / on)."""
+    import os
     import torch
     import torch.distributed as dist
     engine.sync()                                  # the reads may still be in flight on torch's current stream
@@ -288,7 +294,12 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
             t = torch.tensor([max_label], dtype=torch.int64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             max_label = int(t.item())
-    plan = engine.plan(k, stranded, summarizer_kind, min_obs, total, max_label)
+    if merge_dups is None:
+        env = os.environ.get("DBG_SHARD_MERGE")
+        merge_dups = (1 < world <= 4) if env is None else env != "0"
+    if stats is not None:
+        stats["merge_dups"] = bool(merge_dups)
+    plan = engine.plan(k, stranded, summarizer_kind, min_obs, total, max_label, merge_dups=merge_dups)
     bin_off, n_recs = engine.scan(ss, plan)
     layout = None
     force = force_exchange and dist.is_initialized()

@@ -29,7 +29,7 @@ class OracleEngine:
     def max_label(self, ss):
         return int(ss.data.max()) if getattr(ss, "data", None) is not None and len(ss.data) else 0
 
-    def plan(self, k, stranded, kind, min_obs, total, max_label=0):
+    def plan(self, k, stranded, kind, min_obs, total, max_label=0, merge_dups=False):
         return Plan(k, stranded, kind, min_obs, total, self.n_bins)
 
     def scan(self, ss, plan):

@@ -41,9 +41,12 @@ def table_to_host(ctx, tab, k):
     return out
 
 
+@pytest.mark.parametrize("merge", [True, False])
 @pytest.mark.parametrize("kind,k,world,colours", [(0, 47, 2, 4), (1, 47, 2, 4), (0, 31, 3, 4), (0, 63, 2, 4), (1, 51, 2, 40), (1, 31, 3, 64)])
-def test_virtual_ranks_multi_segment(ctx, kind, k, world, colours):
-    """colours > 24: the two-word colour layout, selected on every rank by the plan's global max_label"""
+def test_virtual_ranks_multi_segment(ctx, kind, k, world, colours, merge):
+    """colours > 24: the two-word colour layout, selected on every rank by the plan's global max_label.  merge: the sending
+    ranks merge their identical records first (dbg_shard_plan.merge_dups); rank 0 never does, so weighted and plain records
+    meet in every bin."""
     eng = D.HipEngine(ctx, torch.device("cuda", 0))
     n_reads, per = 6000, 6000 // world
     shards, keep = [], []
@@ -56,12 +59,14 @@ def test_virtual_ranks_multi_segment(ctx, kind, k, world, colours):
     total = sum(eng.count_instances(s, k) for s in shards)
     max_label = max(eng.max_label(s) for s in shards) if kind == 1 else 0      # (an all-reduce MAX in the real flow)
     assert max_label == (colours - 1 if kind == 1 else 0)
-    plan = eng.plan(k, False, kind, 2, total, max_label)
+    plan = eng.plan(k, False, kind, 2, total, max_label, merge_dups=False)
+    plan_m = eng.plan(k, False, kind, 2, total, max_label, merge_dups=merge)
+    assert (plan_m.n_bins, plan_m.rec_words) == (plan.n_bins, plan.rec_words)
     rw, nb = plan.rec_words, plan.n_bins
     bounds = D.owner_bounds(nb, world, plan.bin_group)
     scanned = []
-    for s in shards:
-        bin_off, n = eng.scan(s, plan)
+    for r, s in enumerate(shards):
+        bin_off, n = eng.scan(s, plan_m if r else plan)
         recs = eng.scatter(plan, bin_off, n)
         scanned.append((bin_off, recs))
     if kind == 1 and colours > 24:                              # a plan that understates the labels is refused, not miscounted
@@ -132,3 +137,92 @@ def test_orchestration_world1(ctx):
     want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1), 47, O.COUNT_FILTER_SET, 2, stranded=False)
     assert total == 5000 * 104 and t.keys() == want.keys()
     assert np.array_equal(t.exts, want.exts) and np.array_equal(t.set_off, want.set_off) and np.array_equal(t.set_val, want.set_val)
+
+
+def _records(eng, hs_list, k, kind, merge, stranded=False):
+    """-> (tables of all owners merged into {key: (exts, value)}, records per sending rank)"""
+    import virtual_ranks as V
+    tabs, total, n_recs = V.owner_tables(eng, hs_list, k, stranded, kind, 2, merge_dups=merge, with_records=True)
+    got = {}
+    for tab in tabs:
+        t = table_to_host(eng.ctx, tab, k)
+        eng.free_table(tab)
+        for i, key in enumerate(t.keys()):
+            assert key not in got
+            got[key] = (int(t.exts[i]), t.data(i))
+    return got, n_recs
+
+
+@pytest.mark.parametrize("kind,k,world", [(0, 47, 2), (0, 47, 8), (1, 31, 4), (0, 63, 8), (0, 51, 2), (0, 20, 2)])
+def test_sender_merge_shrinks_the_exchange_and_changes_nothing(ctx, kind, k, world):
+    """30x reads over `world` ranks: a rank holds 30/world copies of most records, the merge leaves about one of each.
+    The tables with and without the merge are the same and equal the oracle's."""
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    n_reads = 16000
+    per = n_reads // world
+    hs_list = [dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.002, stranded=False,
+                                    n_colours=3, first_read=r * per) for r in range(world)]
+    plain, n_plain = _records(eng, hs_list, k, kind, False)
+    merged, n_merged = _records(eng, hs_list, k, kind, True)
+    assert merged == plain
+    hs_all = dbg.synth_reads_host(n_reads=n_reads, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.002, stranded=False, n_colours=3)
+    want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data, 1), k, kind, 2, stranded=False)
+    assert sorted(merged) == want.keys()
+    for i, key in enumerate(want.keys()):
+        e, v = merged[key]
+        assert e == int(want.exts[i])
+        if kind == 1:
+            assert v == [int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]]
+        else:
+            assert v == int(want.count[i])
+    assert all(m <= p for m, p in zip(n_merged, n_plain))
+    # how well it merges: rank 0's records against the number of distinct ones among them (identical records share a bin, and
+    # these bins fit the merge kernel's staging area, so it should find nearly all of them)
+    ss, keep = dev_seqset(eng, hs_list[0], kind == 1)
+    total = sum(int(np.maximum(h.length.astype(np.int64) - k + 1, 0).sum()) for h in hs_list)
+    plan = eng.plan(k, False, kind, 2, total, 2 if kind == 1 else 0, merge_dups=False)
+    bin_off, n = eng.scan(ss, plan)
+    assert n == n_plain[0]
+    recs = eng.scatter(plan, bin_off, n).view(-1, plan.rec_words)
+    distinct = int(torch.unique(recs, dim=0).shape[0])
+    assert distinct <= n_merged[0], (distinct, n_merged[0])
+    if k >= 31:                                                   # (small k: many short records per bin, more than the staging area holds)
+        assert n_merged[0] <= distinct * 1.10 + 8, (distinct, n_merged[0], n_plain[0])
+    if world <= 2 and kind == 0:
+        assert n_merged[0] < 0.6 * n_plain[0]
+
+
+@pytest.mark.parametrize("kind,k,stranded", [(0, 47, False), (1, 33, True), (0, 64, False)])
+def test_sender_merge_heavy_duplicates(ctx, kind, k, stranded):
+    """the same few reads hundreds of times over: weights beyond one record's 16, staging areas that refill, counts that
+    saturate exactly as the oracle's do"""
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    rng = np.random.default_rng(5)
+    base = [rng.integers(0, 4, size=int(rng.integers(k, 200))).astype(np.uint8) for _ in range(12)]    # base codes 0..3
+    base.append(np.zeros(150, np.uint8))
+    base.append(np.tile(np.array([0, 1], np.uint8), 75))
+    hs_list, all_seqs, all_data = [], [], []
+    for r in range(2):
+        seqs = [base[int(i)] for i in rng.integers(0, len(base), size=1500)] + [base[0]] * (700 if r == 0 else 3)
+        data = [int(x) for x in rng.integers(0, 5, size=len(seqs))]
+        hs_list.append(dbg.HostSeqs.from_tuples([(q, 0, d) for q, d in zip(seqs, data)], data_width=1))
+        all_seqs += seqs
+        all_data += data
+    plain, n_plain = _records(eng, hs_list, k, kind, False, stranded)
+    merged, n_merged = _records(eng, hs_list, k, kind, True, stranded)
+    assert merged == plain
+    assert sum(n_merged) < sum(n_plain)            # (most of these bins outgrow their slab and are left alone)
+    with ctx.options(DBG_SLAB_CAP="8192"):        # slabs that hold every bin: a record per 16 copies
+        merged, n_merged = _records(eng, hs_list, k, kind, True, stranded)
+    assert merged == plain
+    assert sum(n_merged) < 0.2 * sum(n_plain)
+    hs_all = dbg.HostSeqs.from_tuples([(q, 0, d) for q, d in zip(all_seqs, all_data)], data_width=1)
+    want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data, 1), k, kind, 2, stranded=stranded)
+    assert sorted(merged) == want.keys()
+    for i, key in enumerate(want.keys()):
+        e, v = merged[key]
+        assert e == int(want.exts[i])
+        if kind == 1:
+            assert v == [int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]]
+        else:
+            assert v == int(want.count[i])

@@ -20,8 +20,9 @@ def dev_seqset(engine, hs, with_data):
     return engine.seqset(words, start, length, data, 1), (words, start, length, data)
 
 
-def owner_tables(eng, host_shards, k, stranded, kind, min_obs):
-    """host_shards: one HostSeqs per virtual rank -> (list of device tables, one per owner; total k-mer instances).
+def owner_tables(eng, host_shards, k, stranded, kind, min_obs, merge_dups=True, with_records=False):
+    """host_shards: one HostSeqs per virtual rank -> (list of device tables, one per owner; total k-mer instances[; records
+    every rank sends, with_records]).  merge_dups: the senders merge their identical records (dbg_shard_plan.merge_dups).
     The caller releases the tables with eng.free_table."""
     world = len(host_shards)
     shards, keep = [], []
@@ -30,12 +31,13 @@ def owner_tables(eng, host_shards, k, stranded, kind, min_obs):
         shards.append(ss)
         keep.append(kp)
     total = sum(eng.count_instances(s, k) for s in shards)
-    plan = eng.plan(k, stranded, kind, min_obs, total, max(eng.max_label(s) for s in shards) if kind == 1 else 0)
+    plan = eng.plan(k, stranded, kind, min_obs, total, max(eng.max_label(s) for s in shards) if kind == 1 else 0, merge_dups=merge_dups)
     rw, nb = plan.rec_words, plan.n_bins
     bounds = D.owner_bounds(nb, world, plan.bin_group)
-    scanned = []
+    scanned, n_recs = [], []
     for s in shards:
         bin_off, n = eng.scan(s, plan)
+        n_recs.append(n)
         scanned.append((bin_off, eng.scatter(plan, bin_off, n)))
     tabs = []
     for owner in range(world):
@@ -54,4 +56,4 @@ def owner_tables(eng, host_shards, k, stranded, kind, min_obs):
             seg_off[s] += base
             base += len(slabs[s]) // rw
         tabs.append(eng.count(plan, recv, seg_off, world, nb_local, total))
-    return tabs, total
+    return (tabs, total, n_recs) if with_records else (tabs, total)
