@@ -226,3 +226,19 @@ def test_sender_merge_heavy_duplicates(ctx, kind, k, stranded):
             assert v == [int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]]
         else:
             assert v == int(want.count[i])
+
+
+@pytest.mark.parametrize("k", [34, 50])
+def test_sender_merge_without_spare_bits(ctx, k):
+    """k = 34 and 50: the record has no 4 spare bits above its meta bits, so a plan that asks for the merge merges nothing
+    (and the counting side must not read base bits as weights)"""
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    hs_list = [dbg.synth_reads_host(n_reads=4000, read_len=150, genome_len=8000 * 150 // 30, error_rate=0.002, stranded=False,
+                                    n_colours=3, first_read=r * 4000) for r in range(2)]
+    plain, n_plain = _records(eng, hs_list, k, 0, False)
+    merged, n_merged = _records(eng, hs_list, k, 0, True)
+    assert merged == plain and n_merged == n_plain
+    hs_all = dbg.synth_reads_host(n_reads=8000, read_len=150, genome_len=8000 * 150 // 30, error_rate=0.002, stranded=False, n_colours=3)
+    want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data, 1), k, 0, 2, stranded=False)
+    assert sorted(merged) == want.keys()
+    assert [merged[key] for key in want.keys()] == [(int(e), int(c)) for e, c in zip(want.exts, want.count)]
