@@ -298,9 +298,18 @@ typedef struct {
                                    merged record carries its multiplicity; the counting side reads it either way, so ranks may
                                    choose independently).  Fewer bytes on the wire: a rank with 1/W of 18x reads still holds
                                    18/W copies of most records */
+    uint32_t n_labels;          /* CountFilterSet with labels >= 64: the sparse alphabet of ALL ranks (at most 64 distinct labels,
+                                   each < 65536): labels[0..n_labels) ascending; colour i of the counting kernel stands for
+                                   labels[i].  0 = labels are their own colours (max_label < 64).  Every rank passes the same
+                                   list (dbg_seqset_label_bitmap_dev + an OR/max-reduction); a rank holding a label outside it
+                                   is refused */
+    uint32_t labels[64];
 } dbg_shard_plan;
 /* largest D1 label of a device-resident sequence set (0 when it carries no data) */
 int  dbg_seqset_max_label_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t* max_label_out);
+/* which D1 labels occur: bitmap_out[2049] (HOST memory): bit (v & 31) of word v >> 5 for every label v < 65536 present;
+ * word 2048 != 0 when a label >= 65536 was seen (such sets take dbg_filter_kmers' generic path) */
+int  dbg_seqset_label_bitmap_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t* bitmap_out);
 
 int  dbg_count_kmer_instances_dev(dbg_ctx* ctx, const dbg_seqset* dev_seqs, uint32_t k, uint64_t* n_out);
 int  dbg_shard_plan_make(dbg_ctx* ctx, dbg_shard_plan* plan);

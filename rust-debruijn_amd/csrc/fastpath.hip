@@ -1575,6 +1575,19 @@ static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<u
     *ok = true;
     return 0;
 }
+// which D1 labels occur: hb[v >> 5] bit (v & 31) for labels < 65536, hb[2048] != 0 when a larger one was seen
+static int seq_label_bitmap(dbg_ctx* c, const SeqDev& s, std::vector<uint32_t>* hb) {
+    hb->assign(2049, 0u);
+    if (!s.data || !s.n) return 0;
+    DBuf<uint32_t> bm;
+    ALLOC_OR_FAIL(c, bm, 2049);
+    HIP_TRY(c, hipMemsetAsync(bm.p, 0, 2049 * 4, c->stream));
+    label_presence_kernel<<<(uint32_t)std::min<uint64_t>(cdiv(s.n, 256), 1024), 256, 0, c->stream>>>(s.data, s.data_width, s.n, bm.p);
+    LAUNCH_CHECK(c, "label_presence");
+    HIP_TRY(c, hipMemcpyAsync(hb->data(), bm.p, 2049 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out) {
     *out = 0;
     if (!s.data || !s.n) return 0;
@@ -2322,8 +2335,21 @@ static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
     if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
         return c->fail(140, "sharded counting supports 16 <= k <= 64");
     // every rank must use the same colour layout: it follows from the plan's global max_label (no per-rank label map here)
-    if (pl->is_set && sp->max_label >= 64) return c->fail(141, "sharded CountFilterSet needs labels < 64 (dbg_shard_plan.max_label)");
-    pl->wide = pl->is_set && sp->max_label >= 24;
+    if (pl->is_set && sp->n_labels) {
+        // a sparse alphabet agreed on by all ranks: colour i stands for labels[i] (ascending)
+        if (sp->n_labels > 64) return c->fail(141, "sharded CountFilterSet: at most 64 distinct labels (dbg_shard_plan.n_labels)");
+        for (uint32_t i = 0; i < sp->n_labels; i++) {
+            if (sp->labels[i] >= 65536u || (i && sp->labels[i] <= sp->labels[i - 1]))
+                return c->fail(141, "sharded CountFilterSet: dbg_shard_plan.labels must be ascending and < 65536");
+            pl->linv.v[i] = sp->labels[i];
+        }
+        pl->linv.on = 1;
+        pl->wide = sp->n_labels > 24;
+    } else {
+        if (pl->is_set && sp->max_label >= 64)
+            return c->fail(141, "sharded CountFilterSet needs labels < 64 (dbg_shard_plan.max_label) or the list of at most 64 distinct labels (dbg_shard_plan.labels)");
+        pl->wide = pl->is_set && sp->max_label >= 24;
+    }
     // records of the sharded flow may carry weights when the record has the spare bits (every rank derives the same answer)
     pl->weighted = !pl->wave && 64 * pl->nbw - 2 * (2 * pl->k - pl->p) - META_BITS >= WEIGHT_BITS;
     if (pl->wide && !sp->n_bins && !c->opt("DBG_FAST_TARGET")) pl->nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl->nbins * 2, (1ull << 23) - 1);
@@ -2335,6 +2361,16 @@ extern "C" int dbg_seqset_max_label_dev(dbg_ctx* c, const dbg_seqset* ds, uint32
     HIP_TRY(c, hipSetDevice(c->device));
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     return seq_max_label(c, s, out);
+}
+
+extern "C" int dbg_seqset_label_bitmap_dev(dbg_ctx* c, const dbg_seqset* ds, uint32_t* bitmap_out) {
+    if (!ds || !bitmap_out) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
+    std::vector<uint32_t> hb;
+    DBG_TRY(seq_label_bitmap(c, s, &hb));
+    std::copy(hb.begin(), hb.end(), bitmap_out);
+    return 0;
 }
 
 extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
@@ -2353,7 +2389,20 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     FastPlan pl;
     DBG_TRY(plan_from(c, sp, &pl));
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
-    if (pl.is_set) {
+    DBuf<uint8_t> lmap_buf;                          // label -> colour index (sparse alphabets); lives until the scan is done
+    if (pl.is_set && sp->n_labels) {
+        std::vector<uint32_t> hb;
+        DBG_TRY(seq_label_bitmap(c, s, &hb));
+        const uint32_t top = sp->labels[sp->n_labels - 1];
+        std::vector<uint8_t> map((size_t)top + 1, 0);
+        for (uint32_t i = 0; i < sp->n_labels; i++) { map[sp->labels[i]] = (uint8_t)i; hb[sp->labels[i] >> 5] &= ~(1u << (sp->labels[i] & 31)); }
+        for (uint32_t w : hb)
+            if (w) return c->fail(141, "sharded CountFilterSet: a label of this rank is not in dbg_shard_plan.labels (the list must hold the labels of ALL ranks)");
+        ALLOC_OR_FAIL(c, lmap_buf, map.size());
+        HIP_TRY(c, hipMemcpyAsync(lmap_buf.p, map.data(), map.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));    // `map` leaves scope
+        pl.lmap = lmap_buf.p;
+    } else if (pl.is_set) {
         uint32_t mx = 0;
         DBG_TRY(seq_max_label(c, s, &mx));
         if (mx >= 64 || mx > std::max(sp->max_label, 23u))

@@ -46,10 +46,25 @@ class HipEngine:
         self.ctx.check(self.lib.dbg_seqset_max_label_dev(self.ctx.h, C.byref(ss), C.byref(m)))
         return m.value
 
-    def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers, max_label=0, merge_dups=True):
-        """merge_dups: this rank merges its identical super-k-mer records before the exchange (dbg_shard_plan.merge_dups)"""
+    def label_presence(self, ss):
+        """-> uint8[65537]: 1 where the D1 label occurs in ss ([65536]: some label >= 65536 does); a max-reduction over the
+        ranks gives the alphabet of the whole job"""
+        bm = (C.c_uint32 * 2049)()
+        self.ctx.check(self.lib.dbg_seqset_label_bitmap_dev(self.ctx.h, C.byref(ss), bm))
+        words = np.frombuffer(bm, dtype=np.uint32)
+        pres = np.zeros(65537, np.uint8)
+        pres[:65536] = np.unpackbits(words[:2048].view(np.uint8), bitorder="little")
+        pres[65536] = 1 if words[2048] else 0
+        return pres
+
+    def plan(self, k, stranded, summarizer_kind, min_obs, total_kmers, max_label=0, merge_dups=True, labels=None):
+        """merge_dups: this rank merges its identical super-k-mer records before the exchange (dbg_shard_plan.merge_dups);
+        labels: CountFilterSet with labels >= 64 -- the ascending list of ALL ranks' distinct labels (at most 64)"""
+        labels = [int(x) for x in labels] if labels is not None else []
         p = _capi.ShardPlan(k, int(bool(stranded)), summarizer_kind, min_obs, total_kmers, 0, 0, 0, max_label,
-                            int(bool(merge_dups)))
+                            int(bool(merge_dups)), len(labels), (C.c_uint32 * 64)(*labels[:64]))
+        if len(labels) > 64:
+            p.n_labels = len(labels)                 # (refused by the library with its own message)
         self.ctx.check(self.lib.dbg_shard_plan_make(self.ctx.h, C.byref(p)))
         return p
 
@@ -294,12 +309,26 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
             t = torch.tensor([max_label], dtype=torch.int64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             max_label = int(t.item())
+    labels = None
+    if summarizer_kind == 1 and max_label >= 64:
+        # labels beyond the 64 colours of the counting kernel: a sparse alphabet is mapped to colour indices, the same way on
+        # every rank -- the union of the ranks' label sets (a max-reduction of presence flags; NCCL has no bitwise OR)
+        pres = torch.from_numpy(engine.label_presence(ss))
+        if world > 1:
+            pres = pres.to(rdev)
+            dist.all_reduce(pres, op=dist.ReduceOp.MAX, group=group)
+            pres = pres.cpu()
+        if int(pres[65536]):
+            raise ValueError("sharded CountFilterSet: labels must be < 65536")
+        labels = torch.nonzero(pres[:65536]).flatten().tolist()
+        if len(labels) > 64:
+            raise ValueError("sharded CountFilterSet: %d distinct labels over all ranks; the sharded path holds 64" % len(labels))
     if merge_dups is None:
         env = os.environ.get("DBG_SHARD_MERGE")
         merge_dups = (1 < world <= 4) if env is None else env != "0"
     if stats is not None:
         stats["merge_dups"] = bool(merge_dups)
-    plan = engine.plan(k, stranded, summarizer_kind, min_obs, total, max_label, merge_dups=merge_dups)
+    plan = engine.plan(k, stranded, summarizer_kind, min_obs, total, max_label, merge_dups=merge_dups, labels=labels)
     bin_off, n_recs = engine.scan(ss, plan)
     layout = None
     force = force_exchange and dist.is_initialized()

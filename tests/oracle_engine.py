@@ -29,7 +29,14 @@ class OracleEngine:
     def max_label(self, ss):
         return int(ss.data.max()) if getattr(ss, "data", None) is not None and len(ss.data) else 0
 
-    def plan(self, k, stranded, kind, min_obs, total, max_label=0, merge_dups=False):
+    def label_presence(self, ss):
+        pres = np.zeros(65537, np.uint8)
+        if getattr(ss, "data", None) is not None:
+            pres[np.minimum(np.asarray(ss.data, dtype=np.int64), 65536)] = 1
+        return pres
+
+    def plan(self, k, stranded, kind, min_obs, total, max_label=0, merge_dups=False, labels=None):
+        self.labels = labels                      # (the oracle counts labels as they are: the list is only recorded)
         return Plan(k, stranded, kind, min_obs, total, self.n_bins)
 
     def scan(self, ss, plan):

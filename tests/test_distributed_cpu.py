@@ -16,7 +16,10 @@ WORLD = 2
 N_READS = 120
 
 
-def _worker(rank, world, port, kind, stranded, out_dir, chunks, n_bins=None):
+SPARSE = np.array([3, 70, 130, 255], dtype=np.uint8)      # a label alphabet beyond the counting kernel's 64 colours
+
+
+def _worker(rank, world, port, kind, stranded, out_dir, chunks, n_bins=None, sparse=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import importlib
@@ -30,9 +33,12 @@ def _worker(rank, world, port, kind, stranded, out_dir, chunks, n_bins=None):
     per = N_READS // world
     hs = dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005,
                               stranded=stranded, n_colours=4, first_read=rank * per)
-    ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
-    tab, total, n_local, n_recs = D.sharded_filter_kmers(OracleEngine(n_bins), ss, 47, stranded, kind, 2, n_chunks=chunks)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, SPARSE[hs.data] if sparse else hs.data, 1)
+    eng = OracleEngine(n_bins)
+    tab, total, n_local, n_recs = D.sharded_filter_kmers(eng, ss, 47, stranded, kind, 2, n_chunks=chunks)
     assert total == N_READS * 104 and n_local == per * 104
+    # labels >= 64: every rank is handed the alphabet of the whole job (a max-reduction of presence flags)
+    assert eng.labels == (SPARSE.tolist() if sparse and kind == 1 else None)
     res = dict(keys=tab.keys(), exts=tab.exts.tolist(), count=tab.count.tolist(), set_off=tab.set_off.tolist(),
                set_val=tab.set_val.tolist())
     pickle.dump(res, open(os.path.join(out_dir, "rank%d.pkl" % rank), "wb"))
@@ -40,9 +46,9 @@ def _worker(rank, world, port, kind, stranded, out_dir, chunks, n_bins=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,stranded,chunks,n_bins", [(0, False, None, None), (1, False, 1, None), (0, True, 3, None),
-                                                         (0, False, None, 5), (1, False, 3, 3)])
-def test_sharded_counting_gloo_world2(tmp_path, kind, stranded, chunks, n_bins):
+@pytest.mark.parametrize("kind,stranded,chunks,n_bins,sparse", [(0, False, None, None, False), (1, False, 1, None, False), (0, True, 3, None, False),
+                                                                (0, False, None, 5, False), (1, False, 3, 3, False), (1, False, None, None, True)])
+def test_sharded_counting_gloo_world2(tmp_path, kind, stranded, chunks, n_bins, sparse):
     """chunks = ranges the owned bins are exchanged and counted in (None = the default pipeline depth); n_bins = 5 or 3:
     the two ranks own different numbers of bins (2 + 3, 1 + 2), fewer than the pipeline depth -- every rank must still
     arrive at the same number of exchange rounds and the same cuts"""
@@ -50,12 +56,12 @@ def test_sharded_counting_gloo_world2(tmp_path, kind, stranded, chunks, n_bins):
     import oracle_lib as O
     O.build()
     dbg = importlib.import_module("rust-debruijn_amd")
-    port = 29600 + kind * 2 + int(stranded) + (n_bins or 0) * 4 + (os.getpid() % 200)
-    mp.spawn(_worker, args=(WORLD, port, kind, stranded, str(tmp_path), chunks, n_bins), nprocs=WORLD, join=True)
+    port = 29600 + kind * 2 + int(stranded) + (n_bins or 0) * 4 + int(sparse) * 64 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(WORLD, port, kind, stranded, str(tmp_path), chunks, n_bins, sparse), nprocs=WORLD, join=True)
     parts = [pickle.load(open(tmp_path / ("rank%d.pkl" % r), "rb")) for r in range(WORLD)]
     hs = dbg.synth_reads_host(n_reads=N_READS, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005,
                               stranded=stranded, n_colours=4)
-    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1), 47, kind, 2, stranded=stranded)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, SPARSE[hs.data] if sparse else hs.data, 1), 47, kind, 2, stranded=stranded)
     merged = {}
     for p in parts:
         assert p["keys"] == sorted(p["keys"])                       # each rank's table is ascending

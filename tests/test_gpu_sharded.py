@@ -242,3 +242,65 @@ def test_sender_merge_without_spare_bits(ctx, k):
     want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data, 1), k, 0, 2, stranded=False)
     assert sorted(merged) == want.keys()
     assert [merged[key] for key in want.keys()] == [(int(e), int(c)) for e, c in zip(want.exts, want.count)]
+
+
+@pytest.mark.parametrize("n_labels,k", [(5, 47), (30, 31), (64, 51)])
+def test_sharded_sparse_label_alphabet(ctx, n_labels, k):
+    """labels far beyond the kernel's 64 colours, at most 64 distinct ones over ALL ranks (no rank holds them all): the plan
+    carries the job's alphabet, every rank maps label -> colour the same way, the label sets come back as labels"""
+    import virtual_ranks as V
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    rng = np.random.default_rng(n_labels)
+    alphabet = np.sort(rng.choice(np.arange(64, 65536), size=n_labels, replace=False)).astype(np.uint16)
+    world, per = 3, 3000
+    hs_list, datas = [], []
+    for r in range(world):
+        hs = dbg.synth_reads_host(n_reads=per, read_len=150, genome_len=world * per * 150 // 30, error_rate=0.002, stranded=False,
+                                  n_colours=n_labels, first_read=r * per)
+        # rank r never sees the labels whose index is r mod world... unless there are too few to go round
+        d = hs.data.astype(np.int64)
+        if n_labels >= 2 * world:
+            d = np.where(d % world == r, (d + 1) % n_labels, d)
+        datas.append(alphabet[d])
+        hs_list.append(dbg.HostSeqs(hs.words, hs.start, hs.length, None, alphabet[d], 2))
+    tabs, total = V.owner_tables(eng, hs_list, k, False, 1, 2)
+    got = {}
+    for tab in tabs:
+        t = table_to_host(ctx, tab, k)
+        eng.free_table(tab)
+        for i, key in enumerate(t.keys()):
+            assert key not in got
+            got[key] = (int(t.exts[i]), t.data(i))
+    hs_all = dbg.synth_reads_host(n_reads=world * per, read_len=150, genome_len=world * per * 150 // 30, error_rate=0.002, stranded=False, n_colours=n_labels)
+    want = O.filter_kmers(O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, np.concatenate(datas), 2), k, 1, 2, stranded=False)
+    assert sorted(got) == want.keys()
+    for i, key in enumerate(want.keys()):
+        e, v = got[key]
+        assert e == int(want.exts[i])
+        assert v == [int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]]
+    # a plan that leaves one of a rank's labels out, an unsorted list, and more than 64 labels are refused
+    ss, keep = V.dev_seqset(eng, hs_list[0], True)
+    mine = np.unique(datas[0]).tolist()
+    with pytest.raises(dbg.DbgError):
+        eng.scan(ss, eng.plan(k, False, 1, 2, total, int(alphabet[-1]), labels=mine[1:]))
+    with pytest.raises(dbg.DbgError):
+        eng.plan(k, False, 1, 2, total, int(alphabet[-1]), labels=mine[::-1] if len(mine) > 1 else [5, 5])
+    with pytest.raises(dbg.DbgError):
+        eng.plan(k, False, 1, 2, total, 70000, labels=list(range(100, 165)))
+    with pytest.raises(dbg.DbgError):                                  # labels >= 64 and no list
+        eng.plan(k, False, 1, 2, total, int(alphabet[-1]))
+
+
+def test_orchestration_world1_sparse_labels(ctx):
+    """distributed.sharded_filter_kmers collects the alphabet itself"""
+    eng = D.HipEngine(ctx, torch.device("cuda", 0))
+    hs = dbg.synth_reads_host(n_reads=5000, read_len=150, error_rate=0.002, stranded=False, n_colours=6)
+    lab = np.array([7, 64, 900, 4096, 40000, 65535], dtype=np.uint16)[hs.data]
+    import virtual_ranks as V
+    ss, keep = V.dev_seqset(eng, dbg.HostSeqs(hs.words, hs.start, hs.length, None, lab, 2), True)
+    tab, total, n_local, n_recs = D.sharded_filter_kmers(eng, ss, 47, False, 1, 2)
+    t = table_to_host(ctx, tab, 47)
+    eng.free_table(tab)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, lab, 2), 47, O.COUNT_FILTER_SET, 2, stranded=False)
+    assert t.keys() == want.keys()
+    assert np.array_equal(t.exts, want.exts) and np.array_equal(t.set_off, want.set_off) and np.array_equal(t.set_val, want.set_val)

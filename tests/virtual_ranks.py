@@ -16,8 +16,8 @@ def dev_seqset(engine, hs, with_data):
     words = torch.from_numpy(hs.words.view(np.int64)).to(dev)
     start = torch.from_numpy(hs.start.view(np.int64)).to(dev)
     length = torch.from_numpy(hs.length.view(np.int32)).to(dev)
-    data = torch.from_numpy(hs.data).to(dev) if with_data else None
-    return engine.seqset(words, start, length, data, 1), (words, start, length, data)
+    data = torch.from_numpy(hs.data.view({1: np.uint8, 2: np.int16, 4: np.int32}[hs.data.dtype.itemsize])).to(dev) if with_data else None
+    return engine.seqset(words, start, length, data, hs.data.dtype.itemsize if with_data else 0), (words, start, length, data)
 
 
 def owner_tables(eng, host_shards, k, stranded, kind, min_obs, merge_dups=True, with_records=False):
@@ -31,7 +31,13 @@ def owner_tables(eng, host_shards, k, stranded, kind, min_obs, merge_dups=True, 
         shards.append(ss)
         keep.append(kp)
     total = sum(eng.count_instances(s, k) for s in shards)
-    plan = eng.plan(k, stranded, kind, min_obs, total, max(eng.max_label(s) for s in shards) if kind == 1 else 0, merge_dups=merge_dups)
+    max_label = max(eng.max_label(s) for s in shards) if kind == 1 else 0          # (all-reduce MAX in the real flow)
+    labels = None
+    if max_label >= 64:                                                             # sparse alphabet: union over the ranks
+        pres = np.maximum.reduce([eng.label_presence(s) for s in shards])
+        assert not pres[65536]
+        labels = np.nonzero(pres[:65536])[0].tolist()
+    plan = eng.plan(k, stranded, kind, min_obs, total, max_label, merge_dups=merge_dups, labels=labels)
     rw, nb = plan.rec_words, plan.n_bins
     bounds = D.owner_bounds(nb, world, plan.bin_group)
     scanned, n_recs = [], []
