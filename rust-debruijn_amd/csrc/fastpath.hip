@@ -1535,7 +1535,7 @@ __global__ void __launch_bounds__(256) label_presence_kernel(const void* data, u
 // their own colour; a sparse alphabet of at most 64 distinct labels (all < 65536) is mapped to colour indices in increasing label
 // order and mapped back when the label sets are written.
 // lmap_buf receives the device table (it must outlive the scan).
-static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<uint8_t>* lmap_buf, bool* ok) {
+static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<uint8_t>* lmap_buf, bool* ok, std::vector<uint32_t>* many = nullptr) {
     *ok = false;
     pl->linv.on = 0; pl->lmap = nullptr; pl->wide = false;
     if (!s.data) return 0;
@@ -1562,7 +1562,10 @@ static int fast_labels_prepare(dbg_ctx* c, const SeqDev& s, FastPlan* pl, DBuf<u
     uint32_t nd = 0;
     for (uint32_t v = 0; v <= h; v++) {
         if (hb[v >> 5] & (1u << (v & 31))) {
-            if (nd == 64) return 0;                         // more than 64 distinct labels: the generic path
+            if (nd == 64) {                                 // more than 64 distinct labels: label-group passes (or the generic path)
+                if (many) { many->clear(); for (uint32_t u = 0; u <= h; u++) if (hb[u >> 5] & (1u << (u & 31))) many->push_back(u); }
+                return 0;
+            }
             pl->linv.v[nd] = v;
             map[v] = (uint8_t)nd++;
         }
@@ -1792,6 +1795,7 @@ struct FastCountState {
     DBuf<uint4> w_rec;                     // WIDE colour sets: 64-bit colour mask + Exts by output position
     DBuf<unsigned long long> out_cursor;
     // report_all_kmers: every distinct key
+    DBuf<unsigned long long>* keep_masks = nullptr;   // WIDE colour sets: hand the sorted 64-bit masks to the caller instead of building the CSR
     bool report_all = false;
     uint64_t all_cap = 0, n_all = 0;
     DBuf<uint64_t> a_hi, a_lo;
@@ -2056,7 +2060,11 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
         c->t_end();
         LAUNCH_CHECK(c, "wide_gather");
     }
-    if (is_set) {
+    if (is_set && st->keep_masks) {
+        if (!pl.wide) return c->fail(136, "fast path: keep_masks needs the wide colour layout");
+        *st->keep_masks = std::move(msk64);
+        o_set_off.release();
+    } else if (is_set) {
         const uint32_t nb = cdiv(std::max<uint64_t>(n_out, 1), CSR_TILE);
         DBuf<uint64_t> part, part_sc;
         ALLOC_OR_FAIL(c, part, nb); ALLOC_OR_FAIL(c, part_sc, (size_t)nb + 1);
@@ -2104,9 +2112,10 @@ static int fast_count_finish(dbg_ctx* c, FastCountState* st, dbg_kmer_table* out
 static int fast_count(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
                       const uint64_t* seg_beg, const uint64_t* seg_end,
                       uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local, uint64_t n_kmers_hint, uint64_t n_recs_hint,
-                      dbg_kmer_table* out, bool report_all = false) {
+                      dbg_kmer_table* out, bool report_all = false, DBuf<unsigned long long>* keep_masks = nullptr) {
     FastCountState st;
     DBG_TRY(fast_count_begin(c, pl, min_obs, n_kmers_hint, &st, report_all));
+    st.keep_masks = keep_masks;
     DBG_TRY(fast_count_bins(c, &st, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, nbins_local, n_kmers_hint, n_recs_hint));
     return fast_count_finish(c, &st, out);
 }
@@ -2265,20 +2274,9 @@ __global__ void __launch_bounds__(64 * MG_WAVES) slab_merge_kernel(uint64_t* __r
     if (lane == 0) { cursor[b] = m; if (cnt != m) atomicAdd(&merged_away[b & (MG_COUNTERS - 1)], (unsigned long long)(cnt - m)); }
 }
 
-// returns 0 and sets *used = true when the fast path produced the table; *used = false means the
-// caller must take the generic path (unsupported shape), nothing was written.
-int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
-                      bool* used) {
-    *used = false;
-    const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET;
-    if (n_kmers == 0) return 0;
-    FastPlan pl;
-    if (!fast_make_plan(c, (int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
-    DBuf<uint8_t> lmap_buf;
-    if (is_set) { bool ok; DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok)); if (!ok) return 0; }
-    // the WIDE colour-set layout keeps two more words per table entry: with 1024-entry tables two workgroups still share a CU's
-    // LDS, so its bins are half the size
-    if (pl.wide && !c->opt("DBG_FAST_TARGET")) pl.nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl.nbins * 2, (1ull << 23) - 1);
+// scan -> slabs -> count -> sort for one plan (colour layout and label map already chosen)
+static int fast_run(dbg_ctx* c, const SeqDev& s, FastPlan pl, uint64_t min_obs, bool report_all, uint64_t n_kmers, dbg_kmer_table* out,
+                    DBuf<unsigned long long>* keep_masks = nullptr) {
     FastScan st;
     DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
     const uint32_t nb = pl.nbins * NCLS;
@@ -2304,10 +2302,39 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
     c->t_end();
     if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] direct slabs: cap=%u records/bin, %llu records, %llu took the overflow path\n", slab_cap,
                                      n_recs_total, (unsigned long long)st.n_recs);
-    const int rc_count = fast_count(c, pl, prm->min_kmer_obs, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, st.n_recs ? 2u : 1u, (uint64_t)nb,
-                                    pl.nbins, n_kmers, n_recs_total, out, prm->report_all_kmers != 0);
+    const int rc_count = fast_count(c, pl, min_obs, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, st.n_recs ? 2u : 1u, (uint64_t)nb,
+                                    pl.nbins, n_kmers, n_recs_total, out, report_all, keep_masks);
     c->drop_spares();
-    DBG_TRY(rc_count);
+    return rc_count;
+}
+
+#include "fast_manylabels.hpp"
+
+// returns 0 and sets *used = true when the fast path produced the table; *used = false means the
+// caller must take the generic path (unsupported shape), nothing was written.
+int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,
+                      bool* used) {
+    *used = false;
+    const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET;
+    if (n_kmers == 0) return 0;
+    FastPlan pl;
+    if (!fast_make_plan(c, (int)prm->k, prm->stranded != 0, is_set, n_kmers, 0, &pl)) return 0;
+    DBuf<uint8_t> lmap_buf;
+    if (is_set) {
+        bool ok;
+        std::vector<uint32_t> many;                 // more than 64 distinct labels (all < 65536): the label-group passes
+        DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok, &many));
+        if (!ok) {
+            if (many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS")) return 0;
+            DBG_TRY(filter_kmers_fast_many(c, s, prm, n_kmers, many, out));
+            *used = true;
+            return 0;
+        }
+    }
+    // the WIDE colour-set layout keeps two more words per table entry: with 1024-entry tables two workgroups still share a CU's
+    // LDS, so its bins are half the size
+    if (pl.wide && !c->opt("DBG_FAST_TARGET")) pl.nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl.nbins * 2, (1ull << 23) - 1);
+    DBG_TRY(fast_run(c, s, pl, prm->min_kmer_obs, prm->report_all_kmers != 0, n_kmers, out));
     *used = true;
     return 0;
 }

@@ -114,14 +114,58 @@ def test_fast_equals_generic_on_synthetic_stream(ctx):
 
 def test_fast_path_refuses_unsupported_shapes(ctx):
     rng = np.random.default_rng(1)
-    seqs = random_reads(rng, 200, 1000, 150, False)
-    ss = O.SeqSet.from_byte_seqs(seqs, data=np.arange(200) * 7 + 40, sizeof_d1=2)
-    with pytest.raises(dbg.DbgError):           # more than 64 distinct labels need the generic (sort-based) CountFilterSet
+    seqs = random_reads(rng, 1100, 1000, 150, False)
+    ss = O.SeqSet.from_byte_seqs(seqs, data=np.arange(1100) * 7 + 40, sizeof_d1=2)
+    with pytest.raises(dbg.DbgError):           # more than 1024 distinct labels need the generic (sort-based) CountFilterSet
         dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     ctx.set_option("DBG_PATH", "auto")
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
     got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     assert_tables_equal(got, want, True)
+
+
+@pytest.mark.parametrize("n_labels,k,stranded,min_obs,report_all", [(65, 47, False, 2, False), (200, 31, True, 1, False), (1024, 63, False, 2, False),
+                                                                    (130, 20, False, 3, True), (500, 51, False, 2, False)])
+def test_fast_label_groups(ctx, n_labels, k, stranded, min_obs, report_all):
+    """more than 64 distinct labels: one CountFilter run for the valid k-mers, one 64-colour run per label group joined into it
+    (fast_manylabels.hpp).  Validity counts observations over ALL labels, the lists come out ascending."""
+    hs = dbg.synth_reads_host(n_reads=5000, read_len=150, error_rate=0.004, stranded=stranded, n_colours=4)
+    rng = np.random.default_rng(n_labels * 31 + k)
+    alphabet = np.sort(rng.choice(np.arange(0, 65536), size=n_labels, replace=False)).astype(np.uint16)
+    lab = alphabet[rng.integers(0, n_labels, size=len(hs.start))]
+    lab[:n_labels] = alphabet                                      # every label occurs
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, lab, 2)
+    want = O.filter_kmers(ss, k, O.COUNT_FILTER_SET, min_obs, stranded=stranded, report_all=report_all)
+    with ctx.options(DBG_DEBUG="1"):
+        got, allk = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), stranded, report_all, 4, k=k, ctx=ctx)
+    assert len(got) > 1000
+    assert_tables_equal(got, want, True)
+    if report_all:
+        assert np.array_equal(got.all_hi, want.all_hi) and np.array_equal(got.all_lo, want.all_lo)
+    with ctx.options(DBG_NO_LABEL_GROUPS="1", DBG_PATH="auto"):    # the same through the generic path
+        gen, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), stranded, report_all, 4, k=k, ctx=ctx)
+    assert_tables_equal(gen, want, True)
+
+
+def test_fast_label_groups_uneven(ctx):
+    """one group holds nearly all reads, one a single read, one only reads shorter than k; k-mers shared by every group"""
+    rng = np.random.default_rng(9)
+    genome = R.random_dna(rng, 3000)
+    seqs, lab = [], []
+    for i in range(1500):
+        a = int(rng.integers(0, 2850))
+        seqs.append(genome[a:a + 150])
+        lab.append(int(rng.integers(0, 64)) * 3)                    # group 0: labels 0..189 step 3
+    seqs.append(genome[100:250]); lab.append(40000)                 # a lone read in the last group
+    for i in range(70):                                             # 70 more labels, on reads too short to hold a k-mer
+        seqs.append(genome[5 * i:5 * i + 30]); lab.append(1000 + i)
+    for i in range(6):                                              # and a third populated group
+        seqs.append(genome[200 * i:200 * i + 190]); lab.append(30000 + i)
+    ss = O.SeqSet.from_byte_seqs(seqs, data=np.array(lab), sizeof_d1=2)
+    for min_obs in (1, 2, 40):
+        want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, min_obs, stranded=False)
+        got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), False, False, 4, k=47, ctx=ctx)
+        assert_tables_equal(got, want, True)
 
 
 @pytest.mark.parametrize("k,stranded,kind", [(47, False, 0), (31, True, 0), (64, False, 0), (47, False, 1), (16, False, 0)])

@@ -401,6 +401,7 @@ def test_fullsize_wide_colour_sets(env):
     torch.cuda.empty_cache()
     ctx.trim()
     colour64 = (torch.arange(N_READS, device="cuda", dtype=torch.int64) % 64).to(torch.uint8)
+    torch.cuda.synchronize()                                         # (the library runs on its own stream)
 
     def run(first, n, summarizer, min_obs):
         ss = capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"][first:].data_ptr(), e["length"][first:].data_ptr(), None,
@@ -451,5 +452,83 @@ def test_fullsize_wide_colour_sets(env):
     lib.dbg_free_table(ctx.h, C.byref(h))
     hs = dbg.synth_reads_host(n_reads=m, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001, stranded=False, n_colours=64)
     want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1), K, O.COUNT_FILTER_SET, 1, stranded=False)
+    assert n == want.n and np.array_equal(g_hi, want.key_hi) and np.array_equal(g_lo, want.key_lo) and np.array_equal(g_ex, want.exts)
+    assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)
+
+
+def test_fullsize_label_groups(env):
+    """More than 64 distinct labels at full size (fast_manylabels.hpp: one CountFilter run for the valid k-mers, one 64-colour run
+    per label group joined into it): 192 labels, label = i mod 64 + 64 * ((i div 64) mod 3) for read i.  Same valid key set as
+    CountFilter(2); every label list strictly ascending within 0..191; against the 64-colour run with label = i mod 64 (the
+    projection of these labels): every k-mer has at least as many labels and at most three times as many; a 10^5-read prefix
+    bit-exact against the oracle."""
+    e = env
+    torch, capi, lib, ctx = e["torch"], e["capi"], e["lib"], e["ctx"]
+    K, N_READS = e["k"], e["n_reads"]
+    torch.cuda.empty_cache()
+    ctx.trim()
+    idx = torch.arange(N_READS, device="cuda", dtype=torch.int64)
+    lab192 = (idx % 64 + 64 * ((idx // 64) % 3)).to(torch.uint8)
+    lab64 = (idx % 64).to(torch.uint8)
+    del idx
+    torch.cuda.synchronize()                                         # the library runs on its own stream: the labels must be complete
+
+    def run(n, labels, summarizer, min_obs):
+        ss = capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"].data_ptr(), e["length"].data_ptr(), None,
+                         labels.data_ptr() if summarizer else None, 1 if summarizer else 0, n)
+        fp = capi.FilterParams(K, 0, summarizer, min_obs, 0, 4)
+        t = capi.KmerTable()
+        ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+        return t
+    t64 = run(N_READS, lab64, 1, 2)
+    s64 = table_stats(e, t64)
+    off = dev_view(t64.set_off, t64.n + 1)
+    sizes64 = (off[1:] - off[:-1]).clone()
+    torch.cuda.synchronize()                                         # (torch's copy must be done before the library frees its arrays)
+    lib.dbg_free_table(ctx.h, C.byref(t64))
+    ctx.trim()
+    tm = run(N_READS, lab192, 1, 2)
+    assert tm.n_passes == 4                                          # CountFilter + three label groups
+    sm = table_stats(e, tm)
+    assert sm["ascending"] and s64["ascending"] and sm["n"] == s64["n"] and sm["keysum"] == s64["keysum"]
+    off = dev_view(tm.set_off, tm.n + 1)
+    nsv = int(tm.n_set_val)
+    sizes = off[1:] - off[:-1]
+    assert int(off[0].item()) == 0 and int(off[-1].item()) == nsv
+    assert bool((sizes >= sizes64).all().item()) and bool((sizes <= 3 * sizes64).all().item())
+    assert int(sizes.max().item()) <= 192
+    is_boundary = torch.zeros(nsv + 1, dtype=torch.bool, device="cuda")
+    is_boundary[off] = True
+    vmin, vmax, step = 1 << 30, -1, 1 << 27
+    val_all = dev_view(tm.set_val, nsv, "<u4")
+    for a in range(0, nsv, step):
+        b = min(a + step, nsv)
+        v = val_all[a:b].to(torch.int64)
+        vmin, vmax = min(vmin, int(v.min().item())), max(vmax, int(v.max().item()))
+        if a == 0:
+            nonasc = (v[1:] <= v[:-1]).nonzero().flatten() + 1
+        else:
+            prev = val_all[a - 1:b - 1].to(torch.int64)
+            nonasc = (v <= prev).nonzero().flatten() + a
+        assert bool(is_boundary[nonasc].all().item())
+    del is_boundary, val_all, sizes, sizes64
+    lib.dbg_free_table(ctx.h, C.byref(tm))
+    assert vmin == 0 and vmax == 191
+    ctx.trim()
+    # prefix of the stream, bit-exact
+    m = min(100_000, N_READS)
+    t = run(m, lab192, 1, 1)
+    h = capi.KmerTable()
+    ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))
+    lib.dbg_free_table(ctx.h, C.byref(t))
+    n = h.n
+    as_np = lambda p, ct, cnt: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(max(cnt, 1),))[:cnt].copy()
+    g_hi, g_lo, g_ex = as_np(h.key_hi, C.c_uint64, n), as_np(h.key_lo, C.c_uint64, n), as_np(h.exts, C.c_uint8, n)
+    g_off, g_val = as_np(h.set_off, C.c_uint64, n + 1), as_np(h.set_val, C.c_uint32, h.n_set_val)
+    lib.dbg_free_table(ctx.h, C.byref(h))
+    hs = dbg.synth_reads_host(n_reads=m, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001, stranded=False, n_colours=4)
+    i = np.arange(m, dtype=np.int64)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, (i % 64 + 64 * ((i // 64) % 3)).astype(np.uint8), 1), K,
+                          O.COUNT_FILTER_SET, 1, stranded=False)
     assert n == want.n and np.array_equal(g_hi, want.key_hi) and np.array_equal(g_lo, want.key_lo) and np.array_equal(g_ex, want.exts)
     assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)

@@ -7,7 +7,7 @@ timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > gpurun_out/${R
 timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; tail -c 600 gpurun_out/${R}_bench_default.json
 timeout 400 bash tools/prof.sh $R --no-host-boundary > gpurun_out/prof_$R.log 2>&1; tail -3 gpurun_out/prof_$R.log
 timeout 900 bash tools/other_configs.sh $R > gpurun_out/${R}_other_configs.log 2>&1; tail -2 gpurun_out/${R}_other_configs.log
-timeout 600 python tools/bench_colours.py 4 24 40 64 > gpurun_out/${R}_colours.txt 2>&1; tail -4 gpurun_out/${R}_colours.txt
+timeout 600 python tools/bench_colours.py 4 24 40 64 100 250 > gpurun_out/${R}_colours.txt 2>&1; tail -4 gpurun_out/${R}_colours.txt
 : > gpurun_out/${R}_generic_dense.txt
 for a in "--k 47 --reads 10000000:generic" "--k 15 --reads 20000000:dense" "--k 11 --reads 20000000:dense" "--k 8 --reads 20000000:dense" "--k 15 --reads 20000000:generic"; do
   args=${a%%:*}; path=${a##*:}
