@@ -103,10 +103,10 @@ __host__ __device__ __forceinline__ uint32_t packed_get(const uint64_t* __restri
     return (uint32_t)((w[o >> 5] >> (62 - 2 * (o & 31))) & 3ull);
 }
 
-// k-mer starting at absolute base offset o: the GPU analogue of DnaString::get_kmer's per-word
+// k-mer starting at absolute base offset o: the analogue of DnaString::get_kmer's per-word
 // set_slice_mut loop (dna_string.rs:123-153): three funnel-shifted words, right-aligned.
-// Words beyond the last one the k-mer touches are never dereferenced.
-__host__ __device__ __forceinline__ K128 packed_get_kmer(const uint64_t* __restrict__ w, uint64_t o, int k) {
+// Host form: words beyond the last one the k-mer touches are never dereferenced.
+__host__ inline K128 packed_get_kmer(const uint64_t* w, uint64_t o, int k) {
     uint64_t wi = o >> 5;
     int s = (int)(o & 31) * 2;
     int need = s + 2 * k;                       // bits consumed starting at word wi
@@ -117,6 +117,33 @@ __host__ __device__ __forceinline__ K128 packed_get_kmer(const uint64_t* __restr
     if (s) { top.hi = (w0 << s) | (w1 >> (64 - s)); top.lo = (w1 << s) | (w2 >> (64 - s)); }
     else   { top.hi = w0; top.lo = w1; }
     return k128_shr(top, 128 - 2 * k);
+}
+// Device form: all three words are loaded UNCONDITIONALLY, with indices clamped to last_word (the index of the buffer's last
+// word; a clamped word never reaches the result).  The form with the second and third word fetched only by the lanes that need
+// them (the host form above) returned wrong words for whole wavefronts now and then -- seen first in the dense path (0.7 % of the
+// two-word k-mers of a 10^8-read run), then as a 1 % failure rate of compress_graph when several processes shared the GPU;
+// tools/micro/kmer_fetch.hip reproduces it in isolation (same inputs, same stream order, only the fetch differs: hundreds of
+// mismatches per 2*10^4 launches with four processes on the GPU, none with unconditional loads).  The ISA of the conditional
+// form waits for its loads on every path; what the hardware does with its partially masked loads under those conditions is
+// not understood.  No device code fetches words conditionally any more.
+__device__ __forceinline__ K128 packed_get_kmer(const uint64_t* __restrict__ w, uint64_t o, int k, uint64_t last_word) {
+    const uint64_t wi = o >> 5;
+    const int s = (int)(o & 31) * 2;
+    const uint64_t i1 = wi + 1 < last_word ? wi + 1 : last_word, i2 = wi + 2 < last_word ? wi + 2 : last_word;
+    const uint64_t w0 = w[wi], w1 = w[i1], w2 = w[i2];
+    K128 top;
+    if (s) { top.hi = (w0 << s) | (w1 >> (64 - s)); top.lo = (w1 << s) | (w2 >> (64 - s)); }
+    else   { top.hi = w0; top.lo = w1; }
+    return k128_shr(top, 128 - 2 * k);
+}
+// p <= 32 bases (one or two words), same rules
+__device__ __forceinline__ uint64_t packed_get_pmer64(const uint64_t* __restrict__ w, uint64_t o, int p, uint64_t last_word) {
+    const uint64_t wi = o >> 5;
+    const int s = (int)(o & 31) * 2;
+    const uint64_t i1 = wi + 1 < last_word ? wi + 1 : last_word;
+    const uint64_t w0 = w[wi], w1 = w[i1];
+    const uint64_t v = s ? (w0 << s) | (w1 >> (64 - s)) : w0;
+    return v >> (64 - 2 * p);
 }
 
 // ---- wave helpers (wave64) ---------------------------------------------------------------

@@ -33,9 +33,9 @@ struct MinPosD { uint32_t val, pos, pmer; };
 
 // find_min(start, stop) (msp.rs:218-228): rightmost minimal position in [start, stop]
 template <class Score>
-__device__ __forceinline__ MinPosD find_min(int p, const Score& score, const uint64_t* __restrict__ w, uint64_t st,
+__device__ __forceinline__ MinPosD find_min(int p, const Score& score, const uint64_t* __restrict__ w, uint64_t last_word, uint64_t st,
                                             uint32_t start, uint32_t stop, uint32_t pmask) {
-    uint32_t pm = (uint32_t)packed_get_kmer(w, st + start, p).lo;
+    uint32_t pm = (uint32_t)packed_get_pmer64(w, st + start, p, last_word);
     MinPosD best{score(pm), start, pm};
     for (uint32_t pos = start + 1; pos <= stop; pos++) {
         pm = ((pm << 2) | packed_get(w, st + pos + p - 1)) & pmask;
@@ -47,18 +47,18 @@ __device__ __forceinline__ MinPosD find_min(int p, const Score& score, const uin
 
 // Runs Scanner::scan over one sequence and calls emit(start, len, minpos) per interval.
 template <class Score, class Emit>
-__device__ __forceinline__ void scan_sequence(int k, int p, const Score& score, const uint64_t* __restrict__ w, uint64_t st,
+__device__ __forceinline__ void scan_sequence(int k, int p, const Score& score, const uint64_t* __restrict__ w, uint64_t last_word, uint64_t st,
                                               uint32_t m, Emit emit) {
     const uint32_t win = (uint32_t)(k - p);
     const uint32_t pmask = p >= 16 ? 0xffffffffu : ((1u << (2 * p)) - 1);
-    MinPosD minp = find_min(p, score, w, st, 0, win, pmask);                                  // msp.rs:232
-    uint32_t end_pm = (uint32_t)packed_get_kmer(w, st + win, p).lo;                    // msp.rs:233
+    MinPosD minp = find_min(p, score, w, last_word, st, 0, win, pmask);                                  // msp.rs:232
+    uint32_t end_pm = (uint32_t)packed_get_pmer64(w, st + win, p, last_word);                    // msp.rs:233
     uint32_t cur_start = 0;
     const uint32_t nwin = m - (uint32_t)k + 1;
     for (uint32_t i = 1; i < nwin; i++) {                                              // msp.rs:237
         end_pm = ((end_pm << 2) | packed_get(w, st + i + win + p - 1)) & pmask;        // incr, msp.rs:239
         if (i > minp.pos) {                                                            // msp.rs:241
-            MinPosD nm = find_min(p, score, w, st, i, i + win, pmask);
+            MinPosD nm = find_min(p, score, w, last_word, st, i, i + win, pmask);
             emit(cur_start, i + (uint32_t)k - 1 - cur_start, minp);
             cur_start = i; minp = nm;
         } else {

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) extract_kernel(SeqDev s, const uint64_t* 
         const uint32_t d1 = load_d1(s.data, s.data_width, si);
         const uint64_t obase = koff[si];
         for (uint32_t j = lane; j < nk; j += 64) {
-            K128 km = packed_get_kmer(s.words, st + j, k);
+            K128 km = packed_get_kmer(s.words, st + j, k, s.n_words ? s.n_words - 1 : 0);
             // lib.rs:820-832: interior exts from the neighbouring bases, boundary exts from seq_exts
             uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << packed_get(s.words, st + j - 1));
             uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << packed_get(s.words, st + j + k));
@@ -63,8 +63,8 @@ __device__ __forceinline__ uint32_t key_top_byte(K128 km, int k) {
     return bits >= 8 ? (uint32_t)k128_shr(km, bits - 8).lo & 0xffu : (uint32_t)(km.lo << (8 - bits)) & 0xffu;
 }
 template <bool STRANDED>
-__device__ __forceinline__ K128 canon_kmer(const uint64_t* __restrict__ w, uint64_t o, int k, bool* flipped) {
-    K128 km = packed_get_kmer(w, o, k);
+__device__ __forceinline__ K128 canon_kmer(const uint64_t* __restrict__ w, uint64_t last_word, uint64_t o, int k, bool* flipped) {
+    K128 km = packed_get_kmer(w, o, k, last_word);
     *flipped = false;
     if (!STRANDED) {
         const K128 rc = kmer_rc(km, k);
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) top_byte_hist_kernel(SeqDev s, int k, uns
         if (len < (uint32_t)k) continue;
         const uint64_t st = s.start[si];
         const uint32_t nk = len - (uint32_t)k + 1;
-        for (uint32_t j = lane; j < nk; j += 64) { bool f; atomicAdd(&h[key_top_byte(canon_kmer<STRANDED>(s.words, st + j, k, &f), k)], 1u); }
+        for (uint32_t j = lane; j < nk; j += 64) { bool f; atomicAdd(&h[key_top_byte(canon_kmer<STRANDED>(s.words, s.n_words ? s.n_words - 1 : 0, st + j, k, &f), k)], 1u); }
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) kmer_counts_range_kernel(SeqDev s, int k,
             for (uint32_t j0 = 0; j0 < nk; j0 += 64) {
                 const uint32_t j = j0 + lane;
                 bool in = false;
-                if (j < nk) { bool f; const uint32_t b = key_top_byte(canon_kmer<STRANDED>(s.words, st + j, k, &f), k); in = b >= b_lo && b < b_hi; }
+                if (j < nk) { bool f; const uint32_t b = key_top_byte(canon_kmer<STRANDED>(s.words, s.n_words ? s.n_words - 1 : 0, st + j, k, &f), k); in = b >= b_lo && b < b_hi; }
                 cnt += (uint32_t)__popcll(__ballot(in));
             }
         }
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) extract_range_kernel(SeqDev s, const uint
             const uint32_t j = j0 + lane;
             bool in = false, flipped = false;
             K128 km{0, 0};
-            if (j < nk) { km = canon_kmer<STRANDED>(s.words, st + j, k, &flipped); const uint32_t b = key_top_byte(km, k); in = b >= b_lo && b < b_hi; }
+            if (j < nk) { km = canon_kmer<STRANDED>(s.words, s.n_words ? s.n_words - 1 : 0, st + j, k, &flipped); const uint32_t b = key_top_byte(km, k); in = b >= b_lo && b < b_hi; }
             const uint64_t m = __ballot(in);
             if (in) {
                 uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << packed_get(s.words, st + j - 1));

@@ -37,14 +37,6 @@ struct FastCfg {
     const uint8_t* lmap;        // D1 label -> dense colour index (sparse label alphabets), or null: the label is the index
 };
 
-// p-mer (p <= 16) at absolute base offset o: two funnel-shifted words, right-aligned
-__device__ __forceinline__ uint32_t packed_get_pmer(const uint64_t* __restrict__ w, uint64_t o, int p) {
-    const uint64_t wi = o >> 5;
-    const int s = (int)(o & 31) * 2;
-    uint64_t v = w[wi] << s;
-    if (s + 2 * p > 64) v |= w[wi + 1] >> (64 - s);
-    return (uint32_t)(v >> (64 - 2 * p));
-}
 // p-mer from the two words that hold it (w1 is ignored when the p-mer ends inside w0): no branches
 __device__ __forceinline__ uint32_t pmer_from_words(uint64_t w0, uint64_t w1, uint32_t s /* bit offset 0..62 */, int p) {
     const uint64_t v = (w0 << s) | ((w1 >> 1) >> (63 - s));
@@ -66,14 +58,6 @@ __device__ __forceinline__ uint64_t rel_word(const uint64_t* __restrict__ wr, ui
     const uint32_t wi = rel >> 5, s = (rel & 31u) * 2u;
     const uint64_t w0 = wr[wi < last_rel ? wi : last_rel], w1 = wr[wi + 1 < last_rel ? wi + 1 : last_rel];
     const uint64_t v = (w0 << s) | ((w1 >> 1) >> (63 - s));
-    return v & (~0ull << (64 - 2 * nb));
-}
-// nb (1..32) bases starting at absolute base offset o, left-aligned in a u64 (rest zero)
-__device__ __forceinline__ uint64_t packed_get_word(const uint64_t* __restrict__ w, uint64_t o, uint32_t nb) {
-    const uint64_t wi = o >> 5;
-    const int s = (int)(o & 31) * 2;
-    uint64_t v = w[wi] << s;
-    if (s + 2 * (int)nb > 64) v |= w[wi + 1] >> (64 - s);
     return v & (~0ull << (64 - 2 * nb));
 }
 // reverse complement of a right-aligned p-mer held in 32 bits

@@ -27,6 +27,8 @@ struct EndIndex {            // sorted terminal k-mers of one side + owning node
     uint32_t n;
 };
 
+// (the node words carry two zero words of slack -- dev_graph_build -- so the k-mer fetches need no clamp)
+constexpr uint64_t NO_CLAMP = ~0ull;
 __device__ __forceinline__ K128 ekey(const EndIndex& t, uint32_t i) { return K128{t.hi ? t.hi[i] : 0ull, t.lo[i]}; }
 __device__ __forceinline__ int64_t search_kmer(const EndIndex& t, K128 q) {          // graph.rs:243-249
     uint32_t lo = 0, hi = t.n;
@@ -59,8 +61,8 @@ __global__ void term_kmers_kernel(const uint64_t* __restrict__ words, const uint
                                   uint64_t* f_hi, uint64_t* f_lo, uint64_t* l_hi, uint64_t* l_lo, uint32_t* ids_a, uint32_t* ids_b) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    K128 f = packed_get_kmer(words, start[i], k);                                   // first_kmer (lib.rs:369-371)
-    K128 l = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);         // last_kmer (lib.rs:374-376)
+    K128 f = packed_get_kmer(words, start[i], k, NO_CLAMP);                                   // first_kmer (lib.rs:369-371)
+    K128 l = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k, NO_CLAMP);         // last_kmer (lib.rs:374-376)
     if (f_hi) { f_hi[i] = f.hi; l_hi[i] = l.hi; }
     f_lo[i] = f.lo; l_lo[i] = l.lo;
     ids_a[i] = i; ids_b[i] = i;
@@ -73,8 +75,8 @@ __global__ void fix_exts_kernel(EndIndex left, EndIndex right, const uint64_t* _
                                 uint8_t* __restrict__ exts_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    K128 lk = packed_get_kmer(words, start[i], k);
-    K128 rk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);
+    K128 lk = packed_get_kmer(words, start[i], k, NO_CLAMP);
+    K128 rk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k, NO_CLAMP);
     uint32_t e = exts_in[i], ne = 0;
     for (uint32_t b = 0; b < 4; b++) {
         if (e & (1u << b)) {
@@ -106,8 +108,8 @@ __global__ void node_link_kernel(EndIndex left, EndIndex right, const uint64_t* 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t e = exts[i];
-    K128 fk = packed_get_kmer(words, start[i], k);
-    K128 lk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);
+    K128 fk = packed_get_kmer(words, start[i], k, NO_CLAMP);
+    K128 lk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k, NO_CLAMP);
     const bool self_pal = !stranded && length[i] == (uint32_t)k && (k % 2 == 0) && k128_eq(fk, kmer_rc(fk, k));   // :121
     for (int dir = 0; dir < 2; dir++) {
         uint32_t out = NL_TERM;
@@ -149,8 +151,8 @@ __global__ void edges_kernel(EndIndex left, EndIndex right, const uint64_t* __re
                              int stranded, const uint8_t* __restrict__ exts, uint32_t* __restrict__ target, uint8_t* __restrict__ info) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    K128 lk = packed_get_kmer(words, start[i], k);                                  // term_kmer(Dir::Left)
-    K128 rk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);        // term_kmer(Dir::Right)
+    K128 lk = packed_get_kmer(words, start[i], k, NO_CLAMP);                                  // term_kmer(Dir::Left)
+    K128 rk = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k, NO_CLAMP);        // term_kmer(Dir::Right)
     const uint32_t e = exts[i];
     for (uint32_t b = 0; b < 4; b++) {
         uint32_t t = EDGE_NONE, f = 0;

@@ -175,8 +175,10 @@ __global__ void unpack_acgt_kernel(const uint64_t* __restrict__ words, uint64_t 
     const uint64_t b = first_base + o;
     const uint64_t wi = b >> 5, last = (first_base + n - 1) >> 5;
     const uint32_t s = 2 * (uint32_t)(b & 31);
-    uint64_t w = words[wi] << s;
-    if (s && wi < last) w |= words[wi + 1] >> (64 - s);
+    // (both words are loaded unconditionally, the second index clamped: see packed_get_kmer in dbg_device.hpp)
+    const uint64_t w0 = words[wi], w1 = words[wi < last ? wi + 1 : last];
+    uint64_t w = w0 << s;
+    if (s && wi < last) w |= w1 >> (64 - s);
     const uint64_t c0 = expand8((uint32_t)(w >> 48)), c1 = expand8((uint32_t)(w >> 32) & 0xffffu),
                    c2 = expand8((uint32_t)(w >> 16) & 0xffffu), c3 = expand8((uint32_t)w & 0xffffu);
     if (o + 32 <= n && ((uintptr_t)(ascii + o) & 15) == 0) {

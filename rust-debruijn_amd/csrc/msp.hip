@@ -37,7 +37,7 @@ __global__ void msp_count_kernel(SeqDev s, MspCfg c, uint32_t* __restrict__ coun
     uint32_t m = s.length[i];
     if (wave_handles(c, m, lane_on) || lane_handles(c, m, lane_on)) return;
     uint32_t n = 0;
-    if (m >= (uint32_t)c.k) scan_sequence(c.k, c.p, MspScore{c}, s.words, s.start[i], m, [&](uint32_t, uint32_t, const MinPosD&) { n++; });
+    if (m >= (uint32_t)c.k) scan_sequence(c.k, c.p, MspScore{c}, s.words, (s.n_words ? s.n_words - 1 : 0), s.start[i], m, [&](uint32_t, uint32_t, const MinPosD&) { n++; });
     counts[i] = n;                                                                     // m < k: empty (msp.rs:294-296)
 }
 
@@ -51,7 +51,7 @@ __global__ void msp_emit_kernel(SeqDev s, MspCfg c, const uint64_t* __restrict__
     const uint64_t st = s.start[i];
     const uint64_t* __restrict__ w = s.words;
     uint64_t o = piece_off[i];
-    scan_sequence(c.k, c.p, MspScore{c}, w, st, m, [&](uint32_t start, uint32_t len, const MinPosD& mp) {
+    scan_sequence(c.k, c.p, MspScore{c}, w, (s.n_words ? s.n_words - 1 : 0), st, m, [&](uint32_t start, uint32_t len, const MinPosD& mp) {
         uint32_t r = pmer_rc(mp.pmer, c.p);
         bucket[o] = mp.pmer < r ? mp.pmer : r;                                        // min_rc().to_u64() (msp.rs:115-117)
         uint32_t le = start > 0 ? (1u << packed_get(w, st + start - 1)) : 0u;         // lib.rs:645-660
@@ -67,7 +67,7 @@ __global__ void msp_emit_kernel(SeqDev s, MspCfg c, const uint64_t* __restrict__
                 uint64_t v = 0;
                 if (b0 < len) {
                     uint32_t nb = len - b0 < 32 ? len - b0 : 32;
-                    v = packed_get_kmer(w, st + start + b0, (int)nb).lo << (64 - 2 * nb);   // left-align nb bases
+                    v = packed_get_pmer64(w, st + start + b0, (int)nb, (s.n_words ? s.n_words - 1 : 0)) << (64 - 2 * nb);   // left-align nb bases
                 }
                 if (q == c.lmer_words - 1) v |= (uint64_t)(len & 0xff);
                 lw[q] = v;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) msp_wave_kernel(SeqDev s, MspCfg c, uint3
         const uint64_t st = s.start[i];
         const uint32_t npos = m - (uint32_t)c.p + 1, nwin = m - (uint32_t)c.k + 1;
         // 1. scores of all p-mers
-        for (uint32_t j = lane; j < npos; j += 64) v[j] = pmer_score(c, (uint32_t)packed_get_kmer(w, st + j, c.p).lo);
+        for (uint32_t j = lane; j < npos; j += 64) v[j] = pmer_score(c, (uint32_t)packed_get_pmer64(w, st + j, c.p, (s.n_words ? s.n_words - 1 : 0)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) msp_wave_kernel(SeqDev s, MspCfg c, uint3
         for (uint32_t t = lane; t < np; t += 64) {
             const uint32_t start = ps[t], len = pl[t], mp = pmn[t];
             const uint64_t o = o0 + t;
-            const uint32_t pmer = (uint32_t)packed_get_kmer(w, st + mp, c.p).lo;
+            const uint32_t pmer = (uint32_t)packed_get_pmer64(w, st + mp, c.p, (s.n_words ? s.n_words - 1 : 0));
             const uint32_t r = pmer_rc(pmer, c.p);
             bucket[o] = pmer < r ? pmer : r;                                          // min_rc().to_u64() (msp.rs:115-117)
             const uint32_t le = start > 0 ? (1u << packed_get(w, st + start - 1)) : 0u;   // lib.rs:645-660
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) msp_wave_kernel(SeqDev s, MspCfg c, uint3
                     uint64_t x = 0;
                     if (b0 < len) {
                         const uint32_t nb = len - b0 < 32 ? len - b0 : 32;
-                        x = packed_get_kmer(w, st + start + b0, (int)nb).lo << (64 - 2 * nb);   // left-align nb bases
+                        x = packed_get_pmer64(w, st + start + b0, (int)nb, (s.n_words ? s.n_words - 1 : 0)) << (64 - 2 * nb);   // left-align nb bases
                     }
                     if (q == c.lmer_words - 1) x |= (uint64_t)(len & 0xff);
                     lw[q] = x;
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256) msp_finish_kernel(SeqDev s, MspCfg c, con
         const uint32_t x = mpos[o];
         const uint32_t start = x & 1023u, len = (x >> 10) & 2047u, mp = x >> 21;
         pstart[o] = start; plen[o] = (uint16_t)len; mpos[o] = mp;
-        const uint32_t pmer = (uint32_t)packed_get_kmer(w, st + mp, c.p).lo;
+        const uint32_t pmer = (uint32_t)packed_get_pmer64(w, st + mp, c.p, (s.n_words ? s.n_words - 1 : 0));
         const uint32_t rcv = pmer_rc(pmer, c.p);
         bucket[o] = pmer < rcv ? pmer : rcv;                                      // min_rc().to_u64() (msp.rs:115-117)
         const uint32_t le = start > 0 ? (1u << packed_get(w, st + start - 1)) : 0u;   // lib.rs:645-660
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) msp_finish_kernel(SeqDev s, MspCfg c, con
                 uint64_t v = 0;
                 if (b0 < len) {
                     const uint32_t nb = len - b0 < 32 ? len - b0 : 32;
-                    v = packed_get_kmer(w, st + start + b0, (int)nb).lo << (64 - 2 * nb);   // left-align nb bases
+                    v = packed_get_pmer64(w, st + start + b0, (int)nb, (s.n_words ? s.n_words - 1 : 0)) << (64 - 2 * nb);   // left-align nb bases
                 }
                 if (q == c.lmer_words - 1) v |= (uint64_t)(len & 0xff);
                 lw[q] = v;

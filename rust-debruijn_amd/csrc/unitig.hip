@@ -396,8 +396,9 @@ __global__ void emit_nodes_kernel(const Jump* __restrict__ J, uint32_t n, int k,
         for (uint32_t o = skip; o < L; o += 32) {
             const uint32_t nb = L - o < 32 ? L - o : 32;
             uint64_t chunk;
-            if (fwd) chunk = packed_get_kmer(nwords, ns + o, (int)nb).lo;
-            else chunk = rc_bases64(packed_get_kmer(nwords, ns + (L - o - nb), (int)nb).lo, nb);   // DnaStringSlice::rc (dna_string.rs:572-578)
+            // (the node words carry two words of slack: graph.hip's dev_graph_build)
+            if (fwd) chunk = packed_get_pmer64(nwords, ns + o, (int)nb, ~0ull);
+            else chunk = rc_bases64(packed_get_pmer64(nwords, ns + (L - o - nb), (int)nb, ~0ull), nb);   // DnaStringSlice::rc (dna_string.rs:572-578)
             or_bits(words, dst + (o - skip), K128{0, chunk}, (int)nb);
         }
         uint32_t eo = 0;

@@ -329,17 +329,18 @@ def test_fast_wide_colour_sets(ctx, k, width, labels):
         assert int(got.set_val.max()) >= 24                                   # the wide layout was needed
 
 
-def test_more_than_64_labels_take_the_generic_path(ctx):
+def test_more_than_1024_labels_take_the_generic_path(ctx):
+    """(65..1024 distinct labels run as label groups on the fast path: test_fast_label_groups)"""
     rng = np.random.default_rng(3)
-    seqs = random_reads(rng, 300, 2000, 150, False)
-    data = rng.integers(0, 200, size=len(seqs))
-    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=1)
+    seqs = random_reads(rng, 1500, 2000, 150, False)
+    data = rng.permutation(1500) * 40 + 7
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=2)
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
     with ctx.options(DBG_PATH="auto"):
-        got, _ = dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+        got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     assert_tables_equal(got, want, True)
     with pytest.raises(dbg.DbgError):                                           # DBG_PATH=fast must not fall back silently
-        dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+        dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
 
 
 @pytest.mark.parametrize("k", [64, 63, 48, 32])

@@ -54,7 +54,8 @@ def draw_case(rng):
         alphabet = {0: np.arange(int(rng.integers(1, 24))),                                  # narrow layout
                     1: np.arange(int(rng.integers(25, 64))),                                 # wide layout
                     2: np.sort(rng.choice(np.arange(200 if width == 1 else 60000), size=int(rng.integers(2, 60)), replace=False)),  # sparse alphabet
-                    3: np.arange(int(rng.integers(70, 120)))}[int(rng.integers(0, 4))]      # generic path
+                    3: np.arange(int(rng.integers(70, 120))),                                # label groups (k >= 16), else the generic path
+                    4: np.sort(rng.choice(np.arange(256 if width == 1 else 65536), size=int(rng.integers(65, 250)), replace=False))}[int(rng.integers(0, 5))]
         data = alphabet[rng.integers(0, len(alphabet), size=n_reads)]
     min_obs = int(rng.choice([1, 1, 2, 3]))
     report_all = bool(rng.integers(0, 2))
@@ -62,7 +63,7 @@ def draw_case(rng):
     # tables, slab overflow), no slabs, the three-array sort form, the plain LSD sort, the wave-per-read scanner
     knobs = [{}, {}, {}, {"DBG_COUNT": "wave"}, {"DBG_FAST_TARGET": "600"}, {"DBG_FAST_TARGET": "50000"}, {"DBG_FAST_NO_SLAB": "1"},
              {"DBG_NO_REC16": "1"}, {"DBG_NO_HYBRID_SORT": "1"}, {"DBG_SCAN": "wave"}, {"DBG_COUNT": "wave", "DBG_FAST_TARGET": "300"},
-             {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}][int(rng.integers(0, 13))]
+             {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}, {"DBG_NO_LABEL_GROUPS": "1"}][int(rng.integers(0, 14))]
     return dict(k=k, stranded=stranded, is_set=is_set, seqs=seqs, exts=exts, data=data, width=width, min_obs=min_obs, report_all=report_all,
                 knobs=knobs)
 
