@@ -1,6 +1,6 @@
 """stress: the second stage (combine + compress_graph) and the per-owner compress, repeated while other processes share the GPU"""
 import sys, os
-sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, importlib, torch
 import oracle_lib as O
 from pkg import dbg
