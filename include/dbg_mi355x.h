@@ -80,7 +80,10 @@ typedef struct {
                                    Kmer::get(3) of a shorter k-mer underflows `k - 1 - pos` (kmer.rs:254-257, :515-518) -- a panic in
                                    the reference's debug builds, reproduced here as an error */
     int32_t  stranded;          /* filter.rs:142 */
-    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min) */
+    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min).  Label sets of any D1 values are served; how fast
+                                   depends on the alphabet: up to 64 distinct labels (< 65536) one pass of the counting kernel,
+                                   65..1024 distinct labels one extra pass per 64 labels (n_passes = 1 + groups), beyond that (or
+                                   labels >= 65536) the sort-based generic path */
     uint64_t min_kmer_obs;      /* filter.rs:41,69 */
     int32_t  report_all_kmers;  /* filter.rs:143 */
     uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero).  Otherwise IGNORED: in the
@@ -284,7 +287,7 @@ int  dbg_unpack_acgt_dev(dbg_ctx* ctx, const uint64_t* words_dev, uint64_t first
 typedef struct {
     uint32_t k;
     int32_t  stranded;
-    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (labels < 24) */
+    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (labels: see max_label / labels below) */
     uint64_t min_kmer_obs;
     uint64_t total_kmers;       /* k-mer instances over ALL ranks: fixes the bin count */
     uint32_t n_bins;            /* in: 0 = derive from total_kmers, otherwise the bin count to use (every rank must pass the
