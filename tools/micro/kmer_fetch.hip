@@ -1,10 +1,23 @@
-// Does packed_get_kmer (conditional second/third word loads) ever differ from three unconditional loads?  Run several copies at once.
+// Does a k-mer fetch with conditional second/third word loads ever differ from three unconditional loads?  Run several copies at once.
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/kmer_fetch tools/micro/kmer_fetch.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <vector>
 #include "../../rust-debruijn_amd/csrc/dbg_device.hpp"
+// the fetch the library's device code used until round 3 (now host-only in dbg_device.hpp): second and third word loaded only when needed
+__device__ __forceinline__ K128 cond_get_kmer(const uint64_t* __restrict__ w, uint64_t o, int k) {
+    uint64_t wi = o >> 5;
+    int s = (int)(o & 31) * 2;
+    int need = s + 2 * k;
+    uint64_t w0 = w[wi];
+    uint64_t w1 = need > 64 ? w[wi + 1] : 0;
+    uint64_t w2 = need > 128 ? w[wi + 2] : 0;
+    K128 top;
+    if (s) { top.hi = (w0 << s) | (w1 >> (64 - s)); top.lo = (w1 << s) | (w2 >> (64 - s)); }
+    else   { top.hi = w0; top.lo = w1; }
+    return k128_shr(top, 128 - 2 * k);
+}
 __device__ __forceinline__ K128 get_kmer3(const uint64_t* __restrict__ w, uint64_t o, int k) {
     const uint64_t wi = o >> 5; const int s = (int)(o & 31) * 2;
     const uint64_t w0 = w[wi], w1 = w[wi + 1], w2 = w[wi + 2];
@@ -16,8 +29,8 @@ __global__ void a_kernel(const uint64_t* __restrict__ words, const uint64_t* __r
                          uint64_t* f_hi, uint64_t* f_lo, uint64_t* l_hi, uint64_t* l_lo) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    K128 f = packed_get_kmer(words, start[i], k);
-    K128 l = packed_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);
+    K128 f = cond_get_kmer(words, start[i], k);
+    K128 l = cond_get_kmer(words, start[i] + length[i] - (uint32_t)k, k);
     f_hi[i] = f.hi; l_hi[i] = l.hi; f_lo[i] = f.lo; l_lo[i] = l.lo;
 }
 __global__ void a3_kernel(const uint64_t* __restrict__ words, const uint64_t* __restrict__ start, const uint32_t* __restrict__ length, uint32_t n, int k,
