@@ -285,8 +285,8 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
     """Distributed filter_kmers: returns this rank's table (the valid k-mers of the bins it owns,
     ascending by key) and the global k-mer instance count.  stats (a dict, optional) receives the exchange volume and the
     exchange time the counting kernels could not hide.  merge_dups: merge identical records on the sending rank before the
-    exchange (default: at 2..4 ranks, where a rank holds enough copies of each record for the merge to remove more wire time
-    than it costs -- DESIGN.md section 5; DBG_SHARD_MERGE=0 / 1 forces it off / on)."""
+    exchange (default: at 2 ranks, the one shape where a link carries more than the counting kernels can hide -- DESIGN.md
+    section 5; DBG_SHARD_MERGE=0 / 1 forces it off / on)."""
     import os
     import torch
     import torch.distributed as dist
@@ -325,7 +325,7 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
             raise ValueError("sharded CountFilterSet: %d distinct labels over all ranks; the sharded path holds 64" % len(labels))
     if merge_dups is None:
         env = os.environ.get("DBG_SHARD_MERGE")
-        merge_dups = (1 < world <= 4) if env is None else env != "0"
+        merge_dups = (world == 2) if env is None else env != "0"
     if stats is not None:
         stats["merge_dups"] = bool(merge_dups)
     plan = engine.plan(k, stranded, summarizer_kind, min_obs, total, max_label, merge_dups=merge_dups, labels=labels)

@@ -11,8 +11,8 @@ for W in ${WORLDS:-2 3 8}; do          # 8 = the target node shape: eight ranks,
   a=$(one $((R * W))); b=$(many $W)
   echo "world $W: single-GPU valid,digest=$a  sharded=$b"
   [ "$a" == "$b" ] || { echo MISMATCH; exit 1; }
-  # the sender-side duplicate merge the other way round (default: on at 2..4 ranks, off above)
-  m=$([ $W -le 4 ] && echo 0 || echo 1)
+  # the sender-side duplicate merge the other way round (default: on at 2 ranks, off above)
+  m=$([ $W -le 2 ] && echo 0 || echo 1)
   b=$(DBG_SHARD_MERGE=$m many $W)
   echo "world $W, DBG_SHARD_MERGE=$m: sharded=$b"
   [ "$a" == "$b" ] || { echo MISMATCH; exit 1; }
