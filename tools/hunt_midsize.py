@@ -15,7 +15,7 @@ for i in range(n_cases):
     n = int(rng.choice([150_000, 400_000, 1_000_000, 2_000_000]))
     k = int(rng.choice([20, 31, 33, 47, 48, 49, 55, 63, 64, 13]))
     kind = int(rng.integers(0, 2))
-    colours = int(rng.choice([4, 24, 40])) if kind else 4
+    colours = int(rng.choice([4, 24, 40, 100, 200])) if kind else 4      # 100, 200: label groups (fast_manylabels.hpp)
     cov = int(rng.choice([3, 30, 100]))
     err = float(rng.choice([0.0, 0.001, 0.01]))
     stranded = bool(rng.integers(0, 2))
