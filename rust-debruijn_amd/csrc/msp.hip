@@ -191,9 +191,15 @@ __global__ void __launch_bounds__(256) msp_wave_kernel(SeqDev s, MspCfg c, uint3
 // A first launch counts the pieces of every read, the second writes (start, len, minimizer_pos) at piece_off[read] + t, and
 // msp_finish_kernel derives bucket, Exts and the Lmer words of every piece from those.
 // ------------------------------------------------------------------------------------------------
-template <bool EMIT>
+// MODE 0: count the pieces of every read.  MODE 1: write them at piece_off[read] + t.  MODE 2 (round 3): count AND keep the first
+// MSP_STASH pieces of every read in stash[read * MSP_STASH + t] -- the second scan of the reads is then only needed for the reads
+// with more pieces than that (MODE 3: MODE 1 restricted to them; a 150-base read has ~7), and msp_finish_kernel takes the pieces
+// from the stash: one pass over the reads instead of two.
+constexpr uint32_t MSP_STASH = 16;
+template <int MODE>
 __global__ void __launch_bounds__(64) msp_lane_kernel(SeqDev s, MspCfg c, uint32_t* __restrict__ counts, const uint64_t* __restrict__ piece_off,
-                                                      uint32_t* __restrict__ packed) {
+                                                      uint32_t* __restrict__ packed, uint32_t* __restrict__ stash, uint32_t* __restrict__ flag) {
+    constexpr bool EMIT = MODE == 1 || MODE == 3;
     extern __shared__ uint32_t s_dyn[];
     const uint32_t lane = threadIdx.x;
     const int k = c.k, p = c.p;
@@ -209,6 +215,7 @@ __global__ void __launch_bounds__(64) msp_lane_kernel(SeqDev s, MspCfg c, uint32
         uint64_t st = 0;
         if (my < s.n) { m = s.length[my]; st = s.start[my]; }
         if (!lane_handles(c, m, true)) m = 0;                       // other kernels (or nothing: m < k gives no pieces)
+        if (MODE == 3 && m && counts[my] <= MSP_STASH) m = 0;       // its pieces are in the stash
         const uint32_t nwin = m ? m - (uint32_t)k + 1 : 0u;
         uint32_t mmax = m;
 #pragma unroll
@@ -238,7 +245,9 @@ __global__ void __launch_bounds__(64) msp_lane_kernel(SeqDev s, MspCfg c, uint32
         };
         auto close = [&](uint32_t i_change) {                       // the piece [cur_start, i_change + k - 1) ends (msp.rs:250-262)
             // one 4-byte store per piece: start (10 bits) | len (11: at most 2k - p <= 2 * 106) << 10 | minimizer_pos (10) << 21
-            if (EMIT) packed[o0 + np] = cur_start | ((i_change + (uint32_t)k - 1 - cur_start) << 10) | ((1023u - (m_key & 1023u)) << 21);
+            const uint32_t x = cur_start | ((i_change + (uint32_t)k - 1 - cur_start) << 10) | ((1023u - (m_key & 1023u)) << 21);
+            if (EMIT) packed[o0 + np] = x;
+            if (MODE == 2 && np < MSP_STASH) stash[my * MSP_STASH + np] = x;
             np++;
             cur_start = i_change;
         };
@@ -323,9 +332,12 @@ __global__ void __launch_bounds__(64) msp_lane_kernel(SeqDev s, MspCfg c, uint32
             }
         }
         if (m) {                                                    // the last piece runs to the end of the read (msp.rs:266-273)
-            if (EMIT) packed[o0 + np] = cur_start | ((m - cur_start) << 10) | ((1023u - (m_key & 1023u)) << 21);
+            const uint32_t x = cur_start | ((m - cur_start) << 10) | ((1023u - (m_key & 1023u)) << 21);
+            if (EMIT) packed[o0 + np] = x;
+            if (MODE == 2 && np < MSP_STASH) stash[my * MSP_STASH + np] = x;
             np++;
             if (!EMIT) counts[my] = np;
+            if (MODE == 2 && np > MSP_STASH) *flag = 1u;            // (any number of lanes may store the same value)
         }
     }
 }
@@ -342,7 +354,7 @@ __global__ void __launch_bounds__(256) perm_max_kernel(const uint32_t* __restric
 // coalesced; a piece finds its read by a 6-step search over the 64 piece offsets held one per lane.
 __global__ void __launch_bounds__(256) msp_finish_kernel(SeqDev s, MspCfg c, const uint64_t* __restrict__ piece_off, uint32_t* __restrict__ bucket,
                                                          uint8_t* __restrict__ exts, uint32_t* __restrict__ pstart, uint16_t* __restrict__ plen,
-                                                         uint32_t* __restrict__ mpos, uint64_t* __restrict__ lmer) {
+                                                         uint32_t* __restrict__ mpos, uint64_t* __restrict__ lmer, const uint32_t* __restrict__ stash) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t rb = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64;
     if (rb >= s.n) return;
@@ -361,8 +373,11 @@ __global__ void __launch_bounds__(256) msp_finish_kernel(SeqDev s, MspCfg c, con
         const uint32_t m = __shfl(m_l, (int)r);
         const uint64_t st = __shfl(st_l, (int)r);
         const bool mine = __shfl((int)lane_read, (int)r) != 0;                      // else: a piece of another kernel's read
+        const uint64_t off_r = __shfl(off_l, (int)r);                               // (before any lane leaves: shuffles need every lane)
         if (o >= o_end || !mine) continue;
-        const uint32_t x = mpos[o];
+        // the packed piece: from the read's stash (its first MSP_STASH pieces), else where the second scan left it
+        const uint64_t t = o - off_r;
+        const uint32_t x = stash && t < MSP_STASH ? stash[(rb + r) * MSP_STASH + t] : mpos[o];
         const uint32_t start = x & 1023u, len = (x >> 10) & 2047u, mp = x >> 21;
         pstart[o] = start; plen[o] = (uint16_t)len; mpos[o] = mp;
         const uint32_t pmer = (uint32_t)packed_get_pmer64(w, st + mp, c.p, (s.n_words ? s.n_words - 1 : 0));
@@ -430,19 +445,29 @@ extern "C" int dbg_msp_sequence_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     const uint32_t W = p->k - p->p + 1;
     const size_t lane_lds = (size_t)(W + 1) * 64 * sizeof(uint32_t);
     const uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 63) / 64, 256ull * 16 * 8));
+    // the lane kernel's stash (64 bytes per read); without the memory for it, or with DBG_MSP=twopass, the reads are scanned twice
+    DBuf<uint32_t> stash, stash_flag;
+    uint32_t h_stash_flag = 0;
+    if (s.n && lane_on && !(c->opt("DBG_MSP") && !strcmp(c->opt("DBG_MSP"), "twopass"))) {
+        if (!stash.alloc(c, s.n * MSP_STASH)) stash.p = nullptr;
+        ALLOC_OR_FAIL(c, stash_flag, 1);
+        HIP_TRY(c, hipMemsetAsync(stash_flag.p, 0, 4, c->stream));
+    }
     if (s.n) {
         const uint32_t wblocks = (uint32_t)std::min<uint64_t>(cdiv(s.n, 4), 256ull * 64);
         HIP_TRY(c, hipMemsetAsync(counts.p, 0, s.n * 4, c->stream));
         c->t_begin("msp_count", s.n);
         msp_count_kernel<<<cdiv(s.n, 64), 64, 0, c->stream>>>(s, cfg, counts.p, lane_on);            // long reads only
         msp_wave_kernel<false><<<wblocks, 256, 0, c->stream>>>(s, cfg, counts.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, lane_on);
-        if (lane_on) msp_lane_kernel<false><<<lane_blocks, 64, lane_lds, c->stream>>>(s, cfg, counts.p, nullptr, nullptr);
+        if (lane_on && stash.p) msp_lane_kernel<2><<<lane_blocks, 64, lane_lds, c->stream>>>(s, cfg, counts.p, nullptr, nullptr, stash.p, stash_flag.p);
+        else if (lane_on) msp_lane_kernel<0><<<lane_blocks, 64, lane_lds, c->stream>>>(s, cfg, counts.p, nullptr, nullptr, nullptr, nullptr);
         c->t_end();
         LAUNCH_CHECK(c, "msp_count");
     }
     DBG_TRY(scan_exclusive_u32_u64(c, counts.p, off.p, s.n));
     uint64_t np = 0;
     HIP_TRY(c, hipMemcpyAsync(&np, off.p + s.n, 8, hipMemcpyDeviceToHost, c->stream));
+    if (stash.p) HIP_TRY(c, hipMemcpyAsync(&h_stash_flag, stash_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     DBuf<uint32_t> bucket, pstart, mpos;
     DBuf<uint8_t> exts;
@@ -457,8 +482,10 @@ extern "C" int dbg_msp_sequence_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
         msp_wave_kernel<true><<<(uint32_t)std::min<uint64_t>(cdiv(s.n, 4), 256ull * 64), 256, 0, c->stream>>>(s, cfg, nullptr, off.p, bucket.p, exts.p,
                                                                                                        pstart.p, plen.p, mpos.p, lmer.p, lane_on);
         if (lane_on) {
-            msp_lane_kernel<true><<<lane_blocks, 64, lane_lds, c->stream>>>(s, cfg, nullptr, off.p, mpos.p);      // packed words wait in mpos
-            msp_finish_kernel<<<cdiv(s.n, 256), 256, 0, c->stream>>>(s, cfg, off.p, bucket.p, exts.p, pstart.p, plen.p, mpos.p, lmer.p);
+            // packed words wait in mpos (second scan) or in the stash
+            if (!stash.p) msp_lane_kernel<1><<<lane_blocks, 64, lane_lds, c->stream>>>(s, cfg, nullptr, off.p, mpos.p, nullptr, nullptr);
+            else if (h_stash_flag) msp_lane_kernel<3><<<lane_blocks, 64, lane_lds, c->stream>>>(s, cfg, counts.p, off.p, mpos.p, nullptr, nullptr);
+            msp_finish_kernel<<<cdiv(s.n, 256), 256, 0, c->stream>>>(s, cfg, off.p, bucket.p, exts.p, pstart.p, plen.p, mpos.p, lmer.p, stash.p);
         }
         c->t_end();
         LAUNCH_CHECK(c, "msp_emit");

@@ -152,6 +152,28 @@ def test_msp_kernel_routes(ctx, k, p):
             b = check_batch(ctx, seqs, k, p, None, rc, lmer_words=4 if 2 * k - p <= 124 else 0)
         for name in ("piece_off", "bucket", "exts", "start", "len", "minimizer_pos"):
             assert np.array_equal(a[name], b[name]), name
+        with ctx.options(DBG_MSP="twopass"):                 # the lane kernel without its piece stash: count pass + emit pass
+            b = check_batch(ctx, seqs, k, p, None, rc, lmer_words=4 if 2 * k - p <= 124 else 0)
+        for name in ("piece_off", "bucket", "exts", "start", "len", "minimizer_pos"):
+            assert np.array_equal(a[name], b[name]), name
+
+
+@pytest.mark.parametrize("k,p", [(47, 8), (31, 6), (21, 4)])
+def test_msp_stash_boundary(ctx, k, p):
+    """The lane kernel keeps a read's first 16 pieces in a stash and re-scans only the reads with more: reads with 1 .. ~60
+    pieces in one batch (the 17th piece is the first to come from the second scan), and a batch in which no read needs it."""
+    rng = np.random.default_rng(k * 100 + p)
+    lens = list(rng.integers(k, 700, size=400)) + [k, k + 1]
+    seqs = [R.random_dna(rng, int(n)) for n in lens]
+    res = check_batch(ctx, seqs, k, p, None, True, lmer_words=3 if 2 * k - p <= 92 else 0)
+    per_read = np.diff(res["piece_off"])
+    assert per_read.max() > 17 and (per_read == 16).any() or per_read.max() > 17       # both sides of the stash size occur
+    with ctx.options(DBG_MSP="twopass"):
+        two = check_batch(ctx, seqs, k, p, None, True, lmer_words=3 if 2 * k - p <= 92 else 0)
+    for name in ("piece_off", "bucket", "exts", "start", "len", "minimizer_pos"):
+        assert np.array_equal(res[name], two[name]), name
+    short = [R.random_dna(rng, int(n)) for n in rng.integers(k, k + 40, size=200)]     # at most a few pieces each: no second scan
+    assert np.diff(check_batch(ctx, short, k, p, None, False)["piece_off"]).max() <= 16
 
 
 def test_msp_permutation_values_beyond_packing(ctx):
