@@ -101,19 +101,43 @@ __global__ void __launch_bounds__(256) ml_setn_kernel(const unsigned long long* 
     for (uint32_t g = 0; g < G; g++) c += (uint32_t)__popcll(masks[(size_t)i * G + g]);
     setn[i] = c;
 }
-// labels of colour (g, bit) = labels[g * 64 + bit]: ascending in g and bit, so every list comes out sorted
+// labels of colour (g, bit) = labels[g * 64 + bit]: ascending in g and bit, so every list comes out sorted.  A wavefront takes 64
+// keys whose lists are one contiguous stretch of set_val: every lane expands its key's masks into the wave's LDS staging area at
+// the list's offset inside that stretch, then the wave copies the stretch out with consecutive lanes on consecutive words (a lane
+// writing its own list straight to memory moved 9*10^9 labels at 0.9 TB/s: 41 ms at 100 labels).  Stretches longer than the staging
+// area go out in pieces; the lanes then re-expand and keep only the entries of the current piece.
+constexpr uint32_t ML_CSR_STAGE = 2048;
 __global__ void __launch_bounds__(256) ml_csr_kernel(const unsigned long long* __restrict__ masks, uint32_t n, uint32_t G, const uint64_t* __restrict__ set_off,
                                                      const uint32_t* __restrict__ labels, uint32_t* __restrict__ set_val) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t o = set_off[i];
-    for (uint32_t g = 0; g < G; g++) {
-        unsigned long long m = masks[(size_t)i * G + g];
-        while (m) {
-            const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
-            m &= m - 1;
-            set_val[o++] = labels[g * 64 + b];
+    __shared__ uint32_t s_stage[4][ML_CSR_STAGE];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t k0 = (blockIdx.x * 4 + wave) * 64;
+    if (k0 >= n) return;
+    const uint32_t i = k0 + lane;
+    const bool on = i < n;
+    const uint64_t base = set_off[k0];
+    const uint64_t end = set_off[k0 + 64 < n ? k0 + 64 : n];
+    const uint64_t mine = on ? set_off[i] - base : 0;                 // my list's offset inside the wave's stretch
+    uint32_t* st = s_stage[wave];
+    for (uint64_t p0 = 0; p0 < end - base; p0 += ML_CSR_STAGE) {      // wave-uniform
+        const uint64_t p1 = p0 + ML_CSR_STAGE < end - base ? p0 + ML_CSR_STAGE : end - base;
+        if (on) {
+            uint64_t o = mine;
+            for (uint32_t g = 0; g < G && o < p1; g++) {
+                unsigned long long m = masks[(size_t)i * G + g];
+                const uint32_t c = (uint32_t)__popcll(m);
+                if (o + c <= p0) { o += c; continue; }                // wholly before this piece
+                while (m && o < p1) {
+                    const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+                    m &= m - 1;
+                    if (o >= p0) st[o - p0] = labels[g * 64 + b];
+                    o++;
+                }
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        for (uint64_t q = p0 + lane; q < p1; q += 64) set_val[base + q] = st[q - p0];
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -222,7 +246,7 @@ static int filter_kmers_fast_many(dbg_ctx* c, const SeqDev& s, const dbg_filter_
     ALLOC_OR_FAIL(c, set_val, std::max<uint64_t>(n_setval, 1));
     if (nv) {
         c->t_begin("set_csr", nv);
-        ml_csr_kernel<<<cdiv(nv, 256), 256, 0, c->stream>>>(masks.p, nv, G, set_off.p, d_labels.p, set_val.p);
+        ml_csr_kernel<<<cdiv(nv, 256), 256, 0, c->stream>>>(masks.p, nv, G, set_off.p, d_labels.p, set_val.p);   // a wave per 64 keys
         c->t_end();
         LAUNCH_CHECK(c, "ml_csr");
     }
