@@ -14,7 +14,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdbg_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result", "-ffp-contract=off"]
+         "-Wno-unused-result", "-ffp-contract=off"] + os.environ.get("DBG_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DDBG_PHASE_TIMES (measurement builds)
 
 
 def _sources():

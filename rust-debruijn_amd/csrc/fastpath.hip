@@ -35,6 +35,7 @@ struct FastCfg {
     int stranded;
     uint32_t nbins;
     const uint8_t* lmap;        // D1 label -> dense colour index (sparse label alphabets), or null: the label is the index
+    int strand_norm;            // store every piece as the smaller of (piece, reverse complement): non-stranded counting with odd k
 };
 
 // p-mer from the two words that hold it (w1 is ignored when the p-mer ends inside w0): no branches
@@ -211,6 +212,36 @@ struct PieceEmitter {
                 const uint32_t nb = b0 < len ? (len - b0 < 32 ? len - b0 : 32) : 0;
                 rv[qq] = nb ? v & (~0ull << (64 - 2 * nb)) : 0ull;
                 if (ps + len < m && len >= b0 && len < b0 + 32) re = 1u << ((uint32_t)(v >> (62u - 2u * (len - b0))) & 3u);   // base right of the piece
+            }
+            // Non-stranded counting canonicalises every k-mer anyway, so a piece may be stored on either strand: storing the smaller of
+            // (piece, reverse complement) makes the copies that reads of the two strands produce IDENTICAL records, which the counting
+            // workgroup (and the sender-side merge of the sharded flow) then merge.  Odd k only: a k-mer that is its own reverse
+            // complement (even k) takes its Exts in the orientation the READ presents it (ties flip, lib.rs:226-230), which a
+            // stored strand would change.
+            if (c.strand_norm) {
+                uint64_t t[NBW], rc[NBW];
+#pragma unroll
+                for (int qq = 0; qq < NBW; qq++) t[qq] = ~rev2_64(rv[NBW - 1 - qq]);       // base i of the piece -> slot 32 NBW - 1 - i
+                const uint32_t S = 2u * (32u * NBW - len), ws = S >> 6, bs = S & 63u;      // the rc sits at the END of the slots: shift it up
+                auto pick = [&](uint32_t i) -> uint64_t {                                   // t[i] or 0, without indexing registers
+                    uint64_t v = 0;
+#pragma unroll
+                    for (int qq = 0; qq < NBW; qq++) v = i == (uint32_t)qq ? t[qq] : v;
+                    return v;
+                };
+                bool less = false, decided = false;
+#pragma unroll
+                for (int qq = 0; qq < NBW; qq++) {
+                    const uint64_t a = pick((uint32_t)qq + ws), b2 = pick((uint32_t)qq + ws + 1);
+                    rc[qq] = (a << bs) | ((b2 >> 1) >> (63u - bs));
+                    if (!decided && rc[qq] != rv[qq]) { decided = true; less = rc[qq] < rv[qq]; }
+                }
+                if (less) {
+#pragma unroll
+                    for (int qq = 0; qq < NBW; qq++) rv[qq] = rc[qq];
+                    const uint32_t e = exts_rc((re << 4) | le);
+                    le = e & 0xfu; re = e >> 4;
+                }
             }
             rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 63u) << 15);
         }
@@ -1647,7 +1678,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     st->pl = pl; st->n_kmers = n_kmers;
     const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
     const uint32_t nbins = pl.nbins * NCLS;                      // sub-bins (bin, length class)
-    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap};
+    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap, (!pl.stranded && (k & 1) && !c->opt("DBG_NO_STRAND_NORM")) ? 1 : 0};
     SeqDev sd = s;
     if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
     DBuf<uint32_t> sflags;

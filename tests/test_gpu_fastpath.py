@@ -355,3 +355,22 @@ def test_fast_tiny_tables_are_sorted(ctx, k, n_valid_target):
     ss = O.SeqSet.from_byte_seqs(seqs)
     got = run_fast(ctx, ss, k, O.COUNT_FILTER, 3, False)
     assert len(got) == n_valid_target
+
+
+@pytest.mark.parametrize("k,kind", [(47, 0), (31, 1), (63, 0), (21, 1)])
+def test_fast_strand_normalised_records(ctx, k, kind):
+    """Non-stranded counting with odd k stores every super-k-mer piece as the smaller of (piece, reverse complement), so that the
+    copies reads of the two strands produce are identical records (they merge in the counting workgroup and in the sender-side
+    merge).  Same table with and without (DBG_NO_STRAND_NORM), on reads from both strands, with read Exts at the ends."""
+    hs = dbg.synth_reads_host(n_reads=4000, read_len=150, error_rate=0.003, stranded=False, n_colours=5)
+    rng = np.random.default_rng(k)
+    exts = rng.integers(0, 256, size=len(hs.start)).astype(np.uint8)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, exts, hs.data if kind else None, 1 if kind else 0)
+    want = O.filter_kmers(ss, k, kind, 2, stranded=False)
+    summ = (dbg.CountFilterSet if kind else dbg.CountFilter)(2)
+    h = dbg.HostSeqs(hs.words, hs.start, hs.length, exts, hs.data if kind else None, 1 if kind else 0)
+    got, _ = dbg.filter_kmers(h, summ, False, False, 4, k=k, ctx=ctx)
+    assert_tables_equal(got, want, bool(kind))
+    with ctx.options(DBG_NO_STRAND_NORM="1"):
+        plain, _ = dbg.filter_kmers(h, summ, False, False, 4, k=k, ctx=ctx)
+    assert_tables_equal(plain, want, bool(kind))
