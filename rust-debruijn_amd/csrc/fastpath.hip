@@ -223,17 +223,16 @@ struct PieceEmitter {
 #pragma unroll
                 for (int qq = 0; qq < NBW; qq++) t[qq] = ~rev2_64(rv[NBW - 1 - qq]);       // base i of the piece -> slot 32 NBW - 1 - i
                 const uint32_t S = 2u * (32u * NBW - len), ws = S >> 6, bs = S & 63u;      // the rc sits at the END of the slots: shift it up
-                auto pick = [&](uint32_t i) -> uint64_t {                                   // t[i] or 0, without indexing registers
-                    uint64_t v = 0;
+                // word shift in two conditional steps (ws <= 3: len >= k >= 16), then the bit shift across neighbours: no register indexing
 #pragma unroll
-                    for (int qq = 0; qq < NBW; qq++) v = i == (uint32_t)qq ? t[qq] : v;
-                    return v;
-                };
+                for (int qq = 0; qq < NBW; qq++) t[qq] = (ws & 1u) ? (qq + 1 < NBW ? t[qq + 1] : 0ull) : t[qq];
+#pragma unroll
+                for (int qq = 0; qq < NBW; qq++) t[qq] = (ws & 2u) ? (qq + 2 < NBW ? t[qq + 2] : 0ull) : t[qq];
                 bool less = false, decided = false;
 #pragma unroll
                 for (int qq = 0; qq < NBW; qq++) {
-                    const uint64_t a = pick((uint32_t)qq + ws), b2 = pick((uint32_t)qq + ws + 1);
-                    rc[qq] = (a << bs) | ((b2 >> 1) >> (63u - bs));
+                    const uint64_t nx = qq + 1 < NBW ? t[qq + 1] : 0ull;
+                    rc[qq] = (t[qq] << bs) | ((nx >> 1) >> (63u - bs));
                     if (!decided && rc[qq] != rv[qq]) { decided = true; less = rc[qq] < rv[qq]; }
                 }
                 if (less) {
