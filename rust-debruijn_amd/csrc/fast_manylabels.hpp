@@ -141,8 +141,10 @@ __global__ void __launch_bounds__(256) ml_csr_kernel(const unsigned long long* _
     }
 }
 
+// *used = false (and nothing written): the rows of masks do not fit the device -- the caller takes the generic path
 static int filter_kmers_fast_many(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, const std::vector<uint32_t>& labels,
-                                  dbg_kmer_table* out) {
+                                  dbg_kmer_table* out, bool* used) {
+    *used = false;
     const int k = (int)prm->k;
     const bool stranded = prm->stranded != 0;
     const uint32_t nd = (uint32_t)labels.size(), G = (nd + 63) / 64;
@@ -195,7 +197,7 @@ static int filter_kmers_fast_many(dbg_ctx* c, const SeqDev& s, const dbg_filter_
 
     // 3. one 64-colour run per group, joined into the rows of masks
     DBuf<unsigned long long> masks;
-    ALLOC_OR_FAIL(c, masks, std::max<size_t>((size_t)nv * G, 1));
+    if (!masks.alloc(c, std::max<size_t>((size_t)nv * G, 1))) return 0;       // (T is released by its guard)
     HIP_TRY(c, hipMemsetAsync(masks.p, 0, std::max<size_t>((size_t)nv * G, 1) * 8, c->stream));
     for (uint32_t g = 0; g < G && nv; g++) {
         const uint64_t a = g_off[g], n_g = g_off[g + 1] - a;
@@ -256,5 +258,6 @@ static int filter_kmers_fast_many(dbg_ctx* c, const SeqDev& s, const dbg_filter_
     if (out->count) { c->dfree(out->count); out->count = nullptr; }
     out->set_off = set_off.take(); out->set_val = set_val.take(); out->n_set_val = n_setval;
     out->n_passes = 1 + G;
+    *used = true;
     return 0;
 }

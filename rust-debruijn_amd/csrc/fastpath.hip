@@ -2340,9 +2340,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok, &many));
         if (!ok) {
             if (many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS")) return 0;
-            DBG_TRY(filter_kmers_fast_many(c, s, prm, n_kmers, many, out));
-            *used = true;
-            return 0;
+            return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
         }
     }
     // the WIDE colour-set layout keeps two more words per table entry: with 1024-entry tables two workgroups still share a CU's
