@@ -158,7 +158,9 @@ def main():
         tab, total, n_local, n_recs = D.sharded_filter_kmers(engine, ss, k, False, 1 if is_set else 0, args.min_obs, stats=st,
                                                                  force_exchange=args.force_exchange)
         for kk, v in st.items():
-            if isinstance(v, list):
+            if isinstance(v, (str, bool)) or v is None:
+                xstats[kk] = v                                   # (transport name, merge / balance flags: not summed over steps)
+            elif isinstance(v, list):
                 old = xstats.get(kk, [0.0] * len(v))
                 xstats[kk] = [a_ + b_ for a_, b_ in zip(old, v)] if len(old) == len(v) else list(v)
             else:
@@ -458,12 +460,17 @@ def main():
             "ranks_seen": ranks_seen, "backend": args.backend if world > 1 else None,
             "exchange": ({"bytes_sent_per_step_all_ranks": xbytes_total // max(args.steps, 1),
                           "exposed_ms_per_step_max_rank": round(exposed_ms / max(args.steps, 1), 3),
-                          "rounds": xstats.get("exchange_rounds", 0) // max(args.steps, 1),
-                          "sender_merge": bool(xstats.get("merge_dups", 0))} if world > 1 else None),
+                          "rounds": int(xstats.get("exchange_rounds", 0)) // max(args.steps, 1),
+                          "sender_merge": bool(xstats.get("merge_dups", 0)),
+                          "ownership": "record histogram (all-reduced), greedy contiguous cut" if xstats.get("balanced") else "equal bin ranges",
+                          "entry_point": "dbg_shard_filter_kmers_dev (C ABI; rounds ordered by HIP events on a communication stream)",
+                          "transport": xstats.get("transport"), "transport_fallback": xstats.get("transport_fallback"),
+                          "setup_ms_per_step_rank0": round(xstats.get("setup_ms", 0.0) / max(args.steps, 1), 3)} if (world > 1 or args.force_exchange) else None),
             "balance": balance,
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
             "host_boundary": hostb, "compress": comp,
         }
+    D.close_transports()
     ctx.close()
     if world > 1 or args.force_exchange:
         import torch.distributed as dist

@@ -333,6 +333,116 @@ int  dbg_shard_count_bins_dev(dbg_ctx* ctx, const uint64_t* recs_dev, const uint
                               uint32_t n_bins_chunk, uint64_t n_kmers_units);
 int  dbg_shard_count_finish(dbg_ctx* ctx, dbg_kmer_table* out);
 
+/* ---- the rank-spanning flow behind the C ABI (round 4) ---------------------------------------------
+ * BASELINE north_star: "Shard MSP buckets across the 8 GPUs of one node with RCCL all-to-all over xGMI".  The reference's
+ * sharded flow is composed by its caller (src/test.rs:433-470: msp_sequence -> per-shard filter_kmers -> per-shard
+ * compress_kmers_with_hash -> BaseGraph::combine -> compress_graph); here the same flow across GPUs runs INSIDE the library,
+ * one process per GPU, and what moves bytes between ranks is this small table of operations.
+ * dbg_transport_rccl_create fills it with RCCL calls on an ncclComm_t the host created (ncclCommInitRank in a Rust host;
+ * dbg_rccl_comm_create below for hosts that do not link RCCL themselves).  A host may also supply its own table (MPI, a test
+ * harness that stages through host memory so that N ranks can share one GPU).
+ *
+ * Contract of every operation: all data buffers are DEVICE pointers; count/offset arrays are host arrays that are only read
+ * during the call.  The operation is ordered on `hip_stream` (a hipStream_t): it may return before the data has moved, and it
+ * is complete once the work enqueued on that stream up to the call's return is complete (a synchronous implementation drains
+ * the stream, moves the data, and returns).  Every rank calls the same operations in the same order.  Return 0 on success;
+ * otherwise the calling entry point fails and dbg_last_error names the operation. */
+typedef struct dbg_transport {
+    void*    self;
+    int32_t  rank, world;
+    /* element-wise reduction over all ranks of n u64 values, in place; op: 0 = sum, 1 = max */
+    int (*all_reduce_u64)(void* self, uint64_t* buf_dev, uint64_t n, int32_t op, void* hip_stream);
+    /* every rank contributes `bytes` bytes; recv_dev receives world * bytes in rank order */
+    int (*all_gather)(void* self, const void* send_dev, void* recv_dev, uint64_t bytes, void* hip_stream);
+    /* variable all-to-all: send_bytes[d] bytes at send_dev + send_off[d] go to rank d; recv_bytes[s] bytes from rank s
+     * arrive at recv_dev + recv_off[s] (RCCL: one ncclGroupStart/End of ncclSend/ncclRecv pairs) */
+    int (*all_to_allv)(void* self, const void* send_dev, const uint64_t* send_off, const uint64_t* send_bytes,
+                       void* recv_dev, const uint64_t* recv_off, const uint64_t* recv_bytes, void* hip_stream);
+    /* point to point; sends and receives between one pair of ranks match in call order */
+    int (*send)(void* self, const void* buf_dev, uint64_t bytes, int32_t peer, void* hip_stream);
+    int (*recv)(void* self, void* buf_dev, uint64_t bytes, int32_t peer, void* hip_stream);
+} dbg_transport;
+
+/* RCCL transport on an existing communicator.  nccl_comm = the host's ncclComm_t (one rank per GPU, rank/world as given to
+ * ncclCommInitRank).  librccl_path: the librccl the communicator came from (NULL = the copy already loaded into the process,
+ * else "librccl.so.1"); the symbols are resolved at run time, so libdbg_mi355x.so itself does not link RCCL and single-GPU
+ * users never load it.  Messages are cut so that no single ncclSend exceeds 1 GiB.  err (may be NULL) receives a message. */
+int  dbg_transport_rccl_create(void* nccl_comm, int32_t rank, int32_t world, const char* librccl_path, dbg_transport** out,
+                               char* err, uint64_t err_len);
+void dbg_transport_destroy(dbg_transport* t);       /* tables made by this library only; the ncclComm_t stays the caller's */
+/* For hosts that do not bind RCCL themselves: ncclGetUniqueId on one rank (id_out: 128 bytes, to be handed to the other ranks
+ * by whatever bootstrap the host has), then ncclCommInitRank on every rank with its GPU current. */
+int  dbg_rccl_unique_id(const char* librccl_path, uint8_t* id_out_128, char* err, uint64_t err_len);
+int  dbg_rccl_comm_create(const char* librccl_path, const uint8_t* id_128, int32_t world, int32_t rank, int32_t device,
+                          void** nccl_comm_out, char* err, uint64_t err_len);
+int  dbg_rccl_comm_destroy(const char* librccl_path, void* nccl_comm);
+
+/* Ownership of the global bin space: rank r owns bins [bounds[r], bounds[r+1]), boundaries multiples of bin_group.
+ * group_records[n_bins / bin_group] = records of every bin group summed over ALL ranks -> contiguous ranges of nearly equal
+ * record count (greedy cut of the cumulative histogram: low-complexity minimizers do not pile up on one owner);
+ * NULL = equal numbers of bins.  Pure host arithmetic, the same on every rank (no GPU needed). */
+int  dbg_shard_owner_bounds(const uint64_t* group_records, uint32_t n_bins, uint32_t bin_group, uint32_t world,
+                            uint32_t* bounds_out /* [world + 1] */);
+/* Exchange rounds: every rank's owned range is cut into n_rounds ranges (cuts_out[d * stride + c], stride = the value of
+ * *n_rounds_io at entry + 1; relative to bounds[d], multiples of bin_group); round c moves range c of every destination while
+ * range c - 1 is counted.  n_rounds is clamped to what the smallest owner can be cut into; the value used is returned in
+ * *n_rounds_io (the stride stays what it was). */
+int  dbg_shard_round_cuts(const uint32_t* bounds, uint32_t world, uint32_t bin_group, uint32_t* n_rounds_io,
+                          uint32_t* cuts_out /* [world * (*n_rounds_io + 1)], sized for the value passed in */);
+
+typedef struct {
+    uint32_t k;
+    int32_t  stranded;
+    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (at most 64 distinct labels < 65536 over all ranks) */
+    uint64_t min_kmer_obs;
+    uint32_t n_rounds;          /* exchange rounds; 0 = chosen so that no message exceeds 1 GiB (at least 4; 8 from 4 ranks on) */
+    int32_t  merge_dups;        /* sender-side duplicate merge: 1 on, 0 off, -1 = the library decides (on at 2 ranks, where one link
+                                   carries everything; afterwards from the exposed exchange time the ctx measured in its last call) */
+    int32_t  balance;           /* 1 = ownership from the all-reduced record histogram of the scan (default), 0 = equal bin ranges */
+    int32_t  force_exchange;    /* world == 1: run the collective route anyway (a functional check of the transport) */
+} dbg_shard_params;
+
+typedef struct {
+    uint64_t total_kmers;       /* k-mer instances over all ranks */
+    uint64_t local_kmers;       /* ... of this rank's reads */
+    uint64_t records_scanned;   /* super-k-mer records this rank produced (after the sender-side merge) */
+    uint64_t records_owned;     /* records of the bins this rank owns, from all ranks */
+    uint64_t bytes_sent;        /* record bytes that left this rank */
+    uint32_t n_bins, owned_lo, owned_hi;
+    uint32_t n_rounds;
+    int32_t  merge_dups;        /* what was used */
+    int32_t  balanced;
+    double   exposed_ms;        /* time the counting kernels waited for exchange rounds (HIP events on the ctx's stream) */
+    double   exposed_ms_round[64];
+    double   setup_ms;          /* host time from entry to the first round on the wire (plan, scan, histogram, layout) */
+} dbg_shard_stats;
+
+/* filter_kmers over the reads of ALL ranks (src/filter.rs:139-231 applied to the union; the reference's scale-out is
+ * msp_sequence shards + per-shard filter_kmers, src/test.rs:433-456).  Every rank passes its own device-resident reads and
+ * receives the ascending table of the valid k-mers of the bins it owns; the tables of the ranks are disjoint and their union
+ * is the table dbg_filter_kmers_dev returns for the concatenated reads.  Collective: every rank calls it with the same
+ * parameters.  Scan -> ownership -> slab compaction in (round, destination, bin) order -> pipelined all-to-all rounds on a
+ * communication stream ordered against the ctx's stream with events (no host synchronisation per round) -> per-bin counting
+ * -> one order-restoring sort.  stats may be NULL. */
+int  dbg_shard_filter_kmers_dev(dbg_ctx* ctx, const dbg_transport* tr, const dbg_seqset* dev_seqs, const dbg_shard_params* p,
+                                dbg_kmer_table* out_dev, dbg_shard_stats* stats);
+
+/* The rank-spanning end of the flow (src/test.rs:459-470): every rank runs compress_kmers_with_hash on the device-resident table
+ * of the bins it owns, then the shard graphs are merged with BaseGraph::combine (src/graph.rs:71-100) + compress_graph
+ * (src/compression.rs:291-349).  Graphs stay in HBM between the steps and travel as device buffers.
+ * reduce = DBG_REDUCE_GATHER: all shard graphs go to `root`, which combines them in rank order and runs one compress_graph --
+ *   the reference's flow literally (the result equals the oracle's node for node).
+ * reduce = DBG_REDUCE_TREE: pairwise combine + compress_graph up a binary tree (ranks r and r + 2^l at level l), so that the
+ *   early merges run in parallel and the root sees the last pair only; the same unitigs, in a different node order / strand
+ *   (compare with tools/compare_gfa.py's canonical form).
+ * CountFilterSet tables: D = class id of the label list, made global first (the ranks' class tables are all-gathered and
+ * renumbered in sorted order of the lists; *classes receives the global table on every rank).
+ * final_out: host BaseGraph on `root` (n_nodes = 0 elsewhere); local_out (may be NULL): this rank's own shard graph. */
+enum { DBG_REDUCE_GATHER = 0, DBG_REDUCE_TREE = 1 };
+int  dbg_shard_compress_dev(dbg_ctx* ctx, const dbg_transport* tr, uint32_t k, int stranded, int spec, int second_spec,
+                            const dbg_kmer_table* table_dev, int32_t reduce, int32_t root, dbg_graph* final_out,
+                            dbg_graph* local_out, dbg_label_classes* classes);
+
 /* ---- synthetic reads: splitmix64, deterministic ----- */
 typedef struct {
     uint64_t n_reads;

@@ -65,6 +65,31 @@ class ShardPlan(C.Structure):
                 ("max_label", C.c_uint32), ("merge_dups", C.c_uint32), ("n_labels", C.c_uint32), ("labels", C.c_uint32 * 64)]
 
 
+# ---- the rank-spanning flow (dbg_transport, dbg_shard_filter_kmers_dev, dbg_shard_compress_dev) ----
+TR_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+TR_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+TR_ALL_TO_ALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, C.c_void_p)
+TR_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+TR_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("self", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("all_reduce_u64", TR_ALL_REDUCE),
+                ("all_gather", TR_ALL_GATHER), ("all_to_allv", TR_ALL_TO_ALLV), ("send", TR_SEND), ("recv", TR_RECV)]
+
+
+class ShardParams(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("stranded", C.c_int32), ("summarizer", C.c_int32), ("min_kmer_obs", C.c_uint64),
+                ("n_rounds", C.c_uint32), ("merge_dups", C.c_int32), ("balance", C.c_int32), ("force_exchange", C.c_int32)]
+
+
+class ShardStats(C.Structure):
+    _fields_ = [("total_kmers", C.c_uint64), ("local_kmers", C.c_uint64), ("records_scanned", C.c_uint64),
+                ("records_owned", C.c_uint64), ("bytes_sent", C.c_uint64), ("n_bins", C.c_uint32), ("owned_lo", C.c_uint32),
+                ("owned_hi", C.c_uint32), ("n_rounds", C.c_uint32), ("merge_dups", C.c_int32), ("balanced", C.c_int32),
+                ("exposed_ms", C.c_double), ("exposed_ms_round", C.c_double * 64), ("setup_ms", C.c_double)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32), ("units", C.c_uint64)]
 
@@ -80,6 +105,8 @@ EXPORTS = [
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
     "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
     "dbg_graph_serialize", "dbg_graph_deserialize", "dbg_free_bytes", "dbg_serde_last_error",
+    "dbg_transport_rccl_create", "dbg_transport_destroy", "dbg_rccl_unique_id", "dbg_rccl_comm_create", "dbg_rccl_comm_destroy",
+    "dbg_shard_owner_bounds", "dbg_shard_round_cuts", "dbg_shard_filter_kmers_dev", "dbg_shard_compress_dev",
     "dbg_pack_acgt", "dbg_pack_acgt_dev", "dbg_pack_acgt_hashn", "dbg_pack_acgt_hashn_dev", "dbg_unpack_acgt", "dbg_unpack_acgt_dev",
 ]
 
@@ -174,6 +201,18 @@ def load():
     lib.dbg_shard_count_begin.argtypes = [C.c_void_p, C.POINTER(ShardPlan), C.c_uint64]
     lib.dbg_shard_count_bins_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     lib.dbg_shard_count_finish.argtypes = [C.c_void_p, C.POINTER(KmerTable)]
+    lib.dbg_transport_rccl_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.POINTER(Transport)), C.c_char_p, C.c_uint64]
+    lib.dbg_transport_destroy.argtypes = [C.POINTER(Transport)]
+    lib.dbg_transport_destroy.restype = None
+    lib.dbg_rccl_unique_id.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_uint64]
+    lib.dbg_rccl_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]
+    lib.dbg_rccl_comm_destroy.argtypes = [C.c_char_p, C.c_void_p]
+    lib.dbg_shard_owner_bounds.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.dbg_shard_round_cuts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+    lib.dbg_shard_filter_kmers_dev.argtypes = [C.c_void_p, C.POINTER(Transport), C.POINTER(SeqSet), C.POINTER(ShardParams),
+                                               C.POINTER(KmerTable), C.POINTER(ShardStats)]
+    lib.dbg_shard_compress_dev.argtypes = [C.c_void_p, C.POINTER(Transport), C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(KmerTable),
+                                           C.c_int32, C.c_int32, C.POINTER(Graph), C.POINTER(Graph), C.POINTER(LabelClasses)]
     lib.dbg_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.dbg_ctx_get_timings.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_uint32, C.POINTER(C.c_uint32)]
     _lib = lib

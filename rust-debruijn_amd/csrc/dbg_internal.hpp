@@ -129,6 +129,17 @@ struct __attribute__((aligned(32))) NodeRec {
     uint32_t exts;
 };
 
+// A BaseGraph (graph.rs:43-50) resident in HBM: what the rank-spanning second stage passes from step to step and sends
+// between ranks (graph.hip).  words carries at least two zero words of slack behind n_words (k-mer fetches need no clamp).
+struct GraphDev {
+    DBuf<uint64_t> words, start;
+    DBuf<uint32_t> length, data;
+    DBuf<uint8_t> exts;
+    uint64_t n_nodes = 0, n_words = 0, n_bases = 0;
+    int stranded = 0;
+    bool filled = false;
+};
+
 // ---- launch helpers -----------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx, name)                                                                 \
     do {                                                                                        \

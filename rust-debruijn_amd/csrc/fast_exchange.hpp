@@ -1,0 +1,401 @@
+// The rank-spanning counting flow behind the C ABI (round 4): dbg_shard_filter_kmers_dev.  Included at the end of fastpath.hip.
+//
+// filter_kmers over the reads of all ranks (src/filter.rs:139-231 on the union; the reference scales out by MSP shards + one
+// filter_kmers per shard, src/test.rs:433-456, src/msp.rs:279-324).  A shard here is the contiguous range of minimizer bins a
+// rank owns.  What the Python orchestration of rounds 2-3 did with torch.distributed (all-reduces, send_layout,
+// exchange_geometry, the < 1 GiB rule, the round pipeline) is done here, in the library, over a dbg_transport:
+//
+//   scan (+ sender-side merge)            ctx stream
+//   record histogram all-reduced          transport, ctx stream            -> ownership bounds (greedy, host)
+//   offsets in (round, destination, bin)  layout kernels, ctx stream
+//   slab compaction in that order         ctx stream                       -> ONE send buffer, every message a contiguous range
+//   per-bin counts to the owners          all_to_allv, ctx stream
+//   round c + 1 of the records            all_to_allv, communication stream  | overlapped with
+//   counting of round c                   bin_count, ctx stream              | (ordered by events, no host wait per round)
+//   sort                                  ctx stream
+//
+// A rank's own records never travel: the counting kernel reads them from the send buffer (segment 0) and the received ones
+// from the round's receive buffer (segments 1 .. W-1).
+#pragma once
+#include <chrono>
+
+namespace {
+
+// layout position of every bin: ranges (round c, destination d) in that order, bins ascending inside a range
+struct LayoutTab {
+    uint32_t world, n_rounds;
+    uint32_t bounds[65];            // [world + 1]
+};
+
+__global__ void __launch_bounds__(256) layout_pos_kernel(LayoutTab lt, const uint32_t* __restrict__ cuts /* [world][n_rounds + 1] */,
+                                                          const uint32_t* __restrict__ range_base /* [n_rounds * world] bins before the range */,
+                                                          const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ pos_of,
+                                                          uint32_t* __restrict__ perm_count) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t d = 0;
+    while (d + 1 < lt.world && b >= lt.bounds[d + 1]) d++;
+    const uint32_t rel = b - lt.bounds[d];
+    const uint32_t* cd = cuts + (size_t)d * (lt.n_rounds + 1);
+    uint32_t lo = 0, hi = lt.n_rounds;                       // largest c with cd[c] <= rel (cd[n_rounds] > rel)
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (cd[m] <= rel) lo = m; else hi = m; }
+    // (empty ranges repeat a cut value: take the last range that starts at or before rel)
+    const uint32_t pos = range_base[lo * lt.world + d] + (rel - cd[lo]);
+    pos_of[b] = pos;
+    perm_count[pos] = count[b];
+}
+
+__global__ void __launch_bounds__(256) layout_off_kernel(const uint32_t* __restrict__ pos_of, const uint64_t* __restrict__ csum, uint32_t nb,
+                                                          uint64_t* __restrict__ off) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) off[b] = csum[pos_of[b]];
+}
+
+__global__ void __launch_bounds__(256) gather_u64_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ idx, uint32_t n,
+                                                          uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+
+__global__ void __launch_bounds__(256) widen_u32_u64_kernel(const uint32_t* __restrict__ in, uint32_t n, uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+// Segment tables of all rounds from the scanned per-source counts.  G[s * nbl + j] = records of source s (in source order: self
+// first) before owned bin j, over the whole owned range (G has W * nbl + 1 entries).  Round c covers owned bins [cut[c], cut[c+1]);
+// its table is seg_c[s][0 .. nbc] with seg_c[s][j - cut[c]] = base[c * W + s] + G[s * nbl + j] - G[s * nbl + cut[c]].
+__global__ void __launch_bounds__(256) seg_tables_kernel(const uint64_t* __restrict__ G, uint32_t nbl, uint32_t W, uint32_t n_rounds,
+                                                          const uint32_t* __restrict__ cut /* [n_rounds + 1] */,
+                                                          const uint64_t* __restrict__ base /* [n_rounds * W] */,
+                                                          const uint64_t* __restrict__ tab_off /* [n_rounds] start of round c's table in seg */,
+                                                          uint64_t* __restrict__ seg) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)W * (nbl + 1)) return;
+    const uint32_t s = (uint32_t)(t / (nbl + 1)), j = (uint32_t)(t % (nbl + 1));
+    const uint64_t g = G[(uint64_t)s * nbl + j] ;
+    uint32_t lo = 0, hi = n_rounds;                          // largest c with cut[c] <= j
+    while (hi - lo > 1) { const uint32_t m = (lo + hi) >> 1; if (cut[m] <= j) lo = m; else hi = m; }
+    // j closes round c - 1 (as its last column) for every round that ends at j and opens / lies inside every round with cut[c] <= j < cut[c + 1]
+    for (int32_t c = (int32_t)lo; c >= 0; c--) {
+        if (j > cut[c + 1]) break;
+        if (j < cut[c]) continue;
+        const uint32_t nbc = cut[c + 1] - cut[c];
+        seg[tab_off[c] + (uint64_t)s * (nbc + 1) + (j - cut[c])] = base[(uint64_t)c * W + s] + g - G[(uint64_t)s * nbl + cut[c]];
+    }
+}
+
+struct XTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+int tr_fail(dbg_ctx* c, const char* op) {
+    return c->fail(160, std::string("sharded flow: transport operation ") + op + " failed");
+}
+
+// all-reduce of a few host values (staged through a small device buffer: the transport moves device memory)
+int xreduce_host(dbg_ctx* c, const dbg_transport* tr, uint64_t* vals, uint32_t n, int op) {
+    if (!tr || tr->world <= 1) return 0;
+    DBuf<uint64_t> d;
+    ALLOC_OR_FAIL(c, d, n);
+    HIP_TRY(c, hipMemcpyAsync(d.p, vals, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (tr->all_reduce_u64(tr->self, d.p, n, op, c->stream)) return tr_fail(c, "all_reduce_u64");
+    HIP_TRY(c, hipMemcpyAsync(vals, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+hipStream_t comm_stream(dbg_ctx* c) { return c->get_copy_stream(); }
+
+}  // namespace
+
+extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, const dbg_seqset* ds, const dbg_shard_params* p,
+                                          dbg_kmer_table* out, dbg_shard_stats* stats) {
+    if (!c) return 1;
+    if (!ds || !p || !out) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    XTimer t_setup;
+    const uint32_t W = tr ? (uint32_t)tr->world : 1u, me = tr ? (uint32_t)tr->rank : 0u;
+    if (W == 0 || me >= W) return c->fail(161, "sharded flow: bad transport (rank / world)");
+    if (W > 64) return c->fail(161, "sharded flow: at most 64 ranks (one record segment per source rank in the counting kernel)");
+    if (tr && W > 1 && (!tr->all_reduce_u64 || !tr->all_to_allv)) return c->fail(161, "sharded flow: the transport lacks all_reduce_u64 / all_to_allv");
+    dbg_shard_stats st_local;
+    dbg_shard_stats* S = stats ? stats : &st_local;
+    memset(S, 0, sizeof(*S));
+    memset(out, 0, sizeof(*out));
+    const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
+    const bool collective = W > 1 || (p->force_exchange && tr);
+
+    // ---- global quantities every rank must agree on ----
+    uint64_t n_local = 0;
+    DBG_TRY(dbg_count_kmer_instances_dev(c, ds, p->k, &n_local));
+    uint64_t sum1[1] = {n_local};
+    DBG_TRY(xreduce_host(c, tr, sum1, 1, 0));
+    uint32_t my_max_label = 0;
+    if (is_set) DBG_TRY(dbg_seqset_max_label_dev(c, ds, &my_max_label));
+    uint64_t mx2[2] = {n_local, my_max_label};
+    DBG_TRY(xreduce_host(c, tr, mx2, 2, 1));
+    const uint64_t total = sum1[0], n_max = mx2[0];
+    const uint32_t max_label = (uint32_t)mx2[1];
+    S->total_kmers = total; S->local_kmers = n_local;
+
+    if (!collective) {
+        // one rank: the sharded table is the whole table
+        dbg_filter_params fp{p->k, p->stranded, p->summarizer, p->min_kmer_obs, 0, 4};
+        DBG_TRY(dbg_filter_kmers_dev(c, ds, &fp, out));
+        S->n_rounds = 0; S->setup_ms = 0.0;
+        return 0;
+    }
+    if (p->k < 16 || p->k > 64) return c->fail(140, "sharded counting supports 16 <= k <= 64");
+
+    dbg_shard_plan sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.k = p->k; sp.stranded = p->stranded; sp.summarizer = p->summarizer; sp.min_kmer_obs = p->min_kmer_obs;
+    sp.total_kmers = std::max<uint64_t>(total, 1); sp.max_label = max_label;
+    if (is_set && max_label >= 64) {
+        // labels beyond the 64 colours of the counting kernel: a sparse alphabet is mapped to colour indices, the same way on every
+        // rank -- the union of the ranks' label sets (a max-reduction of presence flags: the transport has sum and max, no OR)
+        std::vector<uint32_t> bm(2049);
+        DBG_TRY(dbg_seqset_label_bitmap_dev(c, ds, bm.data()));
+        std::vector<uint64_t> pres(65537);
+        for (uint32_t v = 0; v < 65536; v++) pres[v] = (bm[v >> 5] >> (v & 31)) & 1u;
+        pres[65536] = bm[2048] ? 1 : 0;
+        DBG_TRY(xreduce_host(c, tr, pres.data(), 65537, 1));
+        if (pres[65536]) return c->fail(141, "sharded CountFilterSet: labels must be < 65536");
+        uint32_t nl = 0;
+        for (uint32_t v = 0; v < 65536; v++)
+            if (pres[v]) {
+                if (nl == 64) return c->fail(141, "sharded CountFilterSet: more than 64 distinct labels over all ranks; the sharded path holds 64");
+                sp.labels[nl++] = v;
+            }
+        sp.n_labels = nl;
+    }
+    // sender-side merge: asked for, or decided here: on at 2 ranks; otherwise from what this ctx saw last time
+    int merge = p->merge_dups;
+    if (merge < 0) {
+        if (const char* e = c->opt("DBG_SHARD_MERGE")) merge = atoi(e) != 0;
+        else if (W == 2) merge = 1;
+        else if (c->shard_last_valid) merge = (c->shard_last_merge || c->shard_last_exposed_ms > c->shard_last_merge_cost_ms) ? 1 : 0;
+        else merge = 0;
+    }
+    sp.merge_dups = merge ? 1u : 0u;
+    FastPlan pl;
+    DBG_TRY(plan_from(c, &sp, &pl));
+    const uint32_t nb = pl.nbins * NCLS, rw = (uint32_t)pl.rw;
+    sp.n_bins = nb; sp.rec_words = rw; sp.bin_group = NCLS;
+    S->n_bins = nb; S->merge_dups = merge;
+
+    c->t_clear();
+    // ---- scan (+ merge) ----
+    FastScan sc;
+    DBG_TRY(shard_scan_core(c, ds, &sp, pl, &sc));
+    hipStream_t xs = comm_stream(c);
+    if (!xs) return c->fail(100, "sharded flow: no communication stream");
+
+    // ---- ownership ----
+    std::vector<uint32_t> bounds(W + 1);
+    const bool balance = p->balance != 0 && W > 1;
+    if (balance) {
+        DBuf<uint64_t> gh;
+        ALLOC_OR_FAIL(c, gh, nb);
+        widen_u32_u64_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(sc.cursor.p, nb, gh.p);
+        LAUNCH_CHECK(c, "widen_u32_u64");
+        if (tr->all_reduce_u64(tr->self, gh.p, nb, 0, c->stream)) return tr_fail(c, "all_reduce_u64 (record histogram)");
+        std::vector<uint64_t> hh(nb);
+        HIP_TRY(c, hipMemcpyAsync(hh.data(), gh.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        static_assert(NCLS == 1, "group histogram = bin histogram");
+        if (dbg_shard_owner_bounds(hh.data(), nb, NCLS, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
+    } else if (dbg_shard_owner_bounds(nullptr, nb, NCLS, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
+    S->balanced = balance ? 1 : 0;
+    S->owned_lo = bounds[me]; S->owned_hi = bounds[me + 1];
+
+    // ---- rounds ----
+    uint32_t n_rounds = p->n_rounds;
+    if (!n_rounds) {
+        // One message (one peer, one round) stays well under 1 GiB (the transport cuts larger ones, but a round is also the unit
+        // of overlap).  Records are at most ~2.5 bytes per k-mer instance (24-byte records of >= 10 k-mers at k = 47; denser for
+        // small k); every rank must arrive at the same number of rounds, hence the estimate from the largest rank.
+        const uint64_t est = std::max<uint64_t>(n_max, 1) * 4 / W;
+        n_rounds = (uint32_t)std::max<uint64_t>(W < 4 ? 4 : 8, (est + (1ull << 30) - 1) >> 30);
+    }
+    n_rounds = std::min<uint32_t>(n_rounds, 64);
+    const uint32_t stride = n_rounds + 1;
+    std::vector<uint32_t> cuts((size_t)W * stride);
+    if (dbg_shard_round_cuts(bounds.data(), W, NCLS, &n_rounds, cuts.data())) return c->fail(162, "sharded flow: round cuts");
+    const uint32_t R = n_rounds;
+    S->n_rounds = R;
+    // compact [W][R + 1]
+    std::vector<uint32_t> cutc((size_t)W * (R + 1));
+    for (uint32_t d = 0; d < W; d++) for (uint32_t r = 0; r <= R; r++) cutc[(size_t)d * (R + 1) + r] = cuts[(size_t)d * stride + r];
+    const uint32_t* mycut = &cutc[(size_t)me * (R + 1)];
+    const uint32_t nbl = bounds[me + 1] - bounds[me];
+
+    // ---- layout: offsets of every bin in (round, destination, bin) order ----
+    std::vector<uint32_t> range_base((size_t)R * W);
+    {
+        uint32_t acc = 0;
+        for (uint32_t r = 0; r < R; r++) for (uint32_t d = 0; d < W; d++) { range_base[(size_t)r * W + d] = acc; acc += cutc[(size_t)d * (R + 1) + r + 1] - cutc[(size_t)d * (R + 1) + r]; }
+    }
+    DBuf<uint32_t> d_cuts, d_rbase, pos_of, perm_count;
+    DBuf<uint64_t> csum, off, d_idx, d_edge;
+    ALLOC_OR_FAIL(c, d_cuts, cutc.size()); ALLOC_OR_FAIL(c, d_rbase, range_base.size());
+    ALLOC_OR_FAIL(c, pos_of, std::max(nb, 1u)); ALLOC_OR_FAIL(c, perm_count, std::max(nb, 1u));
+    ALLOC_OR_FAIL(c, csum, (size_t)nb + 1); ALLOC_OR_FAIL(c, off, (size_t)nb + 1);
+    HIP_TRY(c, hipMemcpyAsync(d_cuts.p, cutc.data(), cutc.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_rbase.p, range_base.data(), range_base.size() * 4, hipMemcpyHostToDevice, c->stream));
+    LayoutTab lt;
+    lt.world = W; lt.n_rounds = R;
+    for (uint32_t d = 0; d <= W; d++) lt.bounds[d] = bounds[d];
+    layout_pos_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(lt, d_cuts.p, d_rbase.p, sc.cursor.p, nb, pos_of.p, perm_count.p);
+    LAUNCH_CHECK(c, "layout_pos");
+    DBG_TRY(scan_exclusive_u32_u64(c, perm_count.p, csum.p, nb));
+    layout_off_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(pos_of.p, csum.p, nb, off.p);
+    LAUNCH_CHECK(c, "layout_off");
+    // edges of the (round, destination) blocks
+    const uint32_t n_edges = R * W + 1;
+    std::vector<uint64_t> eidx(n_edges), edge(n_edges);
+    for (uint32_t i = 0; i + 1 < n_edges; i++) eidx[i] = range_base[i];
+    eidx[n_edges - 1] = nb;
+    ALLOC_OR_FAIL(c, d_idx, n_edges); ALLOC_OR_FAIL(c, d_edge, n_edges);
+    HIP_TRY(c, hipMemcpyAsync(d_idx.p, eidx.data(), (size_t)n_edges * 8, hipMemcpyHostToDevice, c->stream));
+    gather_u64_kernel<<<cdiv(n_edges, 256), 256, 0, c->stream>>>(csum.p, d_idx.p, n_edges, d_edge.p);
+    LAUNCH_CHECK(c, "gather_u64");
+    HIP_TRY(c, hipMemcpyAsync(edge.data(), d_edge.p, (size_t)n_edges * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_recs = edge[n_edges - 1];
+    S->records_scanned = n_recs;
+    c->t_begin("sk_records", n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
+    c->t_end();
+
+    // ---- per-bin counts of my bins from every source (source order: self first, then the other ranks ascending) ----
+    std::vector<uint32_t> src_rank(W);
+    src_rank[0] = me;
+    for (uint32_t r = 0, i = 1; r < W; r++) if (r != me) src_rank[i++] = r;
+    std::vector<uint32_t> row_of(W);
+    for (uint32_t i = 0; i < W; i++) row_of[src_rank[i]] = i;
+    DBuf<uint32_t> rhist;
+    ALLOC_OR_FAIL(c, rhist, std::max<size_t>((size_t)W * nbl, 1));
+    {
+        std::vector<uint64_t> soff(W), sby(W), roff(W), rby(W);
+        for (uint32_t d = 0; d < W; d++) {
+            soff[d] = (uint64_t)bounds[d] * 4; sby[d] = d == me ? 0 : (uint64_t)(bounds[d + 1] - bounds[d]) * 4;
+            roff[d] = (uint64_t)row_of[d] * nbl * 4; rby[d] = d == me ? 0 : (uint64_t)nbl * 4;
+        }
+        if (nbl) HIP_TRY(c, hipMemcpyAsync(rhist.p, sc.cursor.p + bounds[me], (size_t)nbl * 4, hipMemcpyDeviceToDevice, c->stream));
+        if (W > 1 && tr->all_to_allv(tr->self, sc.cursor.p, soff.data(), sby.data(), rhist.p, roff.data(), rby.data(), c->stream))
+            return tr_fail(c, "all_to_allv (per-bin counts)");
+    }
+    DBuf<uint64_t> G;
+    ALLOC_OR_FAIL(c, G, (size_t)W * nbl + 1);
+    DBG_TRY(scan_exclusive_u32_u64(c, rhist.p, G.p, (uint64_t)W * nbl));
+    // G at the round cuts of every source -> per-round record counts (host)
+    std::vector<uint64_t> gidx((size_t)W * (R + 1)), gval((size_t)W * (R + 1));
+    for (uint32_t s = 0; s < W; s++) for (uint32_t r = 0; r <= R; r++) gidx[(size_t)s * (R + 1) + r] = (uint64_t)s * nbl + mycut[r];
+    DBuf<uint64_t> d_gidx, d_gval;
+    ALLOC_OR_FAIL(c, d_gidx, gidx.size()); ALLOC_OR_FAIL(c, d_gval, gidx.size());
+    HIP_TRY(c, hipMemcpyAsync(d_gidx.p, gidx.data(), gidx.size() * 8, hipMemcpyHostToDevice, c->stream));
+    gather_u64_kernel<<<cdiv(gidx.size(), 256), 256, 0, c->stream>>>(G.p, d_gidx.p, (uint32_t)gidx.size(), d_gval.p);
+    LAUNCH_CHECK(c, "gather_u64");
+    HIP_TRY(c, hipMemcpyAsync(gval.data(), d_gval.p, gidx.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // cnt[r][s] = records of source row s in round r; base: row 0 (self) = absolute offset of block (r, me) in the send buffer,
+    // rows >= 1 = offsets in the round's receive buffer
+    std::vector<uint64_t> cnt((size_t)R * W), base((size_t)R * W), tab_off(R), recv_recs(R);
+    uint64_t seg_words = 0, max_recv = 0, owned = 0;
+    for (uint32_t r = 0; r < R; r++) {
+        uint64_t acc = 0;
+        for (uint32_t s = 0; s < W; s++) {
+            cnt[(size_t)r * W + s] = gval[(size_t)s * (R + 1) + r + 1] - gval[(size_t)s * (R + 1) + r];
+            owned += cnt[(size_t)r * W + s];
+            if (s == 0) base[(size_t)r * W] = edge[(size_t)r * W + me];
+            else { base[(size_t)r * W + s] = acc; acc += cnt[(size_t)r * W + s]; }
+        }
+        if (cnt[(size_t)r * W] != edge[(size_t)r * W + me + 1] - edge[(size_t)r * W + me])
+            return c->fail(163, "sharded flow: layout and histogram disagree about this rank's own records");
+        recv_recs[r] = acc;
+        max_recv = std::max(max_recv, acc);
+        tab_off[r] = seg_words;
+        seg_words += (uint64_t)W * (mycut[r + 1] - mycut[r] + 1);
+    }
+    S->records_owned = owned;
+    DBuf<uint64_t> seg, d_base, d_taboff;
+    DBuf<uint32_t> d_mycut;
+    ALLOC_OR_FAIL(c, seg, std::max<uint64_t>(seg_words, 1)); ALLOC_OR_FAIL(c, d_base, base.size()); ALLOC_OR_FAIL(c, d_taboff, R);
+    ALLOC_OR_FAIL(c, d_mycut, R + 1);
+    HIP_TRY(c, hipMemcpyAsync(d_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_taboff.p, tab_off.data(), (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_mycut.p, mycut, (size_t)(R + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    seg_tables_kernel<<<cdiv((uint64_t)W * (nbl + 1), 256), 256, 0, c->stream>>>(G.p, nbl, W, R, d_mycut.p, d_base.p, d_taboff.p, seg.p);
+    LAUNCH_CHECK(c, "seg_tables");
+
+    // ---- send buffer: slabs compacted in layout order (also completes everything queued so far) ----
+    DBuf<uint64_t> recs;
+    ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(n_recs * rw, 1));
+    DBG_TRY(shard_scatter_core(c, &sc, off.p, recs.p));
+    pos_of.release(); perm_count.release(); csum.release(); off.release(); G.release(); rhist.release();
+
+    // ---- pipelined rounds ----
+    DBuf<uint64_t> rbuf[2];
+    ALLOC_OR_FAIL(c, rbuf[0], std::max<uint64_t>(max_recv * rw, 1));
+    if (R > 1) ALLOC_OR_FAIL(c, rbuf[1], std::max<uint64_t>(max_recv * rw, 1));
+    std::vector<hipEvent_t> ev_done(R), ev_a(R), ev_b(R);
+    for (uint32_t r = 0; r < R; r++) { ev_done[r] = c->get_event(); ev_a[r] = c->get_event(); ev_b[r] = c->get_event(); }
+    auto give_back = [&]() { for (uint32_t r = 0; r < R; r++) { c->event_pool.push_back(ev_done[r]); c->event_pool.push_back(ev_a[r]); c->event_pool.push_back(ev_b[r]); } };
+    std::vector<double> host_ms(R, 0.0);
+    auto launch = [&](uint32_t r) -> int {
+        std::vector<uint64_t> soff(W), sby(W), roff(W), rby(W);
+        for (uint32_t d = 0; d < W; d++) {
+            soff[d] = edge[(size_t)r * W + d] * rw * 8;
+            sby[d] = d == me ? 0 : (edge[(size_t)r * W + d + 1] - edge[(size_t)r * W + d]) * rw * 8;
+            roff[d] = d == me ? 0 : base[(size_t)r * W + row_of[d]] * rw * 8;
+            rby[d] = d == me ? 0 : cnt[(size_t)r * W + row_of[d]] * rw * 8;
+            S->bytes_sent += sby[d];
+        }
+        XTimer th;
+        const int e = W > 1 ? tr->all_to_allv(tr->self, recs.p, soff.data(), sby.data(), rbuf[r & 1].p, roff.data(), rby.data(), xs) : 0;
+        host_ms[r] = th.ms();
+        if (e) return tr_fail(c, "all_to_allv (records)");
+        if (hipEventRecord(ev_done[r], xs) != hipSuccess) return c->fail(100, "hipEventRecord failed");
+        return 0;
+    };
+    S->setup_ms = t_setup.ms();
+    std::unique_ptr<FastCountState> cs(new FastCountState());
+    int rcode = fast_count_begin(c, pl, p->min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get());
+    if (!rcode) rcode = launch(0);
+    for (uint32_t r = 0; r < R && !rcode; r++) {
+        // buffer (r + 1) & 1 was last read by the counting of round r - 1, which has completed (fast_count_bins returns after its
+        // launch has finished), so round r + 1 may go on the wire now and travels while round r is counted
+        if (r + 1 < R) rcode = launch(r + 1);
+        if (rcode) break;
+        (void)hipEventRecord(ev_a[r], c->stream);
+        if (hipStreamWaitEvent(c->stream, ev_done[r], 0) != hipSuccess) { rcode = c->fail(100, "hipStreamWaitEvent failed"); break; }
+        (void)hipEventRecord(ev_b[r], c->stream);
+        const uint32_t nbc = mycut[r + 1] - mycut[r];
+        if (nbc)
+            rcode = fast_count_bins(c, cs.get(), recs.p, rbuf[r & 1].p, 1, seg.p + tab_off[r], seg.p + tab_off[r] + 1, W, (uint64_t)nbc + 1, nbc / NCLS,
+                                    std::max<uint64_t>(n_local, 1) / R, 0);
+        else (void)hipStreamSynchronize(c->stream);
+    }
+    if (rcode) { (void)hipStreamSynchronize(xs); (void)hipStreamSynchronize(c->stream); give_back(); return rcode; }
+    HIP_TRY(c, hipStreamSynchronize(xs));
+    for (uint32_t r = 0; r < R; r++) {
+        float w = 0.f;
+        if (hipEventElapsedTime(&w, ev_a[r], ev_b[r]) != hipSuccess) { (void)hipGetLastError(); w = 0.f; }
+        // a synchronous transport spends the exchange inside the call: that is exposed time as well (an asynchronous one returns
+        // in well under a millisecond)
+        const double ex = (double)w + (host_ms[r] > 1.0 ? host_ms[r] : 0.0);
+        S->exposed_ms_round[r] = ex;
+        S->exposed_ms += ex;
+    }
+    give_back();
+    recs.release(); rbuf[0].release(); rbuf[1].release(); seg.release();
+    DBG_TRY(fast_count_finish(c, cs.get(), out));
+    out->n_kmer_instances = total;
+    // what the next call's merge decision looks at: exposed time beyond the first round (always exposed) against the cost of merging
+    c->shard_last_valid = true; c->shard_last_merge = merge != 0;
+    c->shard_last_exposed_ms = S->exposed_ms - S->exposed_ms_round[0];
+    c->shard_last_merge_cost_ms = 10.0 * (double)n_local / 1.04e10;         // slab_merge: ~9-10 ms per 10^8 reads of 150 bases
+    return 0;
+}

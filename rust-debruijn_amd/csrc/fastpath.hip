@@ -1490,7 +1490,7 @@ struct FastPlan {
     const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
 };
 
-static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
+static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl, bool allow_wave = true) {
     if (k < 16 || k > 64) return false;
     pl->k = k; pl->p = fast_internal_p(k);
     if (const char* e = c->opt("DBG_FAST_P")) pl->p = std::max(4, std::min(std::min(15, k - 8), atoi(e)));     // measurement: internal minimizer length
@@ -1507,7 +1507,7 @@ static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64
     // DBG_COUNT=wave: the wave-per-bin kernel (fast_wavecount.hpp), whose private 256-entry tables want bins an eighth of that
     // (about 1000 k-mer instances, 70 records, 100 distinct k-mers).  Measured slower than the workgroup kernel (DESIGN.md
     // section 7: 88-100 ms against 58 at C2, and the finer bins cost the scan 4-10 ms), so it is not the default.
-    pl->wave = c->opt("DBG_COUNT") && !strcmp(c->opt("DBG_COUNT"), "wave");
+    pl->wave = allow_wave && c->opt("DBG_COUNT") && !strcmp(c->opt("DBG_COUNT"), "wave");
     if (pl->wave) target /= 8;
     if (const char* e = c->opt("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
@@ -2371,7 +2371,10 @@ extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, ui
 
 static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
     if (sp->n_bins % NCLS) return c->fail(144, "n_bins must be a multiple of bin_group");
-    if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
+    // The sharded flow always counts with the workgroup kernel: exchanged records may carry weights (a peer's sender-side merge),
+    // which the wave-per-bin kernel (DBG_COUNT=wave, a per-ctx measurement knob) does not read -- and the knob would also change
+    // the bin count on one rank only.
+    if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl, false))
         return c->fail(140, "sharded counting supports 16 <= k <= 64");
     // every rank must use the same colour layout: it follows from the plan's global max_label (no per-rank label map here)
     if (pl->is_set && sp->n_labels) {
@@ -2390,7 +2393,7 @@ static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
         pl->wide = pl->is_set && sp->max_label >= 24;
     }
     // records of the sharded flow may carry weights when the record has the spare bits (every rank derives the same answer)
-    pl->weighted = !pl->wave && 64 * pl->nbw - 2 * (2 * pl->k - pl->p) - META_BITS >= WEIGHT_BITS;
+    pl->weighted = 64 * pl->nbw - 2 * (2 * pl->k - pl->p) - META_BITS >= WEIGHT_BITS;
     if (pl->wide && !sp->n_bins && !c->opt("DBG_FAST_TARGET")) pl->nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl->nbins * 2, (1ull << 23) - 1);
     return 0;
 }
@@ -2421,12 +2424,9 @@ extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
     return 0;
 }
 
-extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_shard_plan* sp, uint64_t* n_recs,
-                                  uint64_t* bin_off_dev) {
-    HIP_TRY(c, hipSetDevice(c->device));
-    c->t_clear();
-    FastPlan pl;
-    DBG_TRY(plan_from(c, sp, &pl));
+// scan of this rank's reads into the global bin space (+ the sender-side merge): leaves the slabs, the per-bin record counts
+// (st->cursor) and the overflow records in *st
+static int shard_scan_core(dbg_ctx* c, const dbg_seqset* ds, const dbg_shard_plan* sp, FastPlan pl, FastScan* st) {
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     DBuf<uint8_t> lmap_buf;                          // label -> colour index (sparse alphabets); lives until the scan is done
     if (pl.is_set && sp->n_labels) {
@@ -2449,9 +2449,8 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     }
     uint64_t n_kmers = 0;
     DBG_TRY(dbg_count_kmer_instances_dev(c, ds, sp->k, &n_kmers));
-    std::unique_ptr<FastScan> st(new FastScan());
     const uint32_t nb = pl.nbins * NCLS;
-    if (n_kmers) DBG_TRY(fast_scan(c, s, pl, n_kmers, st.get(), true));
+    if (n_kmers) DBG_TRY(fast_scan(c, s, pl, n_kmers, st, true));
     else {
         st->pl = pl; st->slab_cap = 4;
         ALLOC_OR_FAIL(c, st->hist, nb); ALLOC_OR_FAIL(c, st->cursor, nb); ALLOC_OR_FAIL(c, st->slab, 4);
@@ -2479,6 +2478,18 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
         c->t_begin("sk_merged_away", n_away);  // bookkeeping entry: units = records the merge removed (no kernel)
         c->t_end();
     }
+    return 0;
+}
+
+extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_shard_plan* sp, uint64_t* n_recs,
+                                  uint64_t* bin_off_dev) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    FastPlan pl;
+    DBG_TRY(plan_from(c, sp, &pl));
+    std::unique_ptr<FastScan> st(new FastScan());
+    DBG_TRY(shard_scan_core(c, ds, sp, pl, st.get()));
+    const uint32_t nb = pl.nbins * NCLS;
     // per-bin record counts (slab + overflow) -> exclusive offsets of the bin-ordered layout
     DBG_TRY(scan_exclusive_u32_u64(c, st->cursor.p, bin_off_dev, nb));
     HIP_TRY(c, hipMemcpyAsync(&st->n_recs, bin_off_dev + nb, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2490,10 +2501,9 @@ extern "C" int dbg_shard_scan_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_sh
     return 0;
 }
 
-extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, uint64_t* recs_out_dev) {
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (!c->shard_scan.p) return c->fail(142, "dbg_shard_scatter_dev without a preceding dbg_shard_scan_dev");
-    std::unique_ptr<FastScan> st(static_cast<FastScan*>(c->shard_scan.release()));
+// slabs + overflow records -> recs_out in the order bin_off gives (any placement of the bins: bin b's records go to
+// [bin_off[b], bin_off[b] + count[b])); releases the scan state's buffers
+static int shard_scatter_core(dbg_ctx* c, FastScan* st, const uint64_t* bin_off_dev, uint64_t* recs_out_dev) {
     const uint32_t nb = st->pl.nbins * NCLS;
     DBuf<uint64_t> ovf_base;
     ALLOC_OR_FAIL(c, ovf_base, (size_t)nb + 1);
@@ -2505,10 +2515,17 @@ extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, ui
     c->t_end();
     LAUNCH_CHECK(c, "slab_compact");
     st->slab.release(); st->cursor.release();
-    DBG_TRY(fast_scatter(c, st.get(), ovf_base.p, recs_out_dev));     // records that did not fit their slab go behind it
+    DBG_TRY(fast_scatter(c, st, ovf_base.p, recs_out_dev));           // records that did not fit their slab go behind it
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->drop_spares();
     return 0;
+}
+
+extern "C" int dbg_shard_scatter_dev(dbg_ctx* c, const uint64_t* bin_off_dev, uint64_t* recs_out_dev) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->shard_scan.p) return c->fail(142, "dbg_shard_scatter_dev without a preceding dbg_shard_scan_dev");
+    std::unique_ptr<FastScan> st(static_cast<FastScan*>(c->shard_scan.release()));
+    return shard_scatter_core(c, st.get(), bin_off_dev, recs_out_dev);
 }
 
 extern "C" int dbg_shard_count_dev(dbg_ctx* c, const dbg_shard_plan* sp, const uint64_t* recs_dev, const uint64_t* seg_off_dev,
@@ -2552,3 +2569,5 @@ extern "C" int dbg_shard_count_finish(dbg_ctx* c, dbg_kmer_table* out) {
     std::unique_ptr<FastCountState> st(static_cast<FastCountState*>(c->shard_count.release()));
     return fast_count_finish(c, st.get(), out);
 }
+
+#include "fast_exchange.hpp"

@@ -230,9 +230,9 @@ struct DevGraph {
     uint32_t n = 0;
 };
 
+int dev_graph_index(dbg_ctx* c, int k, DevGraph* d);
 int dev_graph_build(dbg_ctx* c, int k, const dbg_graph* g, DevGraph* d) {
     const uint32_t n = (uint32_t)g->n_nodes;
-    const bool has_hi = k > 32;
     d->n = n;
     const size_t na = std::max<uint32_t>(n, 1), nw = std::max<uint64_t>(g->n_seq_words, 1);
     ALLOC_OR_FAIL(c, d->words, nw + 2); ALLOC_OR_FAIL(c, d->start, na); ALLOC_OR_FAIL(c, d->length, na);
@@ -246,6 +246,14 @@ int dev_graph_build(dbg_ctx* c, int k, const dbg_graph* g, DevGraph* d) {
         if (g->data) HIP_TRY(c, hipMemcpyAsync(d->data.p, g->data, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
         else HIP_TRY(c, hipMemsetAsync(d->data.p, 0, (size_t)n * 4, c->stream));
     }
+    return dev_graph_index(c, k, d);
+}
+
+// finish (graph.rs:116-142) over node arrays that are already in HBM: sorted (first k-mer, node) and (last k-mer, node)
+int dev_graph_index(dbg_ctx* c, int k, DevGraph* d) {
+    const uint32_t n = d->n;
+    const bool has_hi = k > 32;
+    const size_t na = std::max<uint32_t>(n, 1);
     if (has_hi) { ALLOC_OR_FAIL(c, d->f_hi, na); ALLOC_OR_FAIL(c, d->l_hi, na); ALLOC_OR_FAIL(c, d->t_hi, na); }
     ALLOC_OR_FAIL(c, d->f_lo, na); ALLOC_OR_FAIL(c, d->l_lo, na); ALLOC_OR_FAIL(c, d->t_lo, na);
     ALLOC_OR_FAIL(c, d->f_id, na); ALLOC_OR_FAIL(c, d->l_id, na); ALLOC_OR_FAIL(c, d->t_id, na);
@@ -553,5 +561,438 @@ extern "C" int dbg_graph_write_gfa(dbg_ctx* c, uint32_t k, const dbg_graph* g, c
     int r = fclose(f);
     free(t);
     if (w != len || r) return c->fail(103, std::string("short write to ") + path);
+    return 0;
+}
+
+
+// ================================================================================================
+// The rank-spanning end of the flow with the graphs resident in HBM (round 4): dbg_shard_compress_dev.
+// Reference flow: per-shard compress_kmers_with_hash -> BaseGraph::combine (graph.rs:71-100) -> compress_graph
+// (compression.rs:291-349), src/test.rs:459-470.  Rounds 2-3 ran it in Python: every rank's graph device -> host numpy ->
+// device -> p2p -> host, and one rank combined on the host.  Here a shard graph never leaves HBM between the steps: the unitig
+// construction hands its buffers over (dbg_ctx::graph_sink), combine is a packing kernel, compress_graph runs its device
+// route on device-resident nodes, and graphs travel as device buffers over the dbg_transport.
+// ================================================================================================
+extern "C" int dbg_compress_table_dev(dbg_ctx* c, uint32_t k, int stranded, int spec, const dbg_kmer_table* t, dbg_graph* out,
+                                      dbg_label_classes* classes);
+namespace {
+
+int g2_fail(dbg_ctx* c, const char* op) { return c->fail(160, std::string("sharded compress: transport operation ") + op + " failed"); }
+
+int graph_dev_from_host(dbg_ctx* c, const dbg_graph* g, GraphDev* d) {
+    const uint64_t n = g->n_nodes, nw = g->n_seq_words;
+    ALLOC_OR_FAIL(c, d->words, nw + 3); ALLOC_OR_FAIL(c, d->start, n + 1); ALLOC_OR_FAIL(c, d->length, std::max<uint64_t>(n, 1));
+    ALLOC_OR_FAIL(c, d->exts, std::max<uint64_t>(n, 1)); ALLOC_OR_FAIL(c, d->data, std::max<uint64_t>(n, 1));
+    HIP_TRY(c, hipMemsetAsync(d->words.p, 0, (nw + 3) * 8, c->stream));
+    if (nw) HIP_TRY(c, hipMemcpyAsync(d->words.p, g->seq_words, nw * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(d->start.p, g->start, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d->length.p, g->length, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d->exts.p, g->exts, n, hipMemcpyHostToDevice, c->stream));
+        if (g->data) HIP_TRY(c, hipMemcpyAsync(d->data.p, g->data, n * 4, hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(c, hipMemsetAsync(d->data.p, 0, n * 4, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    d->n_nodes = n; d->n_words = nw; d->n_bases = g->seq_len_bases; d->stranded = g->stranded; d->filled = true;
+    return 0;
+}
+
+int graph_dev_to_host(dbg_ctx* c, const GraphDev& d, dbg_graph* g) {
+    memset(g, 0, sizeof(*g));
+    const uint64_t n = d.n_nodes, nw = d.n_words;
+    g->n_nodes = n; g->n_seq_words = nw; g->seq_len_bases = d.n_bases; g->stranded = d.stranded;
+    g->seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(nw, 1) * 8);
+    g->start = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n, 1) * 8);
+    g->length = (uint32_t*)dbg_host_alloc(std::max<uint64_t>(n, 1) * 4);
+    g->exts = (uint8_t*)malloc(std::max<uint64_t>(n, 1));
+    g->data = (uint32_t*)malloc(std::max<uint64_t>(n, 1) * 4);
+    if (nw) HIP_TRY(c, hipMemcpyAsync(g->seq_words, d.words.p, nw * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(g->start, d.start.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(g->length, d.length.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(g->exts, d.exts.p, n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(g->data, d.data.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void graph_dev_clear(GraphDev* d) {
+    d->words.release(); d->start.release(); d->length.release(); d->data.release(); d->exts.release();
+    d->n_nodes = d->n_words = d->n_bases = 0; d->filled = false;
+}
+
+// ---- BaseGraph::combine on the device (graph.rs:71-100): node sequences re-added back to back -----------------------------
+__global__ void __launch_bounds__(256) add_offset_kernel(const uint64_t* __restrict__ in, uint64_t n, uint64_t add, uint64_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+// one output word per thread: the (up to 32) bases it holds come from the nodes that cover base positions [32 w, 32 w + 32)
+__global__ void __launch_bounds__(256) combine_pack_kernel(const uint64_t* __restrict__ src_words, const uint64_t* __restrict__ src_start,
+                                                            const uint32_t* __restrict__ length, const uint64_t* __restrict__ out_start,
+                                                            uint64_t n_nodes, uint64_t n_words_out, uint64_t total_bases, uint64_t* __restrict__ out) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words_out) return;
+    uint64_t pos = w * 32;
+    const uint64_t end = pos + 32 < total_bases ? pos + 32 : total_bases;
+    uint64_t lo = 0, hi = n_nodes;                                   // largest node with out_start <= pos (zero-length nodes: the last of them)
+    while (hi - lo > 1) { const uint64_t m = (lo + hi) >> 1; if (out_start[m] <= pos) lo = m; else hi = m; }
+    uint64_t node = lo, acc = 0;
+    while (pos < end) {
+        const uint64_t o = pos - out_start[node], len = length[node];
+        if (o >= len) { node++; continue; }
+        const uint64_t take = (len - o < end - pos) ? len - o : end - pos;       // 1..32 bases of this node
+        const uint64_t sp = src_start[node] + o;
+        const uint64_t w0 = src_words[sp >> 5], w1 = src_words[(sp >> 5) + 1];   // (the source arrays carry a zero word of slack)
+        const uint32_t sh = 2u * (uint32_t)(sp & 31);
+        uint64_t v = sh ? (w0 << sh) | (w1 >> (64u - sh)) : w0;                  // bases from sp on, left-aligned
+        if (take < 32) v &= ~0ull << (64u - 2u * (uint32_t)take);
+        acc |= v >> (2u * (uint32_t)(pos & 31));
+        pos += take;
+    }
+    out[w] = acc;
+}
+
+// graphs in order -> one graph (inputs are consumed)
+int graph_dev_combine(dbg_ctx* c, std::vector<GraphDev*>& gs, GraphDev* out) {
+    uint64_t n = 0, nw_src = 0;
+    bool all_s = true, none_s = true;
+    for (GraphDev* g : gs) { n += g->n_nodes; nw_src += g->n_words + 1; all_s = all_s && g->stranded; none_s = none_s && !g->stranded; }
+    if (!all_s && !none_s) return c->fail(50, "attempted to combine stranded and unstranded graphs (graph.rs:90)");
+    if (n >= (1ull << 32)) return c->fail(51, "combine: more than 2^32-1 nodes");
+    DBuf<uint64_t> src_words, src_start, out_start;
+    DBuf<uint32_t> length, data;
+    DBuf<uint8_t> exts;
+    const uint64_t na = std::max<uint64_t>(n, 1);
+    ALLOC_OR_FAIL(c, src_words, nw_src + 2); ALLOC_OR_FAIL(c, src_start, na); ALLOC_OR_FAIL(c, out_start, n + 1);
+    ALLOC_OR_FAIL(c, length, na); ALLOC_OR_FAIL(c, data, na); ALLOC_OR_FAIL(c, exts, na);
+    HIP_TRY(c, hipMemsetAsync(src_words.p, 0, (nw_src + 2) * 8, c->stream));
+    uint64_t no = 0, wo = 0;
+    for (GraphDev* g : gs) {
+        const uint64_t gn = g->n_nodes;
+        if (g->n_words) HIP_TRY(c, hipMemcpyAsync(src_words.p + wo, g->words.p, g->n_words * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (gn) {
+            add_offset_kernel<<<cdiv(gn, 256), 256, 0, c->stream>>>(g->start.p, gn, wo * 32, src_start.p + no);
+            LAUNCH_CHECK(c, "add_offset");
+            HIP_TRY(c, hipMemcpyAsync(length.p + no, g->length.p, gn * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(data.p + no, g->data.p, gn * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(exts.p + no, g->exts.p, gn, hipMemcpyDeviceToDevice, c->stream));
+        }
+        no += gn; wo += g->n_words + 1;
+    }
+    DBG_TRY(scan_exclusive_u32_u64(c, length.p, out_start.p, n));
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, out_start.p + n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (GraphDev* g : gs) graph_dev_clear(g);
+    const uint64_t nw = (total + 31) / 32;
+    DBuf<uint64_t> words;
+    ALLOC_OR_FAIL(c, words, nw + 3);
+    HIP_TRY(c, hipMemsetAsync(words.p + nw, 0, 3 * 8, c->stream));
+    if (nw) {
+        c->t_begin("graph_combine", n);
+        combine_pack_kernel<<<cdiv(nw, 256), 256, 0, c->stream>>>(src_words.p, src_start.p, length.p, out_start.p, n, nw, total, words.p);
+        c->t_end();
+        LAUNCH_CHECK(c, "combine_pack");
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->words = std::move(words); out->start = std::move(out_start); out->length = std::move(length); out->data = std::move(data);
+    out->exts = std::move(exts);
+    out->n_nodes = n; out->n_words = nw; out->n_bases = total; out->stranded = all_s ? 1 : 0; out->filled = true;
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) short_node_kernel(const uint32_t* __restrict__ length, uint32_t n, uint32_t k, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && length[i] < k) *flag = 1u;
+}
+
+// compress_graph (compression.rs:338-349) on a device-resident graph, no censored nodes: the device route of dbg_compress_graph
+// with nothing staged through the host.  `in` is consumed.  Links that are not mutual / carry a panic marker take the literal
+// host walk of dbg_compress_graph (the graph then does make the trip; such inputs are those the reference panics on).
+int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, GraphDev* out) {
+    const uint64_t n64 = in->n_nodes;
+    if (n64 >= (1ull << 30)) return c->fail(51, "compress_graph: at most 2^30-1 nodes per call in this build");
+    const uint32_t n = (uint32_t)n64;
+    const int g_stranded = in->stranded;
+    if (!n) { *out = std::move(*in); out->stranded = stranded ? 1 : 0; return 0; }
+    DBuf<uint32_t> flag;
+    ALLOC_OR_FAIL(c, flag, 1);
+    HIP_TRY(c, hipMemsetAsync(flag.p, 0, 4, c->stream));
+    short_node_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(in->length.p, n, (uint32_t)k, flag.p);
+    LAUNCH_CHECK(c, "short_node");
+    uint32_t fl = 0;
+    HIP_TRY(c, hipMemcpyAsync(&fl, flag.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (fl) return c->fail(52, "node shorter than k");
+    DevGraph d;
+    d.n = n;
+    d.words = std::move(in->words); d.start = std::move(in->start); d.length = std::move(in->length);
+    d.exts = std::move(in->exts); d.data = std::move(in->data);
+    const uint64_t in_words = in->n_words, in_bases = in->n_bases;
+    DBG_TRY(dev_graph_index(c, k, &d));
+    DBG_TRY(dev_fix_exts(c, k, g_stranded, &d, nullptr));                              // old_graph.fix_exts(Some(&available)), all available :309
+    DBuf<uint32_t> d_link, u_link, u_weight;
+    ALLOC_OR_FAIL(c, d_link, 2 * (size_t)n); ALLOC_OR_FAIL(c, u_link, 2 * (size_t)n); ALLOC_OR_FAIL(c, u_weight, n);
+    c->t_begin("graph_node_links", n);
+    node_link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(d.left, d.right, d.words.p, d.start.p, d.length.p, n, k, stranded, g_stranded, spec,
+                                                           d.exts.p, d.data.p, d_link.p);
+    c->t_end();
+    LAUNCH_CHECK(c, "node_links");
+    bool done = false;
+    const char* mode = c->opt("DBG_COMPRESS");
+    GraphDev sink;
+    if (!(mode && !strcmp(mode, "host"))) {
+        node_links_to_unitig_kernel<<<cdiv(2 * (uint64_t)n, 256), 256, 0, c->stream>>>(d_link.p, d.length.p, n, k, u_link.p, u_weight.p);
+        LAUNCH_CHECK(c, "node_links_to_unitig");
+        UnitigNodes un{u_weight.p, d.words.p, d.start.p, d.length.p, nullptr};
+        dbg_graph ng;
+        c->graph_sink = &sink;
+        const int r = compress_links_device(c, k, n, nullptr, nullptr, d.exts.p, d.data.p, u_link.p, nullptr, spec, stranded, &ng, &done, &un);
+        c->graph_sink = nullptr;
+        if (r) return r;
+        if (!done && mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the node links are not mutual");
+    }
+    if (!done) {
+        // the literal walk (and the reference's panics): through the host entry point
+        // (d.exts holds the Exts fix_exts has already rewritten; the host entry point applies fix_exts again, which changes
+        //  nothing: an extension that links to a node still does)
+        GraphDev back;
+        back.words = std::move(d.words); back.start = std::move(d.start); back.length = std::move(d.length); back.exts = std::move(d.exts);
+        back.data = std::move(d.data); back.n_nodes = n; back.n_words = in_words; back.n_bases = in_bases; back.stranded = g_stranded;
+        dbg_graph hg, ho;
+        DBG_TRY(graph_dev_to_host(c, back, &hg));
+        graph_dev_clear(&back);
+        const int r = dbg_compress_graph(c, (uint32_t)k, stranded, spec, &hg, nullptr, 0, &ho);
+        dbg_free_graph(c, &hg);
+        if (r) return r;
+        const int r2 = graph_dev_from_host(c, &ho, out);
+        dbg_free_graph(c, &ho);
+        return r2;
+    }
+    // ---- graph.finish(); dbg.fix_exts(None) (compression.rs:330-331) ----
+    DevGraph d2;
+    d2.n = (uint32_t)sink.n_nodes;
+    d2.words = std::move(sink.words); d2.start = std::move(sink.start); d2.length = std::move(sink.length);
+    d2.exts = std::move(sink.exts); d2.data = std::move(sink.data);
+    DBG_TRY(dev_graph_index(c, k, &d2));
+    DBG_TRY(dev_fix_exts(c, k, stranded, &d2, nullptr));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->words = std::move(d2.words); out->start = std::move(d2.start); out->length = std::move(d2.length);
+    out->exts = std::move(d2.exts); out->data = std::move(d2.data);
+    out->n_nodes = sink.n_nodes; out->n_words = sink.n_words; out->n_bases = sink.n_bases; out->stranded = stranded ? 1 : 0; out->filled = true;
+    return 0;
+}
+
+// ---- graphs as device buffers over the transport ------------------------------------------------------------------------
+int graph_dev_send(dbg_ctx* c, const dbg_transport* tr, const GraphDev& g, int32_t peer) {
+    DBuf<uint64_t> meta;
+    ALLOC_OR_FAIL(c, meta, 4);
+    const uint64_t m[4] = {g.n_nodes, g.n_words, g.n_bases, (uint64_t)g.stranded};
+    HIP_TRY(c, hipMemcpyAsync(meta.p, m, 32, hipMemcpyHostToDevice, c->stream));
+    if (tr->send(tr->self, meta.p, 32, peer, c->stream)) return g2_fail(c, "send (graph sizes)");
+    if (g.n_words && tr->send(tr->self, g.words.p, g.n_words * 8, peer, c->stream)) return g2_fail(c, "send (sequence words)");
+    if (g.n_nodes) {
+        if (tr->send(tr->self, g.start.p, g.n_nodes * 8, peer, c->stream) || tr->send(tr->self, g.length.p, g.n_nodes * 4, peer, c->stream) ||
+            tr->send(tr->self, g.exts.p, g.n_nodes, peer, c->stream) || tr->send(tr->self, g.data.p, g.n_nodes * 4, peer, c->stream))
+            return g2_fail(c, "send (node arrays)");
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int graph_dev_recv(dbg_ctx* c, const dbg_transport* tr, GraphDev* g, int32_t peer) {
+    DBuf<uint64_t> meta;
+    ALLOC_OR_FAIL(c, meta, 4);
+    if (tr->recv(tr->self, meta.p, 32, peer, c->stream)) return g2_fail(c, "recv (graph sizes)");
+    uint64_t m[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(m, meta.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint64_t n = m[0], nw = m[1];
+    ALLOC_OR_FAIL(c, g->words, nw + 3); ALLOC_OR_FAIL(c, g->start, n + 1); ALLOC_OR_FAIL(c, g->length, std::max<uint64_t>(n, 1));
+    ALLOC_OR_FAIL(c, g->exts, std::max<uint64_t>(n, 1)); ALLOC_OR_FAIL(c, g->data, std::max<uint64_t>(n, 1));
+    HIP_TRY(c, hipMemsetAsync(g->words.p + nw, 0, 3 * 8, c->stream));
+    if (nw && tr->recv(tr->self, g->words.p, nw * 8, peer, c->stream)) return g2_fail(c, "recv (sequence words)");
+    if (n) {
+        if (tr->recv(tr->self, g->start.p, n * 8, peer, c->stream) || tr->recv(tr->self, g->length.p, n * 4, peer, c->stream) ||
+            tr->recv(tr->self, g->exts.p, n, peer, c->stream) || tr->recv(tr->self, g->data.p, n * 4, peer, c->stream))
+            return g2_fail(c, "recv (node arrays)");
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    g->n_nodes = n; g->n_words = nw; g->n_bases = m[2]; g->stranded = (int)m[3]; g->filled = true;
+    return 0;
+}
+
+// ---- label-list classes of all ranks -> one numbering ----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) remap_u32_kernel(uint32_t* __restrict__ data, uint64_t n, const uint32_t* __restrict__ map, uint32_t n_map,
+                                                         uint32_t* __restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = data[i];
+    if (v < n_map) data[i] = map[v]; else *flag = 1u;
+}
+
+// all_gather of one variable-size host blob per rank (sizes first, then the blobs padded to the largest)
+int gather_blobs(dbg_ctx* c, const dbg_transport* tr, const std::vector<uint8_t>& mine, std::vector<std::vector<uint8_t>>* all) {
+    const uint32_t W = (uint32_t)tr->world;
+    all->assign(W, {});
+    if (W == 1) { (*all)[0] = mine; return 0; }
+    if (!tr->all_gather) return c->fail(161, "sharded compress: the transport lacks all_gather");
+    DBuf<uint64_t> d_sz, d_all;
+    ALLOC_OR_FAIL(c, d_sz, 1); ALLOC_OR_FAIL(c, d_all, W);
+    const uint64_t sz = mine.size();
+    HIP_TRY(c, hipMemcpyAsync(d_sz.p, &sz, 8, hipMemcpyHostToDevice, c->stream));
+    if (tr->all_gather(tr->self, d_sz.p, d_all.p, 8, c->stream)) return g2_fail(c, "all_gather (class table sizes)");
+    std::vector<uint64_t> sizes(W);
+    HIP_TRY(c, hipMemcpyAsync(sizes.data(), d_all.p, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t mx = 0;
+    for (uint64_t v : sizes) mx = std::max(mx, v);
+    mx = (mx + 7) & ~7ull;
+    if (!mx) return 0;
+    DBuf<uint8_t> d_mine, d_blobs;
+    ALLOC_OR_FAIL(c, d_mine, mx); ALLOC_OR_FAIL(c, d_blobs, mx * W);
+    HIP_TRY(c, hipMemsetAsync(d_mine.p, 0, mx, c->stream));
+    if (sz) HIP_TRY(c, hipMemcpyAsync(d_mine.p, mine.data(), sz, hipMemcpyHostToDevice, c->stream));
+    if (tr->all_gather(tr->self, d_mine.p, d_blobs.p, mx, c->stream)) return g2_fail(c, "all_gather (class tables)");
+    std::vector<uint8_t> flat(mx * W);
+    HIP_TRY(c, hipMemcpyAsync(flat.data(), d_blobs.p, mx * W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t r = 0; r < W; r++) (*all)[r].assign(flat.begin() + r * mx, flat.begin() + r * mx + sizes[r]);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint32_t k, int stranded, int spec, int second_spec,
+                                      const dbg_kmer_table* table, int32_t reduce, int32_t root, dbg_graph* final_out, dbg_graph* local_out,
+                                      dbg_label_classes* classes) {
+    if (!c) return 1;
+    if (!table || !final_out) return c->fail(10, "null argument");
+    if (!table->on_device) return c->fail(162, "dbg_shard_compress_dev needs a device-resident table");
+    const uint32_t W = tr ? (uint32_t)tr->world : 1u, me = tr ? (uint32_t)tr->rank : 0u;
+    if (W == 0 || me >= W || root < 0 || (uint32_t)root >= W) return c->fail(161, "sharded compress: bad rank / world / root");
+    if (W > 1 && (!tr->send || !tr->recv)) return c->fail(161, "sharded compress: the transport lacks send / recv");
+    if (reduce != DBG_REDUCE_GATHER && reduce != DBG_REDUCE_TREE) return c->fail(161, "sharded compress: unknown reduce mode");
+    if (second_spec < 0) second_spec = spec;
+    HIP_TRY(c, hipSetDevice(c->device));
+    memset(final_out, 0, sizeof(*final_out));
+    if (local_out) memset(local_out, 0, sizeof(*local_out));
+    if (classes) memset(classes, 0, sizeof(*classes));
+
+    // ---- this rank's shard: compress_kmers_with_hash on the table of the bins it owns; the graph stays in HBM ----
+    GraphDev mine;
+    dbg_label_classes lc;
+    memset(&lc, 0, sizeof(lc));
+    {
+        dbg_graph hg;
+        memset(&hg, 0, sizeof(hg));
+        c->graph_sink = &mine;
+        const int r = dbg_compress_table_dev(c, k, stranded, spec, table, &hg, table->set_off ? &lc : nullptr);
+        c->graph_sink = nullptr;
+        if (r) return r;
+        if (!mine.filled) {                     // the literal host walk ran (or the table is empty): the result is on the host
+            if (hg.n_nodes) { const int r2 = graph_dev_from_host(c, &hg, &mine); if (r2) { dbg_free_graph(c, &hg); return r2; } }
+            else { GraphDev e; if (int r3 = graph_dev_from_host(c, &hg, &e)) return r3; mine = std::move(e); }
+            mine.stranded = stranded ? 1 : 0;
+            dbg_free_graph(c, &hg);
+        }
+    }
+    // ---- label-list classes: one numbering for all ranks (ranks of the sorted distinct lists) ----
+    if (table->set_off) {
+        std::vector<uint8_t> blob(8 + (lc.n_classes + 1) * 8 + lc.n_set_val * 4);
+        memcpy(blob.data(), &lc.n_classes, 8);
+        if (lc.set_off) memcpy(blob.data() + 8, lc.set_off, (lc.n_classes + 1) * 8);       // (else: the one zero offset the vector already holds)
+        if (lc.n_set_val) memcpy(blob.data() + 8 + (lc.n_classes + 1) * 8, lc.set_val, lc.n_set_val * 4);
+        std::vector<std::vector<uint8_t>> all;
+        int r = W > 1 ? gather_blobs(c, tr, blob, &all) : 0;
+        if (W == 1) all.assign(1, blob);
+        if (r) { dbg_free_label_classes(&lc); return r; }
+        typedef std::vector<uint32_t> List;
+        std::vector<std::vector<List>> tabs(W);
+        std::vector<List> glob;
+        for (uint32_t rk = 0; rk < W; rk++) {
+            const uint8_t* b = all[rk].data();
+            uint64_t nc = 0;
+            if (all[rk].size() >= 8) memcpy(&nc, b, 8);
+            const uint64_t* off = (const uint64_t*)(b + 8);
+            const uint32_t* val = (const uint32_t*)(b + 8 + (nc + 1) * 8);
+            for (uint64_t i = 0; i < nc; i++) { tabs[rk].emplace_back(val + off[i], val + off[i + 1]); glob.push_back(tabs[rk].back()); }
+        }
+        std::sort(glob.begin(), glob.end());                       // lexicographic, a prefix before its extensions: the order of Rust's Vec<D1> Ord
+        glob.erase(std::unique(glob.begin(), glob.end()), glob.end());
+        std::vector<uint32_t> remap(tabs[me].size());
+        for (size_t i = 0; i < remap.size(); i++) remap[i] = (uint32_t)(std::lower_bound(glob.begin(), glob.end(), tabs[me][i]) - glob.begin());
+        if (mine.n_nodes) {
+            DBuf<uint32_t> d_map, fl;
+            ALLOC_OR_FAIL(c, d_map, std::max<size_t>(remap.size(), 1)); ALLOC_OR_FAIL(c, fl, 1);
+            HIP_TRY(c, hipMemsetAsync(fl.p, 0, 4, c->stream));
+            if (!remap.empty()) HIP_TRY(c, hipMemcpyAsync(d_map.p, remap.data(), remap.size() * 4, hipMemcpyHostToDevice, c->stream));
+            remap_u32_kernel<<<cdiv(mine.n_nodes, 256), 256, 0, c->stream>>>(mine.data.p, mine.n_nodes, d_map.p, (uint32_t)remap.size(), fl.p);
+            LAUNCH_CHECK(c, "remap_u32");
+            uint32_t bad = 0;
+            HIP_TRY(c, hipMemcpyAsync(&bad, fl.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (bad) { dbg_free_label_classes(&lc); return c->fail(164, "sharded compress: a node's class id is outside its rank's class table"); }
+        }
+        dbg_free_label_classes(&lc);
+        if (classes) {
+            uint64_t nv = 0;
+            for (auto& l : glob) nv += l.size();
+            classes->n_classes = glob.size(); classes->n_set_val = nv;
+            classes->set_off = (uint64_t*)malloc((glob.size() + 1) * 8);
+            classes->set_val = (uint32_t*)malloc(std::max<uint64_t>(nv, 1) * 4);
+            uint64_t o = 0;
+            for (size_t i = 0; i < glob.size(); i++) { classes->set_off[i] = o; if (!glob[i].empty()) memcpy(classes->set_val + o, glob[i].data(), glob[i].size() * 4); o += glob[i].size(); }
+            classes->set_off[glob.size()] = o;
+        }
+    }
+    if (local_out) DBG_TRY(graph_dev_to_host(c, mine, local_out));
+
+    // ---- merge the shard graphs ----
+    GraphDev result;
+    bool have_result = false;
+    if (reduce == DBG_REDUCE_GATHER || W == 1) {
+        if (me != (uint32_t)root) DBG_TRY(graph_dev_send(c, tr, mine, root));
+        else {
+            std::vector<GraphDev> got(W);
+            std::vector<GraphDev*> order(W);
+            for (uint32_t r = 0; r < W; r++) {
+                if (r == me) order[r] = &mine;
+                else { DBG_TRY(graph_dev_recv(c, tr, &got[r], (int32_t)r)); order[r] = &got[r]; }
+            }
+            GraphDev comb;
+            DBG_TRY(graph_dev_combine(c, order, &comb));                                       // BaseGraph::combine(shard graphs in shard order), test.rs:468
+            DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result));     // compress_graph, test.rs:469
+            have_result = true;
+        }
+    } else {
+        // binary tree over ranks renumbered so that `root` is 0: at level l, position q with bit l set sends to q - 2^l and leaves
+        const uint32_t pos = (me + W - (uint32_t)root) % W;
+        bool active = true;
+        for (uint32_t st = 1; st < W && active; st <<= 1) {
+            if (pos & st) {
+                const uint32_t to = ((pos - st) + (uint32_t)root) % W;
+                DBG_TRY(graph_dev_send(c, tr, mine, (int32_t)to));
+                graph_dev_clear(&mine);
+                active = false;
+            } else if (pos + st < W) {
+                const uint32_t from = ((pos + st) + (uint32_t)root) % W;
+                GraphDev other, comb, merged;
+                DBG_TRY(graph_dev_recv(c, tr, &other, (int32_t)from));
+                std::vector<GraphDev*> pair{&mine, &other};
+                DBG_TRY(graph_dev_combine(c, pair, &comb));
+                DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &merged));
+                mine = std::move(merged);
+            }
+        }
+        if (pos == 0) {
+            if (W == 1) { GraphDev comb; std::vector<GraphDev*> one{&mine}; DBG_TRY(graph_dev_combine(c, one, &comb)); DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result)); }
+            else result = std::move(mine);
+            have_result = true;
+        }
+    }
+    if (have_result) DBG_TRY(graph_dev_to_host(c, result, final_out));
+    else final_out->stranded = stranded ? 1 : 0;
     return 0;
 }

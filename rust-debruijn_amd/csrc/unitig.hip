@@ -724,10 +724,12 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             // The nodes are emitted in two halves so that results can leave while kernels still run: offsets and lengths are
             // final already, the first half of the sequence words is final when the second half starts.  (A copy into pageable
             // host memory blocks the host thread, not the device: it is issued on a second stream after the kernels it overlaps.)
-            out_early.seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
-            out_early.start = (uint64_t*)dbg_host_alloc((size_t)nn * 8);
-            out_early.length = (uint32_t*)dbg_host_alloc((size_t)nn * 4);
-            hipStream_t cs = c->get_copy_stream();
+            if (!c->graph_sink) {
+                out_early.seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
+                out_early.start = (uint64_t*)dbg_host_alloc((size_t)nn * 8);
+                out_early.length = (uint32_t*)dbg_host_alloc((size_t)nn * 4);
+            }
+            hipStream_t cs = c->graph_sink ? nullptr : c->get_copy_stream();
             c->t_begin("unitig_emit", n);
             if (n_nodes) {
                 const uint32_t half = n_nodes / 2;
@@ -890,10 +892,21 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
                 (void*)uacc.p, (void*)o_data.p, (void*)uexts.p);
     }
     }   // general route
-    // ---- to the host BaseGraph ----
     memset(out, 0, sizeof(*out));
     out->stranded = stranded ? 1 : 0;
     out->n_nodes = n_nodes; out->n_seq_words = n_words; out->seq_len_bases = total_bases;
+    if (GraphDev* sink = c->graph_sink) {
+        // the rank-spanning second stage keeps the graph in HBM: the buffers change hands, nothing is copied (out carries the
+        // sizes only, its arrays stay null)
+        sink->words = std::move(words); sink->start = std::move(ustart); sink->length = std::move(ulen);
+        sink->exts = std::move(o_exts); sink->data = std::move(o_data);
+        sink->n_nodes = n_nodes; sink->n_words = n_words; sink->n_bases = total_bases; sink->stranded = stranded ? 1 : 0;
+        sink->filled = true;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *done = true;
+        return 0;
+    }
+    // ---- to the host BaseGraph ----
     out->seq_words = out_early.seq_words ? out_early.seq_words : (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
     out->start = out_early.start ? out_early.start : (uint64_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
     out->length = out_early.length ? out_early.length : (uint32_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);

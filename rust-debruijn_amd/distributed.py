@@ -7,8 +7,16 @@ contiguous bin range [r*n_bins/W, (r+1)*n_bins/W), and a single variable-size al
 super-k-mer records (RCCL over xGMI on GPUs) moves every bin to its owner.  After the exchange there
 is no further communication: each rank counts and filters the bins it owns.
 
-The orchestration below is engine-agnostic so that it can be exercised on CPU with the gloo backend
-(tests/ plug a CPU checker engine in); the product engine is HipEngine (C ABI -> HIP kernels).
+Since round 4 the product flow runs INSIDE the library, behind the C ABI: dbg_shard_filter_kmers_dev (scan, ownership from
+the all-reduced record histogram, layout, pipelined exchange rounds ordered by events, counting, sort) and
+dbg_shard_compress_dev (per-shard compress, device-resident graphs over the transport, combine + compress_graph), over a
+dbg_transport (rust-debruijn_amd/transport.py: the library's RCCL table, or torch.distributed callbacks).  sharded_filter_kmers /
+sharded_compress below are thin callers of those two entry points when the engine is HipEngine.
+
+The Python orchestration that remains (exchange_and_count, second_stage, ...) is the engine-agnostic model of the same flow:
+tests/ plug a CPU checker engine in and run it with the gloo backend at world size 2 on hosts without a GPU; its geometry
+(owner_bounds, chunk_bounds) comes from the library's own host functions (dbg_shard_owner_bounds, dbg_shard_round_cuts), so
+that the CPU tests exercise the arithmetic the product uses.
 """
 import ctypes as C
 
@@ -129,10 +137,20 @@ class HipEngine:
         return compress_graph(stranded, spec, graph, ctx=self.ctx)
 
 
-def owner_bounds(n_bins, world, group=1):
-    """rank r owns bins [bounds[r], bounds[r+1]); boundaries are multiples of `group` (a bin's length
-    classes stay together)."""
-    return [(r * (n_bins // group) // world) * group for r in range(world + 1)]
+def owner_bounds(n_bins, world, group=1, group_records=None):
+    """rank r owns bins [bounds[r], bounds[r+1]); boundaries are multiples of `group`.  group_records (records per bin group
+    over ALL ranks) -> ranges of nearly equal record count; None -> equal numbers of bins.  The library's own arithmetic
+    (dbg_shard_owner_bounds: host code, no GPU needed)."""
+    lib = _capi.load()
+    out = (C.c_uint32 * (world + 1))()
+    gr = None
+    if group_records is not None:
+        gr = np.ascontiguousarray(group_records, np.uint64)
+        if len(gr) != n_bins // group:
+            raise ValueError("group_records must hold n_bins / group entries")
+    if lib.dbg_shard_owner_bounds(gr.ctypes.data if gr is not None else None, n_bins, group, world, out):
+        raise ValueError("dbg_shard_owner_bounds: bad arguments")
+    return list(out)
 
 
 class _Done:
@@ -165,10 +183,17 @@ def exchange_geometry(n_bins, world, grp=1, n_chunks=None, force=False):
     bounds = owner_bounds(n_bins, world, grp)
     if n_chunks is None:
         n_chunks = 4
-    n_chunks = max(1, min(n_chunks, max(min(bounds[d + 1] - bounds[d] for d in range(world)) // grp, 1)))
     if world == 1 and not force:
         n_chunks = 1
-    cuts = [chunk_bounds(bounds[d + 1] - bounds[d], n_chunks, grp) for d in range(world)]
+    # (dbg_shard_round_cuts: the library's host arithmetic; clamps the rounds to what the smallest owner can be cut into)
+    lib = _capi.load()
+    nr = C.c_uint32(max(1, n_chunks))
+    stride = nr.value + 1
+    cbuf = (C.c_uint32 * (world * stride))()
+    if lib.dbg_shard_round_cuts((C.c_uint32 * (world + 1))(*bounds), world, grp, C.byref(nr), cbuf):
+        raise ValueError("dbg_shard_round_cuts: bad arguments")
+    n_chunks = nr.value
+    cuts = [[cbuf[d * stride + c] for c in range(n_chunks + 1)] for d in range(world)]
     return bounds, n_chunks, cuts
 
 
@@ -280,6 +305,57 @@ def exchange_and_count(engine, plan, bin_off, recs, n_local_kmers, group=None, n
     return engine.count_finish(plan)
 
 
+_TRANSPORTS = {}
+
+
+def transport_for(engine, group=None):
+    """the dbg_transport of this (device, process group): made once, kept for the life of the process"""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    key = (str(engine.device), id(group))
+    if key not in _TRANSPORTS:
+        from . import transport as T
+        _TRANSPORTS[key] = T.make_transport(engine.device, group)
+    return _TRANSPORTS[key]
+
+
+def close_transports():
+    for t in _TRANSPORTS.values():
+        t.close()
+    _TRANSPORTS.clear()
+
+
+def shard_filter_kmers_c(ctx, transport, ss, k, stranded, summarizer_kind, min_obs, n_rounds=0, merge_dups=-1, balance=True,
+                         force_exchange=False):
+    """dbg_shard_filter_kmers_dev: the whole rank-spanning counting flow inside the library.  -> (device KmerTable, ShardStats)"""
+    p = _capi.ShardParams(k, int(bool(stranded)), summarizer_kind, min_obs, n_rounds or 0, merge_dups, int(bool(balance)),
+                          int(bool(force_exchange)))
+    tab, st = _capi.KmerTable(), _capi.ShardStats()
+    ctx.check(ctx.lib.dbg_shard_filter_kmers_dev(ctx.h, transport.ptr if transport is not None else None, C.byref(ss), C.byref(p),
+                                                 C.byref(tab), C.byref(st)))
+    return tab, st
+
+
+def shard_compress_c(ctx, transport, tab, k, stranded, spec, second_spec=None, reduce=0, root=0):
+    """dbg_shard_compress_dev.  -> (final BaseGraph on root / None elsewhere, this rank's shard graph); label-set tables:
+    both carry `.classes` = the global class table, data = global class ids"""
+    from . import _graph_from_c, _classes_from_c
+    fin, loc, cl = _capi.Graph(), _capi.Graph(), _capi.LabelClasses()
+    ctx.check(ctx.lib.dbg_shard_compress_dev(ctx.h, transport.ptr if transport is not None else None, k, int(bool(stranded)), spec.kind,
+                                             (second_spec or spec).kind, C.byref(tab), reduce, root, C.byref(fin), C.byref(loc),
+                                             C.byref(cl)))
+    rank = transport.rank if transport is not None else 0
+    classes = _classes_from_c(cl) if tab.set_off else None
+    local = _graph_from_c(ctx, loc, k)
+    local.classes = classes
+    final = None
+    if rank == root:
+        final = _graph_from_c(ctx, fin, k)
+        final.classes = classes
+    return final, local
+
+
 def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, group=None, n_chunks=None, stats=None, force_exchange=False,
                          merge_dups=None):
     """Distributed filter_kmers: returns this rank's table (the valid k-mers of the bins it owns,
@@ -291,6 +367,20 @@ def sharded_filter_kmers(engine, ss, k, stranded, summarizer_kind, min_obs, grou
     import torch
     import torch.distributed as dist
     engine.sync()                                  # the reads may still be in flight on torch's current stream
+    if isinstance(engine, HipEngine) and not os.environ.get("DBG_PY_ORCHESTRATION"):
+        # the product route: one call into the library
+        tr = transport_for(engine, group)
+        md = -1 if merge_dups is None else int(bool(merge_dups))
+        tab, st = shard_filter_kmers_c(engine.ctx, tr, ss, k, stranded, summarizer_kind, min_obs, n_rounds=n_chunks or 0, merge_dups=md,
+                                       force_exchange=force_exchange and tr is not None)
+        if stats is not None:
+            nr = int(st.n_rounds)
+            stats.update(exchange_bytes_sent=int(st.bytes_sent), exchange_exposed_ms=float(st.exposed_ms), exchange_rounds=nr,
+                         records_owned=int(st.records_owned), exchange_exposed_ms_by_round=[float(st.exposed_ms_round[i]) for i in range(nr)],
+                         merge_dups=bool(st.merge_dups), balanced=bool(st.balanced), setup_ms=float(st.setup_ms),
+                         owned_bins=int(st.owned_hi - st.owned_lo), n_bins=int(st.n_bins),
+                         transport=getattr(tr, "name", None), transport_fallback=getattr(tr, "fallback_reason", None))
+        return tab, int(st.total_kmers), int(st.local_kmers), int(st.records_scanned)
     n_local = engine.count_instances(ss, k)
     total = n_max = n_local
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -438,7 +528,12 @@ def sharded_compress(engine, tab, k, stranded, spec, group=None, dst=0, second_s
     (compress_kmers_with_hash, index resident in HBM), the per-rank unitig graphs travel to rank `dst`, which runs
     BaseGraph::combine + compress_graph across the shard boundaries.  Returns (final graph on dst / None elsewhere,
     this rank's own shard graph)."""
+    import os
     import torch.distributed as dist
+    if isinstance(engine, HipEngine) and not os.environ.get("DBG_PY_ORCHESTRATION"):
+        tr = transport_for(engine, group)
+        mode = 1 if os.environ.get("DBG_SHARD_REDUCE") == "tree" else 0
+        return shard_compress_c(engine.ctx, tr, tab, k, stranded, spec, second_spec, reduce=mode, root=dst)
     local = engine.compress_table(tab, k, stranded, spec)
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
         return second_stage(engine, [local], stranded, second_spec or spec), local

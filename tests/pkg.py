@@ -8,3 +8,4 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 dbg = importlib.import_module("rust-debruijn_amd")
 capi = importlib.import_module("rust-debruijn_amd._capi")
+D = importlib.import_module("rust-debruijn_amd.distributed")
