@@ -164,6 +164,13 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     *used = false;
     const int k = (int)prm->k;
     if (k < 4 || k > 15) return 0;
+    // The table is 4^k entries whatever the input: cleared and compacted in full (8.6 GB at k = 15, 17 GB with label masks).  A
+    // call with few k-mers for its k would pay that for nothing (and push pooled memory out): it takes the generic path unless
+    // DBG_PATH=dense insists.  The count field holds 40 bits: an input of 2^40 instances or more could carry into the Exts.
+    const char* force = c->opt("DBG_PATH");
+    const bool forced = force && !strcmp(force, "dense");
+    if (n_kmers >= (1ull << 40)) return 0;
+    if (!forced && n_kmers < ((1ull << (2 * k)) >> 6)) return 0;
     const bool is_set = prm->summarizer == DBG_COUNT_FILTER_SET, stranded = prm->stranded != 0, report_all = prm->report_all_kmers != 0;
     if (is_set && s.data) {
         uint32_t mx = 0;

@@ -149,6 +149,10 @@ static int filter_kmers_fast_many(dbg_ctx* c, const SeqDev& s, const dbg_filter_
     const bool stranded = prm->stranded != 0;
     const uint32_t nd = (uint32_t)labels.size(), G = (nd + 63) / 64;
     if (G > ML_MAX_GROUPS) return c->fail(137, "fast path: too many labels for the label-group passes");
+    // Step 1 takes the valid k-mers from a CountFilter run, whose validity test reads the u16-saturated count: right for
+    // min_kmer_obs <= 65535 only.  CountFilterSet::summarize compares the unsaturated nobs (filter.rs:85-100), so larger
+    // thresholds take the generic path (which counts in 64 bits).
+    if (prm->min_kmer_obs > 65535) return 0;
     if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] %u distinct labels: %u label groups\n", nd, G);
 
     // 1. the valid k-mers: CountFilter over all reads

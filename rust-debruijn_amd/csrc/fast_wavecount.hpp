@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64) bin_count_wave_kernel(const uint64_t* __re
                     uint32_t mytag = 0, sl = 0, colour = 0;
                     if (pend) {
                         const uint32_t rl = (uint32_t)(PL0 & 0x7f);
-                        if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - META_BITS / 2)) { fl_bad |= 4u; pend = false; bad_bin = true; }
+                        if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - (META_BITS + 1) / 2)) { fl_bad |= 4u; pend = false; bad_bin = true; }
                         const uint64_t lastw = PL0 & ~COLOUR_BITS;
                         uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
                         if (NBW == 3) ha += lastw * 0x9E3779B97F4A7C15ull;

@@ -972,7 +972,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                     {   // a record whose length cannot come from the scan (a wrong segment table, an incomplete exchange) must not
                         // be expanded: its k-mer count would be garbage.  The launch is failed instead.
                         const uint32_t rl = (uint32_t)(pmeta & 0x7f);
-                        if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - META_BITS / 2)) { atomicOr(&gflags[3], 4u); pass_bad = true; }
+                        if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - (META_BITS + 1) / 2)) { atomicOr(&gflags[3], 4u); pass_bad = true; }
                     }
                     const uint64_t lastw = PL0 & ~COLOUR_BITS;
                     uint64_t ha = P0, hb = NBW == 2 ? lastw : P1;
@@ -1407,7 +1407,11 @@ __global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const M* __restr
         uint32_t o = incl - c;
         M x = m[r];
         while (x) { st[o++] = (uint8_t)ffs_mask(x); x &= x - 1; }    // ascending = sort(); dedup() (the map keeps the labels' order)
-        // (one wave: its LDS operations are performed in order, the stores above precede the loads below)
+        // one wave: its LDS operations are performed in order; the barrier + fence keep the compiler from moving the loads
+        // below over the (divergent) stores above, and the loads of this round over the stores of the next
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (uint32_t jb = 0; jb < P; jb += 256) {
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) {                       // every store instruction covers 256 contiguous bytes
@@ -1415,6 +1419,9 @@ __global__ void __launch_bounds__(CSR_THREADS) csr_apply_kernel(const M* __restr
                 if (j < P) set_val[run + j] = s_inv[st[j]];
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         run += P;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) set_off[n] = partial_scanned[gridDim.x];      // total = the scan's last entry

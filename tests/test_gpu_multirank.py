@@ -1,6 +1,7 @@
-"""GPU: the N > 1 path of bench.py end to end on a one-GPU box -- torch.distributed.run with 2 and 3 ranks that share
-cuda:0 (gloo backend, payload staged through the host; rust-debruijn_amd/distributed.py::_all_to_all).  Real kernels, the
-real pipelined exchange + chunked count; the per-rank valid k-mer counts must add up to the single-GPU count over the same
+"""GPU: the N > 1 path of bench.py end to end on a one-GPU box -- torch.distributed.run with 2, 3 and 8 ranks that share
+cuda:0 (gloo backend; the dbg_transport is rust-debruijn_amd/transport.py::TorchTransport, payload staged through the host).
+Every rank calls the C entry points dbg_shard_filter_kmers_dev / dbg_shard_compress_dev: real kernels, the library's own
+ownership, layout, exchange rounds and chunked count; the per-rank tables must add up to the single-GPU table over the same
 reads (every k-mer lives on exactly one rank)."""
 import os
 import subprocess
@@ -88,4 +89,14 @@ def test_sharded_compress_two_ranks_one_gpu():
     r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29731", os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo", "--one-device"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("world,reduce", [(3, "gather"), (3, "tree"), (2, "tree")])
+def test_sharded_compress_more_shapes_one_gpu(world, reduce):
+    """dbg_shard_compress_dev with 3 ranks (an odd tree: one rank sits a level out) and the tree merge: gather is compared node for
+    node with the oracle's combine + compress_graph, the tree in canonical form (same unitigs, other order / strand)."""
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(29741 + world), os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo",
+                        "--one-device", "--reduce", reduce, "--reads", "21000"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

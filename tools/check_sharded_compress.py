@@ -1,6 +1,7 @@
-"""Run under torch.distributed.run: the whole sharded pipeline with the product engine -- sharded filter_kmers (all-to-all of
-minimizer-bin records), per-rank compress_kmers_with_hash, graphs to rank 0, BaseGraph::combine + compress_graph
-(src/test.rs:433-470) -- checked on rank 0 against the oracle's same flow on the same per-rank tables.  Both BASELINE
+"""Run under torch.distributed.run: the whole sharded pipeline through the two rank-spanning entry points of the C ABI --
+dbg_shard_filter_kmers_dev (all-to-all of minimizer-bin records) and dbg_shard_compress_dev (per-rank compress_kmers_with_hash,
+device-resident graphs over the transport, BaseGraph::combine + compress_graph; src/test.rs:433-470) -- checked on rank 0
+against the oracle's same flow on the same per-rank tables.  Both BASELINE
 shapes: k = 47 CountFilter/saturating_add (config 4's flow) and k = 51 CountFilterSet -> ScmapCompress (config 5)."""
 import argparse
 import ctypes as C
@@ -23,6 +24,10 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--reduce", default="gather", choices=["gather", "tree"],
+                    help="gather: all shard graphs to rank 0, one combine + compress_graph (the reference's flow literally: compared node "
+                         "for node).  tree: pairwise combine + compress_graph up a binary tree (same unitigs in another order / strand: "
+                         "compared in canonical form)")
     a = ap.parse_args()
     dbg = importlib.import_module("rust-debruijn_amd")
     capi = importlib.import_module("rust-debruijn_amd._capi")
@@ -50,13 +55,13 @@ def main():
         ctx.lib.dbg_free_table(ctx.h, C.byref(h))
         spec = dbg.ScmapCompress() if kind else dbg.SimpleCompress("saturating_add")
         spec2 = spec if kind else dbg.SimpleCompress("max")
-        final, local = D.sharded_compress(eng, tab, k, False, spec, dst=0, second_spec=spec2)
+        final, local = D.shard_compress_c(ctx, D.transport_for(eng), tab, k, False, spec, spec2, reduce=1 if a.reduce == "tree" else 0, root=0)
         eng.free_table(tab)
         tabs = [None] * world
         dist.all_gather_object(tabs, dict(key_hi=th.key_hi, key_lo=th.key_lo, exts=th.exts, count=th.count, set_off=th.set_off, set_val=th.set_val))
         if rank == 0:
             import oracle_lib as O
-            from graph_canon import graphs_equal
+            from graph_canon import graphs_equal, canonical_nodes
             sets = lambda t: [tuple(int(x) for x in t["set_val"][int(t["set_off"][i]):int(t["set_off"][i + 1])]) for i in range(len(t["key_lo"]))]
             glob = sorted(set(s for t in tabs for s in sets(t))) if kind else None
             shard = []
@@ -64,7 +69,12 @@ def main():
                 data = np.array([glob.index(s) for s in sets(t)], dtype=np.uint32) if kind else t["count"]
                 shard.append(O.compress_kmers(k, False, O.SPEC_SCMAP_EQ if kind else O.SPEC_SAT_ADD, t["key_hi"], t["key_lo"], t["exts"], data))
             want = O.graph_combine(shard).finish().compress_graph(False, O.SPEC_SCMAP_EQ if kind else O.SPEC_MAX)
-            assert final is not None and graphs_equal(final.arrays(), want.arrays()), "sharded compress differs from the oracle (kind %d)" % kind
+            assert final is not None
+            if a.reduce == "gather":
+                assert graphs_equal(final.arrays(), want.arrays()), "sharded compress differs from the oracle (kind %d)" % kind
+            else:
+                assert len(final) == len(want.arrays()["start"]), (len(final), len(want.arrays()["start"]))
+                assert canonical_nodes(final.arrays(), k, False) == canonical_nodes(want.arrays(), k, False), "tree merge: other unitigs than the oracle (kind %d)" % kind
             assert (final.classes == glob) if kind else final.classes is None
             assert sum(len(t["key_lo"]) for t in tabs) > 1000 and len(final) > 10
             print("kind %d: %d ranks, %d valid k-mers, %d unitigs after the second stage" % (kind, world, sum(len(t["key_lo"]) for t in tabs), len(final)), flush=True)
@@ -73,6 +83,7 @@ def main():
         dist.barrier()
     if rank == 0:
         print("sharded compress ok", flush=True)
+    D.close_transports()
     ctx.close()
     dist.destroy_process_group()
 
