@@ -434,7 +434,10 @@ int  dbg_shard_filter_kmers_dev(dbg_ctx* ctx, const dbg_transport* tr, const dbg
  *   the reference's flow literally (the result equals the oracle's node for node).
  * reduce = DBG_REDUCE_TREE: pairwise combine + compress_graph up a binary tree (ranks r and r + 2^l at level l), so that the
  *   early merges run in parallel and the root sees the last pair only; the same unitigs, in a different node order / strand
- *   (compare with tools/compare_gfa.py's canonical form).
+ *   (compare with tools/compare_gfa.py's canonical form).  Inner levels hold a part of the shards: their compress_graph
+ *   treats an extension whose k-mer is in no node yet as the end of the path FOR NOW and skips both fix_exts
+ *   (compression.rs:309, :331 would strip the Exts that point into shards still to come); the root's last merge is the
+ *   reference's compress_graph proper.
  * CountFilterSet tables: D = class id of the label list, made global first (the ranks' class tables are all-gathered and
  * renumbered in sorted order of the lists; *classes receives the global table on every rank).
  * final_out: host BaseGraph on `root` (n_nodes = 0 elsewhere); local_out (may be NULL): this rank's own shard graph. */

@@ -526,9 +526,11 @@ extern "C" int dbg_compress_kmers_no_exts(dbg_ctx* c, uint32_t k, int stranded, 
     return dbg_compress_kmers_with_hash(c, k, stranded, spec, n, key_hi, key_lo, exts.data(), data, seed_order, out);
 }
 
-extern "C" void dbg_free_graph(dbg_ctx*, dbg_graph* g) {
+// (the arrays are pinned blocks of the ctx's result pool when the graph came off the device route, plain malloc'ed memory
+//  otherwise: ctx_hfree tells them apart)
+extern "C" void dbg_free_graph(dbg_ctx* c, dbg_graph* g) {
     if (!g) return;
-    free(g->seq_words); free(g->start); free(g->length); free(g->exts); free(g->data);
+    ctx_hfree(c, g->seq_words); ctx_hfree(c, g->start); ctx_hfree(c, g->length); ctx_hfree(c, g->exts); ctx_hfree(c, g->data);
     memset(g, 0, sizeof(*g));
 }
 

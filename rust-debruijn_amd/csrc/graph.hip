@@ -104,7 +104,7 @@ __global__ void node_link_kernel(EndIndex left, EndIndex right, const uint64_t* 
                                  const uint64_t* __restrict__ start, const uint32_t* __restrict__ length, uint32_t n, int k,
                                  int stranded /* the walk's */, int g_stranded /* the graph's: drives find_link */, int spec,
                                  const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data,
-                                 uint32_t* __restrict__ link /* [2][n] */) {
+                                 uint32_t* __restrict__ link /* [2][n] */, int partial = 0 /* a k-mer that is in no node lives in another shard: the path ends here for now */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t e = exts[i];
@@ -119,7 +119,7 @@ __global__ void node_link_kernel(EndIndex left, EndIndex right, const uint64_t* 
             K128 end_kmer = dir == 0 ? fk : lk;                                        // term_kmer(dir) :127
             K128 next_kmer = dir == 0 ? kmer_extend_left(end_kmer, k, base) : kmer_extend_right(end_kmer, k, base);
             Link L = find_link(left, right, next_kmer, dir, g_stranded, k);           // :130 (self.graph.find_link)
-            if (L.node < 0) out = NL_NOKMER;
+            if (L.node < 0) out = partial ? NL_TERM : NL_NOKMER;
             else {
                 const uint32_t nn = (uint32_t)L.node;
                 bool consistent = length[nn] == (uint32_t)k ||                         // :145-165
@@ -369,7 +369,7 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
                     if (hipMemcpyAsync(ng.exts, d2.exts.p, ng.n_nodes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                         hipStreamSynchronize(c->stream) != hipSuccess) r = c->fail(100, "copy of fixed exts failed");
                 }
-                if (r) { free(ng.seq_words); free(ng.start); free(ng.length); free(ng.exts); free(ng.data); return r; }
+                if (r) { dbg_free_graph(c, &ng); return r; }
                 *out = ng;
                 return 0;
             }
@@ -455,7 +455,7 @@ extern "C" int dbg_compress_graph(dbg_ctx* c, uint32_t k_, int stranded, int spe
             if (hipMemcpyAsync(ng.exts, d2.exts.p, ng.n_nodes, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess) r = c->fail(100, "copy of fixed exts failed");
         }
-        if (r) { free(ng.seq_words); free(ng.start); free(ng.length); free(ng.exts); free(ng.data); return r; }
+        if (r) { dbg_free_graph(c, &ng); return r; }
     }
     *out = ng;
     return 0;
@@ -601,11 +601,11 @@ int graph_dev_to_host(dbg_ctx* c, const GraphDev& d, dbg_graph* g) {
     memset(g, 0, sizeof(*g));
     const uint64_t n = d.n_nodes, nw = d.n_words;
     g->n_nodes = n; g->n_seq_words = nw; g->seq_len_bases = d.n_bases; g->stranded = d.stranded;
-    g->seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(nw, 1) * 8);
-    g->start = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n, 1) * 8);
-    g->length = (uint32_t*)dbg_host_alloc(std::max<uint64_t>(n, 1) * 4);
-    g->exts = (uint8_t*)malloc(std::max<uint64_t>(n, 1));
-    g->data = (uint32_t*)malloc(std::max<uint64_t>(n, 1) * 4);
+    g->seq_words = (uint64_t*)ctx_halloc(c, std::max<uint64_t>(nw, 1) * 8);
+    g->start = (uint64_t*)ctx_halloc(c, std::max<uint64_t>(n, 1) * 8);
+    g->length = (uint32_t*)ctx_halloc(c, std::max<uint64_t>(n, 1) * 4);
+    g->exts = (uint8_t*)ctx_halloc(c, std::max<uint64_t>(n, 1));
+    g->data = (uint32_t*)ctx_halloc(c, std::max<uint64_t>(n, 1) * 4);
     if (nw) HIP_TRY(c, hipMemcpyAsync(g->seq_words, d.words.p, nw * 8, hipMemcpyDeviceToHost, c->stream));
     if (n) {
         HIP_TRY(c, hipMemcpyAsync(g->start, d.start.p, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -710,7 +710,10 @@ __global__ void __launch_bounds__(256) short_node_kernel(const uint32_t* __restr
 // compress_graph (compression.rs:338-349) on a device-resident graph, no censored nodes: the device route of dbg_compress_graph
 // with nothing staged through the host.  `in` is consumed.  Links that are not mutual / carry a panic marker take the literal
 // host walk of dbg_compress_graph (the graph then does make the trip; such inputs are those the reference panics on).
-int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, GraphDev* out) {
+// partial (an inner level of the tree merge): the graph holds SOME of the shards, so an extension whose k-mer is in no node
+// points into a shard that has not arrived yet: such a path ends there for now, and neither fix_exts runs -- stripping the Exts
+// that have no target yet (compression.rs:309, :331) would cut the graph at the shard boundary for good.
+int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, GraphDev* out, bool partial = false) {
     const uint64_t n64 = in->n_nodes;
     if (n64 >= (1ull << 30)) return c->fail(51, "compress_graph: at most 2^30-1 nodes per call in this build");
     const uint32_t n = (uint32_t)n64;
@@ -731,18 +734,18 @@ int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, 
     d.exts = std::move(in->exts); d.data = std::move(in->data);
     const uint64_t in_words = in->n_words, in_bases = in->n_bases;
     DBG_TRY(dev_graph_index(c, k, &d));
-    DBG_TRY(dev_fix_exts(c, k, g_stranded, &d, nullptr));                              // old_graph.fix_exts(Some(&available)), all available :309
+    if (!partial) DBG_TRY(dev_fix_exts(c, k, g_stranded, &d, nullptr));                // old_graph.fix_exts(Some(&available)), all available :309
     DBuf<uint32_t> d_link, u_link, u_weight;
     ALLOC_OR_FAIL(c, d_link, 2 * (size_t)n); ALLOC_OR_FAIL(c, u_link, 2 * (size_t)n); ALLOC_OR_FAIL(c, u_weight, n);
     c->t_begin("graph_node_links", n);
     node_link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(d.left, d.right, d.words.p, d.start.p, d.length.p, n, k, stranded, g_stranded, spec,
-                                                           d.exts.p, d.data.p, d_link.p);
+                                                           d.exts.p, d.data.p, d_link.p, partial ? 1 : 0);
     c->t_end();
     LAUNCH_CHECK(c, "node_links");
     bool done = false;
     const char* mode = c->opt("DBG_COMPRESS");
     GraphDev sink;
-    if (!(mode && !strcmp(mode, "host"))) {
+    if (partial || !(mode && !strcmp(mode, "host"))) {
         node_links_to_unitig_kernel<<<cdiv(2 * (uint64_t)n, 256), 256, 0, c->stream>>>(d_link.p, d.length.p, n, k, u_link.p, u_weight.p);
         LAUNCH_CHECK(c, "node_links_to_unitig");
         UnitigNodes un{u_weight.p, d.words.p, d.start.p, d.length.p, nullptr};
@@ -751,7 +754,7 @@ int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, 
         const int r = compress_links_device(c, k, n, nullptr, nullptr, d.exts.p, d.data.p, u_link.p, nullptr, spec, stranded, &ng, &done, &un);
         c->graph_sink = nullptr;
         if (r) return r;
-        if (!done && mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the node links are not mutual");
+        if (!done && (partial || (mode && !strcmp(mode, "device")))) return c->fail(48, "DBG_COMPRESS=device but the node links are not mutual");
     }
     if (!done) {
         // the literal walk (and the reference's panics): through the host entry point
@@ -775,8 +778,10 @@ int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, 
     d2.n = (uint32_t)sink.n_nodes;
     d2.words = std::move(sink.words); d2.start = std::move(sink.start); d2.length = std::move(sink.length);
     d2.exts = std::move(sink.exts); d2.data = std::move(sink.data);
-    DBG_TRY(dev_graph_index(c, k, &d2));
-    DBG_TRY(dev_fix_exts(c, k, stranded, &d2, nullptr));
+    if (!partial) {
+        DBG_TRY(dev_graph_index(c, k, &d2));
+        DBG_TRY(dev_fix_exts(c, k, stranded, &d2, nullptr));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->words = std::move(d2.words); out->start = std::move(d2.start); out->length = std::move(d2.length);
     out->exts = std::move(d2.exts); out->data = std::move(d2.data);
@@ -982,7 +987,9 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
                 DBG_TRY(graph_dev_recv(c, tr, &other, (int32_t)from));
                 std::vector<GraphDev*> pair{&mine, &other};
                 DBG_TRY(graph_dev_combine(c, pair, &comb));
-                DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &merged));
+                // every merge but the root's last one sees a part of the shards only
+                const bool last = pos == 0 && 2 * st >= W;
+                DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &merged, !last));
                 mine = std::move(merged);
             }
         }

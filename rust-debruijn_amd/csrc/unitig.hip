@@ -725,9 +725,11 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             // final already, the first half of the sequence words is final when the second half starts.  (A copy into pageable
             // host memory blocks the host thread, not the device: it is issued on a second stream after the kernels it overlaps.)
             if (!c->graph_sink) {
-                out_early.seq_words = (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
-                out_early.start = (uint64_t*)dbg_host_alloc((size_t)nn * 8);
-                out_early.length = (uint32_t*)dbg_host_alloc((size_t)nn * 4);
+                // (pinned blocks from the ctx's result pool: a copy into pageable memory runs at a third of the link's rate and
+                //  takes a page fault per 4 KB of a fresh array -- 680 MB of graph at config-3 size cost ~40 ms that way)
+                out_early.seq_words = (uint64_t*)ctx_halloc(c, std::max<uint64_t>(n_words, 1) * 8);
+                out_early.start = (uint64_t*)ctx_halloc(c, (size_t)nn * 8);
+                out_early.length = (uint32_t*)ctx_halloc(c, (size_t)nn * 4);
             }
             hipStream_t cs = c->graph_sink ? nullptr : c->get_copy_stream();
             c->t_begin("unitig_emit", n);
@@ -907,11 +909,11 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         return 0;
     }
     // ---- to the host BaseGraph ----
-    out->seq_words = out_early.seq_words ? out_early.seq_words : (uint64_t*)dbg_host_alloc(std::max<uint64_t>(n_words, 1) * 8);
-    out->start = out_early.start ? out_early.start : (uint64_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 8ull);
-    out->length = out_early.length ? out_early.length : (uint32_t*)dbg_host_alloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
-    out->exts = (uint8_t*)malloc(std::max<uint32_t>(n_nodes, 1));
-    out->data = (uint32_t*)malloc(std::max<uint32_t>(n_nodes, 1) * 4ull);
+    out->seq_words = out_early.seq_words ? out_early.seq_words : (uint64_t*)ctx_halloc(c, std::max<uint64_t>(n_words, 1) * 8);
+    out->start = out_early.start ? out_early.start : (uint64_t*)ctx_halloc(c, std::max<uint32_t>(n_nodes, 1) * 8ull);
+    out->length = out_early.length ? out_early.length : (uint32_t*)ctx_halloc(c, std::max<uint32_t>(n_nodes, 1) * 4ull);
+    out->exts = (uint8_t*)ctx_halloc(c, std::max<uint32_t>(n_nodes, 1));
+    out->data = (uint32_t*)ctx_halloc(c, std::max<uint32_t>(n_nodes, 1) * 4ull);
     c->t_begin("graph_to_host", n_nodes);
     if (n_words > early_words)
         HIP_TRY(c, hipMemcpyAsync(out->seq_words + early_words, words.p + early_words, (n_words - early_words) * 8, hipMemcpyDeviceToHost, c->stream));

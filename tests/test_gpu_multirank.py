@@ -92,7 +92,7 @@ def test_sharded_compress_two_ranks_one_gpu():
     assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("world,reduce", [(3, "gather"), (3, "tree"), (2, "tree")])
+@pytest.mark.parametrize("world,reduce", [(3, "gather"), (3, "tree"), (2, "tree"), (4, "tree")])
 def test_sharded_compress_more_shapes_one_gpu(world, reduce):
     """dbg_shard_compress_dev with 3 ranks (an odd tree: one rank sits a level out) and the tree merge: gather is compared node for
     node with the oracle's combine + compress_graph, the tree in canonical form (same unitigs, other order / strand)."""
@@ -100,3 +100,17 @@ def test_sharded_compress_more_shapes_one_gpu(world, reduce):
                         "--master-port", str(29741 + world), os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo",
                         "--one-device", "--reduce", reduce, "--reads", "21000"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_ownership_follows_the_record_histogram_on_low_complexity_reads():
+    """8 ranks on the one GPU, 5 % poly-A / di- / tri-nucleotide repeat reads (tools/check_balance.py): with ownership cut from the
+    all-reduced record histogram (dbg_shard_params.balance, dbg_shard_owner_bounds) every rank owns the same number of records to
+    within 5 %, equal bin ranges do not; both give the single call's table."""
+    import json
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", "29761", os.path.join(ROOT, "tools", "check_balance.py"), "--backend", "gloo", "--one-device",
+                        "--reads", "100000"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["world"] == 8
+    assert d["balanced"]["records_owned_max_over_mean"] <= 1.05 < d["equal_bins"]["records_owned_max_over_mean"]
