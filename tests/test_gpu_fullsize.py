@@ -255,7 +255,7 @@ def _lookup(torch, hi_t, lo_t, qhi, qlo):
     return out.cpu().numpy()
 
 
-@only_c2
+@pytest.mark.parametrize("env", [CASES[0], CASES[1]], ids=[CASE_IDS[0], CASE_IDS[1]], indirect=True)
 def test_fullsize_compress_invariants(env):
     """BASELINE config 3 at full size: CountFilter(2) table -> compress_kmers_with_hash on the device (index left in HBM).
     Size-independent properties of the reference's result (compression.rs:355-583; the tests of test.rs:236-349 check the
@@ -321,11 +321,19 @@ def test_fullsize_compress_invariants(env):
     lib.dbg_free_table(ctx.h, C.byref(t))
 
 
-@pytest.mark.parametrize("env", [CASES[0], CASES[1]], ids=[CASE_IDS[0], CASE_IDS[1]], indirect=True)
-@pytest.mark.parametrize("kind", [0, 1])
-def test_fullsize_sharded_two_virtual_ranks(env, kind):
-    """The sharded entry points at full size: two virtual ranks hold one half of the reads each, scan them into the bins of one
-    global plan (dbg_shard_scan / _scatter), each owner counts its half of the bins from two bin-ordered source segments
+def _sharded_cases():
+    """(case, kind, world): k = 47 and 63 with two virtual ranks and both summarizers; k = 51 (config 5's key width and summarizer)
+    with two; k = 47 with EIGHT owners -- the target node's shape: 3 bits finer ownership, eight source segments per bin"""
+    out = []
+    for ci, kind, world in ((0, 0, 2), (0, 1, 2), (1, 0, 2), (1, 1, 2), (2, 1, 2), (0, 0, 8)):
+        out.append(pytest.param(CASES[ci], kind, world, id="%s-kind%d-w%d" % (CASE_IDS[ci], kind, world)))
+    return out
+
+
+@pytest.mark.parametrize("env,kind,world", _sharded_cases(), indirect=["env"])
+def test_fullsize_sharded_virtual_ranks(env, kind, world):
+    """The sharded entry points at full size: `world` virtual ranks hold an equal share of the reads each, scan them into the bins of
+    one global plan (dbg_shard_scan / _scatter), each owner counts its share of the bins from `world` bin-ordered source segments
     (dbg_shard_count_begin / _bins / _finish in three ranges, as the pipelined exchange drives it) -- what a rank sees after the
     all-to-all.  Per owner: strictly ascending keys; over both owners: every instance counted once, and the order-independent
     digests of (key, Exts, count | label list) add up to the digest of the single-call table over the same reads (every k-mer
@@ -344,10 +352,10 @@ def test_fullsize_sharded_two_virtual_ranks(env, kind):
     ctx.trim()
     want = dict(table_stats(e, whole), digest=D.table_digest(whole, dev))
     lib.dbg_free_table(ctx.h, C.byref(whole))
-    world, half = 2, N_READS // 2
+    share = N_READS // world
     shards = []
     for r in range(world):
-        first, n = r * half, (half if r == 0 else N_READS - half)
+        first, n = r * share, (share if r + 1 < world else N_READS - share * (world - 1))
         shards.append(capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"][first:].data_ptr(), e["length"][first:].data_ptr(), None,
                                   e["colour"][first:].data_ptr() if kind == 1 else None, 1 if kind == 1 else 0, n))
     total = sum(eng.count_instances(s, K) for s in shards)

@@ -114,3 +114,14 @@ def test_ownership_follows_the_record_histogram_on_low_complexity_reads():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ok"] and d["world"] == 8
     assert d["balanced"]["records_owned_max_over_mean"] <= 1.05 < d["equal_bins"]["records_owned_max_over_mean"]
+
+
+def test_config4_and_config5_flow_1e6_reads_two_ranks():
+    """BASELINE configs 4 and 5 as flows, at 10^6 reads over two ranks (one GPU, gloo): dbg_shard_filter_kmers_dev ->
+    dbg_shard_compress_dev (k = 47 counts / saturating_add then max; k = 51 CountFilterSet -> label-list classes -> ScmapCompress)
+    -> combine -> compress_graph.  The union of the ranks' tables is the oracle's filter_kmers over all reads, and the final graph
+    is the oracle's, node for node (src/test.rs:433-470)."""
+    r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29771", os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo", "--one-device",
+                        "--reads", "1000000", "--check-table"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--check-table", action="store_true",
+                    help="also compare the union of the per-rank tables with the oracle's filter_kmers over all reads (CPU: ~20 s per 10^6 reads)")
     ap.add_argument("--reduce", default="gather", choices=["gather", "tree"],
                     help="gather: all shard graphs to rank 0, one combine + compress_graph (the reference's flow literally: compared node "
                          "for node).  tree: pairwise combine + compress_graph up a binary tree (same unitigs in another order / strand: "
@@ -62,12 +64,40 @@ def main():
         if rank == 0:
             import oracle_lib as O
             from graph_canon import graphs_equal, canonical_nodes
-            sets = lambda t: [tuple(int(x) for x in t["set_val"][int(t["set_off"][i]):int(t["set_off"][i + 1])]) for i in range(len(t["key_lo"]))]
-            glob = sorted(set(s for t in tabs for s in sets(t))) if kind else None
+            # label lists -> class ids in the job-wide numbering (ranks of the sorted distinct lists), vectorised: labels < 64, so a
+            # list is a 64-bit mask, and only the few DISTINCT masks are ever turned into tuples
+            def masks(t):
+                n, off = len(t["key_lo"]), t["set_off"].astype(np.int64)
+                m = np.zeros(n, np.uint64)
+                np.bitwise_or.at(m, np.repeat(np.arange(n), np.diff(off)), np.uint64(1) << t["set_val"].astype(np.uint64))
+                return m
+            glob = None
+            if kind:
+                ms = [masks(t) for t in tabs]
+                distinct = np.unique(np.concatenate(ms))
+                as_tuple = lambda m: tuple(b for b in range(64) if (int(m) >> b) & 1)
+                glob = sorted(as_tuple(m) for m in distinct)
+                gid = {m: glob.index(as_tuple(m)) for m in distinct.tolist()}
+                lut = np.array([gid[m] for m in distinct.tolist()], dtype=np.uint32)
             shard = []
-            for t in tabs:
-                data = np.array([glob.index(s) for s in sets(t)], dtype=np.uint32) if kind else t["count"]
+            for i, t in enumerate(tabs):
+                data = lut[np.searchsorted(distinct, ms[i])] if kind else t["count"]
                 shard.append(O.compress_kmers(k, False, O.SPEC_SCMAP_EQ if kind else O.SPEC_SAT_ADD, t["key_hi"], t["key_lo"], t["exts"], data))
+            if a.check_table:
+                hs_all = dbg.synth_reads_host(n_reads=per * world, read_len=150, genome_len=a.reads * 150 // 30, error_rate=0.001,
+                                              stranded=False, n_colours=5)
+                so = O.SeqSet(hs_all.words, hs_all.start, hs_all.length, None, hs_all.data if kind else None, 1 if kind else 0)
+                wt = O.filter_kmers(so, k, O.COUNT_FILTER_SET if kind else O.COUNT_FILTER, 2, stranded=False)
+                # every k-mer lives on exactly one rank: the tables, merged by key, are the oracle's table
+                hi = np.concatenate([t["key_hi"] for t in tabs]); lo = np.concatenate([t["key_lo"] for t in tabs])
+                order = np.lexsort((lo, hi))
+                assert len(order) == wt.n and np.array_equal(hi[order], wt.key_hi) and np.array_equal(lo[order], wt.key_lo)
+                assert np.array_equal(np.concatenate([t["exts"] for t in tabs])[order], wt.exts)
+                if kind:
+                    wm = masks(dict(key_lo=wt.key_lo, set_off=wt.set_off, set_val=wt.set_val))
+                    assert np.array_equal(np.concatenate(ms)[order], wm)
+                else:
+                    assert np.array_equal(np.concatenate([t["count"] for t in tabs])[order], wt.count)
             want = O.graph_combine(shard).finish().compress_graph(False, O.SPEC_SCMAP_EQ if kind else O.SPEC_MAX)
             assert final is not None
             if a.reduce == "gather":
