@@ -395,7 +395,7 @@ typedef struct {
     int32_t  stranded;
     int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (at most 64 distinct labels < 65536 over all ranks) */
     uint64_t min_kmer_obs;
-    uint32_t n_rounds;          /* exchange rounds; 0 = chosen so that no message exceeds 1 GiB (at least 4; 8 from 4 ranks on) */
+    uint32_t n_rounds;          /* exchange rounds; 0 = 4 (8 from 4 ranks on), more when a round's receive buffer would pass 8 GiB */
     int32_t  merge_dups;        /* sender-side duplicate merge: 1 on, 0 off, -1 = the library decides (on at 2 ranks, where one link
                                    carries everything; afterwards from the exposed exchange time the ctx measured in its last call) */
     int32_t  balance;           /* 1 = ownership from the all-reduced record histogram of the scan (default), 0 = equal bin ranges */

@@ -214,11 +214,13 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     // ---- rounds ----
     uint32_t n_rounds = p->n_rounds;
     if (!n_rounds) {
-        // One message (one peer, one round) stays well under 1 GiB (the transport cuts larger ones, but a round is also the unit
-        // of overlap).  Records are at most ~2.5 bytes per k-mer instance (24-byte records of >= 10 k-mers at k = 47; denser for
-        // small k); every rank must arrive at the same number of rounds, hence the estimate from the largest rank.
-        const uint64_t est = std::max<uint64_t>(n_max, 1) * 4 / W;
-        n_rounds = (uint32_t)std::max<uint64_t>(W < 4 ? 4 : 8, (est + (1ull << 30) - 1) >> 30);
+        // Rounds are the unit of overlap (round c + 1 travels while round c is counted) and of receive-buffer memory (two buffers of
+        // one round's incoming records); the transport itself keeps every message under 1 GiB.  Four rounds leave a quarter of the
+        // exchange exposed, eight an eighth -- more only when a round's receive buffer would pass 8 GiB.  Records are at most ~2.5
+        // bytes per k-mer instance (24-byte records of >= 10 k-mers at k = 47; denser for small k); every rank must arrive at the
+        // same number, hence the estimate from the largest rank.
+        const uint64_t est_in = (uint64_t)((double)std::max<uint64_t>(n_max, 1) * 2.5 * (double)(W - 1) / (double)W);
+        n_rounds = (uint32_t)std::max<uint64_t>(W < 4 ? 4 : 8, (est_in + (8ull << 30) - 1) >> 33);
     }
     n_rounds = std::min<uint32_t>(n_rounds, 64);
     const uint32_t stride = n_rounds + 1;
