@@ -72,6 +72,12 @@ typedef struct {
     uint64_t        n_seqs;
 } dbg_seqset;
 
+/* The _dev entry points take a dbg_seqset of DEVICE pointers.  A host that does not drive the HIP runtime itself (a Rust shim
+ * without HIP bindings) gets one with dbg_seqset_to_device: the checked, staged upload of the host-pointer calls, the device
+ * buffers left in the caller's hands; dbg_seqset_free_device returns them to the ctx. */
+int  dbg_seqset_to_device(dbg_ctx* ctx, const dbg_seqset* host_seqs, dbg_seqset* dev_out);
+void dbg_seqset_free_device(dbg_ctx* ctx, dbg_seqset* dev);
+
 /* ---- filter_kmers (src/filter.rs:139-231) -------------------------------- */
 enum { DBG_COUNT_FILTER = 0, DBG_COUNT_FILTER_SET = 1 };
 

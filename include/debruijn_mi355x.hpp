@@ -320,6 +320,50 @@ inline DnaString from_acgt_bytes_hashn(Context& ctx, const std::string& ascii, c
     return d;
 }
 
+// ---- the rank-spanning flow (one process per GPU): src/test.rs:433-470 across ranks, two calls into the library -------------
+// A Transport wraps the C table of collective operations: Transport::rccl(comm, rank, world) for a host that made its ncclComm_t
+// with ncclCommInitRank, or none (one rank).  sharded_pipeline = filter_kmers over the reads of ALL ranks (this rank passes its own)
+// -> per-shard compress_kmers_with_hash -> BaseGraph::combine -> compress_graph; the final graph arrives on `root` (empty elsewhere).
+struct Transport {
+    dbg_transport* t = nullptr;
+    Transport() {}
+    static Transport rccl(void* nccl_comm, int rank, int world, const char* librccl_path = nullptr) {
+        Transport tr;
+        char err[512] = {0};
+        if (dbg_transport_rccl_create(nccl_comm, rank, world, librccl_path, &tr.t, err, sizeof(err))) throw Panic(err);
+        return tr;
+    }
+    Transport(Transport&& o) noexcept : t(o.t) { o.t = nullptr; }
+    Transport(const Transport&) = delete;
+    ~Transport() { if (t) dbg_transport_destroy(t); }
+    int rank() const { return t ? t->rank : 0; }
+    int world() const { return t ? t->world : 1; }
+};
+
+template <class K, class S1, class S2>
+BaseGraph<K, uint16_t> sharded_pipeline(Context& ctx, const Transport& tr, const std::vector<std::tuple<DnaString, Exts, uint8_t>>& my_seqs,
+                                        const CountFilter& summarizer, bool stranded, const S1& spec, const S2& second_spec,
+                                        int reduce = DBG_REDUCE_GATHER, int root = 0, dbg_shard_stats* stats = nullptr) {
+    detail::Flat<DnaString> f(my_seqs);
+    f.ss.data = nullptr; f.ss.data_width = 0;                      // CountFilter ignores D1 (filter.rs:52-62)
+    dbg_seqset dev{};
+    ctx.check(dbg_seqset_to_device(ctx.raw(), &f.ss, &dev));
+    dbg_shard_params p{(uint32_t)K::k(), stranded, DBG_COUNT_FILTER, summarizer.min_kmer_obs, 0, -1, 1, 0};
+    dbg_kmer_table t{};
+    int rc = dbg_shard_filter_kmers_dev(ctx.raw(), tr.t, &dev, &p, &t, stats);
+    dbg_seqset_free_device(ctx.raw(), &dev);
+    ctx.check(rc);
+    dbg_graph fin{};
+    rc = dbg_shard_compress_dev(ctx.raw(), tr.t, (uint32_t)K::k(), stranded, spec.kind(), second_spec.kind(), &t, reduce, root, &fin, nullptr, nullptr);
+    dbg_free_table(ctx.raw(), &t);
+    ctx.check(rc);
+    BaseGraph<K, uint16_t> out;
+    out.stranded = stranded;
+    if (tr.rank() == root) detail::graph_from_c(fin, &out);
+    dbg_free_graph(ctx.raw(), &fin);
+    return out;
+}
+
 // compress_graph (compression.rs:338-349)
 template <class K, class D, class S>
 BaseGraph<K, D> compress_graph(Context& ctx, bool stranded, const S& spec, const BaseGraph<K, D>& old_graph,

@@ -97,7 +97,7 @@ class KernelTime(C.Structure):
 # every symbol include/dbg_mi355x.h declares
 EXPORTS = [
     "dbg_ctx_create", "dbg_ctx_destroy", "dbg_last_error", "dbg_version", "dbg_ctx_set_stream",
-    "dbg_ctx_set_scratch_budget", "dbg_ctx_set_option", "dbg_ctx_trim", "dbg_seqset_max_label_dev", "dbg_seqset_label_bitmap_dev", "dbg_filter_kmers", "dbg_filter_kmers_dev", "dbg_free_table", "dbg_table_to_host",
+    "dbg_ctx_set_scratch_budget", "dbg_ctx_set_option", "dbg_ctx_trim", "dbg_seqset_max_label_dev", "dbg_seqset_label_bitmap_dev", "dbg_seqset_to_device", "dbg_seqset_free_device", "dbg_filter_kmers", "dbg_filter_kmers_dev", "dbg_free_table", "dbg_table_to_host",
     "dbg_remove_censored_exts", "dbg_msp_sequence", "dbg_msp_sequence_dev", "dbg_free_pieces",
     "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_kmer_set_exts", "dbg_compress_kmers_no_exts", "dbg_free_graph", "dbg_label_classes_dev", "dbg_free_label_classes", "dbg_compress_table_dev", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
@@ -140,6 +140,9 @@ def load():
     lib.dbg_ctx_trim.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.dbg_seqset_max_label_dev.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(C.c_uint32)]
     lib.dbg_seqset_label_bitmap_dev.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(C.c_uint32)]
+    lib.dbg_seqset_to_device.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(SeqSet)]
+    lib.dbg_seqset_free_device.argtypes = [C.c_void_p, C.POINTER(SeqSet)]
+    lib.dbg_seqset_free_device.restype = None
     lib.dbg_filter_kmers.argtypes = [C.c_void_p, C.POINTER(SeqSet), C.POINTER(FilterParams), C.POINTER(KmerTable)]
     lib.dbg_filter_kmers_dev.argtypes = lib.dbg_filter_kmers.argtypes
     lib.dbg_free_table.argtypes = [C.c_void_p, C.POINTER(KmerTable)]

@@ -351,6 +351,28 @@ static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs) {
     return 0;
 }
 
+// A sequence set resident in HBM for hosts that do not drive the HIP runtime themselves (a Rust shim without HIP bindings): the
+// same checked, staged upload the host-pointer calls perform, with the device buffers handed to the caller (pool blocks of the ctx;
+// dbg_seqset_free_device returns them).
+extern "C" int dbg_seqset_to_device(dbg_ctx* c, const dbg_seqset* hs, dbg_seqset* dev_out) {
+    if (!c) return 1;
+    if (!hs || !dev_out) return c->fail(10, "null argument");
+    if (hs->n_seqs && (!hs->words || !hs->start || !hs->length)) return c->fail(10, "null argument");
+    if (hs->data && hs->data_width != 1 && hs->data_width != 2 && hs->data_width != 4) return c->fail(15, "data_width must be 1, 2 or 4");
+    DBG_TRY(check_host_seqset(c, hs));
+    HIP_TRY(c, hipSetDevice(c->device));
+    DevSeqSet d;
+    DBG_TRY(upload_seqset(c, hs, &d));
+    *dev_out = d.view;
+    d.words.take(); d.start.take(); d.length.take(); d.exts.take(); d.data.take();      // the caller's now (live pool blocks)
+    return 0;
+}
+extern "C" void dbg_seqset_free_device(dbg_ctx* c, dbg_seqset* dev) {
+    if (!c || !dev) return;
+    c->dfree((void*)dev->words); c->dfree((void*)dev->start); c->dfree((void*)dev->length); c->dfree((void*)dev->exts); c->dfree((void*)dev->data);
+    memset(dev, 0, sizeof(*dev));
+}
+
 extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filter_params* p, dbg_kmer_table* out) {
     DBG_TRY(validate_filter(c, hs, p));
     DBG_TRY(check_host_seqset(c, hs));

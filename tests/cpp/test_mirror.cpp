@@ -164,6 +164,25 @@ int main() {
             }
             if (n_l != want_l) return 8;
         }
+        // the rank-spanning pipeline through the mirror, one rank (no transport): dbg_seqset_to_device -> dbg_shard_filter_kmers_dev ->
+        // dbg_shard_compress_dev == filter_kmers -> compress_kmers_with_hash -> combine -> compress_graph composed call by call
+        {
+            auto contigs = simple_random_contigs(rng);
+            std::vector<std::tuple<DnaString, Exts, uint8_t>> cs;
+            for (auto& c : contigs) if (c.size() >= 47) cs.emplace_back(DnaString::from_bytes(c), Exts::empty(), (uint8_t)0);
+            Transport none;
+            dbg_shard_stats st{};
+            auto g1 = sharded_pipeline<Kmer<47>>(ctx, none, cs, CountFilter(1), false, SimpleCompress(), SimpleCompress(Reduce::Max), DBG_REDUCE_GATHER, 0, &st);
+            auto fk = filter_kmers<Kmer<47>>(ctx, cs, CountFilter(1), false, false, 4);
+            auto g0 = compress_kmers_with_hash<Kmer<47>>(ctx, false, SimpleCompress(), fk.first);
+            auto g2 = compress_graph<Kmer<47>, uint16_t>(ctx, false, SimpleCompress(Reduce::Max), combine<Kmer<47>, uint16_t>(ctx, {g0}));
+            if (g1.len() == 0 || g1.len() != g2.len() || g1.sequences.sequence.len != g2.sequences.sequence.len) return 70;
+            if (g1.sequences.start != g2.sequences.start || g1.sequences.length != g2.sequences.length || g1.data != g2.data) return 71;
+            for (size_t i = 0; i < g1.len(); i++) if (g1.exts[i].val != g2.exts[i].val) return 72;
+            const size_t nw = (g1.sequences.sequence.len + 31) / 32;
+            for (size_t i = 0; i < nw; i++) if (g1.sequences.sequence.storage[i] != g2.sequences.sequence.storage[i]) return 73;
+            if (st.total_kmers == 0 || st.total_kmers != st.local_kmers) return 74;
+        }
         // the reference would panic on memory_size = 0 (filter.rs:158)
         bool threw = false;
         try { filter_kmers<Kmer<31>>(ctx, seqs, CountFilter(1), false, false, 0); } catch (const Panic&) { threw = true; }
