@@ -75,6 +75,64 @@ __device__ __forceinline__ bool is_palindrome(K128 a, int k) { return (k & 1) ==
 __device__ __forceinline__ uint32_t num_ext_dir(uint32_t e, int dir) { return __popc((e >> (4 * dir)) & 0xfu); }      // lib.rs:687-690
 __device__ __forceinline__ bool join_test(int spec, uint32_t a, uint32_t b) { return spec == DBG_SPEC_SCMAP_EQ ? a == b : true; }
 
+// One direction of one k-mer: everything of try_extend_kmer (compression.rs:382-444) that does not depend on the greedy state.
+// Every neighbour relation is seen from both ends -- k-mer i looks its neighbour j up, j looks i up -- and a lookup is two or
+// three random cache lines in a 10 GB table: the kernel's whole cost.  With consistent Exts the second lookup tells nothing new:
+// when i (unique extension towards j) has found j, j's Exts say whether j's own link in the facing direction D is the mirror
+// image (j has exactly one extension there and it is the base that leads back to i).  So the lookup is made from ONE end, the
+// end with the smaller key ("designated"; the keys are known before the lookup), which also writes the facing link of j when it
+// is derivable; a second pass evaluates, with its own lookup, every link that is still unset (the other end had a branch, no
+// extension, or the Exts are not symmetric) and assembles the node records.  Half the lookups in the interior of unitigs.
+//   j's evaluation in direction D, derived from i's (dir): flip' = flip, next_dir' = 1 - dir, incoming' = num_ext_dir(e_i, dir) = 1,
+//   pal' = is_palindrome(i) = false, join_test is symmetric -- so its link is (i << 1 | 1 - dir) if can_join, Terminal if not;
+//   valid only if i's key is canonical (non-stranded), j is no palindrome, and j's single extension in D is the expected base.
+constexpr uint32_t LINK_UNSET = 0xFFFFFFFEu;   // (ids are < 2^30 - 1: the largest link word is PANIC | id << 1 | 1 <= 0xFFFFFFFD)
+struct LinkEval {
+    uint32_t out;          // link word of (i, dir); LINK_UNSET: not evaluated (another k-mer's thread is designated)
+    bool rev_ok;           // the facing link of the neighbour follows from this evaluation
+    uint32_t rev_id, rev_dir, rev_val;
+};
+template <bool DESIGNATED_ONLY>
+__device__ __forceinline__ LinkEval eval_link(const KeysDev& t, const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data, uint64_t i,
+                                              K128 kmer, uint32_t e, bool self_pal, bool canon_i, int dir, int k, int stranded, int spec) {
+    LinkEval r{LINK_TERM, false, 0u, 0u, 0u};
+    if (num_ext_dir(e, dir) != 1 || self_pal) return r;                            // compression.rs:386
+    const uint32_t bits = (e >> (4 * dir)) & 0xfu;
+    const uint32_t base = 31 - __clz(bits);                                        // get_unique_extension (lib.rs:704-717)
+    K128 next = dir == 0 ? kmer_extend_left(kmer, k, base) : kmer_extend_right(kmer, k, base);   // :392
+    bool flip = false;
+    if (!stranded) {                                                               // :396-400
+        K128 rc = kmer_rc(next, k);
+        if (!k128_lt(next, rc)) { next = rc; flip = true; }
+    }
+    if (DESIGNATED_ONLY && k128_lt(next, kmer)) { r.out = LINK_UNSET; return r; }  // the neighbour's thread is designated for this pair
+    const int next_dir = flip ? 1 - dir : dir;                                     // :402
+    const bool pal = !stranded && is_palindrome(next, k);                          // :403
+    uint32_t ne = 0;
+    const int64_t nid = t.rec ? find_key_rec(t, next, &ne) : find_key(t, next);    // :410
+    if (nid < 0) return r;
+    const int new_incoming_dir = flip ? dir : 1 - dir;                             // dir.flip().cond_flip(flip) :419
+    if (!t.rec) ne = exts[nid];
+    const uint32_t incoming = num_ext_dir(ne, new_incoming_dir);                   // :422
+    // join_test :426 -- only ScmapCompress looks at the data: for the SimpleCompress specs the neighbour's D is not fetched (a fourth
+    // random cache line per lookup otherwise)
+    const bool can_join = spec != DBG_SPEC_SCMAP_EQ || !data || join_test(spec, data[i], data[nid]);
+    if (incoming == 0 && !pal) r.out = LINK_PANIC | ((uint32_t)nid << 1) | (uint32_t)next_dir;
+    else if (can_join && incoming == 1 && !pal) r.out = ((uint32_t)nid << 1) | (uint32_t)next_dir;   // :435-437
+    if (DESIGNATED_ONLY && incoming == 1 && !pal && canon_i) {
+        const uint32_t far = dir == 1 ? kmer_get(kmer, k, 0) : (uint32_t)(kmer.lo & 3ull);       // the base of i that j's extension must name
+        const uint32_t want = flip ? 3u - far : far;
+        if (((ne >> (4 * new_incoming_dir)) & 0xfu) == (1u << want)) {
+            r.rev_ok = true; r.rev_id = (uint32_t)nid; r.rev_dir = (uint32_t)new_incoming_dir;
+            r.rev_val = can_join ? (((uint32_t)i << 1) | (uint32_t)(1 - dir)) : LINK_TERM;
+        }
+    }
+    return r;
+}
+
+// PHASE 0: every link from its own lookup, node records written (the plain form).  PHASE 1: designated lookups + derived facing
+// links (link[] pre-set to LINK_UNSET).  PHASE 2: the links still unset from their own lookup, then the node records.
+template <int PHASE>
 __global__ void link_kernel(KeysDev t, const uint8_t* __restrict__ exts, const uint32_t* __restrict__ data, int k,
                             int stranded, int spec, uint32_t* __restrict__ link /* [2][n] */, NodeRec* __restrict__ nrec /* or null */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,39 +140,46 @@ __global__ void link_kernel(KeysDev t, const uint8_t* __restrict__ exts, const u
     K128 kmer = key_at(t, i);
     uint32_t e = exts[i];
     bool self_pal = !stranded && is_palindrome(kmer, k);
+    const bool canon_i = stranded || !k128_lt(kmer_rc(kmer, k), kmer);
     uint32_t both[2];
     for (int dir = 0; dir < 2; dir++) {
-        uint32_t out = LINK_TERM;
-        if (num_ext_dir(e, dir) == 1 && !self_pal) {                                   // compression.rs:386
-            uint32_t bits = (e >> (4 * dir)) & 0xfu;
-            uint32_t base = 31 - __clz(bits);                                          // get_unique_extension (lib.rs:704-717)
-            K128 next = dir == 0 ? kmer_extend_left(kmer, k, base) : kmer_extend_right(kmer, k, base);   // :392
-            bool flip = false;
-            if (!stranded) {                                                           // :396-400
-                K128 rc = kmer_rc(next, k);
-                if (!k128_lt(next, rc)) { next = rc; flip = true; }
+        if (PHASE == 2) {
+            uint32_t v = link[(uint64_t)dir * t.n + i];
+            if (v == LINK_UNSET) {
+                v = eval_link<false>(t, exts, data, i, kmer, e, self_pal, canon_i, dir, k, stranded, spec).out;
+                link[(uint64_t)dir * t.n + i] = v;
             }
-            int next_dir = flip ? 1 - dir : dir;                                       // :402
-            bool pal = !stranded && is_palindrome(next, k);                            // :403
-            uint32_t ne = 0;
-            const int64_t nid = t.rec ? find_key_rec(t, next, &ne) : find_key(t, next);   // :410
-            if (nid >= 0) {
-                int new_incoming_dir = flip ? dir : 1 - dir;                           // dir.flip().cond_flip(flip) :419
-                if (!t.rec) ne = exts[nid];
-                uint32_t incoming = num_ext_dir(ne, new_incoming_dir);                 // :422
-                bool can_join = join_test(spec, data ? data[i] : 0u, data ? data[nid] : 0u);   // :426
-                if (incoming == 0 && !pal) out = LINK_PANIC | ((uint32_t)nid << 1) | (uint32_t)next_dir;
-                else if (can_join && incoming == 1 && !pal) out = ((uint32_t)nid << 1) | (uint32_t)next_dir;   // :435-437
-            }
+            both[dir] = v;
+            continue;
         }
-        link[(uint64_t)dir * t.n + i] = out;
-        both[dir] = out;
+        const LinkEval r = eval_link<PHASE == 1>(t, exts, data, i, kmer, e, self_pal, canon_i, dir, k, stranded, spec);
+        if (r.out != LINK_UNSET) link[(uint64_t)dir * t.n + i] = r.out;
+        if (PHASE == 1 && r.rev_ok) link[(uint64_t)r.rev_dir * t.n + r.rev_id] = r.rev_val;
+        both[dir] = r.out;
     }
-    if (nrec) {
+    if (nrec && PHASE != 1) {
         NodeRec r;
         r.lo = kmer.lo; r.hi = kmer.hi; r.link[0] = both[0]; r.link[1] = both[1]; r.data = data ? data[i] : 0u; r.exts = e;
         nrec[i] = r;
     }
+}
+
+// links of every k-mer (+ node records): two passes with one lookup per neighbour pair, or (DBG_LINKS=plain) one pass with two
+static int build_links(dbg_ctx* c, const KeysDev& t, const uint8_t* exts_dev, const uint32_t* data_dev, int k, int stranded, int spec,
+                       uint32_t* link_dev, NodeRec* nrec_dev) {
+    const uint64_t n = t.n;
+    const char* mode = c->opt("DBG_LINKS");
+    if (mode && !strcmp(mode, "plain")) {
+        link_kernel<0><<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, data_dev, k, stranded, spec, link_dev, nrec_dev);
+        LAUNCH_CHECK(c, "link_kernel");
+        return 0;
+    }
+    HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)link_dev, (int)LINK_UNSET, 2 * n, c->stream));
+    link_kernel<1><<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, data_dev, k, stranded, spec, link_dev, nullptr);
+    LAUNCH_CHECK(c, "link_kernel<1>");
+    link_kernel<2><<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, data_dev, k, stranded, spec, link_dev, nrec_dev);
+    LAUNCH_CHECK(c, "link_kernel<2>");
+    return 0;
 }
 
 // pidx[p] = lower bound of prefix p: position i fills the entries of every prefix in (prefix(key[i-1]), prefix(key[i])]
@@ -302,9 +367,9 @@ extern "C" int dbg_compress_kmers_with_hash(dbg_ctx* c, uint32_t k_, int strande
         c->t_begin("compress_links", n);
         DBuf<NodeRec> d_nrec;                                      // optional: without it the chain walks read the separate arrays
         if (!c->opt("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
-        link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_exts.p, d_data.p, k, stranded, spec, d_link.p, d_nrec.p);
+        const int lr = build_links(c, t, d_exts.p, d_data.p, k, stranded, spec, d_link.p, d_nrec.p);
         c->t_end();
-        LAUNCH_CHECK(c, "link_kernel");
+        if (lr) return lr;
         d_rec.release();                                           // back to the pool; later users are ordered behind the kernel on the stream
         const char* mode = c->opt("DBG_COMPRESS");                 // device | host | (default) auto
         const bool want_device = !(mode && !strcmp(mode, "host"));
@@ -447,9 +512,9 @@ extern "C" int dbg_compress_kmers_with_hash_dev(dbg_ctx* c, uint32_t k_, int str
     c->t_begin("compress_links", n);
     DBuf<NodeRec> d_nrec;
     if (!c->opt("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);
-    link_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, exts_dev, d_data, k, stranded, spec, d_link.p, d_nrec.p);
+    const int lr = build_links(c, t, exts_dev, d_data, k, stranded, spec, d_link.p, d_nrec.p);
     c->t_end();
-    LAUNCH_CHECK(c, "link_kernel");
+    if (lr) return lr;
     d_rec.release();
     bool done = false;
     DBG_TRY(compress_links_device(c, k, (uint32_t)n, t.hi, t.lo, exts_dev, d_data, d_link.p, nullptr, spec, stranded, out, &done, nullptr, d_nrec.p));

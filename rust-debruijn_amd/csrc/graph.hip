@@ -127,7 +127,7 @@ __global__ void node_link_kernel(EndIndex left, EndIndex right, const uint64_t* 
                                   (dir == 1 && L.side == 0 && !L.flip) || (dir == 1 && L.side == 1 && L.flip);
                 bool next_pal = !stranded && (k % 2 == 0) && k128_eq(next_kmer, kmer_rc(next_kmer, k));          // :174
                 if (!consistent) out = NL_INCONSISTENT;
-                else if (next_pal || !join_ok(spec, data ? data[i] : 0u, data ? data[nn] : 0u)) out = NL_TERM;   // :173-182
+                else if (next_pal || (spec == DBG_SPEC_SCMAP_EQ && data && !join_ok(spec, data[i], data[nn]))) out = NL_TERM;   // :173-182 (only ScmapCompress reads the data)
                 else {
                     uint32_t incoming = __popc((exts[nn] >> (4 * L.side)) & 0xfu);     // num_ext_dir(next_side_incoming) :187
                     int outgoing = 1 - L.side;                                         // next_side_incoming.flip() :185
