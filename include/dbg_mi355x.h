@@ -376,6 +376,12 @@ typedef struct dbg_transport {
 int  dbg_transport_rccl_create(void* nccl_comm, int32_t rank, int32_t world, const char* librccl_path, dbg_transport** out,
                                char* err, uint64_t err_len);
 void dbg_transport_destroy(dbg_transport* t);       /* tables made by this library only; the ncclComm_t stays the caller's */
+/* In-process transport: the ranks are THREADS of one process -- one per GPU, or several sharing a GPU -- each with its own ctx and
+ * its own table (out[0..world)).  Device buffers of all ranks live in one address space, so the variable all-to-all is
+ * device-to-device copies (peer copies over xGMI between different GPUs) issued by the receiving rank between two barriers of the
+ * threads; no RCCL.  Synchronous (an operation drains the caller's stream, moves the data, returns); a rank that does not arrive
+ * within 300 s breaks the group (every pending and later operation fails).  Release each table with dbg_transport_destroy. */
+int  dbg_transport_inprocess_create(int32_t world, dbg_transport** out /* [world] */);
 /* For hosts that do not bind RCCL themselves: ncclGetUniqueId on one rank (id_out: 128 bytes, to be handed to the other ranks
  * by whatever bootstrap the host has), then ncclCommInitRank on every rank with its GPU current. */
 int  dbg_rccl_unique_id(const char* librccl_path, uint8_t* id_out_128, char* err, uint64_t err_len);

@@ -105,7 +105,7 @@ EXPORTS = [
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
     "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
     "dbg_graph_serialize", "dbg_graph_deserialize", "dbg_free_bytes", "dbg_serde_last_error",
-    "dbg_transport_rccl_create", "dbg_transport_destroy", "dbg_rccl_unique_id", "dbg_rccl_comm_create", "dbg_rccl_comm_destroy",
+    "dbg_transport_rccl_create", "dbg_transport_destroy", "dbg_transport_inprocess_create", "dbg_rccl_unique_id", "dbg_rccl_comm_create", "dbg_rccl_comm_destroy",
     "dbg_shard_owner_bounds", "dbg_shard_round_cuts", "dbg_shard_filter_kmers_dev", "dbg_shard_compress_dev",
     "dbg_pack_acgt", "dbg_pack_acgt_dev", "dbg_pack_acgt_hashn", "dbg_pack_acgt_hashn_dev", "dbg_unpack_acgt", "dbg_unpack_acgt_dev",
 ]
@@ -205,6 +205,7 @@ def load():
     lib.dbg_shard_count_bins_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     lib.dbg_shard_count_finish.argtypes = [C.c_void_p, C.POINTER(KmerTable)]
     lib.dbg_transport_rccl_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.POINTER(Transport)), C.c_char_p, C.c_uint64]
+    lib.dbg_transport_inprocess_create.argtypes = [C.c_int32, C.POINTER(C.POINTER(Transport))]
     lib.dbg_transport_destroy.argtypes = [C.POINTER(Transport)]
     lib.dbg_transport_destroy.restype = None
     lib.dbg_rccl_unique_id.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_uint64]

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 namespace {
@@ -150,9 +151,7 @@ extern "C" int dbg_transport_rccl_create(void* nccl_comm, int32_t rank, int32_t 
     return 0;
 }
 
-extern "C" void dbg_transport_destroy(dbg_transport* t) {
-    if (t && t->self == (void*)t) delete (RcclTransport*)t->self;
-}
+
 
 extern "C" int dbg_rccl_unique_id(const char* librccl_path, uint8_t* id_out, char* err, uint64_t err_len) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the header this file documents");
@@ -190,6 +189,164 @@ extern "C" int dbg_rccl_comm_destroy(const char* librccl_path, void* comm) {
     if (!comm) return 0;
     if (!load_rccl(librccl_path, &api, &why)) return 2;
     return api.CommDestroy((ncclComm_t)comm) == ncclSuccess ? 0 : 3;
+}
+
+// ---- in-process transport: the ranks are THREADS of one process, one per GPU (or several sharing a GPU) -----------------------
+// A host that drives all GPUs of a node from one process needs no RCCL: device buffers of all ranks live in one address space, so
+// the variable all-to-all is a set of hipMemcpyAsync device-to-device copies (peer copies over xGMI between different GPUs) issued by
+// the RECEIVING rank on its own stream, between two barriers of the ranks' threads.  Small reductions go through a shared host
+// array.  Synchronous in the sense of the contract (an operation drains the caller's stream, moves the data, returns).  Also what
+// tests/cpp/test_shard_threads.cpp runs the rank-spanning entry points with: N ranks on the one GPU of the test box, no Python.
+#include <condition_variable>
+#include <thread>
+namespace {
+struct InprocShared {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    bool broken = false;
+    // what every rank publishes for the operation in flight
+    std::vector<const void*> ptr;                  // send buffer / reduction input (device)
+    std::vector<std::vector<uint64_t>> off, bytes; // all_to_allv: per destination
+    std::vector<std::vector<uint64_t>> host;       // all_reduce / all_gather staging (host)
+    // point to point: mailbox[to][from]
+    struct Mail { const void* p = nullptr; uint64_t bytes = 0; bool full = false, taken = false; };
+    std::vector<std::vector<Mail>> mail;
+    int refs = 0;
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return true; }
+        // a rank that never arrives (its entry point failed) must not hang the others for ever
+        if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen || broken; })) { broken = true; cv.notify_all(); return false; }
+        return !broken;
+    }
+};
+struct InprocTransport {
+    dbg_transport tab;
+    InprocShared* sh;
+};
+
+int ip_sync(void* stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? 0 : 1; }
+
+int ip_all_reduce(void* self, uint64_t* buf, uint64_t n, int32_t op, void* stream) {
+    InprocTransport* t = (InprocTransport*)self;
+    InprocShared* sh = t->sh;
+    const int me = t->tab.rank, W = sh->world;
+    std::vector<uint64_t>& mine = sh->host[me];
+    mine.resize(n);
+    if (n && hipMemcpyAsync(mine.data(), buf, n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 1;
+    if (ip_sync(stream) || !sh->barrier()) return 1;
+    std::vector<uint64_t> acc(n, 0);
+    for (int r = 0; r < W; r++) {
+        const std::vector<uint64_t>& v = sh->host[r];
+        if (v.size() != n) return 1;                                    // the ranks disagree about the operation
+        for (uint64_t i = 0; i < n; i++) acc[i] = op == 1 ? std::max(acc[i], v[i]) : acc[i] + v[i];
+    }
+    if (!sh->barrier()) return 1;                                       // everybody has read the slots
+    if (n && hipMemcpyAsync(buf, acc.data(), n * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
+    return ip_sync(stream);                                             // `acc` leaves scope
+}
+int ip_all_gather(void* self, const void* send, void* recv, uint64_t bytes, void* stream) {
+    InprocTransport* t = (InprocTransport*)self;
+    InprocShared* sh = t->sh;
+    const int me = t->tab.rank, W = sh->world;
+    sh->ptr[me] = send;
+    if (ip_sync(stream) || !sh->barrier()) return 1;
+    for (int r = 0; r < W; r++)
+        if (bytes && hipMemcpyAsync((char*)recv + (uint64_t)r * bytes, sh->ptr[r], bytes, hipMemcpyDefault, (hipStream_t)stream) != hipSuccess) return 1;
+    if (ip_sync(stream) || !sh->barrier()) return 1;                    // the senders' buffers may change again
+    return 0;
+}
+int ip_all_to_allv(void* self, const void* send, const uint64_t* soff, const uint64_t* sbytes, void* recv, const uint64_t* roff,
+                   const uint64_t* rbytes, void* stream) {
+    InprocTransport* t = (InprocTransport*)self;
+    InprocShared* sh = t->sh;
+    const int me = t->tab.rank, W = sh->world;
+    sh->ptr[me] = send;
+    sh->off[me].assign(soff, soff + W);
+    sh->bytes[me].assign(sbytes, sbytes + W);
+    if (ip_sync(stream) || !sh->barrier()) return 1;
+    for (int i = 0; i < W; i++) {
+        const int s = (me + i) % W;
+        if (sh->bytes[s][me] != rbytes[s]) return 1;                    // sender and receiver disagree about the message
+        if (rbytes[s] && hipMemcpyAsync((char*)recv + roff[s], (const char*)sh->ptr[s] + sh->off[s][me], rbytes[s], hipMemcpyDefault, (hipStream_t)stream) != hipSuccess)
+            return 1;
+    }
+    if (ip_sync(stream) || !sh->barrier()) return 1;
+    return 0;
+}
+int ip_send(void* self, const void* buf, uint64_t bytes, int32_t peer, void* stream) {
+    InprocTransport* t = (InprocTransport*)self;
+    InprocShared* sh = t->sh;
+    if (peer < 0 || peer >= sh->world || ip_sync(stream)) return 1;
+    InprocShared::Mail& m = sh->mail[peer][t->tab.rank];
+    std::unique_lock<std::mutex> lk(sh->mu);
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(300), [&] { return !m.full || sh->broken; }) || sh->broken) return 1;
+    m.p = buf; m.bytes = bytes; m.full = true; m.taken = false;
+    sh->cv.notify_all();
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(300), [&] { return m.taken || sh->broken; }) || sh->broken) return 1;   // the receiver has copied
+    m.full = false;
+    sh->cv.notify_all();
+    return 0;
+}
+int ip_recv(void* self, void* buf, uint64_t bytes, int32_t peer, void* stream) {
+    InprocTransport* t = (InprocTransport*)self;
+    InprocShared* sh = t->sh;
+    if (peer < 0 || peer >= sh->world) return 1;
+    InprocShared::Mail& m = sh->mail[t->tab.rank][peer];
+    const void* src = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(sh->mu);
+        if (!sh->cv.wait_for(lk, std::chrono::seconds(300), [&] { return (m.full && !m.taken) || sh->broken; }) || sh->broken) return 1;
+        if (m.bytes != bytes) { sh->broken = true; sh->cv.notify_all(); return 1; }
+        src = m.p;
+    }
+    int rc = 0;
+    if (bytes && hipMemcpyAsync(buf, src, bytes, hipMemcpyDefault, (hipStream_t)stream) != hipSuccess) rc = 1;
+    if (!rc) rc = ip_sync(stream);
+    std::unique_lock<std::mutex> lk(sh->mu);
+    m.taken = true;
+    if (rc) sh->broken = true;
+    sh->cv.notify_all();
+    return rc;
+}
+std::mutex g_inproc_mu;
+}  // namespace
+
+extern "C" int dbg_transport_inprocess_create(int32_t world, dbg_transport** out /* [world] */) {
+    if (world < 1 || world > 64 || !out) return 1;
+    InprocShared* sh = new InprocShared();
+    sh->world = world;
+    sh->ptr.assign(world, nullptr);
+    sh->off.assign(world, {}); sh->bytes.assign(world, {}); sh->host.assign(world, {});
+    sh->mail.assign(world, std::vector<InprocShared::Mail>(world));
+    sh->refs = world;
+    for (int r = 0; r < world; r++) {
+        InprocTransport* t = new InprocTransport();
+        t->sh = sh;
+        t->tab.self = t; t->tab.rank = r; t->tab.world = world;
+        t->tab.all_reduce_u64 = ip_all_reduce; t->tab.all_gather = ip_all_gather; t->tab.all_to_allv = ip_all_to_allv;
+        t->tab.send = ip_send; t->tab.recv = ip_recv;
+        out[r] = &t->tab;
+    }
+    return 0;
+}
+
+extern "C" void dbg_transport_destroy(dbg_transport* t) {
+    if (!t || t->self != (void*)t) return;                  // not a table this library made
+    if (t->all_reduce_u64 == rccl_all_reduce) { delete (RcclTransport*)t->self; return; }
+    if (t->all_reduce_u64 == ip_all_reduce) {
+        InprocTransport* it = (InprocTransport*)t->self;
+        InprocShared* sh = it->sh;
+        bool last;
+        { std::lock_guard<std::mutex> g(g_inproc_mu); last = --sh->refs == 0; }
+        delete it;
+        if (last) delete sh;
+    }
 }
 
 // ---- exchange geometry: pure host arithmetic, identical on every rank ---------------------------------------------------
