@@ -65,10 +65,14 @@ __device__ __forceinline__ int64_t find_key_rec(const KeysDev& t, K128 q, uint32
     }
     return -1;
 }
-__global__ void pack_keys_kernel(KeysDev t, const uint8_t* __restrict__ exts, ulonglong2* __restrict__ rec) {
+// (sorted_flag, optional: |= 1 unless the keys are strictly ascending -- the check the device-resident entry point needs, made
+//  while the keys are in registers anyway instead of in a pass of its own)
+__global__ void pack_keys_kernel(KeysDev t, const uint8_t* __restrict__ exts, ulonglong2* __restrict__ rec, uint32_t* __restrict__ sorted_flag = nullptr) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n) return;
-    rec[i] = make_ulonglong2(t.lo[i], (t.hi ? t.hi[i] : 0ull) | ((uint64_t)exts[i] << 56));
+    const uint64_t lo = t.lo[i], hi = t.hi ? t.hi[i] : 0ull;
+    rec[i] = make_ulonglong2(lo, hi | ((uint64_t)exts[i] << 56));
+    if (sorted_flag && i && !k128_lt(key_at(t, i - 1), K128{hi, lo})) atomicOr(sorted_flag, 1u);
 }
 
 __device__ __forceinline__ bool is_palindrome(K128 a, int k) { return (k & 1) == 0 && k128_eq(a, kmer_rc(a, k)); }   // lib.rs:244-246
@@ -269,10 +273,10 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
                           dbg_graph* out, bool* done, const UnitigNodes* nodes = nullptr, const NodeRec* nrec = nullptr);
 
 // packed {key, Exts} records for the link builder's probes (k <= 60); *t gets them attached
-static int attach_key_records(dbg_ctx* c, KeysDev* t, int k, const uint8_t* exts_dev, DBuf<ulonglong2>* store) {
+static int attach_key_records(dbg_ctx* c, KeysDev* t, int k, const uint8_t* exts_dev, DBuf<ulonglong2>* store, uint32_t* sorted_flag = nullptr) {
     if (k > 60 || !t->n || c->opt("DBG_NO_KEY_RECORDS")) return 0;
     ALLOC_OR_FAIL(c, (*store), t->n);
-    pack_keys_kernel<<<cdiv(t->n, 256), 256, 0, c->stream>>>(*t, exts_dev, store->p);
+    pack_keys_kernel<<<cdiv(t->n, 256), 256, 0, c->stream>>>(*t, exts_dev, store->p, sorted_flag);
     LAUNCH_CHECK(c, "pack_keys");
     t->rec = store->p;
     return 0;
@@ -500,15 +504,19 @@ extern "C" int dbg_compress_kmers_with_hash_dev(dbg_ctx* c, uint32_t k_, int str
     KeysDev t{has_hi ? key_hi_dev : nullptr, key_lo_dev, n};
     uint32_t fl = 0;
     HIP_TRY(c, hipMemsetAsync(d_flag.p, 0, 4, c->stream));
-    sorted_check_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_flag.p);
-    LAUNCH_CHECK(c, "sorted_check");
+    // ascending keys are checked BEFORE the prefix index is built (its fill loops assume them); where the packed records are made
+    // the check rides along with the packing, otherwise it is a pass of its own
+    DBuf<ulonglong2> d_rec;
+    DBG_TRY(attach_key_records(c, &t, k, exts_dev, &d_rec, d_flag.p));
+    if (!t.rec) {
+        sorted_check_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(t, d_flag.p);
+        LAUNCH_CHECK(c, "sorted_check");
+    }
     HIP_TRY(c, hipMemcpyAsync(&fl, d_flag.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (fl) return c->fail(49, "dbg_compress_kmers_with_hash_dev needs strictly ascending keys");
     DBuf<uint32_t> d_pidx;
     DBG_TRY(attach_prefix_index(c, &t, k, &d_pidx));
-    DBuf<ulonglong2> d_rec;
-    DBG_TRY(attach_key_records(c, &t, k, exts_dev, &d_rec));
     c->t_begin("compress_links", n);
     DBuf<NodeRec> d_nrec;
     if (!c->opt("DBG_NO_NODE_RECORDS")) (void)d_nrec.alloc(c, n);

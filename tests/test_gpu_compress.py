@@ -181,6 +181,35 @@ def test_device_resident_index(ctx, compress_mode):
         assert graphs_equal(got.arrays(), want.arrays())
 
 
+@pytest.mark.parametrize("k", [47, 63])
+def test_device_resident_index_refuses_unsorted_keys(ctx, k):
+    """dbg_compress_kmers_with_hash_dev needs strictly ascending keys (its neighbour lookups are searches in that order): two rows
+    swapped, or one repeated, and the call fails -- checked while the keys are packed (k <= 60) or in a pass of its own (k > 60)."""
+    import ctypes as C
+    import torch
+    capi = __import__("importlib").import_module("rust-debruijn_amd._capi")
+    rng = np.random.default_rng(k)
+    seqs = [(c, 0, None) for c in R.random_contigs(rng)]
+    t, _ = dbg.filter_kmers(seqs, dbg.CountFilter(1), False, False, 4, k=k, ctx=ctx)
+    n = len(t)
+    assert n > 100
+    for case in ("ok", "swapped", "repeated"):
+        hi, lo = t.key_hi.copy(), t.key_lo.copy()
+        if case == "swapped":
+            hi[[40, 41]], lo[[40, 41]] = hi[[41, 40]], lo[[41, 40]]
+        if case == "repeated":
+            hi[n - 1], lo[n - 1] = hi[n - 2], lo[n - 2]
+        d = [torch.from_numpy(a.view(np.int64)).cuda() for a in (hi, lo)] + [torch.from_numpy(t.exts.copy()).cuda()]
+        torch.cuda.synchronize()
+        g = capi.Graph()
+        rc = ctx.lib.dbg_compress_kmers_with_hash_dev(ctx.h, k, 0, 0, n, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), None, None, C.byref(g))
+        if case == "ok":
+            assert rc == 0 and g.n_nodes > 0
+            ctx.lib.dbg_free_graph(ctx.h, C.byref(g))
+        else:
+            assert rc != 0 and b"ascending" in ctx.lib.dbg_last_error(ctx.h)
+
+
 @pytest.mark.parametrize("k,stranded,spec_i", [(47, False, 0), (31, True, 2), (63, False, 1)])
 def test_compress_long_chains(ctx, compress_mode, k, stranded, spec_i):
     """Error-free reads of a random genome: a handful of nodes, each tens of thousands of k-mers long.  The chain route
