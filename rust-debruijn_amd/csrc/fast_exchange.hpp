@@ -57,9 +57,14 @@ __global__ void __launch_bounds__(256) gather_u64_kernel(const uint64_t* __restr
     if (i < n) out[i] = src[idx[i]];
 }
 
-__global__ void __launch_bounds__(256) widen_u32_u64_kernel(const uint32_t* __restrict__ in, uint32_t n, uint64_t* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
+// records per coarse group of f consecutive bins (the last group may be shorter)
+__global__ void __launch_bounds__(256) coarse_hist_kernel(const uint32_t* __restrict__ count, uint32_t nb, uint32_t f, uint32_t ng, uint64_t* __restrict__ out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    uint64_t s = 0;
+    const uint32_t lo = g * f, hi = lo + f < nb ? lo + f : nb;
+    for (uint32_t b = lo; b < hi; b++) s += count[b];
+    out[g] = s;
 }
 
 // Segment tables of all rounds from the scanned per-source counts.  G[s * nbl + j] = records of source s (in source order: self
@@ -197,16 +202,25 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     std::vector<uint32_t> bounds(W + 1);
     const bool balance = p->balance != 0 && W > 1;
     if (balance) {
+        // Records per COARSE group of f consecutive bins (f a power of two that leaves every rank >= 4096 groups to be cut from): the
+        // all-reduce and the host's greedy cut then handle 10^4..10^5 values instead of one per bin -- at eight ranks of 10^8 reads
+        // the per-bin form was 67 MB through pageable memory and two host loops over 8*10^6 entries, every step.  Ownership boundaries
+        // become multiples of f bins: a granularity of f / (bins per rank) <= 1/4096 of a rank's share.
+        uint32_t f = 1;
+        while ((uint64_t)f * 2 * 4096 * W <= nb) f *= 2;
+        const uint32_t ng = (nb + f - 1) / f;
         DBuf<uint64_t> gh;
-        ALLOC_OR_FAIL(c, gh, nb);
-        widen_u32_u64_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(sc.cursor.p, nb, gh.p);
-        LAUNCH_CHECK(c, "widen_u32_u64");
-        if (tr->all_reduce_u64(tr->self, gh.p, nb, 0, c->stream)) return tr_fail(c, "all_reduce_u64 (record histogram)");
-        std::vector<uint64_t> hh(nb);
-        HIP_TRY(c, hipMemcpyAsync(hh.data(), gh.p, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+        ALLOC_OR_FAIL(c, gh, ng);
+        coarse_hist_kernel<<<cdiv(ng, 256), 256, 0, c->stream>>>(sc.cursor.p, nb, f, ng, gh.p);
+        LAUNCH_CHECK(c, "coarse_hist");
+        if (tr->all_reduce_u64(tr->self, gh.p, ng, 0, c->stream)) return tr_fail(c, "all_reduce_u64 (record histogram)");
+        std::vector<uint64_t> hh(ng);
+        HIP_TRY(c, hipMemcpyAsync(hh.data(), gh.p, (size_t)ng * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        static_assert(NCLS == 1, "group histogram = bin histogram");
-        if (dbg_shard_owner_bounds(hh.data(), nb, NCLS, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
+        static_assert(NCLS == 1, "a coarse group is f whole bin groups");
+        if (dbg_shard_owner_bounds(hh.data(), ng, 1, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
+        for (uint32_t r = 0; r <= W; r++) bounds[r] = (uint32_t)std::min<uint64_t>((uint64_t)bounds[r] * f, nb);
+        bounds[W] = nb;
     } else if (dbg_shard_owner_bounds(nullptr, nb, NCLS, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
     S->balanced = balance ? 1 : 0;
     S->owned_lo = bounds[me]; S->owned_hi = bounds[me + 1];
