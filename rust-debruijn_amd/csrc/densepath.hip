@@ -13,12 +13,15 @@
 // first, because a few thousand hot addresses would serialise the device's atomic units.
 #include "dbg_internal.hpp"
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out);      // fastpath.hip
 
 namespace {
 constexpr int DENSE_LDS_K = 7;                  // k <= 7: 4^k x u32 fits a workgroup's LDS
+constexpr int DENSE_RANGE_K = 8;                // k = 8: two key-range passes with 32768 counters in LDS each: 12 -> 67 Gkmer/s.  (k = 9 would take
+                                                // eight passes: measured 157 ms against 154 for the global atomics -- no gain, not enabled)
 
 __device__ __forceinline__ uint32_t load_label(const void* data, uint32_t width, uint64_t i) {
     if (width == 1) return ((const uint8_t*)data)[i];
@@ -26,11 +29,17 @@ __device__ __forceinline__ uint32_t load_label(const void* data, uint32_t width,
     return ((const uint32_t*)data)[i];
 }
 
-template <bool STRANDED, bool IS_SET, bool LDS_COUNT>
-__global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, unsigned long long* __restrict__ tab) {
+// LDS_COUNT: 0 = every count is a global atomic; 1 = the whole key space in this workgroup's LDS (k <= 7); 2 (round 4, k = 8) = the
+// key space cut into ranges of DENSE_RANGE keys, blockIdx.y names the range: every range pass walks all reads and counts the k-mers
+// of its range in 128 KB of LDS (one 1024-thread workgroup per CU) -- re-extracting a k-mer is ~45 vector instructions, an
+// uncontended LDS atomic a few cycles, against a device atomic on one of 3*10^4..1.3*10^5 hot addresses.
+constexpr uint32_t DENSE_RANGE_BITS = 15, DENSE_RANGE = 1u << DENSE_RANGE_BITS;
+template <bool STRANDED, bool IS_SET, int LDS_COUNT>
+__global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kernel(SeqDev s, int k, unsigned long long* __restrict__ tab) {
     constexpr uint32_t ES = IS_SET ? 2 : 1;                          // 64-bit words per entry: {count | Exts << 40} [, label mask]
-    extern __shared__ uint32_t s_cnt[];                              // LDS_COUNT: 4^k counters of this workgroup
-    const uint32_t nkeys = 1u << (2 * k);
+    extern __shared__ uint32_t s_cnt[];                              // LDS_COUNT: counters of this workgroup (4^k, or one range)
+    const uint32_t nkeys = LDS_COUNT == 2 ? DENSE_RANGE : 1u << (2 * k);
+    const uint32_t range = LDS_COUNT == 2 ? blockIdx.y : 0u;
     if (LDS_COUNT) {
         for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
@@ -47,27 +56,32 @@ __global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, unsig
         unsigned long long lbit = 0;
         if (IS_SET) lbit = 1ull << (s.data ? load_label(s.data, s.data_width, si) & 63u : 0u);
         for (uint32_t j = lane; j < nk; j += 64) {
-            // the k-mer (at most 30 bits) lies in two consecutive words; both are fetched unconditionally (index clamped to the buffer)
-            K128 km;
-            {
-                const uint64_t o = st + j, wi = o >> 5;
-                const int sft = (int)(o & 31) * 2;
-                const uint64_t w0 = s.words[wi], w1 = s.words[wi + 1 < s.n_words ? wi + 1 : wi];
-                const uint64_t top = sft ? (w0 << sft) | (w1 >> (64 - sft)) : w0;
-                km = K128{0ull, top >> (64 - 2 * k)};
-            }
-            // lib.rs:820-832: interior exts from the neighbouring bases, boundary exts from seq_exts
-            const uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << packed_get(s.words, st + j - 1));
-            const uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << packed_get(s.words, st + j + k));
-            uint32_t ex = left | right;
+            // the k-mer (at most 30 bits) and its right neighbour lie in two consecutive words; both are fetched unconditionally (index
+            // clamped to the buffer); the left neighbour is in the first of them, or the last base of the word before when the k-mer starts a word
+            const uint64_t o = st + j, wi = o >> 5;
+            const uint32_t bo = (uint32_t)(o & 31);
+            const int sft = (int)bo * 2;
+            // (all three loads are issued unconditionally: a word load inside a divergent branch is what tools/micro/kmer_fetch.hip
+            //  showed returning wrong words for whole wavefronts -- round 3; the selection is done on the loaded values)
+            const uint64_t w0 = s.words[wi], w1 = s.words[wi + 1 < s.n_words ? wi + 1 : wi], wm = s.words[wi ? wi - 1 : 0];
+            const uint64_t top = sft ? (w0 << sft) | (w1 >> (64 - sft)) : w0;
+            K128 km{0ull, top >> (64 - 2 * k)};
+            bool flip = false;
             if (!STRANDED) {
                 const K128 rc = kmer_rc(km, k);
-                if (!k128_lt(km, rc)) { km = rc; ex = exts_rc(ex); }             // ties flip (lib.rs:226-230)
+                if (!k128_lt(km, rc)) { km = rc; flip = true; }                  // ties flip (lib.rs:226-230)
             }
             const uint32_t key = (uint32_t)km.lo;
+            if (LDS_COUNT == 2 && (key >> DENSE_RANGE_BITS) != range) continue;          // another range pass counts it
+            // lib.rs:820-832: interior exts from the neighbouring bases, boundary exts from seq_exts
+            auto base_at = [&](uint32_t q) -> uint32_t { return (uint32_t)((q < 32 ? w0 >> (62 - 2 * q) : w1 >> (62 - 2 * (q - 32))) & 3ull); };
+            const uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << (bo ? base_at(bo - 1) : (uint32_t)(wm & 3ull)));
+            const uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << base_at(bo + (uint32_t)k));
+            uint32_t ex = left | right;
+            if (flip) ex = exts_rc(ex);
             unsigned long long* e = tab + (uint64_t)key * ES;
             unsigned long long old;
-            if (LDS_COUNT) { atomicAdd(&s_cnt[key], 1u); old = e[0]; }
+            if (LDS_COUNT) { atomicAdd(&s_cnt[LDS_COUNT == 2 ? key & (DENSE_RANGE - 1) : key], 1u); old = e[0]; }
             else old = atomicAdd(&e[0], 1ull);
             // (a stale value can only lack bits that are set by now: the OR is then sent needlessly, never skipped wrongly)
             if (((uint32_t)(old >> 40) & ex) != ex) atomicOr(&e[0], (unsigned long long)ex << 40);
@@ -76,7 +90,10 @@ __global__ void __launch_bounds__(256) dense_count_kernel(SeqDev s, int k, unsig
     }
     if (LDS_COUNT) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) { const uint32_t v = s_cnt[i]; if (v) atomicAdd(&tab[(uint64_t)i * ES], (unsigned long long)v); }
+        for (uint32_t i = threadIdx.x; i < nkeys; i += blockDim.x) {
+            const uint32_t v = s_cnt[i];
+            if (v) atomicAdd(&tab[(uint64_t)(LDS_COUNT == 2 ? range * DENSE_RANGE + i : i) * ES], (unsigned long long)v);
+        }
     }
 }
 
@@ -190,11 +207,15 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     if (s.n && n_kmers) {
         const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 3) / 4, 256ull * 16));
         const bool lds = k <= DENSE_LDS_K;
-        const size_t shm = lds ? (size_t)nkeys * 4 : 0;
+        // k = 8: key-range passes with the counts in LDS (DBG_DENSE_RANGES=0: the global-atomic form, for A/B measurements)
+        const bool ranges = !lds && k <= DENSE_RANGE_K && !(c->opt("DBG_DENSE_RANGES") && !strcmp(c->opt("DBG_DENSE_RANGES"), "0"));
+        const size_t shm = lds ? (size_t)nkeys * 4 : (ranges ? (size_t)DENSE_RANGE * 4 : 0);
+        const dim3 grid = ranges ? dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 15) / 16, 256ull)), nkeys >> DENSE_RANGE_BITS) : dim3(blocks);
+        const uint32_t threads = ranges ? 1024u : 256u;
         c->t_begin("dense_count", n_kmers);
 #define DL(ST, SET, LD) do { if (shm) HIP_TRY(c, hipFuncSetAttribute((const void*)dense_count_kernel<ST, SET, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        dense_count_kernel<ST, SET, LD><<<blocks, 256, shm, c->stream>>>(s, k, tab.p); } while (0)
-#define DGO(ST, SET) do { if (lds) DL(ST, SET, true); else DL(ST, SET, false); } while (0)
+        dense_count_kernel<ST, SET, LD><<<grid, threads, shm, c->stream>>>(s, k, tab.p); } while (0)
+#define DGO(ST, SET) do { if (lds) DL(ST, SET, 1); else if (ranges) DL(ST, SET, 2); else DL(ST, SET, 0); } while (0)
         if (stranded) { if (is_set) DGO(true, true); else DGO(true, false); }
         else { if (is_set) DGO(false, true); else DGO(false, false); }
 #undef DGO
