@@ -3,10 +3,12 @@
 R=r04
 export PYTHONUNBUFFERED=1
 mkdir -p gpurun_out
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; tail -c 300 gpurun_out/${R}_bench_default.json; echo
 timeout 400 bash tools/prof.sh $R --no-host-boundary > gpurun_out/prof_$R.log 2>&1; tail -3 gpurun_out/prof_$R.log
 timeout 900 bash tools/pmc.sh $R --reads 60000000 --steps 2 --warmup 0 --no-cpu-baseline --compress-reads 0 --no-host-boundary > gpurun_out/pmc_$R.log 2>&1
 python tools/pmc_traffic.py gpurun_out/pmc_$R gpurun_out/${R}_pmc_traffic_60Mreads.json $((60000000*104*2)) 2 > gpurun_out/pmc_${R}_traffic.log 2>&1; tail -3 gpurun_out/pmc_${R}_traffic.log
+# the default bench AFTER the counter passes: it reads the traffic file of this very tree (profiles/ on the box; copy it home afterwards)
+cp gpurun_out/${R}_pmc_traffic_60Mreads.json profiles/
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; tail -c 300 gpurun_out/${R}_bench_default.json; echo
 PMC_SCRIPT=tools/bench_compress.py timeout 900 bash tools/pmc.sh ${R}_compress 10000000 none > gpurun_out/pmc_${R}_compress.log 2>&1; tail -2 gpurun_out/pmc_${R}_compress.log
 timeout 900 bash tools/other_configs.sh $R > gpurun_out/${R}_other_configs.log 2>&1; tail -2 gpurun_out/${R}_other_configs.log
 cd /tmp && export TMPDIR=/tmp
