@@ -42,6 +42,7 @@ extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
