@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ start_by_rank, uint32_t* __restrict__ seed_by_rank,
                                                          uint32_t* __restrict__ next, unsigned long long* __restrict__ kmers_seen,
                                                          uint32_t* __restrict__ capped,
-                                                         const NodeRec* __restrict__ nrec /* or null */, uint32_t* __restrict__ link_flags) {
+                                                         const NodeRec* __restrict__ nrec /* or null */, uint32_t* __restrict__ link_flags,
+                                                         uint32_t* __restrict__ done_bits = nullptr /* one bit per state: its chain has been walked from the other end */) {
     // With node records both links of a k-mer arrive in the one line a step reads, so the walk itself verifies that every link
     // it takes is answered by the facing link of its target (check_links_kernel's test; every link of an open chain is taken
     // by one of the chain's two walkers): *link_flags |= 2 on a mismatch.
@@ -490,7 +491,11 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
             T = ends[item];
             cur = T >> 1; face = T & 1u;                          // `face` = the side of cur that points towards T
             m = 0; best = R_INF; expect_back = U_TERM;
-            active = true;
+            // ONE walk per chain (round 4): the walker that reaches a chain's far end marks that end, and an end that is marked when
+            // its turn comes is skipped.  A stale or late mark only costs a second walk (both then find the same seed, length and left
+            // end; the claim on flag_by_rank lets one of them record).  With the ends dealt in list order to ~5*10^5 walkers at a
+            // time, ~97 % of the chains are walked once instead of twice.
+            active = !(done_bits && ((__hip_atomic_load(&done_bits[T >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (T & 31u)) & 1u));
         }
         if (!__any(active)) {
             if (wf.done()) break;
@@ -510,7 +515,17 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
                 expect_back = (cur << 1) | face;                   // what the next k-mer's facing link must say
             } else more = state_usable(link, nullptr, n, cur, 1u - face, &L);
             if (!more) {                                           // far end reached
-                if (seed_left_faces_T) {                           // T is the left end of the unitig
+                const uint32_t F = (cur << 1) | (1u - face);       // the far end as a state: (k-mer, its terminal side)
+                if (done_bits) {
+                    // the left end of the unitig (in the seed's stored orientation) is T when the seed's left side faces T, else F
+                    if (atomicCAS(&flag_by_rank[best], 0u, 1u) == 0u) {
+                        len_by_rank[best] = m + (uint32_t)k - 1;
+                        start_by_rank[best] = seed_left_faces_T ? T : F;
+                        seed_by_rank[best] = seed;
+                        total += m;
+                    }
+                    if (F != T) atomicOr(&done_bits[F >> 5], 1u << (F & 31u));
+                } else if (seed_left_faces_T) {                    // two walks per chain: the one that started at the left end records
                     flag_by_rank[best] = 1;
                     len_by_rank[best] = m + (uint32_t)k - 1;
                     start_by_rank[best] = T;
@@ -684,10 +699,16 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         uint32_t n_ends = 0;
         HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        DBuf<uint32_t> done_bits;
+        const bool one_walk = !(c->opt("DBG_CHAIN_WALKS") && !strcmp(c->opt("DBG_CHAIN_WALKS"), "2"));
+        if (n_ends && one_walk) {
+            ALLOC_OR_FAIL(c, done_bits, (size_t)(n2 + 31) / 32 + 1);
+            HIP_TRY(c, hipMemsetAsync(done_bits.p, 0, ((size_t)(n2 + 31) / 32 + 1) * 4, c->stream));
+        }
         if (n_ends) {
             chain_scan_kernel<<<std::min<uint32_t>(cdiv(n_ends, 256), 2048), 256, 0, c->stream>>>(
                 link_dev, rank_dev, n, LA.p, n_ends, k, flag_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p,
-                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, links_checked ? nullptr : nrec, flags.p);
+                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, links_checked ? nullptr : nrec, flags.p, done_bits.p);
             LAUNCH_CHECK(c, "chain_scan");
         }
         uint32_t res[4] = {0, 0, 0, 0};
