@@ -1050,6 +1050,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
                     const uint32_t wg = (s_w[tid >> 1] >> (16 * (tid & 1u))) & 0xffffu;
                     const uint32_t rl = (uint32_t)(s_slab[(NBW - 1) * NT + tid] & 0x7f);
                     nkr = wg ? rl - (uint32_t)k + 1u : 0u;
+#ifdef DBG_ABL_DROP_CUT   // measurement only (WRONG counts): pieces cut by a read end are not expanded -- the bound on what merging them into their whole piece can save
+                    { const uint32_t rx = (uint32_t)(s_slab[(NBW - 1) * NT + tid] >> 7) & 0xffu; if (((rx & 0xfu) == 0u) != ((rx & 0xf0u) == 0u)) nkr = 0u; }
+#endif
                 }
                 if (tid == 0) { s_m = nstaged; s_cproc = 0; s_nextq = 0; }
                 // Chunks are entered into the map by length (CH, CH-1, ..., 1): the 64 chunks a wave takes then roll the
