@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t load_label(const void* data, uint32_t width,
 // uncontended LDS atomic a few cycles, against a device atomic on one of 3*10^4..1.3*10^5 hot addresses.
 constexpr uint32_t DENSE_RANGE_BITS = 15, DENSE_RANGE = 1u << DENSE_RANGE_BITS;
 template <bool STRANDED, bool IS_SET, int LDS_COUNT>
-__global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kernel(SeqDev s, int k, unsigned long long* __restrict__ tab) {
+__global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, unsigned long long* __restrict__ tab) {
     constexpr uint32_t ES = IS_SET ? 2 : 1;                          // 64-bit words per entry: {count | Exts << 40} [, label mask]
     extern __shared__ uint32_t s_cnt[];                              // LDS_COUNT: counters of this workgroup (4^k, or one range)
     const uint32_t nkeys = LDS_COUNT == 2 ? DENSE_RANGE : 1u << (2 * k);
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kerne
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t si = wave; si < s.n; si += n_waves) {
+    for (uint64_t si = r0 + wave; si < r1; si += n_waves) {
         const uint32_t len = s.length[si];
         if (len < (uint32_t)k) continue;                                       // lib.rs:813
         const uint64_t st = s.start[si];
@@ -94,6 +94,291 @@ __global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kerne
             const uint32_t v = s_cnt[i];
             if (v) atomicAdd(&tab[(uint64_t)(LDS_COUNT == 2 ? range * DENSE_RANGE + i : i) * ES], (unsigned long long)v);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 9 <= k <= 15 (round 4): PARTITION, then count in LDS.  A directly addressed table needs one device atomic per k-mer instance, and random
+// device-scope atomics complete at 1.7-2.4*10^10 per second whatever is done to them (tools/micro/atomic_noret.hip): 13-23 Gkmer/s.
+// Instead the instances -- {key bits | Exts [| label]} words of 4 (CountFilter) or 8 bytes (CountFilterSet) -- are first brought into the
+// order of their key's top bits: final partition f = key >> 15 holds the instances of 32768 consecutive keys, which one workgroup then
+// counts in 128 KB of LDS and adds to the table's entries f * 32768 ... (its own: no atomics).  The partitioning is a counting sort in
+// at most two levels of <= 256 parts: (A) one pass over the reads counts the instances of every final partition (LDS histogram per
+// workgroup, flushed once) -> exact offsets; (B) a second pass extracts the instances and scatters them by the top <= 8 key bits:
+// a wavefront collects 2048 instances in LDS, ranks them within their part with LDS atomics, reserves every part's stretch of the
+// tile with ONE global atomic and writes the instances there; (C, k >= 12) the same again inside every level-1 part on the next <= 7
+// bits; (D) count.  Exts and labels are ORed into the table entry only where bits are missing, as in the kernels above (the entries of a
+// partition are 256-512 KB: cache-resident while its workgroup runs).  Reads are taken in batches that bound the two instance buffers.
+// ------------------------------------------------------------------------------------------------
+#ifndef DBG_PART_TILE1
+#define DBG_PART_TILE1 1024
+#endif
+#ifndef DBG_PART_TILE2
+#define DBG_PART_TILE2 2048
+#endif
+constexpr uint32_t PART_TILE1 = DBG_PART_TILE1, PART_TILE2 = DBG_PART_TILE2;     // instances a wavefront collects before it writes them out (level 1 / level 2)
+constexpr uint32_t PART_MAX = 256;              // parts per level
+template <bool IS_SET> struct DenseInst { typedef uint32_t type; };
+template <> struct DenseInst<true> { typedef unsigned long long type; };
+// instance word: CountFilter  u32 = key bits (< 2^24) | Exts << 24;  CountFilterSet  u64 = key bits | Exts << 32 | label << 40
+template <bool IS_SET> __device__ __forceinline__ typename DenseInst<IS_SET>::type dense_inst_make(uint32_t keybits, uint32_t ex, uint32_t label) {
+    if (IS_SET) return (typename DenseInst<IS_SET>::type)((unsigned long long)keybits | ((unsigned long long)ex << 32) | ((unsigned long long)label << 40));
+    return (typename DenseInst<IS_SET>::type)(keybits | (ex << 24));
+}
+__device__ __forceinline__ uint32_t dense_inst_key(uint32_t w) { return w & 0xffffffu; }
+__device__ __forceinline__ uint32_t dense_inst_key(unsigned long long w) { return (uint32_t)w; }
+__device__ __forceinline__ uint32_t dense_inst_ex(uint32_t w) { return w >> 24; }
+__device__ __forceinline__ uint32_t dense_inst_ex(unsigned long long w) { return (uint32_t)(w >> 32) & 0xffu; }
+
+// k-mer j of a read (iter_kmer_exts + min_rc_flip + Exts::rc, as in dense_count_kernel): canonical key and, when WITH_EX, its Exts
+template <bool STRANDED, bool WITH_EX>
+__device__ __forceinline__ void dense_kmer_at(const SeqDev& s, int k, uint64_t st, uint32_t len, uint32_t sexts, uint32_t j, uint32_t* key_out, uint32_t* ex_out) {
+    const uint64_t o = st + j, wi = o >> 5;
+    const uint32_t bo = (uint32_t)(o & 31);
+    const int sft = (int)bo * 2;
+    // (unconditional loads, indices clamped: see dense_count_kernel)
+    const uint64_t w0 = s.words[wi], w1 = s.words[wi + 1 < s.n_words ? wi + 1 : wi], wm = s.words[wi ? wi - 1 : 0];
+    const uint64_t top = sft ? (w0 << sft) | (w1 >> (64 - sft)) : w0;
+    K128 km{0ull, top >> (64 - 2 * k)};
+    bool flip = false;
+    if (!STRANDED) {
+        const K128 rc = kmer_rc(km, k);
+        if (!k128_lt(km, rc)) { km = rc; flip = true; }
+    }
+    *key_out = (uint32_t)km.lo;
+    if (WITH_EX) {
+        auto base_at = [&](uint32_t q) -> uint32_t { return (uint32_t)((q < 32 ? w0 >> (62 - 2 * q) : w1 >> (62 - 2 * (q - 32))) & 3ull); };
+        const uint32_t left = j == 0 ? (sexts & 0x0fu) : (1u << (bo ? base_at(bo - 1) : (uint32_t)(wm & 3ull)));
+        const uint32_t right = (j + (uint32_t)k == len) ? (sexts & 0xf0u) : (16u << base_at(bo + (uint32_t)k));
+        uint32_t ex = left | right;
+        if (flip) ex = exts_rc(ex);
+        *ex_out = ex;
+    }
+}
+
+// (A) one pass over the reads [r0, r1) counts, for every wavefront w of the grid and every level-1 part p, the instances that wavefront w of
+// pass (B) -- which takes the same reads: read r0 + w, r0 + w + n_waves, ... -- will write into part p: wave_cnt[p * n_waves + w].  Scanned in
+// that order they are every wavefront's exact offsets: pass (B) needs no shared cursor.  With a second level, the instances of every final
+// partition are counted too (one LDS histogram per workgroup, flushed once).
+template <bool STRANDED>
+__global__ void __launch_bounds__(1024) dense_part_hist_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, uint32_t shift1, uint32_t p1n, uint32_t n_final /* 0: one level */,
+                                                               uint32_t* __restrict__ wave_cnt, unsigned long long* __restrict__ fine_cnt) {
+    extern __shared__ uint32_t s_h[];                                // 16 waves x p1n, then n_final
+    uint32_t* const s_fine = s_h + 16 * p1n;
+    for (uint32_t i = threadIdx.x; i < 16 * p1n + n_final; i += blockDim.x) s_h[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t* const mine = s_h + (threadIdx.x >> 6) * p1n;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t si = r0 + wave; si < r1; si += n_waves) {
+        const uint32_t len = s.length[si];
+        if (len < (uint32_t)k) continue;
+        const uint64_t st = s.start[si];
+        const uint32_t nk = len - (uint32_t)k + 1;
+        for (uint32_t j = lane; j < nk; j += 64) {
+            uint32_t key, ex;
+            dense_kmer_at<STRANDED, false>(s, k, st, len, 0u, j, &key, &ex);
+            atomicAdd(&mine[key >> shift1], 1u);
+            if (n_final) atomicAdd(&s_fine[key >> DENSE_RANGE_BITS], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = lane; p < p1n; p += 64) wave_cnt[(uint64_t)p * n_waves + wave] = mine[p];
+    for (uint32_t i = threadIdx.x; i < n_final; i += blockDim.x) { const uint32_t v = s_fine[i]; if (v) atomicAdd(&fine_cnt[i], (unsigned long long)v); }
+}
+// one level: final partition p starts where its first wavefront's stretch starts
+__global__ void dense_part_fineoff_kernel(const uint64_t* __restrict__ wave_off, uint64_t n_waves, uint32_t p1n, uint64_t* __restrict__ fine_off) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= p1n) fine_off[p] = wave_off[(uint64_t)p * n_waves];
+}
+
+// a wavefront's tile: instances with their part; the tile's instances per part are counted as they arrive
+template <class INST, uint32_t TILE>
+struct PartTile {
+    INST raw[TILE], sorted[TILE];
+    uint8_t part[TILE], spart[TILE];
+    uint32_t hist[PART_MAX], loc[PART_MAX];
+    unsigned long long base[PART_MAX];                               // PRIVATE: where this wavefront's next instance of the part goes
+    unsigned long long delta[PART_MAX];                              // sorted position q of the tile -> out[delta[part] + q]
+};
+// The tile is brought into part order in LDS (counting sort: the parts' counts are known, an instance's place within its part is drawn
+// from the part's LDS counter), every part's stretch of the output is set aside -- from the wavefront's own running offsets when they
+// were computed beforehand (PRIVATE: level 1, where <= 256 cursors shared by every wavefront would be 256 hot addresses: same-address
+// device atomics complete at ~10^8/s), else with one global atomic per part -- and the sorted tile leaves with neighbouring lanes
+// writing neighbouring words (writing each instance straight to its place cost 17 of 30 ms at k = 11: 64 separate 4-byte stores per
+// instruction).
+template <bool PRIVATE, class INST, uint32_t TILE>
+__device__ __forceinline__ void part_tile_flush(PartTile<INST, TILE>& t, uint32_t fill, uint32_t n_parts, unsigned long long* __restrict__ cursor, INST* __restrict__ out) {
+    const uint32_t lane = threadIdx.x;
+    __syncthreads();                                                 // (one wavefront per workgroup: orders the LDS traffic)
+    // exclusive offsets of the parts inside the tile: lane l owns parts 4l .. 4l+3 (PART_MAX = 256)
+    {
+        uint32_t h[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { h[q] = 4 * lane + q < n_parts ? t.hist[4 * lane + q] : 0u; sum += h[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t p = 4 * lane + q;
+            if (p < n_parts) {
+                t.loc[p] = run;
+                unsigned long long at = 0;
+                if (PRIVATE) { at = t.base[p]; t.base[p] = at + h[q]; }
+                else if (h[q]) at = atomicAdd(&cursor[p], (unsigned long long)h[q]);
+                t.delta[p] = at - run;
+                t.hist[p] = 0;
+            }
+            run += h[q];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < fill; i += 64) {
+        const uint32_t p = t.part[i];
+        const uint32_t q = t.loc[p] + atomicAdd(&t.hist[p], 1u);
+        t.sorted[q] = t.raw[i];
+        t.spart[q] = (uint8_t)p;
+    }
+    __syncthreads();
+    for (uint32_t q = lane; q < fill; q += 64) out[t.delta[t.spart[q]] + q] = t.sorted[q];
+    for (uint32_t p = lane; p < n_parts; p += 64) t.hist[p] = 0;
+    __syncthreads();
+}
+
+// (B) level 1: wavefront blockIdx.x extracts the instances of its reads and scatters them by key >> shift1 into its own stretches
+// (wave_off, from pass A); the instance keeps the key bits below
+template <bool STRANDED, bool IS_SET>
+__global__ void __launch_bounds__(64) dense_part_scatter1_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, uint32_t shift1, uint32_t n_parts,
+                                                                 const uint64_t* __restrict__ wave_off, typename DenseInst<IS_SET>::type* __restrict__ out) {
+    typedef typename DenseInst<IS_SET>::type INST;
+    __shared__ PartTile<INST, PART_TILE1> t;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t p = lane; p < PART_MAX; p += 64) { t.hist[p] = 0; t.base[p] = p < n_parts ? wave_off[(uint64_t)p * gridDim.x + blockIdx.x] : 0ull; }
+    __syncthreads();
+    uint32_t fill = 0;                                               // wave-uniform
+    const uint32_t keep = (1u << shift1) - 1u;
+    // a read's length / start / Exts / label are a chain of dependent loads in front of its words: the next read's are requested while
+    // this one is processed (unconditionally, index clamped -- see dense_count_kernel)
+    auto meta_of = [&](uint64_t si, uint32_t& len, uint64_t& st, uint32_t& sexts, uint32_t& label) {
+        len = s.length[si]; st = s.start[si];
+        sexts = s.exts ? s.exts[si] : 0u;
+        label = (IS_SET && s.data) ? load_label(s.data, s.data_width, si) & 63u : 0u;
+    };
+    uint64_t si = r0 + blockIdx.x;
+    uint32_t len_n = 0, sexts_n = 0, label_n = 0;
+    uint64_t st_n = 0;
+    if (si < r1) meta_of(si, len_n, st_n, sexts_n, label_n);
+    for (; si < r1; si += gridDim.x) {
+        const uint32_t len = len_n, sexts = sexts_n, label = label_n;
+        const uint64_t st = st_n;
+        meta_of(si + gridDim.x < r1 ? si + gridDim.x : si, len_n, st_n, sexts_n, label_n);
+        if (len < (uint32_t)k) continue;
+        const uint32_t nk = len - (uint32_t)k + 1;
+        // three windows of 64 k-mers per step (a 150-base read in one): their word loads are all in flight before the first LDS access
+        for (uint32_t j0 = 0; j0 < nk; j0 += 192) {
+            if (fill + 192 > PART_TILE1) { part_tile_flush<true>(t, fill, n_parts, nullptr, out); fill = 0; }
+            uint32_t key[3], ex[3];
+            bool on[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const uint32_t j = j0 + 64u * u + lane;
+                on[u] = j < nk;
+                dense_kmer_at<STRANDED, true>(s, k, st, len, sexts, on[u] ? j : 0u, &key[u], &ex[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const uint64_t bal = __ballot(on[u]);
+                if (on[u]) {
+                    const uint32_t pos = fill + (uint32_t)__popcll(bal & lt), p = key[u] >> shift1;
+                    t.raw[pos] = dense_inst_make<IS_SET>(key[u] & keep, ex[u], label);
+                    t.part[pos] = (uint8_t)p;
+                    atomicAdd(&t.hist[p], 1u);
+                }
+                fill += (uint32_t)__popcll(bal);
+            }
+        }
+    }
+    if (fill) part_tile_flush<true>(t, fill, n_parts, nullptr, out);
+}
+
+// (C) level 2: the instances of level-1 part blockIdx.y, scattered by their next key bits (those above the 15 that name the LDS counter)
+template <bool IS_SET>
+__global__ void __launch_bounds__(64) dense_part_scatter2_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
+                                                                 uint32_t l2, unsigned long long* __restrict__ cursor2, typename DenseInst<IS_SET>::type* __restrict__ out) {
+    typedef typename DenseInst<IS_SET>::type INST;
+    __shared__ PartTile<INST, PART_TILE2> t;
+    const uint32_t lane = threadIdx.x, p1 = blockIdx.y, n_sub = 1u << l2;
+    for (uint32_t p = lane; p < PART_MAX; p += 64) t.hist[p] = 0;
+    __syncthreads();
+    const uint64_t beg = fine_off[(uint64_t)p1 << l2], end = fine_off[(uint64_t)(p1 + 1) << l2];
+    for (uint64_t t0 = beg + (uint64_t)blockIdx.x * PART_TILE2; t0 < end; t0 += (uint64_t)gridDim.x * PART_TILE2) {
+        const uint32_t fill = (uint32_t)(end - t0 < PART_TILE2 ? end - t0 : PART_TILE2);
+        // (eight loads in flight per lane: with the LDS traffic between them the compiler waits for every load where it is used)
+        for (uint32_t i0 = lane; i0 < fill; i0 += 64 * 8) {
+            INST w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u; w[u] = in[t0 + (i < fill ? i : fill - 1)]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + 64u * u;
+                if (i < fill) {
+                    const uint32_t sub = (dense_inst_key(w[u]) >> DENSE_RANGE_BITS) & (n_sub - 1u);
+                    t.raw[i] = w[u];
+                    t.part[i] = (uint8_t)sub;
+                    atomicAdd(&t.hist[sub], 1u);
+                }
+            }
+        }
+        part_tile_flush<false>(t, fill, n_sub, cursor2 + ((uint64_t)p1 << l2), out);
+    }
+}
+
+// (D) count: the instances of final partition blockIdx.x (split blockIdx.y of gridDim.y) in LDS -- count (24 bits) and Exts (8 bits) of a key
+// in one word, so that an instance touches no global memory but its own word (CountFilterSet: the label mask stays in the table entry) --
+// then into the partition's own table entries.  A workgroup's share is taken in stretches of < 2^24 instances: the count cannot carry.
+template <bool IS_SET>
+__global__ void __launch_bounds__(1024) dense_part_count_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
+                                                                unsigned long long* __restrict__ tab) {
+    typedef typename DenseInst<IS_SET>::type INST;
+    constexpr uint32_t ES = IS_SET ? 2 : 1;
+    extern __shared__ uint32_t s_cnt[];                              // DENSE_RANGE words: count | Exts << 24
+    const uint32_t f = blockIdx.x;
+    const uint64_t beg0 = fine_off[f], n = fine_off[f + 1] - beg0;
+    const uint64_t beg = beg0 + n * blockIdx.y / gridDim.y, end = beg0 + n * (blockIdx.y + 1) / gridDim.y;
+    unsigned long long* const mytab = tab + ((uint64_t)f << DENSE_RANGE_BITS) * ES;
+    for (uint64_t c0 = beg; c0 < end; c0 += (1ull << 24) - 1) {
+        const uint64_t c1 = end - c0 < (1ull << 24) - 1 ? end : c0 + (1ull << 24) - 1;
+        for (uint32_t i = threadIdx.x; i < DENSE_RANGE; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+        for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
+            const INST w = in[i];
+            const uint32_t low = dense_inst_key(w) & (DENSE_RANGE - 1), ex = dense_inst_ex(w);
+            const uint32_t old = atomicAdd(&s_cnt[low], 1u);
+            // (a stale value can only lack bits that are set by now: the OR is then sent needlessly, never skipped wrongly)
+            if (((old >> 24) & ex) != ex) atomicOr(&s_cnt[low], ex << 24);
+            if (IS_SET) {
+                unsigned long long* e = mytab + (uint64_t)low * ES;
+                const unsigned long long lbit = 1ull << ((uint32_t)((unsigned long long)w >> 40) & 63u);
+                if ((e[1] & lbit) == 0) atomicOr(&e[1], lbit);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < DENSE_RANGE; i += blockDim.x) {
+            const uint32_t v = s_cnt[i];
+            if (!v) continue;
+            unsigned long long* e = &mytab[(uint64_t)i * ES];
+            const unsigned long long add = (unsigned long long)(v & 0xffffffu), exb = (unsigned long long)(v >> 24) << 40;
+            if (gridDim.y > 1) { atomicAdd(e, add); if ((__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & exb) != exb) atomicOr(e, exb); }
+            else {
+                // the partition is this workgroup's alone: a load and a store that go to the memory side
+                const unsigned long long old = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(e, (old + add) | exb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -204,17 +489,19 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     ALLOC_OR_FAIL(c, t_valid, n_tiles); ALLOC_OR_FAIL(c, t_all, n_tiles); ALLOC_OR_FAIL(c, t_lab, n_tiles);
     ALLOC_OR_FAIL(c, o_valid, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_all, (size_t)n_tiles + 1); ALLOC_OR_FAIL(c, o_lab, (size_t)n_tiles + 1);
     HIP_TRY(c, hipMemsetAsync(tab.p, 0, tab_words * 8, c->stream));
-    if (s.n && n_kmers) {
-        const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 3) / 4, 256ull * 16));
+    // reads [r0_, r1_) counted with one device atomic per instance (k <= 8: in LDS first)
+    auto count_atomic = [&](uint64_t r0_, uint64_t r1_) -> int {
+        const uint64_t nr = r1_ - r0_;
+        const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nr + 3) / 4, 256ull * 16));
         const bool lds = k <= DENSE_LDS_K;
         // k = 8: key-range passes with the counts in LDS (DBG_DENSE_RANGES=0: the global-atomic form, for A/B measurements)
         const bool ranges = !lds && k <= DENSE_RANGE_K && !(c->opt("DBG_DENSE_RANGES") && !strcmp(c->opt("DBG_DENSE_RANGES"), "0"));
         const size_t shm = lds ? (size_t)nkeys * 4 : (ranges ? (size_t)DENSE_RANGE * 4 : 0);
-        const dim3 grid = ranges ? dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 15) / 16, 256ull)), nkeys >> DENSE_RANGE_BITS) : dim3(blocks);
+        const dim3 grid = ranges ? dim3((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nr + 15) / 16, 256ull)), nkeys >> DENSE_RANGE_BITS) : dim3(blocks);
         const uint32_t threads = ranges ? 1024u : 256u;
         c->t_begin("dense_count", n_kmers);
 #define DL(ST, SET, LD) do { if (shm) HIP_TRY(c, hipFuncSetAttribute((const void*)dense_count_kernel<ST, SET, LD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-        dense_count_kernel<ST, SET, LD><<<grid, threads, shm, c->stream>>>(s, k, tab.p); } while (0)
+        dense_count_kernel<ST, SET, LD><<<grid, threads, shm, c->stream>>>(s, r0_, r1_, k, tab.p); } while (0)
 #define DGO(ST, SET) do { if (lds) DL(ST, SET, 1); else if (ranges) DL(ST, SET, 2); else DL(ST, SET, 0); } while (0)
         if (stranded) { if (is_set) DGO(true, true); else DGO(true, false); }
         else { if (is_set) DGO(false, true); else DGO(false, false); }
@@ -222,6 +509,87 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
 #undef DL
         c->t_end();
         LAUNCH_CHECK(c, "dense_count");
+        return 0;
+    };
+    // 9 <= k <= 15: partition, then count in LDS (DBG_DENSE_PART=0: the atomic form, for A/B measurements).  Batches of reads bound the
+    // two instance buffers; a batch whose buffers cannot be had is counted with atomics into the same table.
+    const bool partitioned = k > DENSE_RANGE_K && !(c->opt("DBG_DENSE_PART") && !strcmp(c->opt("DBG_DENSE_PART"), "0"));
+    if (s.n && n_kmers && !partitioned) DBG_TRY(count_atomic(0, s.n));
+    if (s.n && n_kmers && partitioned) {
+        const uint32_t F = 2u * (uint32_t)k - DENSE_RANGE_BITS, n_final = 1u << F;      // final partitions: key >> 15
+        const uint32_t L1 = std::min(F, 8u), L2 = F - L1, P1 = 1u << L1, shift1 = 2u * (uint32_t)k - L1;
+        const uint64_t inst_cap = c->opt("DBG_DENSE_BATCH") ? (uint64_t)atoll(c->opt("DBG_DENSE_BATCH")) : 4000000000ull;
+        const uint64_t reads_per_batch = std::max<uint64_t>(1, (uint64_t)((double)s.n * std::min(1.0, (double)inst_cap / (double)n_kmers)));
+        DBuf<unsigned long long> fine_cnt, cursor;
+        DBuf<uint64_t> fine_off, wave_off;
+        DBuf<uint32_t> wave_cnt;
+        ALLOC_OR_FAIL(c, fine_cnt, n_final); ALLOC_OR_FAIL(c, cursor, n_final); ALLOC_OR_FAIL(c, fine_off, (size_t)n_final + 1);
+        for (uint64_t r0_ = 0; r0_ < s.n; r0_ += reads_per_batch) {
+            const uint64_t r1_ = std::min<uint64_t>(s.n, r0_ + reads_per_batch), nr = r1_ - r0_;
+            // the grid of pass A (16 wavefronts per workgroup) and of pass B (one per workgroup) hold the same number of wavefronts
+            const uint32_t hist_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nr + 15) / 16, 512ull));
+            const uint64_t n_waves = (uint64_t)hist_blocks * 16;
+            ALLOC_OR_FAIL(c, wave_cnt, (size_t)P1 * n_waves); ALLOC_OR_FAIL(c, wave_off, (size_t)P1 * n_waves + 1);
+            if (L2) HIP_TRY(c, hipMemsetAsync(fine_cnt.p, 0, (size_t)n_final * 8, c->stream));
+            c->t_begin("dense_part_hist", n_kmers);
+            {
+                const size_t shm = ((size_t)16 * P1 + (L2 ? n_final : 0)) * 4;
+#define HL(ST) do { HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_hist_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+                dense_part_hist_kernel<ST><<<hist_blocks, 1024, shm, c->stream>>>(s, r0_, r1_, k, shift1, P1, L2 ? n_final : 0u, wave_cnt.p, fine_cnt.p); } while (0)
+                if (stranded) HL(true); else HL(false);
+#undef HL
+            }
+            c->t_end();
+            LAUNCH_CHECK(c, "dense_part_hist");
+            DBG_TRY(scan_exclusive_u32_u64(c, wave_cnt.p, wave_off.p, (uint64_t)P1 * n_waves));
+            if (L2) DBG_TRY(scan_exclusive_u64(c, (const uint64_t*)fine_cnt.p, fine_off.p, n_final));
+            else dense_part_fineoff_kernel<<<cdiv(P1 + 1, 256), 256, 0, c->stream>>>(wave_off.p, n_waves, P1, fine_off.p);
+            uint64_t n_inst = 0;
+            HIP_TRY(c, hipMemcpyAsync(&n_inst, wave_off.p + (uint64_t)P1 * n_waves, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (!n_inst) continue;
+            const size_t isz = is_set ? 8 : 4;
+            DBuf<uint8_t> buf1, buf2;
+            if (!buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * isz))) {        // no room: this batch takes the atomic form
+                buf1.release(); buf2.release();
+                DBG_TRY(count_atomic(r0_, r1_));
+                continue;
+            }
+            c->t_begin("dense_part_scatter", n_kmers);
+            {
+#define SL(ST, SET) dense_part_scatter1_kernel<ST, SET><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p)
+                if (stranded) { if (is_set) SL(true, true); else SL(true, false); }
+                else { if (is_set) SL(false, true); else SL(false, false); }
+#undef SL
+            }
+            LAUNCH_CHECK(c, "dense_part_scatter1");
+            const uint8_t* final_buf = buf1.p;
+            if (L2) {
+                HIP_TRY(c, hipMemcpyAsync(cursor.p, fine_off.p, (size_t)n_final * 8, hipMemcpyDeviceToDevice, c->stream));
+                const dim3 grid(16, P1);
+                if (is_set) dense_part_scatter2_kernel<true><<<grid, 64, 0, c->stream>>>((const unsigned long long*)buf1.p, fine_off.p, L2, cursor.p, (unsigned long long*)buf2.p);
+                else dense_part_scatter2_kernel<false><<<grid, 64, 0, c->stream>>>((const uint32_t*)buf1.p, fine_off.p, L2, cursor.p, (uint32_t*)buf2.p);
+                LAUNCH_CHECK(c, "dense_part_scatter2");
+                final_buf = buf2.p;
+            }
+            c->t_end();
+            c->t_begin("dense_part_count", n_kmers);
+            {
+                const uint32_t splits = std::max(1u, 512u / n_final);
+                const dim3 grid(n_final, splits);
+                const size_t shm = (size_t)DENSE_RANGE * 4;
+                if (is_set) {
+                    HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                    dense_part_count_kernel<true><<<grid, 1024, shm, c->stream>>>((const unsigned long long*)final_buf, fine_off.p, tab.p);
+                } else {
+                    HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+                    dense_part_count_kernel<false><<<grid, 1024, shm, c->stream>>>((const uint32_t*)final_buf, fine_off.p, tab.p);
+                }
+            }
+            c->t_end();
+            LAUNCH_CHECK(c, "dense_part_count");
+            HIP_TRY(c, hipStreamSynchronize(c->stream));               // the buffers go back to the pool
+        }
     }
     c->t_begin("dense_compact", nkeys);
     if (is_set) dense_tile_counts_kernel<true><<<n_tiles, 256, 0, c->stream>>>(tab.p, nkeys, prm->min_kmer_obs, t_valid.p, t_all.p, t_lab.p);

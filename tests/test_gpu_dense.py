@@ -90,3 +90,21 @@ def test_dense_equals_generic_and_refuses_other_shapes(ctx):
     ss = O.SeqSet.from_byte_seqs(seqs, data=rng.integers(0, 200, size=len(seqs)), sizeof_d1=1)
     with pytest.raises(dbg.DbgError):                            # labels >= 64
         dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=12, ctx=ctx)
+
+
+@pytest.mark.parametrize("k", [9, 12, 15])
+def test_dense_partitioned_batches_and_forms(ctx, k):
+    """9 <= k <= 15 count in LDS after partitioning the k-mer instances by their key's top bits (one level for k <= 11, two above).  Reads
+    are taken in batches that bound the instance buffers: with batches of ~5 000 instances (many batches accumulating in one table), with
+    one batch, and in the device-atomic form (DBG_DENSE_PART=0) the table is the oracle's; ragged reads, homopolymers (one hot partition),
+    labels."""
+    rng = np.random.default_rng(900 + k)
+    seqs = random_reads(rng, 400, 2000, 150, False, ragged=True)
+    seqs += [np.zeros(700, np.uint8), np.full(333, 3, np.uint8), np.tile(np.array([0, 1, 2, 3], np.uint8), 100)]
+    data = rng.integers(0, 40, size=len(seqs))
+    for is_set in (False, True):
+        ss = O.SeqSet.from_byte_seqs(seqs, data=data if is_set else None, sizeof_d1=1 if is_set else 0)
+        summ = O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER
+        for opts in (dict(DBG_DENSE_BATCH="5000"), dict(), dict(DBG_DENSE_PART="0")):
+            with ctx.options(**opts):
+                run_dense(ctx, ss, k, summ, 2, False, data_width=1 if is_set else 0)

@@ -18,3 +18,5 @@ cd $GRAFT_REPO_ROOT; grep "dev-index" gpurun_out/prof_${R}_compress.log | tail -
 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-boundary --compress-reads 0 --force-exchange --backend nccl > gpurun_out/${R}_bench_force_exchange.json 2> gpurun_out/${R}_bench_force_exchange.err; tail -c 900 gpurun_out/${R}_bench_force_exchange.json | head -c 600; echo
 # 8 ranks on the one GPU: ownership on the low-complexity stream
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29811 tools/check_balance.py --one-device --backend gloo --reads 250000 2>/dev/null | grep '^{' | tail -1 > gpurun_out/${R}_balance_8ranks.json; cut -c1-400 gpurun_out/${R}_balance_8ranks.json
+# dense path: LDS / partitioned forms against the device-atomic form
+timeout 900 bash tools/dense_ab.sh 8 9 10 11 12 13 14 15 > gpurun_out/${R}_generic_dense.txt 2>&1; grep "=1" gpurun_out/${R}_generic_dense.txt | cut -c1-60
