@@ -111,13 +111,12 @@ __global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kerne
 // partition are 256-512 KB: cache-resident while its workgroup runs).  Reads are taken in batches that bound the two instance buffers.
 // ------------------------------------------------------------------------------------------------
 #ifndef DBG_PART_TILE1
-#define DBG_PART_TILE1 1024
+#define DBG_PART_TILE1 512
 #endif
 #ifndef DBG_PART_TILE2
 #define DBG_PART_TILE2 2048
 #endif
 constexpr uint32_t PART_TILE1 = DBG_PART_TILE1, PART_TILE2 = DBG_PART_TILE2;     // instances a wavefront collects before it writes them out (level 1 / level 2)
-constexpr uint32_t PART_MAX = 256;              // parts per level
 template <bool IS_SET> struct DenseInst { typedef uint32_t type; };
 template <> struct DenseInst<true> { typedef unsigned long long type; };
 // instance word: CountFilter  u32 = key bits (< 2^24) | Exts << 24;  CountFilterSet  u64 = key bits | Exts << 32 | label << 40
@@ -192,14 +191,16 @@ __global__ void dense_part_fineoff_kernel(const uint64_t* __restrict__ wave_off,
     if (p <= p1n) fine_off[p] = wave_off[(uint64_t)p * n_waves];
 }
 
-// a wavefront's tile: instances with their part; the tile's instances per part are counted as they arrive
-template <class INST, uint32_t TILE>
+// a wavefront's tile: instances with their part; the tile's instances per part are counted as they arrive.  Offsets are 32-bit: a batch
+// holds fewer than 2^32 instances (the host sees to it).  LDS per wavefront decides how many wavefronts a CU holds, and that decides the
+// speed of these latency-bound kernels: 7 KB with 512 four-byte instances and 128 parts.
+template <class INST, uint32_t TILE, uint32_t NP>
 struct PartTile {
     INST raw[TILE], sorted[TILE];
     uint8_t part[TILE], spart[TILE];
-    uint32_t hist[PART_MAX], loc[PART_MAX];
-    unsigned long long base[PART_MAX];                               // PRIVATE: where this wavefront's next instance of the part goes
-    unsigned long long delta[PART_MAX];                              // sorted position q of the tile -> out[delta[part] + q]
+    uint32_t hist[NP], loc[NP];
+    uint32_t base[NP];                                               // PRIVATE: where this wavefront's next instance of the part goes
+    uint32_t delta[NP];                                              // sorted position q of the tile -> out[delta[part] + q]   (mod 2^32)
 };
 // The tile is brought into part order in LDS (counting sort: the parts' counts are known, an instance's place within its part is drawn
 // from the part's LDS counter), every part's stretch of the output is set aside -- from the wavefront's own running offsets when they
@@ -207,27 +208,28 @@ struct PartTile {
 // device atomics complete at ~10^8/s), else with one global atomic per part -- and the sorted tile leaves with neighbouring lanes
 // writing neighbouring words (writing each instance straight to its place cost 17 of 30 ms at k = 11: 64 separate 4-byte stores per
 // instruction).
-template <bool PRIVATE, class INST, uint32_t TILE>
-__device__ __forceinline__ void part_tile_flush(PartTile<INST, TILE>& t, uint32_t fill, uint32_t n_parts, unsigned long long* __restrict__ cursor, INST* __restrict__ out) {
+template <bool PRIVATE, class INST, uint32_t TILE, uint32_t NP>
+__device__ __forceinline__ void part_tile_flush(PartTile<INST, TILE, NP>& t, uint32_t fill, uint32_t n_parts, unsigned long long* __restrict__ cursor, INST* __restrict__ out) {
     const uint32_t lane = threadIdx.x;
+    constexpr int PER = NP / 64;
     __syncthreads();                                                 // (one wavefront per workgroup: orders the LDS traffic)
-    // exclusive offsets of the parts inside the tile: lane l owns parts 4l .. 4l+3 (PART_MAX = 256)
+    // exclusive offsets of the parts inside the tile: lane l owns parts PER * l .. PER * l + PER - 1
     {
-        uint32_t h[4], sum = 0;
+        uint32_t h[PER], sum = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) { h[q] = 4 * lane + q < n_parts ? t.hist[4 * lane + q] : 0u; sum += h[q]; }
+        for (int q = 0; q < PER; q++) { h[q] = PER * lane + q < n_parts ? t.hist[PER * lane + q] : 0u; sum += h[q]; }
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += o; }
         uint32_t run = incl - sum;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t p = 4 * lane + q;
+        for (int q = 0; q < PER; q++) {
+            const uint32_t p = PER * lane + q;
             if (p < n_parts) {
                 t.loc[p] = run;
-                unsigned long long at = 0;
+                uint32_t at = 0;
                 if (PRIVATE) { at = t.base[p]; t.base[p] = at + h[q]; }
-                else if (h[q]) at = atomicAdd(&cursor[p], (unsigned long long)h[q]);
+                else if (h[q]) at = (uint32_t)atomicAdd(&cursor[p], (unsigned long long)h[q]);
                 t.delta[p] = at - run;
                 t.hist[p] = 0;
             }
@@ -242,21 +244,21 @@ __device__ __forceinline__ void part_tile_flush(PartTile<INST, TILE>& t, uint32_
         t.spart[q] = (uint8_t)p;
     }
     __syncthreads();
-    for (uint32_t q = lane; q < fill; q += 64) out[t.delta[t.spart[q]] + q] = t.sorted[q];
+    for (uint32_t q = lane; q < fill; q += 64) out[(uint32_t)(t.delta[t.spart[q]] + q)] = t.sorted[q];
     for (uint32_t p = lane; p < n_parts; p += 64) t.hist[p] = 0;
     __syncthreads();
 }
 
 // (B) level 1: wavefront blockIdx.x extracts the instances of its reads and scatters them by key >> shift1 into its own stretches
 // (wave_off, from pass A); the instance keeps the key bits below
-template <bool STRANDED, bool IS_SET>
+template <bool STRANDED, bool IS_SET, uint32_t NP>
 __global__ void __launch_bounds__(64) dense_part_scatter1_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, uint32_t shift1, uint32_t n_parts,
                                                                  const uint64_t* __restrict__ wave_off, typename DenseInst<IS_SET>::type* __restrict__ out) {
     typedef typename DenseInst<IS_SET>::type INST;
-    __shared__ PartTile<INST, PART_TILE1> t;
+    __shared__ PartTile<INST, PART_TILE1, NP> t;
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = lanemask_lt();
-    for (uint32_t p = lane; p < PART_MAX; p += 64) { t.hist[p] = 0; t.base[p] = p < n_parts ? wave_off[(uint64_t)p * gridDim.x + blockIdx.x] : 0ull; }
+    for (uint32_t p = lane; p < NP; p += 64) { t.hist[p] = 0; t.base[p] = p < n_parts ? (uint32_t)wave_off[(uint64_t)p * gridDim.x + blockIdx.x] : 0u; }
     __syncthreads();
     uint32_t fill = 0;                                               // wave-uniform
     const uint32_t keep = (1u << shift1) - 1u;
@@ -309,9 +311,9 @@ template <bool IS_SET>
 __global__ void __launch_bounds__(64) dense_part_scatter2_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
                                                                  uint32_t l2, unsigned long long* __restrict__ cursor2, typename DenseInst<IS_SET>::type* __restrict__ out) {
     typedef typename DenseInst<IS_SET>::type INST;
-    __shared__ PartTile<INST, PART_TILE2> t;
+    __shared__ PartTile<INST, PART_TILE2, 128> t;                     // (at most 7 bits are left for the second level)
     const uint32_t lane = threadIdx.x, p1 = blockIdx.y, n_sub = 1u << l2;
-    for (uint32_t p = lane; p < PART_MAX; p += 64) t.hist[p] = 0;
+    for (uint32_t p = lane; p < 128; p += 64) t.hist[p] = 0;
     __syncthreads();
     const uint64_t beg = fine_off[(uint64_t)p1 << l2], end = fine_off[(uint64_t)(p1 + 1) << l2];
     for (uint64_t t0 = beg + (uint64_t)blockIdx.x * PART_TILE2; t0 < end; t0 += (uint64_t)gridDim.x * PART_TILE2) {
@@ -571,14 +573,16 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             if (!n_inst) continue;
             const size_t isz = is_set ? 8 : 4;
             DBuf<uint8_t> buf1, buf2;
-            if (!buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * isz))) {        // no room: this batch takes the atomic form
+            // no room, or more instances than the kernels' 32-bit offsets hold (a batch of unusually long reads): this batch takes the atomic form
+            if (n_inst >= (1ull << 32) || !buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * isz))) {
                 buf1.release(); buf2.release();
                 DBG_TRY(count_atomic(r0_, r1_));
                 continue;
             }
             c->t_begin("dense_part_scatter", n_kmers);
             {
-#define SL(ST, SET) dense_part_scatter1_kernel<ST, SET><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p)
+#define SL(ST, SET) do { if (P1 <= 128) dense_part_scatter1_kernel<ST, SET, 128><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p); \
+                else dense_part_scatter1_kernel<ST, SET, 256><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p); } while (0)
                 if (stranded) { if (is_set) SL(true, true); else SL(true, false); }
                 else { if (is_set) SL(false, true); else SL(false, false); }
 #undef SL
