@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kerne
 #define DBG_PART_TILE1 512
 #endif
 #ifndef DBG_PART_TILE2
-#define DBG_PART_TILE2 2048
+#define DBG_PART_TILE2 4096
 #endif
 constexpr uint32_t PART_TILE1 = DBG_PART_TILE1, PART_TILE2 = DBG_PART_TILE2;     // instances a wavefront collects before it writes them out (level 1 / level 2)
 template <bool IS_SET> struct DenseInst { typedef uint32_t type; };
@@ -306,35 +306,71 @@ __global__ void __launch_bounds__(64) dense_part_scatter1_kernel(SeqDev s, uint6
     if (fill) part_tile_flush<true>(t, fill, n_parts, nullptr, out);
 }
 
-// (C) level 2: the instances of level-1 part blockIdx.y, scattered by their next key bits (those above the 15 that name the LDS counter)
+// (C) level 2: the instances of level-1 part blockIdx.y, scattered by their next key bits (those above the 15 that name the LDS counter).
+// The work is uniform here (no reads to walk), so a 256-thread workgroup shares one tile: 4096 four-byte (2048 eight-byte) instances are
+// loaded with 16 (8) independent loads per thread, brought into sub-part order in LDS, every sub-part's stretch reserved with one global
+// atomic per tile, and written out with neighbouring threads on neighbouring words (runs of >= 32 instances at 128 sub-parts).
 template <bool IS_SET>
-__global__ void __launch_bounds__(64) dense_part_scatter2_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
-                                                                 uint32_t l2, unsigned long long* __restrict__ cursor2, typename DenseInst<IS_SET>::type* __restrict__ out) {
+__global__ void __launch_bounds__(256) dense_part_scatter2_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
+                                                                  uint32_t l2, unsigned long long* __restrict__ cursor2, typename DenseInst<IS_SET>::type* __restrict__ out) {
     typedef typename DenseInst<IS_SET>::type INST;
-    __shared__ PartTile<INST, PART_TILE2, 128> t;                     // (at most 7 bits are left for the second level)
-    const uint32_t lane = threadIdx.x, p1 = blockIdx.y, n_sub = 1u << l2;
-    for (uint32_t p = lane; p < 128; p += 64) t.hist[p] = 0;
-    __syncthreads();
+    constexpr uint32_t TILE = PART_TILE2 / (IS_SET ? 2 : 1), PER = TILE / 256;
+    __shared__ INST raw[TILE], sorted[TILE];
+    __shared__ uint8_t part[TILE], spart[TILE];
+    __shared__ uint32_t hist[256], loc[256], delta[256];
+    const uint32_t tid = threadIdx.x, p1 = blockIdx.y, n_sub = 1u << l2;          // n_sub <= 256: at most 8 bits are left for the second level
+    hist[tid] = 0;
     const uint64_t beg = fine_off[(uint64_t)p1 << l2], end = fine_off[(uint64_t)(p1 + 1) << l2];
-    for (uint64_t t0 = beg + (uint64_t)blockIdx.x * PART_TILE2; t0 < end; t0 += (uint64_t)gridDim.x * PART_TILE2) {
-        const uint32_t fill = (uint32_t)(end - t0 < PART_TILE2 ? end - t0 : PART_TILE2);
-        // (eight loads in flight per lane: with the LDS traffic between them the compiler waits for every load where it is used)
-        for (uint32_t i0 = lane; i0 < fill; i0 += 64 * 8) {
-            INST w[8];
+    unsigned long long* const cur = cursor2 + ((uint64_t)p1 << l2);
+    __syncthreads();
+    for (uint64_t t0 = beg + (uint64_t)blockIdx.x * TILE; t0 < end; t0 += (uint64_t)gridDim.x * TILE) {
+        const uint32_t fill = (uint32_t)(end - t0 < TILE ? end - t0 : TILE);
+        INST w[PER];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 64u * u; w[u] = in[t0 + (i < fill ? i : fill - 1)]; }
+        for (uint32_t u = 0; u < PER; u++) { const uint32_t i = tid + 256u * u; w[u] = in[t0 + (i < fill ? i : fill - 1)]; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const uint32_t i = i0 + 64u * u;
-                if (i < fill) {
-                    const uint32_t sub = (dense_inst_key(w[u]) >> DENSE_RANGE_BITS) & (n_sub - 1u);
-                    t.raw[i] = w[u];
-                    t.part[i] = (uint8_t)sub;
-                    atomicAdd(&t.hist[sub], 1u);
-                }
+        for (uint32_t u = 0; u < PER; u++) {
+            const uint32_t i = tid + 256u * u;
+            if (i < fill) {
+                const uint32_t sub = (dense_inst_key(w[u]) >> DENSE_RANGE_BITS) & (n_sub - 1u);
+                raw[i] = w[u];
+                part[i] = (uint8_t)sub;
+                atomicAdd(&hist[sub], 1u);
             }
         }
-        part_tile_flush<false>(t, fill, n_sub, cursor2 + ((uint64_t)p1 << l2), out);
+        __syncthreads();
+        if (tid < 64) {                                              // exclusive offsets of the sub-parts inside the tile; their stretches of the output
+            uint32_t h[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { h[q] = hist[4 * tid + q]; sum += h[q]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (tid >= (uint32_t)d) incl += o; }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t p = 4 * tid + q;
+                loc[p] = run;
+                delta[p] = (h[q] ? (uint32_t)atomicAdd(&cur[p], (unsigned long long)h[q]) : 0u) - run;
+                hist[p] = 0;
+                run += h[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+            const uint32_t i = tid + 256u * u;
+            if (i < fill) {
+                const uint32_t p = part[i];
+                const uint32_t q = loc[p] + atomicAdd(&hist[p], 1u);
+                sorted[q] = raw[i];
+                spart[q] = (uint8_t)p;
+            }
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < fill; q += 256) out[(uint32_t)(delta[spart[q]] + q)] = sorted[q];
+        hist[tid] = 0;
+        __syncthreads();
     }
 }
 
@@ -540,7 +576,11 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
     if (s.n && n_kmers && !partitioned) DBG_TRY(count_atomic(0, s.n));
     if (s.n && n_kmers && partitioned) {
         const uint32_t F = 2u * (uint32_t)k - DENSE_RANGE_BITS, n_final = 1u << F;      // final partitions: key >> 15
-        const uint32_t L1 = std::min(F, 8u), L2 = F - L1, P1 = 1u << L1, shift1 = 2u * (uint32_t)k - L1;
+        // one level up to 128 partitions (k <= 11); above that the bits are shared between the two levels -- few parts make the level-1 tiles'
+        // runs long (its wavefronts collect 512 instances), a handful of sub-parts would make the level-2 counters hot; level 2 takes up to 8 bits
+        uint32_t L1 = F <= 7 ? F : std::max(F - 8u, std::min((F + 1) / 2, 6u));     // k = 12 .. 15: 5 + 4, 6 + 5, 6 + 7, 7 + 8 bits (measured: DBG_DENSE_L1)
+        if (c->opt("DBG_DENSE_L1")) L1 = std::min(std::max((uint32_t)atoi(c->opt("DBG_DENSE_L1")), F > 8 ? F - 8 : 1u), std::min(F, 8u));   // (measurements)
+        const uint32_t L2 = F - L1, P1 = 1u << L1, shift1 = 2u * (uint32_t)k - L1;
         const uint64_t inst_cap = c->opt("DBG_DENSE_BATCH") ? (uint64_t)atoll(c->opt("DBG_DENSE_BATCH")) : 4000000000ull;
         const uint64_t reads_per_batch = std::max<uint64_t>(1, (uint64_t)((double)s.n * std::min(1.0, (double)inst_cap / (double)n_kmers)));
         DBuf<unsigned long long> fine_cnt, cursor;
@@ -591,9 +631,9 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             const uint8_t* final_buf = buf1.p;
             if (L2) {
                 HIP_TRY(c, hipMemcpyAsync(cursor.p, fine_off.p, (size_t)n_final * 8, hipMemcpyDeviceToDevice, c->stream));
-                const dim3 grid(16, P1);
-                if (is_set) dense_part_scatter2_kernel<true><<<grid, 64, 0, c->stream>>>((const unsigned long long*)buf1.p, fine_off.p, L2, cursor.p, (unsigned long long*)buf2.p);
-                else dense_part_scatter2_kernel<false><<<grid, 64, 0, c->stream>>>((const uint32_t*)buf1.p, fine_off.p, L2, cursor.p, (uint32_t*)buf2.p);
+                const dim3 grid(std::max(8u, 4096u / P1), P1);                // (~4096 workgroups whatever the fan-out of level 1)
+                if (is_set) dense_part_scatter2_kernel<true><<<grid, 256, 0, c->stream>>>((const unsigned long long*)buf1.p, fine_off.p, L2, cursor.p, (unsigned long long*)buf2.p);
+                else dense_part_scatter2_kernel<false><<<grid, 256, 0, c->stream>>>((const uint32_t*)buf1.p, fine_off.p, L2, cursor.p, (uint32_t*)buf2.p);
                 LAUNCH_CHECK(c, "dense_part_scatter2");
                 final_buf = buf2.p;
             }
