@@ -128,6 +128,9 @@ __device__ __forceinline__ uint32_t dense_inst_key(uint32_t w) { return w & 0xff
 __device__ __forceinline__ uint32_t dense_inst_key(unsigned long long w) { return (uint32_t)w; }
 __device__ __forceinline__ uint32_t dense_inst_ex(uint32_t w) { return w >> 24; }
 __device__ __forceinline__ uint32_t dense_inst_ex(unsigned long long w) { return (uint32_t)(w >> 32) & 0xffu; }
+// CountFilterSet with ONE partition level (k <= 11): only 15 key bits are left, so the label rides in the 4-byte word too: key | label << 16 | Exts << 24
+__device__ __forceinline__ uint32_t dense_inst_label(uint32_t w) { return (w >> 16) & 63u; }
+__device__ __forceinline__ uint32_t dense_inst_label(unsigned long long w) { return (uint32_t)(w >> 40) & 63u; }
 
 // k-mer j of a read (iter_kmer_exts + min_rc_flip + Exts::rc, as in dense_count_kernel): canonical key and, when WITH_EX, its Exts
 template <bool STRANDED, bool WITH_EX>
@@ -251,10 +254,10 @@ __device__ __forceinline__ void part_tile_flush(PartTile<INST, TILE, NP>& t, uin
 
 // (B) level 1: wavefront blockIdx.x extracts the instances of its reads and scatters them by key >> shift1 into its own stretches
 // (wave_off, from pass A); the instance keeps the key bits below
-template <bool STRANDED, bool IS_SET, uint32_t NP>
+template <bool STRANDED, bool IS_SET, uint32_t NP, bool COMPACT = false>
 __global__ void __launch_bounds__(64) dense_part_scatter1_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, uint32_t shift1, uint32_t n_parts,
-                                                                 const uint64_t* __restrict__ wave_off, typename DenseInst<IS_SET>::type* __restrict__ out) {
-    typedef typename DenseInst<IS_SET>::type INST;
+                                                                 const uint64_t* __restrict__ wave_off, typename DenseInst<IS_SET && !COMPACT>::type* __restrict__ out) {
+    typedef typename DenseInst<IS_SET && !COMPACT>::type INST;
     __shared__ PartTile<INST, PART_TILE1, NP> t;
     const uint32_t lane = threadIdx.x;
     const uint64_t lt = lanemask_lt();
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(64) dense_part_scatter1_kernel(SeqDev s, uint6
                 const uint64_t bal = __ballot(on[u]);
                 if (on[u]) {
                     const uint32_t pos = fill + (uint32_t)__popcll(bal & lt), p = key[u] >> shift1;
-                    t.raw[pos] = dense_inst_make<IS_SET>(key[u] & keep, ex[u], label);
+                    t.raw[pos] = COMPACT ? (INST)((key[u] & keep) | (label << 16) | (ex[u] << 24)) : (INST)dense_inst_make<IS_SET && !COMPACT>(key[u] & keep, ex[u], label);
                     t.part[pos] = (uint8_t)p;
                     atomicAdd(&t.hist[p], 1u);
                 }
@@ -377,10 +380,9 @@ __global__ void __launch_bounds__(256) dense_part_scatter2_kernel(const typename
 // (D) count: the instances of final partition blockIdx.x (split blockIdx.y of gridDim.y) in LDS -- count (24 bits) and Exts (8 bits) of a key
 // in one word, so that an instance touches no global memory but its own word -- then into the partition's own table entries (the labels of
 // CountFilterSet: dense_part_labels_kernel).  A workgroup's share is taken in stretches of < 2^24 instances: the count cannot carry.
-template <bool IS_SET>
-__global__ void __launch_bounds__(1024) dense_part_count_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
+template <bool IS_SET, class INST>
+__global__ void __launch_bounds__(1024) dense_part_count_kernel(const INST* __restrict__ in, const uint64_t* __restrict__ fine_off,
                                                                 unsigned long long* __restrict__ tab) {
-    typedef typename DenseInst<IS_SET>::type INST;
     constexpr uint32_t ES = IS_SET ? 2 : 1;
     extern __shared__ uint32_t s_cnt[];                              // DENSE_RANGE words: count | Exts << 24
     const uint32_t f = blockIdx.x;
@@ -417,7 +419,8 @@ __global__ void __launch_bounds__(1024) dense_part_count_kernel(const typename D
 
 // CountFilterSet: the label masks of final partition blockIdx.x, 32 labels (group `grp`) at a time in LDS -- one more pass over the partition's
 // instances per group of 32 labels in use, instead of a random read of the table entry per instance (34 of 44 ms at k = 11)
-__global__ void __launch_bounds__(1024) dense_part_labels_kernel(const unsigned long long* __restrict__ in, const uint64_t* __restrict__ fine_off,
+template <class INST>
+__global__ void __launch_bounds__(1024) dense_part_labels_kernel(const INST* __restrict__ in, const uint64_t* __restrict__ fine_off,
                                                                  unsigned long long* __restrict__ tab, uint32_t grp) {
     extern __shared__ uint32_t s_m[];                                // DENSE_RANGE masks of 32 labels
     const uint32_t f = blockIdx.x;
@@ -427,8 +430,8 @@ __global__ void __launch_bounds__(1024) dense_part_labels_kernel(const unsigned 
     for (uint32_t i = threadIdx.x; i < DENSE_RANGE; i += blockDim.x) s_m[i] = 0;
     __syncthreads();
     for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        const unsigned long long w = in[i];
-        const uint32_t low = (uint32_t)w & (DENSE_RANGE - 1), label = (uint32_t)(w >> 40) & 63u;
+        const INST w = in[i];
+        const uint32_t low = dense_inst_key(w) & (DENSE_RANGE - 1), label = dense_inst_label(w);
         if ((label >> 5) != grp) continue;
         const uint32_t bit = 1u << (label & 31u);
         if ((s_m[low] & bit) == 0u) atomicOr(&s_m[low], bit);
@@ -579,7 +582,7 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
         // one level up to 128 partitions (k <= 11); above that the bits are shared between the two levels -- few parts make the level-1 tiles'
         // runs long (its wavefronts collect 512 instances), a handful of sub-parts would make the level-2 counters hot; level 2 takes up to 8 bits
         uint32_t L1 = F <= 7 ? F : std::max(F - 8u, std::min((F + 1) / 2, 6u));     // k = 12 .. 15: 5 + 4, 6 + 5, 6 + 7, 7 + 8 bits (measured: DBG_DENSE_L1)
-        if (c->opt("DBG_DENSE_L1")) L1 = std::min(std::max((uint32_t)atoi(c->opt("DBG_DENSE_L1")), F > 8 ? F - 8 : 1u), std::min(F, 8u));   // (measurements)
+        if (c->opt("DBG_DENSE_L1")) L1 = std::min(std::max((uint32_t)atoi(c->opt("DBG_DENSE_L1")), F > 8 ? F - 8 : 1u), std::min(F, 7u));   // (measurements)
         const uint32_t L2 = F - L1, P1 = 1u << L1, shift1 = 2u * (uint32_t)k - L1;
         const uint64_t inst_cap = c->opt("DBG_DENSE_BATCH") ? (uint64_t)atoll(c->opt("DBG_DENSE_BATCH")) : 4000000000ull;
         const uint64_t reads_per_batch = std::max<uint64_t>(1, (uint64_t)((double)s.n * std::min(1.0, (double)inst_cap / (double)n_kmers)));
@@ -611,7 +614,8 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             HIP_TRY(c, hipMemcpyAsync(&n_inst, wave_off.p + (uint64_t)P1 * n_waves, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (!n_inst) continue;
-            const size_t isz = is_set ? 8 : 4;
+            const bool compact = is_set && !L2;                          // one level: the label fits the 4-byte instance
+            const size_t isz = is_set && !compact ? 8 : 4;
             DBuf<uint8_t> buf1, buf2;
             // no room, or more instances than the kernels' 32-bit offsets hold (a batch of unusually long reads): this batch takes the atomic form
             if (n_inst >= (1ull << 32) || !buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * isz))) {
@@ -621,8 +625,8 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             }
             c->t_begin("dense_part_scatter", n_kmers);
             {
-#define SL(ST, SET) do { if (P1 <= 128) dense_part_scatter1_kernel<ST, SET, 128><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p); \
-                else dense_part_scatter1_kernel<ST, SET, 256><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p); } while (0)
+#define SL(ST, SET) do { if (SET && compact) dense_part_scatter1_kernel<ST, SET, 128, true><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (uint32_t*)buf1.p); \
+                else dense_part_scatter1_kernel<ST, SET, 128><<<(uint32_t)n_waves, 64, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, wave_off.p, (DenseInst<SET>::type*)buf1.p); } while (0)
                 if (stranded) { if (is_set) SL(true, true); else SL(true, false); }
                 else { if (is_set) SL(false, true); else SL(false, false); }
 #undef SL
@@ -643,16 +647,15 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
                 const uint32_t splits = std::max(1u, 512u / n_final);
                 const dim3 grid(n_final, splits);
                 const size_t shm = (size_t)DENSE_RANGE * 4;
-                if (is_set) {
-                    HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                    dense_part_count_kernel<true><<<grid, 1024, shm, c->stream>>>((const unsigned long long*)final_buf, fine_off.p, tab.p);
-                    HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_labels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                    for (uint32_t grp = 0; grp <= mx / 32; grp++)
-                        dense_part_labels_kernel<<<grid, 1024, shm, c->stream>>>((const unsigned long long*)final_buf, fine_off.p, tab.p, grp);
-                } else {
-                    HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-                    dense_part_count_kernel<false><<<grid, 1024, shm, c->stream>>>((const uint32_t*)final_buf, fine_off.p, tab.p);
-                }
+#define CNT(SET, T) do { HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_count_kernel<SET, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+                    dense_part_count_kernel<SET, T><<<grid, 1024, shm, c->stream>>>((const T*)final_buf, fine_off.p, tab.p); } while (0)
+#define LAB(T) do { HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_labels_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+                    for (uint32_t grp = 0; grp <= mx / 32; grp++) dense_part_labels_kernel<T><<<grid, 1024, shm, c->stream>>>((const T*)final_buf, fine_off.p, tab.p, grp); } while (0)
+                if (!is_set) CNT(false, uint32_t);
+                else if (compact) { CNT(true, uint32_t); LAB(uint32_t); }
+                else { CNT(true, unsigned long long); LAB(unsigned long long); }
+#undef LAB
+#undef CNT
             }
             c->t_end();
             LAUNCH_CHECK(c, "dense_part_count");
