@@ -20,8 +20,8 @@ int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out);      // fastpath.
 
 namespace {
 constexpr int DENSE_LDS_K = 7;                  // k <= 7: 4^k x u32 fits a workgroup's LDS
-constexpr int DENSE_RANGE_K = 8;                // k = 8: two key-range passes with 32768 counters in LDS each: 12 -> 67 Gkmer/s.  (k = 9 would take
-                                                // eight passes: measured 157 ms against 154 for the global atomics -- no gain, not enabled)
+constexpr int DENSE_RANGE_K = 8;                // k = 8 with DBG_DENSE_PART=0: two key-range passes with 32768 counters in LDS each: 12 -> 67 Gkmer/s (k = 9 would take
+                                                // eight passes: measured 157 ms against 154 for the global atomics -- no gain).  By default k >= 8 partitions its instances (below).
 
 __device__ __forceinline__ uint32_t load_label(const void* data, uint32_t width, uint64_t i) {
     if (width == 1) return ((const uint8_t*)data)[i];
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(LDS_COUNT == 2 ? 1024 : 256) dense_count_kerne
 }
 
 // ------------------------------------------------------------------------------------------------
-// 9 <= k <= 15 (round 4): PARTITION, then count in LDS.  A directly addressed table needs one device atomic per k-mer instance, and random
+// 8 <= k <= 15 (round 4): PARTITION, then count in LDS.  A directly addressed table needs one device atomic per k-mer instance, and random
 // device-scope atomics complete at 1.7-2.4*10^10 per second whatever is done to them (tools/micro/atomic_noret.hip): 13-23 Gkmer/s.
 // Instead the instances -- {key bits | Exts [| label]} words of 4 (CountFilter) or 8 bytes (CountFilterSet) -- are first brought into the
 // order of their key's top bits: final partition f = key >> 15 holds the instances of 32768 consecutive keys, which one workgroup then
@@ -172,16 +172,26 @@ __global__ void __launch_bounds__(1024) dense_part_hist_kernel(SeqDev s, uint64_
     const uint32_t lane = threadIdx.x & 63;
     uint32_t* const mine = s_h + (threadIdx.x >> 6) * p1n;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    for (uint64_t si = r0 + wave; si < r1; si += n_waves) {
-        const uint32_t len = s.length[si];
+    uint64_t si = r0 + wave;
+    uint32_t len_n = 0;
+    uint64_t st_n = 0;
+    if (si < r1) { len_n = s.length[si]; st_n = s.start[si]; }
+    for (; si < r1; si += n_waves) {
+        const uint32_t len = len_n;
+        const uint64_t st = st_n;
+        { const uint64_t nx = si + n_waves < r1 ? si + n_waves : si; len_n = s.length[nx]; st_n = s.start[nx]; }   // the next read's, requested early
         if (len < (uint32_t)k) continue;
-        const uint64_t st = s.start[si];
         const uint32_t nk = len - (uint32_t)k + 1;
-        for (uint32_t j = lane; j < nk; j += 64) {
-            uint32_t key, ex;
-            dense_kmer_at<STRANDED, false>(s, k, st, len, 0u, j, &key, &ex);
-            atomicAdd(&mine[key >> shift1], 1u);
-            if (n_final) atomicAdd(&s_fine[key >> DENSE_RANGE_BITS], 1u);
+        for (uint32_t j0 = lane; j0 < nk; j0 += 192) {                 // (three windows of 64 k-mers: their word loads are in flight together)
+            uint32_t key[3], ex;
+#pragma unroll
+            for (int u = 0; u < 3; u++) dense_kmer_at<STRANDED, false>(s, k, st, len, 0u, j0 + 64u * u < nk ? j0 + 64u * u : 0u, &key[u], &ex);
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                if (j0 + 64u * u >= nk) continue;
+                atomicAdd(&mine[key[u] >> shift1], 1u);
+                if (n_final) atomicAdd(&s_fine[key[u] >> DENSE_RANGE_BITS], 1u);
+            }
         }
     }
     __syncthreads();
@@ -393,12 +403,19 @@ __global__ void __launch_bounds__(1024) dense_part_count_kernel(const INST* __re
         const uint64_t c1 = end - c0 < (1ull << 24) - 1 ? end : c0 + (1ull << 24) - 1;
         for (uint32_t i = threadIdx.x; i < DENSE_RANGE; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
-        for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
-            const INST w = in[i];
-            const uint32_t low = dense_inst_key(w) & (DENSE_RANGE - 1), ex = dense_inst_ex(w);
-            const uint32_t old = atomicAdd(&s_cnt[low], 1u);
-            // (a stale value can only lack bits that are set by now: the OR is then sent needlessly, never skipped wrongly)
-            if (((old >> 24) & ex) != ex) atomicOr(&s_cnt[low], ex << 24);
+        // (four loads in flight per thread: the kernel waits for instance words, not for the LDS)
+        for (uint64_t i0 = c0 + threadIdx.x; i0 < c1; i0 += 4ull * blockDim.x) {
+            INST w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint64_t i = i0 + (uint64_t)u * blockDim.x; w[u] = in[i < c1 ? i : c1 - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (i0 + (uint64_t)u * blockDim.x >= c1) continue;
+                const uint32_t low = dense_inst_key(w[u]) & (DENSE_RANGE - 1), ex = dense_inst_ex(w[u]);
+                const uint32_t old = atomicAdd(&s_cnt[low], 1u);
+                // (a stale value can only lack bits that are set by now: the OR is then sent needlessly, never skipped wrongly)
+                if (((old >> 24) & ex) != ex) atomicOr(&s_cnt[low], ex << 24);
+            }
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < DENSE_RANGE; i += blockDim.x) {
@@ -429,12 +446,17 @@ __global__ void __launch_bounds__(1024) dense_part_labels_kernel(const INST* __r
     if (beg == end) return;
     for (uint32_t i = threadIdx.x; i < DENSE_RANGE; i += blockDim.x) s_m[i] = 0;
     __syncthreads();
-    for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-        const INST w = in[i];
-        const uint32_t low = dense_inst_key(w) & (DENSE_RANGE - 1), label = dense_inst_label(w);
-        if ((label >> 5) != grp) continue;
-        const uint32_t bit = 1u << (label & 31u);
-        if ((s_m[low] & bit) == 0u) atomicOr(&s_m[low], bit);
+    for (uint64_t i0 = beg + threadIdx.x; i0 < end; i0 += 4ull * blockDim.x) {
+        INST w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint64_t i = i0 + (uint64_t)u * blockDim.x; w[u] = in[i < end ? i : end - 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t low = dense_inst_key(w[u]) & (DENSE_RANGE - 1), label = dense_inst_label(w[u]);
+            if (i0 + (uint64_t)u * blockDim.x >= end || (label >> 5) != grp) continue;
+            const uint32_t bit = 1u << (label & 31u);
+            if ((s_m[low] & bit) == 0u) atomicOr(&s_m[low], bit);
+        }
     }
     __syncthreads();
     unsigned long long* const mytab = tab + ((uint64_t)f << DENSE_RANGE_BITS) * 2;
@@ -573,9 +595,9 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
         LAUNCH_CHECK(c, "dense_count");
         return 0;
     };
-    // 9 <= k <= 15: partition, then count in LDS (DBG_DENSE_PART=0: the atomic form, for A/B measurements).  Batches of reads bound the
+    // 8 <= k <= 15: partition, then count in LDS (DBG_DENSE_PART=0: the atomic form -- k = 8: the key-range passes -- for A/B measurements).  Batches of reads bound the
     // two instance buffers; a batch whose buffers cannot be had is counted with atomics into the same table.
-    const bool partitioned = k > DENSE_RANGE_K && !(c->opt("DBG_DENSE_PART") && !strcmp(c->opt("DBG_DENSE_PART"), "0"));
+    const bool partitioned = k >= DENSE_RANGE_K && !(c->opt("DBG_DENSE_PART") && !strcmp(c->opt("DBG_DENSE_PART"), "0"));
     if (s.n && n_kmers && !partitioned) DBG_TRY(count_atomic(0, s.n));
     if (s.n && n_kmers && partitioned) {
         const uint32_t F = 2u * (uint32_t)k - DENSE_RANGE_BITS, n_final = 1u << F;      // final partitions: key >> 15

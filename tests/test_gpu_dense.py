@@ -92,9 +92,9 @@ def test_dense_equals_generic_and_refuses_other_shapes(ctx):
         dbg.filter_kmers(to_host_seqs(ss, 1), dbg.CountFilterSet(1), False, False, 4, k=12, ctx=ctx)
 
 
-@pytest.mark.parametrize("k", [9, 12, 15])
+@pytest.mark.parametrize("k", [8, 9, 12, 15])
 def test_dense_partitioned_batches_and_forms(ctx, k):
-    """9 <= k <= 15 count in LDS after partitioning the k-mer instances by their key's top bits (one level for k <= 11, two above).  Reads
+    """8 <= k <= 15 count in LDS after partitioning the k-mer instances by their key's top bits (one level for k <= 11, two above).  Reads
     are taken in batches that bound the instance buffers: with batches of ~5 000 instances (many batches accumulating in one table), with
     one batch, and in the device-atomic form (DBG_DENSE_PART=0) the table is the oracle's; ragged reads, homopolymers (one hot partition),
     labels."""
@@ -105,6 +105,6 @@ def test_dense_partitioned_batches_and_forms(ctx, k):
     for is_set in (False, True):
         ss = O.SeqSet.from_byte_seqs(seqs, data=data if is_set else None, sizeof_d1=1 if is_set else 0)
         summ = O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER
-        for opts in (dict(DBG_DENSE_BATCH="5000"), dict(), dict(DBG_DENSE_PART="0")):
+        for opts in (dict(DBG_DENSE_BATCH="5000"), dict(), dict(DBG_DENSE_PART="0"), dict(DBG_DENSE_PART="0", DBG_DENSE_RANGES="0")):   # (k = 8 without partitions: key-range passes in LDS, or atomics)
             with ctx.options(**opts):
                 run_dense(ctx, ss, k, summ, 2, False, data_width=1 if is_set else 0)
