@@ -319,6 +319,145 @@ __global__ void __launch_bounds__(64) dense_part_scatter1_kernel(SeqDev s, uint6
     if (fill) part_tile_flush<true>(t, fill, n_parts, nullptr, out);
 }
 
+// ---- level 1, second form (DBG_DENSE_RAW, the default): extract once into a raw buffer, then scatter uniform tiles ----
+// The kernels above walk reads inside the scatter: one wavefront per workgroup (reads differ in length), 512-instance tiles, three dependent
+// phases per tile -- latency-bound.  Here the instances are first EXTRACTED in read order (a read's instances are consecutive: offsets from a
+// scan of the reads' k-mer counts; every store coalesced) into {key, Exts [| label << 8]} arrays, one workgroup per block of 512 consecutive
+// reads, which also counts the block's instances per level-1 part; scanned in (part, block) order these are every block's exact offsets.  The
+// scatter then is the level-2 kernel's twin: a 256-thread workgroup per block takes its stretch of the raw arrays in tiles of 4096, 16 loads
+// in flight per thread, counting sort in LDS, write-out behind the block's own running offsets.
+constexpr uint32_t DENSE_BLK = 512;              // reads per block
+template <bool IS_SET> struct DenseAux { typedef uint8_t type; };
+template <> struct DenseAux<true> { typedef uint16_t type; };
+__global__ void dense_nk_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, uint32_t* __restrict__ nk) {
+    const uint64_t i = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r1) { const uint32_t len = s.length[i]; nk[i - r0] = len >= (uint32_t)k ? len - (uint32_t)k + 1u : 0u; }
+}
+template <bool STRANDED, bool IS_SET>
+__global__ void __launch_bounds__(256) dense_extract_kernel(SeqDev s, uint64_t r0, uint64_t r1, int k, uint32_t shift1, uint32_t p1n, const uint64_t* __restrict__ inst_off,
+                                                            uint32_t n_blocks, uint32_t* __restrict__ raw_key, typename DenseAux<IS_SET>::type* __restrict__ raw_aux,
+                                                            uint32_t* __restrict__ blk_cnt) {
+    typedef typename DenseAux<IS_SET>::type AUX;
+    __shared__ uint32_t s_h[4][128];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t i = tid; i < 4 * 128; i += 256) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t rb = r0 + (uint64_t)blockIdx.x * DENSE_BLK, re = rb + DENSE_BLK < r1 ? rb + DENSE_BLK : r1;
+    // a read's length / start / Exts / label / offset are a chain of dependent loads in front of its words: the next read's are requested
+    // while this one is processed (unconditionally, index clamped -- see dense_count_kernel)
+    auto meta_of = [&](uint64_t si, uint32_t& len, uint64_t& st, uint32_t& sexts, uint32_t& label, uint64_t& off) {
+        len = s.length[si]; st = s.start[si]; off = inst_off[si - r0];
+        sexts = s.exts ? s.exts[si] : 0u;
+        label = (IS_SET && s.data) ? load_label(s.data, s.data_width, si) & 63u : 0u;
+    };
+    uint64_t si = rb + wv;
+    uint32_t len_n = 0, sexts_n = 0, label_n = 0;
+    uint64_t st_n = 0, off_n = 0;
+    if (si < re) meta_of(si, len_n, st_n, sexts_n, label_n, off_n);
+    for (; si < re; si += 4) {
+        const uint32_t len = len_n, sexts = sexts_n, label = label_n;
+        const uint64_t st = st_n, off = off_n;
+        meta_of(si + 4 < re ? si + 4 : si, len_n, st_n, sexts_n, label_n, off_n);
+        if (len < (uint32_t)k) continue;
+        const uint32_t nk = len - (uint32_t)k + 1;
+        for (uint32_t j0 = lane; j0 < nk; j0 += 192) {                 // three windows of 64 k-mers: their word loads are in flight together
+            uint32_t key[3], ex[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) dense_kmer_at<STRANDED, true>(s, k, st, len, sexts, j0 + 64u * u < nk ? j0 + 64u * u : 0u, &key[u], &ex[u]);
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const uint32_t j = j0 + 64u * u;
+                if (j >= nk) continue;
+                raw_key[off + j] = key[u];
+                raw_aux[off + j] = (AUX)(ex[u] | (IS_SET ? label << 8 : 0u));
+                atomicAdd(&s_h[wv][key[u] >> shift1], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < p1n) blk_cnt[(uint64_t)tid * n_blocks + blockIdx.x] = s_h[0][tid] + s_h[1][tid] + s_h[2][tid] + s_h[3][tid];
+}
+template <bool IS_SET, bool COMPACT>
+__global__ void __launch_bounds__(256) dense_part_scatter1t_kernel(const uint32_t* __restrict__ raw_key, const typename DenseAux<IS_SET>::type* __restrict__ raw_aux,
+                                                                   const uint64_t* __restrict__ inst_off, uint64_t nr, uint32_t shift1, uint32_t n_parts,
+                                                                   const uint64_t* __restrict__ blk_off, uint32_t n_blocks,
+                                                                   typename DenseInst<IS_SET && !COMPACT>::type* __restrict__ out) {
+    typedef typename DenseInst<IS_SET && !COMPACT>::type INST;
+    constexpr uint32_t TILE = PART_TILE2 / (sizeof(INST) == 8 ? 2 : 1), PER = TILE / 256;
+    __shared__ INST raw[TILE], sorted[TILE];
+    __shared__ uint8_t part[TILE], spart[TILE];
+    __shared__ uint32_t hist[128], loc[128], delta[128], base[128];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    if (tid < 128) { hist[tid] = 0; base[tid] = tid < n_parts ? (uint32_t)blk_off[(uint64_t)tid * n_blocks + b] : 0u; }
+    const uint64_t rb = (uint64_t)b * DENSE_BLK, re = rb + DENSE_BLK < nr ? rb + DENSE_BLK : nr;
+    const uint64_t beg = inst_off[rb], end = inst_off[re];
+    const uint32_t keep = (1u << shift1) - 1u;
+    __syncthreads();
+    for (uint64_t t0 = beg; t0 < end; t0 += TILE) {
+        const uint32_t fill = (uint32_t)(end - t0 < TILE ? end - t0 : TILE);
+        uint32_t kk[PER], aa[PER];
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) { const uint32_t i = tid + 256u * u; const uint64_t g = t0 + (i < fill ? i : fill - 1); kk[u] = raw_key[g]; aa[u] = raw_aux[g]; }
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+            const uint32_t i = tid + 256u * u;
+            if (i < fill) {
+                const uint32_t p = kk[u] >> shift1, ex = aa[u] & 0xffu, label = aa[u] >> 8;
+                raw[i] = COMPACT ? (INST)((kk[u] & keep) | (label << 16) | (ex << 24)) : (INST)dense_inst_make<IS_SET && !COMPACT>(kk[u] & keep, ex, label);
+                part[i] = (uint8_t)p;
+                atomicAdd(&hist[p], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {                                              // exclusive offsets of the parts inside the tile; their stretches behind the block's running offsets
+            const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+            uint32_t incl = h0 + h1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (tid >= (uint32_t)d) incl += o; }
+            const uint32_t q0 = incl - h0 - h1, q1 = q0 + h0;
+            loc[2 * tid] = q0; loc[2 * tid + 1] = q1;
+            const uint32_t b0 = base[2 * tid], b1 = base[2 * tid + 1];
+            delta[2 * tid] = b0 - q0; delta[2 * tid + 1] = b1 - q1;
+            base[2 * tid] = b0 + h0; base[2 * tid + 1] = b1 + h1;
+            hist[2 * tid] = 0; hist[2 * tid + 1] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < PER; u++) {
+            const uint32_t i = tid + 256u * u;
+            if (i < fill) {
+                const uint32_t p = part[i];
+                const uint32_t q = loc[p] + atomicAdd(&hist[p], 1u);
+                sorted[q] = raw[i];
+                spart[q] = (uint8_t)p;
+            }
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < fill; q += 256) out[(uint32_t)(delta[spart[q]] + q)] = sorted[q];
+        if (tid < 128) hist[tid] = 0;
+        __syncthreads();
+    }
+}
+// two levels: instances per final partition, counted over the level-1 output (part p1 = blockIdx.y lies at [part_off[p1 * stride], part_off[(p1 + 1) * stride]))
+template <class INST>
+__global__ void __launch_bounds__(256) dense_fine_hist_kernel(const INST* __restrict__ in, const uint64_t* __restrict__ part_off, uint64_t stride, uint32_t l2,
+                                                              unsigned long long* __restrict__ fine_cnt) {
+    __shared__ uint32_t hist[256];
+    const uint32_t tid = threadIdx.x, p1 = blockIdx.y, n_sub = 1u << l2;
+    hist[tid] = 0;
+    __syncthreads();
+    const uint64_t beg = part_off[(uint64_t)p1 * stride], end = part_off[(uint64_t)(p1 + 1) * stride];
+    for (uint64_t i0 = beg + (uint64_t)blockIdx.x * 2048 + tid; i0 < end; i0 += (uint64_t)gridDim.x * 2048) {
+        INST w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint64_t i = i0 + 256ull * u; w[u] = in[i < end ? i : end - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (i0 + 256ull * u < end) atomicAdd(&hist[(dense_inst_key(w[u]) >> DENSE_RANGE_BITS) & (n_sub - 1u)], 1u);
+    }
+    __syncthreads();
+    if (tid < n_sub && hist[tid]) atomicAdd(&fine_cnt[((uint64_t)p1 << l2) | tid], (unsigned long long)hist[tid]);
+}
+
 // (C) level 2: the instances of level-1 part blockIdx.y, scattered by their next key bits (those above the 15 that name the LDS counter).
 // The work is uniform here (no reads to walk), so a 256-thread workgroup shares one tile: 4096 four-byte (2048 eight-byte) instances are
 // loaded with 16 (8) independent loads per thread, brought into sub-part order in LDS, every sub-part's stretch reserved with one global
@@ -608,12 +747,63 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
         const uint32_t L2 = F - L1, P1 = 1u << L1, shift1 = 2u * (uint32_t)k - L1;
         const uint64_t inst_cap = c->opt("DBG_DENSE_BATCH") ? (uint64_t)atoll(c->opt("DBG_DENSE_BATCH")) : 4000000000ull;
         const uint64_t reads_per_batch = std::max<uint64_t>(1, (uint64_t)((double)s.n * std::min(1.0, (double)inst_cap / (double)n_kmers)));
+        const bool raw_form = !(c->opt("DBG_DENSE_RAW") && !strcmp(c->opt("DBG_DENSE_RAW"), "0"));
         DBuf<unsigned long long> fine_cnt, cursor;
         DBuf<uint64_t> fine_off, wave_off;
         DBuf<uint32_t> wave_cnt;
         ALLOC_OR_FAIL(c, fine_cnt, n_final); ALLOC_OR_FAIL(c, cursor, n_final); ALLOC_OR_FAIL(c, fine_off, (size_t)n_final + 1);
         for (uint64_t r0_ = 0; r0_ < s.n; r0_ += reads_per_batch) {
             const uint64_t r1_ = std::min<uint64_t>(s.n, r0_ + reads_per_batch), nr = r1_ - r0_;
+            const bool compact = is_set && !L2;                          // one level: the label fits the 4-byte instance
+            const size_t isz = is_set && !compact ? 8 : 4;
+            const uint8_t* final_buf = nullptr;
+            DBuf<uint8_t> buf1, buf2;
+            bool counted = false;                                        // (this batch went to the atomic form)
+            if (raw_form) {
+                // ---- level 1, second form: instance offsets of the reads, extraction into the raw arrays + per-block counts, tile scatter ----
+                const uint32_t n_blocks = (uint32_t)cdiv(nr, DENSE_BLK);
+                DBuf<uint32_t> nkv, blk_cnt, raw_key;
+                DBuf<uint64_t> inst_off, blk_off;
+                DBuf<uint8_t> raw_aux;
+                ALLOC_OR_FAIL(c, nkv, nr); ALLOC_OR_FAIL(c, inst_off, nr + 1);
+                ALLOC_OR_FAIL(c, blk_cnt, (size_t)P1 * n_blocks); ALLOC_OR_FAIL(c, blk_off, (size_t)P1 * n_blocks + 1);
+                c->t_begin("dense_part_hist", n_kmers);
+                dense_nk_kernel<<<cdiv(nr, 256), 256, 0, c->stream>>>(s, r0_, r1_, k, nkv.p);
+                LAUNCH_CHECK(c, "dense_nk");
+                DBG_TRY(scan_exclusive_u32_u64(c, nkv.p, inst_off.p, nr));
+                uint64_t n_inst = 0;
+                HIP_TRY(c, hipMemcpyAsync(&n_inst, inst_off.p + nr, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (!n_inst) { c->t_end(); continue; }
+                if (n_inst >= (1ull << 32) || !raw_key.alloc(c, n_inst) || !raw_aux.alloc(c, n_inst * (is_set ? 2 : 1)) || !buf1.alloc(c, n_inst * isz) ||
+                    (L2 && !buf2.alloc(c, n_inst * isz))) {
+                    c->t_end();
+                    raw_key.release(); raw_aux.release(); buf1.release(); buf2.release();
+                    DBG_TRY(count_atomic(r0_, r1_));
+                    continue;
+                }
+#define EX(ST, SET) dense_extract_kernel<ST, SET><<<n_blocks, 256, 0, c->stream>>>(s, r0_, r1_, k, shift1, P1, inst_off.p, n_blocks, raw_key.p, (DenseAux<SET>::type*)raw_aux.p, blk_cnt.p)
+                if (stranded) { if (is_set) EX(true, true); else EX(true, false); }
+                else { if (is_set) EX(false, true); else EX(false, false); }
+#undef EX
+                c->t_end();
+                LAUNCH_CHECK(c, "dense_extract");
+                DBG_TRY(scan_exclusive_u32_u64(c, blk_cnt.p, blk_off.p, (uint64_t)P1 * n_blocks));
+                c->t_begin("dense_part_scatter", n_kmers);
+                if (!is_set) dense_part_scatter1t_kernel<false, false><<<n_blocks, 256, 0, c->stream>>>(raw_key.p, raw_aux.p, inst_off.p, nr, shift1, P1, blk_off.p, n_blocks, (uint32_t*)buf1.p);
+                else if (compact) dense_part_scatter1t_kernel<true, true><<<n_blocks, 256, 0, c->stream>>>(raw_key.p, (const uint16_t*)raw_aux.p, inst_off.p, nr, shift1, P1, blk_off.p, n_blocks, (uint32_t*)buf1.p);
+                else dense_part_scatter1t_kernel<true, false><<<n_blocks, 256, 0, c->stream>>>(raw_key.p, (const uint16_t*)raw_aux.p, inst_off.p, nr, shift1, P1, blk_off.p, n_blocks, (unsigned long long*)buf1.p);
+                LAUNCH_CHECK(c, "dense_part_scatter1t");
+                if (L2) {
+                    HIP_TRY(c, hipMemsetAsync(fine_cnt.p, 0, (size_t)n_final * 8, c->stream));
+                    const dim3 hgrid(std::max(8u, 2048u / P1), P1);
+                    if (is_set) dense_fine_hist_kernel<unsigned long long><<<hgrid, 256, 0, c->stream>>>((const unsigned long long*)buf1.p, blk_off.p, n_blocks, L2, fine_cnt.p);
+                    else dense_fine_hist_kernel<uint32_t><<<hgrid, 256, 0, c->stream>>>((const uint32_t*)buf1.p, blk_off.p, n_blocks, L2, fine_cnt.p);
+                    LAUNCH_CHECK(c, "dense_fine_hist");
+                    DBG_TRY(scan_exclusive_u64(c, (const uint64_t*)fine_cnt.p, fine_off.p, n_final));
+                } else dense_part_fineoff_kernel<<<cdiv(P1 + 1, 256), 256, 0, c->stream>>>(blk_off.p, n_blocks, P1, fine_off.p);
+                HIP_TRY(c, hipStreamSynchronize(c->stream));           // (the raw arrays go back to the pool before level 2 asks for nothing more: they leave scope here)
+            } else {
             // the grid of pass A (16 wavefronts per workgroup) and of pass B (one per workgroup) hold the same number of wavefronts
             const uint32_t hist_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((nr + 15) / 16, 512ull));
             const uint64_t n_waves = (uint64_t)hist_blocks * 16;
@@ -636,9 +826,6 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             HIP_TRY(c, hipMemcpyAsync(&n_inst, wave_off.p + (uint64_t)P1 * n_waves, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (!n_inst) continue;
-            const bool compact = is_set && !L2;                          // one level: the label fits the 4-byte instance
-            const size_t isz = is_set && !compact ? 8 : 4;
-            DBuf<uint8_t> buf1, buf2;
             // no room, or more instances than the kernels' 32-bit offsets hold (a batch of unusually long reads): this batch takes the atomic form
             if (n_inst >= (1ull << 32) || !buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * isz))) {
                 buf1.release(); buf2.release();
@@ -654,7 +841,9 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
 #undef SL
             }
             LAUNCH_CHECK(c, "dense_part_scatter1");
-            const uint8_t* final_buf = buf1.p;
+            }   // (first form of level 1)
+            (void)counted;
+            final_buf = buf1.p;
             if (L2) {
                 HIP_TRY(c, hipMemcpyAsync(cursor.p, fine_off.p, (size_t)n_final * 8, hipMemcpyDeviceToDevice, c->stream));
                 const dim3 grid(std::max(8u, 4096u / P1), P1);                // (~4096 workgroups whatever the fan-out of level 1)

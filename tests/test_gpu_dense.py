@@ -105,6 +105,9 @@ def test_dense_partitioned_batches_and_forms(ctx, k):
     for is_set in (False, True):
         ss = O.SeqSet.from_byte_seqs(seqs, data=data if is_set else None, sizeof_d1=1 if is_set else 0)
         summ = O.COUNT_FILTER_SET if is_set else O.COUNT_FILTER
-        for opts in (dict(DBG_DENSE_BATCH="5000"), dict(), dict(DBG_DENSE_PART="0"), dict(DBG_DENSE_PART="0", DBG_DENSE_RANGES="0")):   # (k = 8 without partitions: key-range passes in LDS, or atomics)
+        # (DBG_DENSE_RAW=0: level 1 walks the reads inside the scatter instead of extracting into a raw buffer first; k = 8 without partitions:
+        #  key-range passes in LDS, or atomics)
+        for opts in (dict(DBG_DENSE_BATCH="5000"), dict(), dict(DBG_DENSE_RAW="0"), dict(DBG_DENSE_RAW="0", DBG_DENSE_BATCH="7000"), dict(DBG_DENSE_PART="0"),
+                     dict(DBG_DENSE_PART="0", DBG_DENSE_RANGES="0")):
             with ctx.options(**opts):
                 run_dense(ctx, ss, k, summ, 2, False, data_width=1 if is_set else 0)

@@ -65,7 +65,8 @@ def draw_case(rng):
              {"DBG_NO_REC16": "1"}, {"DBG_NO_HYBRID_SORT": "1"}, {"DBG_SCAN": "wave"}, {"DBG_COUNT": "wave", "DBG_FAST_TARGET": "300"},
              {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}, {"DBG_NO_LABEL_GROUPS": "1"}, {"DBG_NO_STRAND_NORM": "1"},
              # (k <= 15: the directly addressed table whatever the input's size -- k >= 9 partitions its k-mer instances, in one batch or in many)
-             {"DBG_PATH": "dense"}, {"DBG_PATH": "dense", "DBG_DENSE_BATCH": "3000"}, {"DBG_PATH": "dense", "DBG_DENSE_PART": "0"}][int(rng.integers(0, 18))]
+             {"DBG_PATH": "dense"}, {"DBG_PATH": "dense", "DBG_DENSE_BATCH": "3000"}, {"DBG_PATH": "dense", "DBG_DENSE_PART": "0"},
+             {"DBG_PATH": "dense", "DBG_DENSE_RAW": "0"}][int(rng.integers(0, 19))]
     if knobs.get("DBG_PATH") == "dense" and (k > 15 or (is_set and data is not None and int(np.max(data)) >= 64)):
         knobs = {}                                               # (DBG_PATH=dense insists: other shapes are refused, test_gpu_dense.py)
     return dict(k=k, stranded=stranded, is_set=is_set, seqs=seqs, exts=exts, data=data, width=width, min_obs=min_obs, report_all=report_all,
