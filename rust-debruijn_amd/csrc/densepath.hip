@@ -462,12 +462,13 @@ __global__ void __launch_bounds__(256) dense_fine_hist_kernel(const INST* __rest
 // The work is uniform here (no reads to walk), so a 256-thread workgroup shares one tile: 4096 four-byte (2048 eight-byte) instances are
 // loaded with 16 (8) independent loads per thread, brought into sub-part order in LDS, every sub-part's stretch reserved with one global
 // atomic per tile, and written out with neighbouring threads on neighbouring words (runs of >= 32 instances at 128 sub-parts).
+// (CountFilterSet: 8-byte instances in, 4-byte ones out -- after this level only 15 key bits are left and the label fits: key | label << 16 | Exts << 24)
 template <bool IS_SET>
 __global__ void __launch_bounds__(256) dense_part_scatter2_kernel(const typename DenseInst<IS_SET>::type* __restrict__ in, const uint64_t* __restrict__ fine_off,
-                                                                  uint32_t l2, unsigned long long* __restrict__ cursor2, typename DenseInst<IS_SET>::type* __restrict__ out) {
+                                                                  uint32_t l2, unsigned long long* __restrict__ cursor2, uint32_t* __restrict__ out) {
     typedef typename DenseInst<IS_SET>::type INST;
     constexpr uint32_t TILE = PART_TILE2 / (IS_SET ? 2 : 1), PER = TILE / 256;
-    __shared__ INST raw[TILE], sorted[TILE];
+    __shared__ uint32_t raw[TILE], sorted[TILE];
     __shared__ uint8_t part[TILE], spart[TILE];
     __shared__ uint32_t hist[256], loc[256], delta[256];
     const uint32_t tid = threadIdx.x, p1 = blockIdx.y, n_sub = 1u << l2;          // n_sub <= 256: at most 8 bits are left for the second level
@@ -485,7 +486,7 @@ __global__ void __launch_bounds__(256) dense_part_scatter2_kernel(const typename
             const uint32_t i = tid + 256u * u;
             if (i < fill) {
                 const uint32_t sub = (dense_inst_key(w[u]) >> DENSE_RANGE_BITS) & (n_sub - 1u);
-                raw[i] = w[u];
+                raw[i] = IS_SET ? (dense_inst_key(w[u]) & (DENSE_RANGE - 1)) | (dense_inst_label(w[u]) << 16) | (dense_inst_ex(w[u]) << 24) : (uint32_t)w[u];
                 part[i] = (uint8_t)sub;
                 atomicAdd(&hist[sub], 1u);
             }
@@ -776,7 +777,7 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 if (!n_inst) { c->t_end(); continue; }
                 if (n_inst >= (1ull << 32) || !raw_key.alloc(c, n_inst) || !raw_aux.alloc(c, n_inst * (is_set ? 2 : 1)) || !buf1.alloc(c, n_inst * isz) ||
-                    (L2 && !buf2.alloc(c, n_inst * isz))) {
+                    (L2 && !buf2.alloc(c, n_inst * 4))) {
                     c->t_end();
                     raw_key.release(); raw_aux.release(); buf1.release(); buf2.release();
                     DBG_TRY(count_atomic(r0_, r1_));
@@ -827,7 +828,7 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (!n_inst) continue;
             // no room, or more instances than the kernels' 32-bit offsets hold (a batch of unusually long reads): this batch takes the atomic form
-            if (n_inst >= (1ull << 32) || !buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * isz))) {
+            if (n_inst >= (1ull << 32) || !buf1.alloc(c, n_inst * isz) || (L2 && !buf2.alloc(c, n_inst * 4))) {
                 buf1.release(); buf2.release();
                 DBG_TRY(count_atomic(r0_, r1_));
                 continue;
@@ -847,7 +848,7 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
             if (L2) {
                 HIP_TRY(c, hipMemcpyAsync(cursor.p, fine_off.p, (size_t)n_final * 8, hipMemcpyDeviceToDevice, c->stream));
                 const dim3 grid(std::max(8u, 4096u / P1), P1);                // (~4096 workgroups whatever the fan-out of level 1)
-                if (is_set) dense_part_scatter2_kernel<true><<<grid, 256, 0, c->stream>>>((const unsigned long long*)buf1.p, fine_off.p, L2, cursor.p, (unsigned long long*)buf2.p);
+                if (is_set) dense_part_scatter2_kernel<true><<<grid, 256, 0, c->stream>>>((const unsigned long long*)buf1.p, fine_off.p, L2, cursor.p, (uint32_t*)buf2.p);
                 else dense_part_scatter2_kernel<false><<<grid, 256, 0, c->stream>>>((const uint32_t*)buf1.p, fine_off.p, L2, cursor.p, (uint32_t*)buf2.p);
                 LAUNCH_CHECK(c, "dense_part_scatter2");
                 final_buf = buf2.p;
@@ -863,8 +864,7 @@ int filter_kmers_dense(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm
 #define LAB(T) do { HIP_TRY(c, hipFuncSetAttribute((const void*)dense_part_labels_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
                     for (uint32_t grp = 0; grp <= mx / 32; grp++) dense_part_labels_kernel<T><<<grid, 1024, shm, c->stream>>>((const T*)final_buf, fine_off.p, tab.p, grp); } while (0)
                 if (!is_set) CNT(false, uint32_t);
-                else if (compact) { CNT(true, uint32_t); LAB(uint32_t); }
-                else { CNT(true, unsigned long long); LAB(unsigned long long); }
+                else { CNT(true, uint32_t); LAB(uint32_t); }             // (the final buffer's instances are 4-byte words for CountFilterSet too)
 #undef LAB
 #undef CNT
             }
