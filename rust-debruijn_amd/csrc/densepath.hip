@@ -370,7 +370,17 @@ __global__ void __launch_bounds__(256) dense_extract_kernel(SeqDev s, uint64_t r
                 if (j >= nk) continue;
                 raw_key[off + j] = key[u];
                 raw_aux[off + j] = (AUX)(ex[u] | (IS_SET ? label << 8 : 0u));
-                atomicAdd(&s_h[wv][key[u] >> shift1], 1u);
+                if (p1n > 4) atomicAdd(&s_h[wv][key[u] >> shift1], 1u);
+            }
+            if (p1n <= 4) {                                              // two or four parts (k = 8): 64 lanes on 2-4 LDS addresses serialise -- count by ballot
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const bool on = j0 + 64u * u < nk;
+                    for (uint32_t p = 0; p < p1n; p++) {
+                        const uint32_t c = (uint32_t)__popcll(__ballot(on && (key[u] >> shift1) == p));
+                        if (lane == 0 && c) s_h[wv][p] += c;
+                    }
+                }
             }
         }
     }
@@ -401,11 +411,17 @@ __global__ void __launch_bounds__(256) dense_part_scatter1t_kernel(const uint32_
 #pragma unroll
         for (uint32_t u = 0; u < PER; u++) {
             const uint32_t i = tid + 256u * u;
+            const uint32_t p = kk[u] >> shift1, ex = aa[u] & 0xffu, label = aa[u] >> 8;
             if (i < fill) {
-                const uint32_t p = kk[u] >> shift1, ex = aa[u] & 0xffu, label = aa[u] >> 8;
                 raw[i] = COMPACT ? (INST)((kk[u] & keep) | (label << 16) | (ex << 24)) : (INST)dense_inst_make<IS_SET && !COMPACT>(kk[u] & keep, ex, label);
                 part[i] = (uint8_t)p;
-                atomicAdd(&hist[p], 1u);
+                if (n_parts > 4) atomicAdd(&hist[p], 1u);
+            }
+            if (n_parts <= 4) {                                          // (k = 8: see dense_extract_kernel)
+                for (uint32_t q = 0; q < n_parts; q++) {
+                    const uint32_t c = (uint32_t)__popcll(__ballot(i < fill && p == q));
+                    if ((tid & 63u) == 0 && c) atomicAdd(&hist[q], c);
+                }
             }
         }
         __syncthreads();
@@ -422,14 +438,41 @@ __global__ void __launch_bounds__(256) dense_part_scatter1t_kernel(const uint32_
             hist[2 * tid] = 0; hist[2 * tid + 1] = 0;
         }
         __syncthreads();
+        if (n_parts > 4) {
 #pragma unroll
-        for (uint32_t u = 0; u < PER; u++) {
-            const uint32_t i = tid + 256u * u;
-            if (i < fill) {
-                const uint32_t p = part[i];
-                const uint32_t q = loc[p] + atomicAdd(&hist[p], 1u);
-                sorted[q] = raw[i];
-                spart[q] = (uint8_t)p;
+            for (uint32_t u = 0; u < PER; u++) {
+                const uint32_t i = tid + 256u * u;
+                if (i < fill) {
+                    const uint32_t p = part[i];
+                    const uint32_t q = loc[p] + atomicAdd(&hist[p], 1u);
+                    sorted[q] = raw[i];
+                    spart[q] = (uint8_t)p;
+                }
+            }
+        } else {
+            // few parts: a wavefront's places come from ballots -- its members of part pp over all its rows are counted first, ONE returning atomic
+            // per part sets their stretch aside, and the ballots, taken again, give every member its place in it
+            const uint64_t lt = lanemask_lt();
+            uint32_t pv[PER];
+#pragma unroll
+            for (uint32_t u = 0; u < PER; u++) { const uint32_t i = tid + 256u * u; pv[u] = i < fill ? part[i] : 0xffu; }
+            for (uint32_t pp = 0; pp < n_parts; pp++) {
+                uint32_t tot = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < PER; u++) tot += (uint32_t)__popcll(__ballot(pv[u] == pp));
+                uint32_t b = 0;
+                if ((tid & 63u) == 0 && tot) b = atomicAdd(&hist[pp], tot);
+                b = __shfl(b, 0) + loc[pp];
+#pragma unroll
+                for (uint32_t u = 0; u < PER; u++) {
+                    const uint64_t m = __ballot(pv[u] == pp);
+                    if (pv[u] == pp) {
+                        const uint32_t i = tid + 256u * u, q = b + (uint32_t)__popcll(m & lt);
+                        sorted[q] = raw[i];
+                        spart[q] = (uint8_t)pp;
+                    }
+                    b += (uint32_t)__popcll(m);
+                }
             }
         }
         __syncthreads();
