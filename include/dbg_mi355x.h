@@ -352,7 +352,15 @@ int  dbg_shard_count_finish(dbg_ctx* ctx, dbg_kmer_table* out);
  * during the call.  The operation is ordered on `hip_stream` (a hipStream_t): it may return before the data has moved, and it
  * is complete once the work enqueued on that stream up to the call's return is complete (a synchronous implementation drains
  * the stream, moves the data, and returns).  Every rank calls the same operations in the same order.  Return 0 on success;
- * otherwise the calling entry point fails and dbg_last_error names the operation. */
+ * otherwise the calling entry point fails and dbg_last_error names the operation.
+ *
+ * Failures (round 5).  The reference is one process, where a failure is a panic that unwinds everything (src/filter.rs:167,
+ * src/graph.rs:87-91); across processes the two entry points below give the equivalent: ALL RANKS FAIL TOGETHER.  A rank-local
+ * failure (out of memory, a bad label, a kernel error) never makes a rank leave a collective phase early: every phase ends in a
+ * one-word status all-reduce, and when any rank failed every rank returns the same non-zero code before the phase's data moves
+ * (dbg_last_error names the phase and the failing rank).  A failure of the transport itself cannot be agreed on: the rank aborts
+ * the communicator (abort below), so that its peers' operations fail or their bounded waits end, and returns.  After an agreed
+ * failure ctx and transport remain usable; after an abort the transport is dead. */
 typedef struct dbg_transport {
     void*    self;
     int32_t  rank, world;
@@ -367,6 +375,13 @@ typedef struct dbg_transport {
     /* point to point; sends and receives between one pair of ranks match in call order */
     int (*send)(void* self, const void* buf_dev, uint64_t bytes, int32_t peer, void* hip_stream);
     int (*recv)(void* self, void* buf_dev, uint64_t bytes, int32_t peer, void* hip_stream);
+    /* Failure handling (round 5; both may be NULL).  poll: 0 while the communicator is healthy, non-zero once it has failed
+     * (RCCL: ncclCommGetAsyncError) -- the library calls it while it waits for communication, next to a deadline
+     * (ctx option DBG_COMM_TIMEOUT_S, default 300).  abort: tear the communication down so that peers blocked in it fail
+     * instead of hanging (RCCL: ncclCommAbort); every later operation of the table fails.  The library calls it when an
+     * operation returns non-zero, poll reports a failure, or a wait passes the deadline. */
+    int  (*poll)(void* self);
+    void (*abort)(void* self);
 } dbg_transport;
 
 /* RCCL transport on an existing communicator.  nccl_comm = the host's ncclComm_t (one rank per GPU, rank/world as given to
@@ -376,11 +391,16 @@ typedef struct dbg_transport {
 int  dbg_transport_rccl_create(void* nccl_comm, int32_t rank, int32_t world, const char* librccl_path, dbg_transport** out,
                                char* err, uint64_t err_len);
 void dbg_transport_destroy(dbg_transport* t);       /* tables made by this library only; the ncclComm_t stays the caller's */
+/* 1 once a table made by this library has been aborted or has broken (after a transport failure or a timed-out wait inside
+ * dbg_shard_filter_kmers_dev / dbg_shard_compress_dev).  For the RCCL table that means ncclCommAbort has freed the ncclComm_t:
+ * the host must not destroy it again, and needs a new communicator to go on. */
+int  dbg_transport_aborted(const dbg_transport* t);
 /* In-process transport: the ranks are THREADS of one process -- one per GPU, or several sharing a GPU -- each with its own ctx and
  * its own table (out[0..world)).  Device buffers of all ranks live in one address space, so the variable all-to-all is
  * device-to-device copies (peer copies over xGMI between different GPUs) issued by the receiving rank between two barriers of the
  * threads; no RCCL.  Synchronous (an operation drains the caller's stream, moves the data, returns); a rank that does not arrive
- * within 300 s breaks the group (every pending and later operation fails).  Release each table with dbg_transport_destroy. */
+ * within 300 s (environment DBG_INPROC_TIMEOUT_S at creation) breaks the group, and so does any failing operation and abort
+ * (every pending and later operation fails).  Release each table with dbg_transport_destroy. */
 int  dbg_transport_inprocess_create(int32_t world, dbg_transport** out /* [world] */);
 /* For hosts that do not bind RCCL themselves: ncclGetUniqueId on one rank (id_out: 128 bytes, to be handed to the other ranks
  * by whatever bootstrap the host has), then ncclCommInitRank on every rank with its GPU current. */
@@ -409,7 +429,9 @@ typedef struct {
     uint64_t min_kmer_obs;
     uint32_t n_rounds;          /* exchange rounds; 0 = 4 (8 from 4 ranks on), more when a round's receive buffer would pass 8 GiB */
     int32_t  merge_dups;        /* sender-side duplicate merge: 1 on, 0 off, -1 = the library decides (on at 2 ranks, where one link
-                                   carries everything; afterwards from the exposed exchange time the ctx measured in its last call) */
+                                   carries everything; otherwise by a vote of all ranks -- max-reduced, so every rank uses the same
+                                   setting -- from the exposed exchange and wire time each ctx measured in its last call,
+                                   re-evaluated every call) */
     int32_t  balance;           /* 1 = ownership from the all-reduced record histogram of the scan (default), 0 = equal bin ranges */
     int32_t  force_exchange;    /* world == 1: run the collective route anyway (a functional check of the transport) */
 } dbg_shard_params;

@@ -71,11 +71,14 @@ TR_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uin
 TR_ALL_TO_ALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, C.c_void_p)
 TR_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
 TR_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p)
+TR_POLL = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TR_ABORT = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class Transport(C.Structure):
     _fields_ = [("self", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("all_reduce_u64", TR_ALL_REDUCE),
-                ("all_gather", TR_ALL_GATHER), ("all_to_allv", TR_ALL_TO_ALLV), ("send", TR_SEND), ("recv", TR_RECV)]
+                ("all_gather", TR_ALL_GATHER), ("all_to_allv", TR_ALL_TO_ALLV), ("send", TR_SEND), ("recv", TR_RECV),
+                ("poll", TR_POLL), ("abort", TR_ABORT)]
 
 
 class ShardParams(C.Structure):
@@ -105,7 +108,7 @@ EXPORTS = [
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
     "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
     "dbg_graph_serialize", "dbg_graph_deserialize", "dbg_free_bytes", "dbg_serde_last_error",
-    "dbg_transport_rccl_create", "dbg_transport_destroy", "dbg_transport_inprocess_create", "dbg_rccl_unique_id", "dbg_rccl_comm_create", "dbg_rccl_comm_destroy",
+    "dbg_transport_rccl_create", "dbg_transport_destroy", "dbg_transport_aborted", "dbg_transport_inprocess_create", "dbg_rccl_unique_id", "dbg_rccl_comm_create", "dbg_rccl_comm_destroy",
     "dbg_shard_owner_bounds", "dbg_shard_round_cuts", "dbg_shard_filter_kmers_dev", "dbg_shard_compress_dev",
     "dbg_pack_acgt", "dbg_pack_acgt_dev", "dbg_pack_acgt_hashn", "dbg_pack_acgt_hashn_dev", "dbg_unpack_acgt", "dbg_unpack_acgt_dev",
 ]
@@ -208,6 +211,7 @@ def load():
     lib.dbg_transport_inprocess_create.argtypes = [C.c_int32, C.POINTER(C.POINTER(Transport))]
     lib.dbg_transport_destroy.argtypes = [C.POINTER(Transport)]
     lib.dbg_transport_destroy.restype = None
+    lib.dbg_transport_aborted.argtypes = [C.POINTER(Transport)]
     lib.dbg_rccl_unique_id.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_uint64]
     lib.dbg_rccl_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_char_p, C.c_uint64]
     lib.dbg_rccl_comm_destroy.argtypes = [C.c_char_p, C.c_void_p]

@@ -18,6 +18,7 @@
 // from the round's receive buffer (segments 1 .. W-1).
 #pragma once
 #include <chrono>
+#include "shard_comm.hpp"
 
 namespace {
 
@@ -102,23 +103,14 @@ struct XTimer {
     double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-int tr_fail(dbg_ctx* c, const char* op) {
-    return c->fail(160, std::string("sharded flow: transport operation ") + op + " failed");
-}
-
-// all-reduce of a few host values (staged through a small device buffer: the transport moves device memory)
-int xreduce_host(dbg_ctx* c, const dbg_transport* tr, uint64_t* vals, uint32_t n, int op) {
-    if (!tr || tr->world <= 1) return 0;
-    DBuf<uint64_t> d;
-    ALLOC_OR_FAIL(c, d, n);
-    HIP_TRY(c, hipMemcpyAsync(d.p, vals, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    if (tr->all_reduce_u64(tr->self, d.p, n, op, c->stream)) return tr_fail(c, "all_reduce_u64");
-    HIP_TRY(c, hipMemcpyAsync(vals, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-hipStream_t comm_stream(dbg_ctx* c) { return c->get_comm_stream(); }
+// events of one call, returned to the ctx's pool however the call ends
+struct EventSet {
+    dbg_ctx* c;
+    std::vector<hipEvent_t> ev;
+    explicit EventSet(dbg_ctx* c_) : c(c_) {}
+    hipEvent_t get() { ev.push_back(c->get_event()); return ev.back(); }
+    ~EventSet() { for (hipEvent_t e : ev) c->event_pool.push_back(e); }
+};
 
 }  // namespace
 
@@ -138,18 +130,45 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     memset(out, 0, sizeof(*out));
     const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
     const bool collective = W > 1 || (p->force_exchange && tr);
+    // Failure agreement (shard_comm.hpp): every phase below runs its rank-local work to the end with the status kept in `lrc`, and
+    // ends in X.agree() before the phase's data moves; all ranks leave with the same verdict.
+    ShardComm X(c, tr, collective);
+    DBG_TRY(X.prepare());
+    int lrc = 0;
 
-    // ---- global quantities every rank must agree on ----
+    // ---- phase "count": global quantities every rank must agree on ----
     uint64_t n_local = 0;
-    DBG_TRY(dbg_count_kmer_instances_dev(c, ds, p->k, &n_local));
-    uint64_t sum1[1] = {n_local};
-    DBG_TRY(xreduce_host(c, tr, sum1, 1, 0));
     uint32_t my_max_label = 0;
-    if (is_set) DBG_TRY(dbg_seqset_max_label_dev(c, ds, &my_max_label));
-    uint64_t mx2[2] = {n_local, my_max_label};
-    DBG_TRY(xreduce_host(c, tr, mx2, 2, 1));
-    const uint64_t total = sum1[0], n_max = mx2[0];
-    const uint32_t max_label = (uint32_t)mx2[1];
+    lrc = [&]() -> int {
+        if (X.inject("count")) return X.injected("count");
+        DBG_TRY(dbg_count_kmer_instances_dev(c, ds, p->k, &n_local));
+        if (is_set) DBG_TRY(dbg_seqset_max_label_dev(c, ds, &my_max_label));
+        return 0;
+    }();
+    if (lrc) { n_local = 0; my_max_label = 0; }
+    // The sender-side merge, when the library is to decide (merge_dups = -1), is decided by ALL ranks together -- a vote from what
+    // each ctx measured in its previous call, max-reduced with the other global quantities -- and it is re-evaluated every call:
+    //   last call without the merge: on, if the exchange time the counting could not hide (beyond the first round, which is always
+    //     exposed) exceeded what the merge costs;
+    //   last call with the merge: it stays on while the wire time it saved -- wire time x (records before / after the merge - 1), all
+    //     of which would have been exposed on top of what already was -- still exceeds its cost.
+    uint64_t vote = 0;
+    if (p->merge_dups < 0 && !c->opt("DBG_SHARD_MERGE") && W != 2 && c->shard_last_valid) {
+        double cost = c->shard_last_merge_cost_ms;
+        if (const char* e = c->opt("DBG_SHARD_MERGE_COST_MS")) cost = atof(e);      // (tests: what the merge is taken to cost)
+        if (!c->shard_last_merge) vote = c->shard_last_exposed_ms > cost ? 1 : 0;
+        else {
+            const double ratio = std::max(1.0, c->shard_last_merge_ratio);
+            vote = c->shard_last_exposed_ms + c->shard_last_wire_ms * (ratio - 1.0) > cost ? 1 : 0;
+        }
+    }
+    uint64_t mx3[3] = {n_local, my_max_label, vote};
+    DBG_TRY(X.agree(lrc, "count", mx3, 3));
+    uint64_t sum1[1] = {n_local};
+    DBG_TRY(X.reduce(sum1, 1, 0, "all_reduce_u64 (k-mer instances)"));
+    const uint64_t total = sum1[0], n_max = mx3[0];
+    const uint32_t max_label = (uint32_t)mx3[1];
+    vote = mx3[2];
     S->total_kmers = total; S->local_kmers = n_local;
 
     if (!collective) {
@@ -159,6 +178,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         S->n_rounds = 0; S->setup_ms = 0.0;
         return 0;
     }
+    // (argument checks on values every rank holds alike need no agreement)
     if (p->k < 16 || p->k > 64) return c->fail(140, "sharded counting supports 16 <= k <= 64");
 
     dbg_shard_plan sp;
@@ -166,14 +186,16 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     sp.k = p->k; sp.stranded = p->stranded; sp.summarizer = p->summarizer; sp.min_kmer_obs = p->min_kmer_obs;
     sp.total_kmers = std::max<uint64_t>(total, 1); sp.max_label = max_label;
     if (is_set && max_label >= 64) {
+        // ---- phase "labels" ----
         // labels beyond the 64 colours of the counting kernel: a sparse alphabet is mapped to colour indices, the same way on every
         // rank -- the union of the ranks' label sets (a max-reduction of presence flags: the transport has sum and max, no OR)
-        std::vector<uint32_t> bm(2049);
-        DBG_TRY(dbg_seqset_label_bitmap_dev(c, ds, bm.data()));
+        std::vector<uint32_t> bm(2049, 0u);
+        lrc = X.inject("labels") ? X.injected("labels") : dbg_seqset_label_bitmap_dev(c, ds, bm.data());
+        DBG_TRY(X.agree(lrc, "labels"));
         std::vector<uint64_t> pres(65537);
         for (uint32_t v = 0; v < 65536; v++) pres[v] = (bm[v >> 5] >> (v & 31)) & 1u;
         pres[65536] = bm[2048] ? 1 : 0;
-        DBG_TRY(xreduce_host(c, tr, pres.data(), 65537, 1));
+        DBG_TRY(X.reduce(pres.data(), 65537, 1, "all_reduce_u64 (label presence)"));
         if (pres[65536]) return c->fail(141, "sharded CountFilterSet: labels must be < 65536");
         uint32_t nl = 0;
         for (uint32_t v = 0; v < 65536; v++)
@@ -183,51 +205,59 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
             }
         sp.n_labels = nl;
     }
-    // sender-side merge: asked for, or decided here: on at 2 ranks; otherwise from what this ctx saw last time
+    // sender-side merge: asked for, or decided above: on at 2 ranks, otherwise the ranks' vote
     int merge = p->merge_dups;
     if (merge < 0) {
         if (const char* e = c->opt("DBG_SHARD_MERGE")) merge = atoi(e) != 0;
         else if (W == 2) merge = 1;
-        else if (c->shard_last_valid) merge = (c->shard_last_merge || c->shard_last_exposed_ms > c->shard_last_merge_cost_ms) ? 1 : 0;
-        else merge = 0;
+        else merge = vote ? 1 : 0;
     }
     sp.merge_dups = merge ? 1u : 0u;
+
+    // ---- phase "scan": plan, scan (+ merge), record histogram of the coarse bin groups ----
     FastPlan pl;
-    DBG_TRY(plan_from(c, &sp, &pl));
-    const uint32_t nb = pl.nbins * NCLS, rw = (uint32_t)pl.rw;
+    FastScan sc;
+    uint32_t nb = 0, rw = 0, f = 1, ng = 0;
+    const bool balance = p->balance != 0 && W > 1;
+    DBuf<uint64_t> gh;
+    c->t_clear();
+    lrc = [&]() -> int {
+        DBG_TRY(plan_from(c, &sp, &pl));
+        nb = pl.nbins * NCLS; rw = (uint32_t)pl.rw;
+        if (X.inject("scan")) return X.injected("scan");
+        DBG_TRY(shard_scan_core(c, ds, &sp, pl, &sc));
+        if (balance) {
+            // Records per COARSE group of f consecutive bins (f a power of two that leaves every rank >= 4096 groups to be cut from): the
+            // all-reduce and the host's greedy cut then handle 10^4..10^5 values instead of one per bin -- at eight ranks of 10^8 reads
+            // the per-bin form was 67 MB through pageable memory and two host loops over 8*10^6 entries, every step.  Ownership boundaries
+            // become multiples of f bins: a granularity of f / (bins per rank) <= 1/4096 of a rank's share.
+            while ((uint64_t)f * 2 * 4096 * W <= nb) f *= 2;
+            ng = (nb + f - 1) / f;
+            if (X.inject("hist")) return X.injected("hist");
+            ALLOC_OR_FAIL(c, gh, ng);
+            coarse_hist_kernel<<<cdiv(ng, 256), 256, 0, c->stream>>>(sc.cursor.p, nb, f, ng, gh.p);
+            LAUNCH_CHECK(c, "coarse_hist");
+        }
+        return 0;
+    }();
+    DBG_TRY(X.agree(lrc, "scan"));
     sp.n_bins = nb; sp.rec_words = rw; sp.bin_group = NCLS;
     S->n_bins = nb; S->merge_dups = merge;
-
-    c->t_clear();
-    // ---- scan (+ merge) ----
-    FastScan sc;
-    DBG_TRY(shard_scan_core(c, ds, &sp, pl, &sc));
-    hipStream_t xs = comm_stream(c);
-    if (!xs) return c->fail(100, "sharded flow: no communication stream");
+    hipStream_t xs = c->get_comm_stream();
 
     // ---- ownership ----
     std::vector<uint32_t> bounds(W + 1);
-    const bool balance = p->balance != 0 && W > 1;
     if (balance) {
-        // Records per COARSE group of f consecutive bins (f a power of two that leaves every rank >= 4096 groups to be cut from): the
-        // all-reduce and the host's greedy cut then handle 10^4..10^5 values instead of one per bin -- at eight ranks of 10^8 reads
-        // the per-bin form was 67 MB through pageable memory and two host loops over 8*10^6 entries, every step.  Ownership boundaries
-        // become multiples of f bins: a granularity of f / (bins per rank) <= 1/4096 of a rank's share.
-        uint32_t f = 1;
-        while ((uint64_t)f * 2 * 4096 * W <= nb) f *= 2;
-        const uint32_t ng = (nb + f - 1) / f;
-        DBuf<uint64_t> gh;
-        ALLOC_OR_FAIL(c, gh, ng);
-        coarse_hist_kernel<<<cdiv(ng, 256), 256, 0, c->stream>>>(sc.cursor.p, nb, f, ng, gh.p);
-        LAUNCH_CHECK(c, "coarse_hist");
-        if (tr->all_reduce_u64(tr->self, gh.p, ng, 0, c->stream)) return tr_fail(c, "all_reduce_u64 (record histogram)");
+        if (tr->all_reduce_u64(tr->self, gh.p, ng, 0, c->stream)) return X.op_failed("all_reduce_u64 (record histogram)");
         std::vector<uint64_t> hh(ng);
-        HIP_TRY(c, hipMemcpyAsync(hh.data(), gh.p, (size_t)ng * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (hipMemcpyAsync(hh.data(), gh.p, (size_t)ng * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the record histogram"); }
+        DBG_TRY(X.wait_stream(c->stream, "the all-reduced record histogram"));
         static_assert(NCLS == 1, "a coarse group is f whole bin groups");
+        // (pure host arithmetic on values every rank holds alike: the ranks succeed or fail together)
         if (dbg_shard_owner_bounds(hh.data(), ng, 1, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
         for (uint32_t r = 0; r <= W; r++) bounds[r] = (uint32_t)std::min<uint64_t>((uint64_t)bounds[r] * f, nb);
         bounds[W] = nb;
+        gh.release();
     } else if (dbg_shard_owner_bounds(nullptr, nb, NCLS, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
     S->balanced = balance ? 1 : 0;
     S->owned_lo = bounds[me]; S->owned_hi = bounds[me + 1];
@@ -255,116 +285,77 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     const uint32_t* mycut = &cutc[(size_t)me * (R + 1)];
     const uint32_t nbl = bounds[me + 1] - bounds[me];
 
-    // ---- layout: offsets of every bin in (round, destination, bin) order ----
+    // ---- phase "layout": offsets of every bin in (round, destination, bin) order; room for the per-bin counts of my bins ----
     std::vector<uint32_t> range_base((size_t)R * W);
     {
         uint32_t acc = 0;
         for (uint32_t r = 0; r < R; r++) for (uint32_t d = 0; d < W; d++) { range_base[(size_t)r * W + d] = acc; acc += cutc[(size_t)d * (R + 1) + r + 1] - cutc[(size_t)d * (R + 1) + r]; }
     }
-    DBuf<uint32_t> d_cuts, d_rbase, pos_of, perm_count;
+    DBuf<uint32_t> d_cuts, d_rbase, pos_of, perm_count, rhist;
     DBuf<uint64_t> csum, off, d_idx, d_edge;
-    ALLOC_OR_FAIL(c, d_cuts, cutc.size()); ALLOC_OR_FAIL(c, d_rbase, range_base.size());
-    ALLOC_OR_FAIL(c, pos_of, std::max(nb, 1u)); ALLOC_OR_FAIL(c, perm_count, std::max(nb, 1u));
-    ALLOC_OR_FAIL(c, csum, (size_t)nb + 1); ALLOC_OR_FAIL(c, off, (size_t)nb + 1);
-    HIP_TRY(c, hipMemcpyAsync(d_cuts.p, cutc.data(), cutc.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_rbase.p, range_base.data(), range_base.size() * 4, hipMemcpyHostToDevice, c->stream));
-    LayoutTab lt;
-    lt.world = W; lt.n_rounds = R;
-    for (uint32_t d = 0; d <= W; d++) lt.bounds[d] = bounds[d];
-    layout_pos_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(lt, d_cuts.p, d_rbase.p, sc.cursor.p, nb, pos_of.p, perm_count.p);
-    LAUNCH_CHECK(c, "layout_pos");
-    DBG_TRY(scan_exclusive_u32_u64(c, perm_count.p, csum.p, nb));
-    layout_off_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(pos_of.p, csum.p, nb, off.p);
-    LAUNCH_CHECK(c, "layout_off");
-    // edges of the (round, destination) blocks
     const uint32_t n_edges = R * W + 1;
-    std::vector<uint64_t> eidx(n_edges), edge(n_edges);
-    for (uint32_t i = 0; i + 1 < n_edges; i++) eidx[i] = range_base[i];
-    eidx[n_edges - 1] = nb;
-    ALLOC_OR_FAIL(c, d_idx, n_edges); ALLOC_OR_FAIL(c, d_edge, n_edges);
-    HIP_TRY(c, hipMemcpyAsync(d_idx.p, eidx.data(), (size_t)n_edges * 8, hipMemcpyHostToDevice, c->stream));
-    gather_u64_kernel<<<cdiv(n_edges, 256), 256, 0, c->stream>>>(csum.p, d_idx.p, n_edges, d_edge.p);
-    LAUNCH_CHECK(c, "gather_u64");
-    HIP_TRY(c, hipMemcpyAsync(edge.data(), d_edge.p, (size_t)n_edges * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> eidx(n_edges), edge(n_edges, 0);
+    // source order of the counting side: self first, then the other ranks ascending
+    std::vector<uint32_t> src_rank(W), row_of(W);
+    src_rank[0] = me;
+    for (uint32_t r = 0, i = 1; r < W; r++) if (r != me) src_rank[i++] = r;
+    for (uint32_t i = 0; i < W; i++) row_of[src_rank[i]] = i;
+    lrc = [&]() -> int {
+        if (!xs) return c->fail(100, "sharded flow: no communication stream");
+        if (X.inject("layout")) return X.injected("layout");
+        ALLOC_OR_FAIL(c, d_cuts, cutc.size()); ALLOC_OR_FAIL(c, d_rbase, range_base.size());
+        ALLOC_OR_FAIL(c, pos_of, std::max(nb, 1u)); ALLOC_OR_FAIL(c, perm_count, std::max(nb, 1u));
+        ALLOC_OR_FAIL(c, csum, (size_t)nb + 1); ALLOC_OR_FAIL(c, off, (size_t)nb + 1);
+        HIP_TRY(c, hipMemcpyAsync(d_cuts.p, cutc.data(), cutc.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_rbase.p, range_base.data(), range_base.size() * 4, hipMemcpyHostToDevice, c->stream));
+        LayoutTab lt;
+        lt.world = W; lt.n_rounds = R;
+        for (uint32_t d = 0; d <= W; d++) lt.bounds[d] = bounds[d];
+        layout_pos_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(lt, d_cuts.p, d_rbase.p, sc.cursor.p, nb, pos_of.p, perm_count.p);
+        LAUNCH_CHECK(c, "layout_pos");
+        DBG_TRY(scan_exclusive_u32_u64(c, perm_count.p, csum.p, nb));
+        layout_off_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(pos_of.p, csum.p, nb, off.p);
+        LAUNCH_CHECK(c, "layout_off");
+        // edges of the (round, destination) blocks
+        for (uint32_t i = 0; i + 1 < n_edges; i++) eidx[i] = range_base[i];
+        eidx[n_edges - 1] = nb;
+        ALLOC_OR_FAIL(c, d_idx, n_edges); ALLOC_OR_FAIL(c, d_edge, n_edges);
+        HIP_TRY(c, hipMemcpyAsync(d_idx.p, eidx.data(), (size_t)n_edges * 8, hipMemcpyHostToDevice, c->stream));
+        gather_u64_kernel<<<cdiv(n_edges, 256), 256, 0, c->stream>>>(csum.p, d_idx.p, n_edges, d_edge.p);
+        LAUNCH_CHECK(c, "gather_u64");
+        HIP_TRY(c, hipMemcpyAsync(edge.data(), d_edge.p, (size_t)n_edges * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (X.inject("counts")) return X.injected("counts");
+        ALLOC_OR_FAIL(c, rhist, std::max<size_t>((size_t)W * nbl, 1));
+        if (nbl) HIP_TRY(c, hipMemcpyAsync(rhist.p, sc.cursor.p + bounds[me], (size_t)nbl * 4, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }();
+    DBG_TRY(X.agree(lrc, "layout"));
     const uint64_t n_recs = edge[n_edges - 1];
     S->records_scanned = n_recs;
     c->t_begin("sk_records", n_recs);    // bookkeeping entry: units = super-k-mer records (no kernel)
     c->t_end();
 
-    // ---- per-bin counts of my bins from every source (source order: self first, then the other ranks ascending) ----
-    std::vector<uint32_t> src_rank(W);
-    src_rank[0] = me;
-    for (uint32_t r = 0, i = 1; r < W; r++) if (r != me) src_rank[i++] = r;
-    std::vector<uint32_t> row_of(W);
-    for (uint32_t i = 0; i < W; i++) row_of[src_rank[i]] = i;
-    DBuf<uint32_t> rhist;
-    ALLOC_OR_FAIL(c, rhist, std::max<size_t>((size_t)W * nbl, 1));
-    {
+    // ---- per-bin counts of my bins from every source ----
+    if (W > 1) {
         std::vector<uint64_t> soff(W), sby(W), roff(W), rby(W);
         for (uint32_t d = 0; d < W; d++) {
             soff[d] = (uint64_t)bounds[d] * 4; sby[d] = d == me ? 0 : (uint64_t)(bounds[d + 1] - bounds[d]) * 4;
             roff[d] = (uint64_t)row_of[d] * nbl * 4; rby[d] = d == me ? 0 : (uint64_t)nbl * 4;
         }
-        if (nbl) HIP_TRY(c, hipMemcpyAsync(rhist.p, sc.cursor.p + bounds[me], (size_t)nbl * 4, hipMemcpyDeviceToDevice, c->stream));
-        if (W > 1 && tr->all_to_allv(tr->self, sc.cursor.p, soff.data(), sby.data(), rhist.p, roff.data(), rby.data(), c->stream))
-            return tr_fail(c, "all_to_allv (per-bin counts)");
+        if (tr->all_to_allv(tr->self, sc.cursor.p, soff.data(), sby.data(), rhist.p, roff.data(), rby.data(), c->stream))
+            return X.op_failed("all_to_allv (per-bin counts)");
+        DBG_TRY(X.wait_stream(c->stream, "the per-bin record counts of the other ranks"));
     }
-    DBuf<uint64_t> G;
-    ALLOC_OR_FAIL(c, G, (size_t)W * nbl + 1);
-    DBG_TRY(scan_exclusive_u32_u64(c, rhist.p, G.p, (uint64_t)W * nbl));
-    // G at the round cuts of every source -> per-round record counts (host)
-    std::vector<uint64_t> gidx((size_t)W * (R + 1)), gval((size_t)W * (R + 1));
-    for (uint32_t s = 0; s < W; s++) for (uint32_t r = 0; r <= R; r++) gidx[(size_t)s * (R + 1) + r] = (uint64_t)s * nbl + mycut[r];
-    DBuf<uint64_t> d_gidx, d_gval;
-    ALLOC_OR_FAIL(c, d_gidx, gidx.size()); ALLOC_OR_FAIL(c, d_gval, gidx.size());
-    HIP_TRY(c, hipMemcpyAsync(d_gidx.p, gidx.data(), gidx.size() * 8, hipMemcpyHostToDevice, c->stream));
-    gather_u64_kernel<<<cdiv(gidx.size(), 256), 256, 0, c->stream>>>(G.p, d_gidx.p, (uint32_t)gidx.size(), d_gval.p);
-    LAUNCH_CHECK(c, "gather_u64");
-    HIP_TRY(c, hipMemcpyAsync(gval.data(), d_gval.p, gidx.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // cnt[r][s] = records of source row s in round r; base: row 0 (self) = absolute offset of block (r, me) in the send buffer,
-    // rows >= 1 = offsets in the round's receive buffer
-    std::vector<uint64_t> cnt((size_t)R * W), base((size_t)R * W), tab_off(R), recv_recs(R);
-    uint64_t seg_words = 0, max_recv = 0, owned = 0;
-    for (uint32_t r = 0; r < R; r++) {
-        uint64_t acc = 0;
-        for (uint32_t s = 0; s < W; s++) {
-            cnt[(size_t)r * W + s] = gval[(size_t)s * (R + 1) + r + 1] - gval[(size_t)s * (R + 1) + r];
-            owned += cnt[(size_t)r * W + s];
-            if (s == 0) base[(size_t)r * W] = edge[(size_t)r * W + me];
-            else { base[(size_t)r * W + s] = acc; acc += cnt[(size_t)r * W + s]; }
-        }
-        if (cnt[(size_t)r * W] != edge[(size_t)r * W + me + 1] - edge[(size_t)r * W + me])
-            return c->fail(163, "sharded flow: layout and histogram disagree about this rank's own records");
-        recv_recs[r] = acc;
-        max_recv = std::max(max_recv, acc);
-        tab_off[r] = seg_words;
-        seg_words += (uint64_t)W * (mycut[r + 1] - mycut[r] + 1);
-    }
-    S->records_owned = owned;
-    DBuf<uint64_t> seg, d_base, d_taboff;
-    DBuf<uint32_t> d_mycut;
-    ALLOC_OR_FAIL(c, seg, std::max<uint64_t>(seg_words, 1)); ALLOC_OR_FAIL(c, d_base, base.size()); ALLOC_OR_FAIL(c, d_taboff, R);
-    ALLOC_OR_FAIL(c, d_mycut, R + 1);
-    HIP_TRY(c, hipMemcpyAsync(d_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_taboff.p, tab_off.data(), (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_mycut.p, mycut, (size_t)(R + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    seg_tables_kernel<<<cdiv((uint64_t)W * (nbl + 1), 256), 256, 0, c->stream>>>(G.p, nbl, W, R, d_mycut.p, d_base.p, d_taboff.p, seg.p);
-    LAUNCH_CHECK(c, "seg_tables");
 
-    // ---- send buffer: slabs compacted in layout order, ROUND BY ROUND.  Only round 0 has to be in place before the first message
-    //      leaves (the first round is the one whose exchange nothing hides: it starts 5 ms earlier per 10^8 reads this way); the
-    //      compaction of round r >= 1 is queued on the communication stream right in front of that round's all-to-all and runs next
-    //      to the counting of round r - 1.  Measured on one GPU: the overlap itself buys nothing -- the counting kernel loses the
-    //      1.65 ms the copy takes (13.3 -> 14.9 ms per round; 119.1 against 119.6 ms per step) -- it only moves the work off the
-    //      path in front of the first message.  The few records that outgrew their slab are placed behind their bins first
-    //      (their positions follow from the counts alone). ----
-    DBuf<uint64_t> recs, ovf_base;
-    ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(n_recs * rw, 1));
-    ALLOC_OR_FAIL(c, ovf_base, (size_t)nb + 1);
-    ovf_base_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(sc.cursor.p, sc.slab_cap, off.p, nb, ovf_base.p);
-    LAUNCH_CHECK(c, "ovf_base");
+    // ---- phase "tables": segment tables of all rounds, the send buffer with round 0 compacted, receive buffers, counting state.
+    //      Everything the rounds need is reserved HERE, so that no rank can run out of memory between two rounds' messages. ----
+    std::vector<uint64_t> cnt((size_t)R * W), base((size_t)R * W), tab_off(R), recv_recs(R);
+    uint64_t max_recv = 0, owned = 0;
+    DBuf<uint64_t> seg, recs, ovf_base, rbuf[2];
+    EventSet events(c);
+    std::vector<hipEvent_t> ev_done(R), ev_a(R), ev_b(R), ev_w0(R), ev_w1(R);
+    std::unique_ptr<FastCountState> cs(new FastCountState());
     auto compact_round = [&](uint32_t r, hipStream_t stream) -> int {
         for (uint32_t d = 0; d < W; d++) {
             const uint32_t b0 = bounds[d] + cutc[(size_t)d * (R + 1) + r], b1 = bounds[d] + cutc[(size_t)d * (R + 1) + r + 1];
@@ -378,21 +369,79 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         }
         return 0;
     };
-    c->t_begin("slab_compact", n_recs / R);
-    DBG_TRY(compact_round(0, c->stream));
-    c->t_end();
-    DBG_TRY(fast_scatter(c, &sc, ovf_base.p, recs.p));                // (releases the scan's read-order buffers)
-    HIP_TRY(c, hipStreamSynchronize(c->stream));                     // everything queued so far is complete: layout, tables, round 0
-    pos_of.release(); perm_count.release(); csum.release(); G.release(); rhist.release();
+    lrc = [&]() -> int {
+        if (X.inject("tables")) return X.injected("tables");
+        DBuf<uint64_t> G;
+        ALLOC_OR_FAIL(c, G, (size_t)W * nbl + 1);
+        DBG_TRY(scan_exclusive_u32_u64(c, rhist.p, G.p, (uint64_t)W * nbl));
+        // G at the round cuts of every source -> per-round record counts (host)
+        std::vector<uint64_t> gidx((size_t)W * (R + 1)), gval((size_t)W * (R + 1));
+        for (uint32_t s = 0; s < W; s++) for (uint32_t r = 0; r <= R; r++) gidx[(size_t)s * (R + 1) + r] = (uint64_t)s * nbl + mycut[r];
+        DBuf<uint64_t> d_gidx, d_gval;
+        ALLOC_OR_FAIL(c, d_gidx, gidx.size()); ALLOC_OR_FAIL(c, d_gval, gidx.size());
+        HIP_TRY(c, hipMemcpyAsync(d_gidx.p, gidx.data(), gidx.size() * 8, hipMemcpyHostToDevice, c->stream));
+        gather_u64_kernel<<<cdiv(gidx.size(), 256), 256, 0, c->stream>>>(G.p, d_gidx.p, (uint32_t)gidx.size(), d_gval.p);
+        LAUNCH_CHECK(c, "gather_u64");
+        HIP_TRY(c, hipMemcpyAsync(gval.data(), d_gval.p, gidx.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // cnt[r][s] = records of source row s in round r; base: row 0 (self) = absolute offset of block (r, me) in the send buffer,
+        // rows >= 1 = offsets in the round's receive buffer
+        uint64_t seg_words = 0;
+        for (uint32_t r = 0; r < R; r++) {
+            uint64_t acc = 0;
+            for (uint32_t s = 0; s < W; s++) {
+                cnt[(size_t)r * W + s] = gval[(size_t)s * (R + 1) + r + 1] - gval[(size_t)s * (R + 1) + r];
+                owned += cnt[(size_t)r * W + s];
+                if (s == 0) base[(size_t)r * W] = edge[(size_t)r * W + me];
+                else { base[(size_t)r * W + s] = acc; acc += cnt[(size_t)r * W + s]; }
+            }
+            if (cnt[(size_t)r * W] != edge[(size_t)r * W + me + 1] - edge[(size_t)r * W + me])
+                return c->fail(163, "sharded flow: layout and histogram disagree about this rank's own records");
+            recv_recs[r] = acc;
+            max_recv = std::max(max_recv, acc);
+            tab_off[r] = seg_words;
+            seg_words += (uint64_t)W * (mycut[r + 1] - mycut[r] + 1);
+        }
+        DBuf<uint64_t> d_base, d_taboff;
+        DBuf<uint32_t> d_mycut;
+        ALLOC_OR_FAIL(c, seg, std::max<uint64_t>(seg_words, 1)); ALLOC_OR_FAIL(c, d_base, base.size()); ALLOC_OR_FAIL(c, d_taboff, R);
+        ALLOC_OR_FAIL(c, d_mycut, R + 1);
+        HIP_TRY(c, hipMemcpyAsync(d_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_taboff.p, tab_off.data(), (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_mycut.p, mycut, (size_t)(R + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        seg_tables_kernel<<<cdiv((uint64_t)W * (nbl + 1), 256), 256, 0, c->stream>>>(G.p, nbl, W, R, d_mycut.p, d_base.p, d_taboff.p, seg.p);
+        LAUNCH_CHECK(c, "seg_tables");
+        // ---- send buffer: slabs compacted in layout order, ROUND BY ROUND.  Only round 0 has to be in place before the first message
+        //      leaves (the first round is the one whose exchange nothing hides: it starts 5 ms earlier per 10^8 reads this way); the
+        //      compaction of round r >= 1 is queued on the communication stream right in front of that round's all-to-all and runs next
+        //      to the counting of round r - 1.  Measured on one GPU: the overlap itself buys nothing -- the counting kernel loses the
+        //      1.65 ms the copy takes (13.3 -> 14.9 ms per round; 119.1 against 119.6 ms per step) -- it only moves the work off the
+        //      path in front of the first message.  The few records that outgrew their slab are placed behind their bins first
+        //      (their positions follow from the counts alone). ----
+        if (X.inject("recs")) return X.injected("recs");
+        ALLOC_OR_FAIL(c, recs, std::max<uint64_t>(n_recs * rw, 1));
+        ALLOC_OR_FAIL(c, ovf_base, (size_t)nb + 1);
+        ovf_base_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(sc.cursor.p, sc.slab_cap, off.p, nb, ovf_base.p);
+        LAUNCH_CHECK(c, "ovf_base");
+        c->t_begin("slab_compact", n_recs / R);
+        DBG_TRY(compact_round(0, c->stream));
+        c->t_end();
+        DBG_TRY(fast_scatter(c, &sc, ovf_base.p, recs.p));                // (releases the scan's read-order buffers)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));                     // everything queued so far is complete: layout, tables, round 0
+        pos_of.release(); perm_count.release(); csum.release(); G.release(); rhist.release();
+        if (X.inject("rbuf")) return X.injected("rbuf");
+        ALLOC_OR_FAIL(c, rbuf[0], std::max<uint64_t>(max_recv * rw, 1));
+        if (R > 1) ALLOC_OR_FAIL(c, rbuf[1], std::max<uint64_t>(max_recv * rw, 1));
+        for (uint32_t r = 0; r < R; r++) { ev_done[r] = events.get(); ev_a[r] = events.get(); ev_b[r] = events.get(); ev_w0[r] = events.get(); ev_w1[r] = events.get(); }
+        if (X.inject("count_begin")) return X.injected("count_begin");
+        return fast_count_begin(c, pl, p->min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get());
+    }();
+    DBG_TRY(X.agree(lrc, "tables"));
+    S->records_owned = owned;
 
     // ---- pipelined rounds ----
-    DBuf<uint64_t> rbuf[2];
-    ALLOC_OR_FAIL(c, rbuf[0], std::max<uint64_t>(max_recv * rw, 1));
-    if (R > 1) ALLOC_OR_FAIL(c, rbuf[1], std::max<uint64_t>(max_recv * rw, 1));
-    std::vector<hipEvent_t> ev_done(R), ev_a(R), ev_b(R);
-    for (uint32_t r = 0; r < R; r++) { ev_done[r] = c->get_event(); ev_a[r] = c->get_event(); ev_b[r] = c->get_event(); }
-    auto give_back = [&]() { for (uint32_t r = 0; r < R; r++) { c->event_pool.push_back(ev_done[r]); c->event_pool.push_back(ev_a[r]); c->event_pool.push_back(ev_b[r]); } };
-    std::vector<double> host_ms(R, 0.0);
+    std::vector<double> host_ms(R, 0.0), wait_ms(R, 0.0);
+    int tr_rc = 0;                     // a transport failure: nothing left to agree on (the communicator is aborted)
     auto launch = [&](uint32_t r) -> int {
         std::vector<uint64_t> soff(W), sby(W), roff(W), rby(W);
         for (uint32_t d = 0; d < W; d++) {
@@ -402,52 +451,75 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
             rby[d] = d == me ? 0 : cnt[(size_t)r * W + row_of[d]] * rw * 8;
             S->bytes_sent += sby[d];
         }
-        if (r) DBG_TRY(compact_round(r, xs));                          // this round's part of the send buffer, in stream order before its messages
+        // this round's part of the send buffer, in stream order before its messages.  (A launch failure here is local: the messages
+        // still go out -- with whatever the buffer holds -- so that no peer waits for them; the status is agreed after the rounds.)
+        if (r) { const int e = compact_round(r, xs); if (e && !lrc) lrc = e; }
+        (void)hipEventRecord(ev_w0[r], xs);
         XTimer th;
         const int e = W > 1 ? tr->all_to_allv(tr->self, recs.p, soff.data(), sby.data(), rbuf[r & 1].p, roff.data(), rby.data(), xs) : 0;
         host_ms[r] = th.ms();
-        if (e) return tr_fail(c, "all_to_allv (records)");
-        if (hipEventRecord(ev_done[r], xs) != hipSuccess) return c->fail(100, "hipEventRecord failed");
+        if (e) return tr_rc = X.op_failed("all_to_allv (records)");
+        (void)hipEventRecord(ev_w1[r], xs);
+        if (hipEventRecord(ev_done[r], xs) != hipSuccess) { (void)hipGetLastError(); return tr_rc = X.op_failed("hipEventRecord behind all_to_allv"); }
         return 0;
     };
     S->setup_ms = t_setup.ms();
-    std::unique_ptr<FastCountState> cs(new FastCountState());
-    int rcode = fast_count_begin(c, pl, p->min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get());
-    if (!rcode) rcode = launch(0);
-    for (uint32_t r = 0; r < R && !rcode; r++) {
+    // A rank whose counting fails (lrc != 0) keeps taking part in the remaining rounds' exchanges -- its peers' messages must find
+    // their receives -- and only stops counting; the status is agreed after the last round.
+    if (launch(0)) return tr_rc;
+    for (uint32_t r = 0; r < R; r++) {
         // buffer (r + 1) & 1 was last read by the counting of round r - 1, which has completed (fast_count_bins returns after its
-        // launch has finished), so round r + 1 may go on the wire now and travels while round r is counted
-        if (r + 1 < R) rcode = launch(r + 1);
-        if (rcode) break;
+        // launch has finished: its read-back of the output size is a host wait), so round r + 1 may go on the wire now and travels
+        // while round r is counted
+        if (r + 1 < R && launch(r + 1)) break;
+        // the host waits for round r's records itself, with a deadline and an eye on the communicator: the ctx stream is idle here, so
+        // this wait IS the exchange time the counting could not hide
+        XTimer tw;
+        if ((tr_rc = X.wait_event(ev_done[r], "an exchange round's records"))) break;
+        wait_ms[r] = tw.ms();
         (void)hipEventRecord(ev_a[r], c->stream);
-        if (hipStreamWaitEvent(c->stream, ev_done[r], 0) != hipSuccess) { rcode = c->fail(100, "hipStreamWaitEvent failed"); break; }
+        if (hipStreamWaitEvent(c->stream, ev_done[r], 0) != hipSuccess) { (void)hipGetLastError(); if (!lrc) lrc = c->fail(100, "hipStreamWaitEvent failed"); }
         (void)hipEventRecord(ev_b[r], c->stream);
         const uint32_t nbc = mycut[r + 1] - mycut[r];
-        if (nbc)
-            rcode = fast_count_bins(c, cs.get(), recs.p, rbuf[r & 1].p, 1, seg.p + tab_off[r], seg.p + tab_off[r] + 1, W, (uint64_t)nbc + 1, nbc / NCLS,
-                                    std::max<uint64_t>(n_local, 1) / R, 0);
+        if (!lrc && X.inject("round") && r == std::min<uint32_t>(1, R - 1)) lrc = X.injected("round");
+        if (nbc && !lrc)
+            lrc = fast_count_bins(c, cs.get(), recs.p, rbuf[r & 1].p, 1, seg.p + tab_off[r], seg.p + tab_off[r] + 1, W, (uint64_t)nbc + 1, nbc / NCLS,
+                                  std::max<uint64_t>(n_local, 1) / R, 0);
         else (void)hipStreamSynchronize(c->stream);
     }
-    if (rcode) { (void)hipStreamSynchronize(xs); (void)hipStreamSynchronize(c->stream); give_back(); return rcode; }
-    HIP_TRY(c, hipStreamSynchronize(xs));
+    if (tr_rc) { (void)hipStreamSynchronize(c->stream); return tr_rc; }
+    DBG_TRY(X.wait_stream(xs, "the last exchange round"));
+    double wire_ms = 0.0;
     for (uint32_t r = 0; r < R; r++) {
-        float w = 0.f;
+        float w = 0.f, wire = 0.f;
         if (hipEventElapsedTime(&w, ev_a[r], ev_b[r]) != hipSuccess) { (void)hipGetLastError(); w = 0.f; }
+        if (hipEventElapsedTime(&wire, ev_w0[r], ev_w1[r]) != hipSuccess) { (void)hipGetLastError(); wire = 0.f; }
         // a synchronous transport spends the exchange inside the call: that is exposed time as well (an asynchronous one returns
         // in well under a millisecond)
-        const double ex = (double)w + (host_ms[r] > 1.0 ? host_ms[r] : 0.0);
+        const double ex = (double)w + (wait_ms[r] > 0.05 ? wait_ms[r] : 0.0) + (host_ms[r] > 1.0 ? host_ms[r] : 0.0);
         S->exposed_ms_round[r] = ex;
         S->exposed_ms += ex;
+        if (r) wire_ms += std::max<double>(wire, host_ms[r] > 1.0 ? host_ms[r] : 0.0);
     }
-    give_back();
     sc.slab.release(); sc.cursor.release(); off.release(); ovf_base.release();
     c->drop_spares();
     recs.release(); rbuf[0].release(); rbuf[1].release(); seg.release();
-    DBG_TRY(fast_count_finish(c, cs.get(), out));
+
+    // ---- phase "finish": one order-restoring sort of everything counted ----
+    if (!lrc && X.inject("finish")) lrc = X.injected("finish");
+    if (!lrc) lrc = fast_count_finish(c, cs.get(), out);
+    const int arc = X.agree(lrc, "finish");
+    if (arc) {
+        if (!lrc) { dbg_free_table(c, out); memset(out, 0, sizeof(*out)); }    // this rank's table is of no use without the others'
+        return arc;
+    }
     out->n_kmer_instances = total;
-    // what the next call's merge decision looks at: exposed time beyond the first round (always exposed) against the cost of merging
+    // what the next call's merge vote looks at: exposed and wire time beyond the first round (always exposed), the merge's cost and
+    // what it removed
     c->shard_last_valid = true; c->shard_last_merge = merge != 0;
     c->shard_last_exposed_ms = S->exposed_ms - S->exposed_ms_round[0];
+    c->shard_last_wire_ms = wire_ms;
+    c->shard_last_merge_ratio = n_recs ? (double)(n_recs + sc.n_merged_away) / (double)n_recs : 1.0;
     c->shard_last_merge_cost_ms = 10.0 * (double)n_local / 1.04e10;         // slab_merge: ~9-10 ms per 10^8 reads of 150 bases
     return 0;
 }

@@ -1468,7 +1468,6 @@ __global__ void __launch_bounds__(256) max_label_kernel(const void* data, uint32
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])); if (m) atomicMax(out, m); }
 }
-#include "fast_wavecount.hpp"
 
 // Placement probe for the slab block (see slab_alloc_probed): the scan's memory pattern -- random record-sized writes over the
 // whole block -- timed on the block itself.
@@ -1492,7 +1491,6 @@ int fast_internal_p(int k) { return k >= 23 ? 15 : (k >= 21 ? 13 : std::max(4, k
 struct FastPlan {
     int k, p, nbw, rw;
     bool stranded, is_set, has_hi;
-    bool wave = false;                                  // bins sized for the wave-per-bin counting kernel (256-entry tables)
     bool wide = false;                                  // colour sets of 25..64 colours: two mask words per table entry, payload gathered after the sort
     bool weighted = false;                              // sharded flow: records may carry a weight (sender-side duplicate merge) in the WEIGHT_BITS above the meta bits
     uint32_t nbins;
@@ -1500,10 +1498,10 @@ struct FastPlan {
     const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
 };
 
-static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl, bool allow_wave = true) {
+static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64_t total_kmers, uint32_t force_bins, FastPlan* pl) {
     if (k < 16 || k > 64) return false;
     pl->k = k; pl->p = fast_internal_p(k);
-    if (const char* e = c->opt("DBG_FAST_P")) pl->p = std::max(4, std::min(std::min(15, k - 8), atoi(e)));     // measurement: internal minimizer length
+    if (const char* e = c->opt("DBG_FAST_P")) pl->p = std::max(4, std::min(std::min(15, k - 3), atoi(e)));     // measurement: internal minimizer length (windows of >= 4 p-mers)
     pl->nbw = std::max(2, (2 * (2 * k - pl->p) + META_BITS + 63) / 64);   // words per record: bases + META_BITS
     if (pl->nbw > 4) return false;
     pl->rw = pl->nbw;
@@ -1514,15 +1512,10 @@ static bool fast_make_plan(dbg_ctx* c, int k, bool stranded, bool is_set, uint64
     // with k: measured optima on 30x reads with e = 0.1 %: k=31 8-12k, k=47 8k, k=51 7-8k, k=63 6k (a bin that
     // overflows is only re-split, at the price of streaming it again).
     uint64_t target = std::min<uint64_t>(10000, std::max<uint64_t>(5000, 380000 / (uint64_t)k));
-    // DBG_COUNT=wave: the wave-per-bin kernel (fast_wavecount.hpp), whose private 256-entry tables want bins an eighth of that
-    // (about 1000 k-mer instances, 70 records, 100 distinct k-mers).  Measured slower than the workgroup kernel (DESIGN.md
-    // section 7: 88-100 ms against 58 at C2, and the finer bins cost the scan 4-10 ms), so it is not the default.
-    pl->wave = allow_wave && c->opt("DBG_COUNT") && !strcmp(c->opt("DBG_COUNT"), "wave");
-    if (pl->wave) target /= 8;
     if (const char* e = c->opt("DBG_FAST_TARGET")) target = std::max<uint64_t>(256, strtoull(e, nullptr, 10));
     uint64_t nb64 = force_bins ? force_bins : std::max<uint64_t>(1, total_kmers / target);
     // (the workgroup kernel launches one 512-thread workgroup per bin, and a grid holds fewer than 2^32 threads)
-    const uint64_t nb_max = pl->wave ? (1ull << 26) : (1ull << 23) - 1;
+    const uint64_t nb_max = (1ull << 23) - 1;
     if (nb64 > nb_max) nb64 = nb_max;
     pl->nbins = (uint32_t)nb64;
     return true;
@@ -1534,6 +1527,7 @@ struct FastScan {
     DBuf<uint32_t> hist, tmp_bin;
     DBuf<uint64_t> tmp_recs;
     uint64_t n_tmp = 0, n_recs = 0, n_kmers = 0;
+    uint64_t n_merged_away = 0;                         // records the sender-side merge removed (sharded flow)
     // direct mode: per-bin slabs of slab_cap records + fill counts (records beyond the slab are in tmp_*)
     DBuf<uint64_t> slab;
     DBuf<uint32_t> cursor;
@@ -1891,40 +1885,7 @@ static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, ui
     }
     ALLOC_OR_FAIL(c, st->gflags, 16);
     HIP_TRY(c, hipMemsetAsync(st->out_cursor.p, 0, 8, c->stream));
-    // (wave kernel: every resident wave may hold one partly filled chunk of WV_CHUNK output records)
-    return fast_count_alloc(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1) +
-                                       (pl.wave && !report_all ? (uint64_t)WV_CHUNK * 8192 : 0));
-}
-
-// The wave kernel reserved output records [.., *cur) in chunks and left one hole per wave (fast_wavecount.hpp): move the last
-// records into the holes; *cur becomes the number of records.
-static int fast_close_holes(dbg_ctx* c, FastCountState* st, const WaveHole* holes_dev, uint32_t nh, unsigned long long* cur) {
-    std::vector<WaveHole> hh(nh);
-    HIP_TRY(c, hipMemcpyAsync(hh.data(), holes_dev, (size_t)nh * sizeof(WaveHole), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long H = 0;
-    for (auto& h : hh) H += h.len;
-    const unsigned long long R = *cur, V = R - H;
-    *cur = V;
-    if (H == 0 || V == R) return 0;
-    const uint64_t tail = R - V;
-    if (tail >= (1ull << 32)) return c->fail(136, "fast path: hole region too large");
-    DBuf<uint32_t> marks, mpre, dpre;
-    ALLOC_OR_FAIL(c, marks, tail); ALLOC_OR_FAIL(c, mpre, tail + 1); ALLOC_OR_FAIL(c, dpre, (size_t)nh + 1);
-    c->t_begin("count_fixup", tail);
-    HIP_TRY(c, hipMemsetAsync(marks.p, 0, tail * 4, c->stream));
-    holes_mark_kernel<<<nh, 256, 0, c->stream>>>(holes_dev, nh, V, marks.p);
-    LAUNCH_CHECK(c, "holes_mark");
-    holes_dest_scan_kernel<<<1, 1024, 0, c->stream>>>(holes_dev, nh, V, dpre.p);
-    LAUNCH_CHECK(c, "holes_dest_scan");
-    DBG_TRY(scan_exclusive_u32(c, marks.p, mpre.p, tail));
-    FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    if (st->use16) holes_move_kernel<true><<<cdiv(tail, 256), 256, 0, c->stream>>>(holes_dev, nh, V, (uint32_t)tail, marks.p, mpre.p, dpre.p, fo, st->pl.has_hi ? 1 : 0);
-    else holes_move_kernel<false><<<cdiv(tail, 256), 256, 0, c->stream>>>(holes_dev, nh, V, (uint32_t)tail, marks.p, mpre.p, dpre.p, fo, st->pl.has_hi ? 1 : 0);
-    c->t_end();
-    LAUNCH_CHECK(c, "holes_move");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return fast_count_alloc(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1));
 }
 
 // per-bin LDS hash tables over `nbins_local` bins whose records arrive as n_src segments; valid k-mers are appended to the state
@@ -1947,38 +1908,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
                    st->report_all ? st->all_cursor.p : nullptr, st->all_cap};
         unsigned long long* out_cursor_p = st->out_cursor.p;
         uint32_t* gflags_p = st->gflags.p;
-        const bool wave_mode = pl.wave && !st->report_all && !pl.wide;   // (the all-k-mers list and the wide colour sets leave through the workgroup kernel)
-        uint32_t n_waves = 0;
-        DBuf<WaveHole> holes;
-        if (nbins_local && wave_mode) {
-            // persistent single-wave workgroups, bins dealt round-robin: as many as are resident at once
-            const int tb = c->opt("DBG_FAST_TABLE") ? atoi(c->opt("DBG_FAST_TABLE")) : 256;
-            int per_cu = 0, n_cu = 0;
-            HIP_TRY(c, hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-#define WOCC(KW, NBW, SET, TT) HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bin_count_wave_kernel<KW, NBW, SET, TT>, 64, 0))
-#define WL(KW, NBW, SET, TT) bin_count_wave_kernel<KW, NBW, SET, TT><<<n_waves, 64, 0, c->stream>>>( \
-            recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, nbins_local, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p, holes.p)
-#define WGO(WHAT, KW, NBW, SET) do { if (tb == 512) WHAT(KW, NBW, SET, 512); else WHAT(KW, NBW, SET, 256); } while (0)
-#define WSEL(WHAT) do { \
-            if (!has_hi) { if (is_set) WGO(WHAT, 1, 2, true); else WGO(WHAT, 1, 2, false); } \
-            else if (nbw == 2) { if (is_set) WGO(WHAT, 2, 2, true); else WGO(WHAT, 2, 2, false); } \
-            else if (nbw == 3) { if (is_set) WGO(WHAT, 2, 3, true); else WGO(WHAT, 2, 3, false); } \
-            else { if (is_set) WGO(WHAT, 2, 4, true); else WGO(WHAT, 2, 4, false); } } while (0)
-            WSEL(WOCC);
-            if (per_cu < 1) per_cu = 1;
-            n_waves = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * (uint64_t)std::max(n_cu, 1), nbins_local);
-            if (const char* e = c->opt("DBG_WAVE_GRID")) n_waves = (uint32_t)std::min<uint64_t>(std::max(1, atoi(e)), nbins_local);
-            ALLOC_OR_FAIL(c, holes, n_waves);
-            if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] wave kernel: %d waves per CU x %d CUs -> %u waves, table %d\n", per_cu, n_cu, n_waves, tb == 512 ? 512 : 256);
-            c->t_begin("bin_count", n_kmers_units);
-            WSEL(WL);
-            c->t_end();
-            LAUNCH_CHECK(c, "bin_count_wave");
-#undef WSEL
-#undef WGO
-#undef WL
-#undef WOCC
-        } else if (nbins_local) {
+        if (nbins_local) {
             if ((uint64_t)nbins_local * 512 >= (1ull << 32)) return c->fail(135, "fast path: too many bins for the workgroup counting kernel (a grid holds < 2^32 threads)");
             c->t_begin("bin_count", n_kmers_units);
             const int nt_env = c->opt("DBG_FAST_NT") ? atoi(c->opt("DBG_FAST_NT")) : 512;
@@ -2036,7 +1966,6 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
             if (fl & 8u) DBG_TRY(fast_count_alloc_all(c, st, cur_all + cur_all / 16 + 1024));
             continue;
         }
-        if (n_waves) DBG_TRY(fast_close_holes(c, st, holes.p, n_waves, &cur));
         st->n_out = cur;
         st->n_all = cur_all;
         break;
@@ -2381,10 +2310,7 @@ extern "C" int dbg_count_kmer_instances_dev(dbg_ctx* c, const dbg_seqset* ds, ui
 
 static int plan_from(dbg_ctx* c, const dbg_shard_plan* sp, FastPlan* pl) {
     if (sp->n_bins % NCLS) return c->fail(144, "n_bins must be a multiple of bin_group");
-    // The sharded flow always counts with the workgroup kernel: exchanged records may carry weights (a peer's sender-side merge),
-    // which the wave-per-bin kernel (DBG_COUNT=wave, a per-ctx measurement knob) does not read -- and the knob would also change
-    // the bin count on one rank only.
-    if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl, false))
+    if (!fast_make_plan(c, (int)sp->k, sp->stranded != 0, sp->summarizer == DBG_COUNT_FILTER_SET, sp->total_kmers, sp->n_bins / NCLS, pl))
         return c->fail(140, "sharded counting supports 16 <= k <= 64");
     // every rank must use the same colour layout: it follows from the plan's global max_label (no per-rank label map here)
     if (pl->is_set && sp->n_labels) {
@@ -2485,6 +2411,7 @@ static int shard_scan_core(dbg_ctx* c, const dbg_seqset* ds, const dbg_shard_pla
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         unsigned long long n_away = 0;
         for (unsigned long long v : h_away) n_away += v;
+        st->n_merged_away = n_away;
         c->t_begin("sk_merged_away", n_away);  // bookkeeping entry: units = records the merge removed (no kernel)
         c->t_end();
     }

@@ -575,9 +575,9 @@ extern "C" int dbg_graph_write_gfa(dbg_ctx* c, uint32_t k, const dbg_graph* g, c
 // ================================================================================================
 extern "C" int dbg_compress_table_dev(dbg_ctx* c, uint32_t k, int stranded, int spec, const dbg_kmer_table* t, dbg_graph* out,
                                       dbg_label_classes* classes);
+#include "shard_comm.hpp"
 namespace {
 
-int g2_fail(dbg_ctx* c, const char* op) { return c->fail(160, std::string("sharded compress: transport operation ") + op + " failed"); }
 
 int graph_dev_from_host(dbg_ctx* c, const dbg_graph* g, GraphDev* d) {
     const uint64_t n = g->n_nodes, nw = g->n_seq_words;
@@ -754,7 +754,10 @@ int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, 
         const int r = compress_links_device(c, k, n, nullptr, nullptr, d.exts.p, d.data.p, u_link.p, nullptr, spec, stranded, &ng, &done, &un);
         c->graph_sink = nullptr;
         if (r) return r;
-        if (!done && (partial || (mode && !strcmp(mode, "device")))) return c->fail(48, "DBG_COMPRESS=device but the node links are not mutual");
+        if (!done && partial)
+            return c->fail(48, "tree reduce: the node links of a partial merge are not mutual (inconsistent Exts: input on which the reference's compress_graph "
+                               "panics or depends on visiting order); DBG_REDUCE_GATHER takes the literal walk for such input");
+        if (!done && mode && !strcmp(mode, "device")) return c->fail(48, "DBG_COMPRESS=device but the node links are not mutual");
     }
     if (!done) {
         // the literal walk (and the reference's panics): through the host entry point
@@ -790,41 +793,59 @@ int graph_dev_compress(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, 
 }
 
 // ---- graphs as device buffers over the transport ------------------------------------------------------------------------
-int graph_dev_send(dbg_ctx* c, const dbg_transport* tr, const GraphDev& g, int32_t peer) {
+// A graph travels in two steps with an agreement of all ranks in between (shard_comm.hpp): first its sizes, so that the receiver
+// can reserve its buffers -- the one thing that may fail on its side -- and only when every rank has what it needs, the arrays.
+struct GraphMeta { uint64_t n_nodes, n_words, n_bases, stranded; };
+
+int graph_send_meta(dbg_ctx* c, ShardComm& X, const GraphDev& g, int32_t peer) {
+    const dbg_transport* tr = X.tr;
     DBuf<uint64_t> meta;
-    ALLOC_OR_FAIL(c, meta, 4);
+    if (!meta.alloc(c, 4)) { X.abort(); return c->fail(101, "sharded compress: no device memory for the graph sizes (communicator aborted)"); }
     const uint64_t m[4] = {g.n_nodes, g.n_words, g.n_bases, (uint64_t)g.stranded};
-    HIP_TRY(c, hipMemcpyAsync(meta.p, m, 32, hipMemcpyHostToDevice, c->stream));
-    if (tr->send(tr->self, meta.p, 32, peer, c->stream)) return g2_fail(c, "send (graph sizes)");
-    if (g.n_words && tr->send(tr->self, g.words.p, g.n_words * 8, peer, c->stream)) return g2_fail(c, "send (sequence words)");
-    if (g.n_nodes) {
-        if (tr->send(tr->self, g.start.p, g.n_nodes * 8, peer, c->stream) || tr->send(tr->self, g.length.p, g.n_nodes * 4, peer, c->stream) ||
-            tr->send(tr->self, g.exts.p, g.n_nodes, peer, c->stream) || tr->send(tr->self, g.data.p, g.n_nodes * 4, peer, c->stream))
-            return g2_fail(c, "send (node arrays)");
-    }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hipMemcpyAsync(meta.p, m, 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the graph sizes"); }
+    if (tr->send(tr->self, meta.p, 32, peer, c->stream)) return X.op_failed("send (graph sizes)");
+    return X.wait_stream(c->stream, "the graph sizes to be sent");
+}
+int graph_recv_meta(dbg_ctx* c, ShardComm& X, GraphMeta* gm, int32_t peer) {
+    const dbg_transport* tr = X.tr;
+    DBuf<uint64_t> meta;
+    if (!meta.alloc(c, 4)) { X.abort(); return c->fail(101, "sharded compress: no device memory for the graph sizes (communicator aborted)"); }
+    if (tr->recv(tr->self, meta.p, 32, peer, c->stream)) return X.op_failed("recv (graph sizes)");
+    uint64_t m[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(m, meta.p, 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the graph sizes"); }
+    DBG_TRY(X.wait_stream(c->stream, "the graph sizes of a peer"));
+    gm->n_nodes = m[0]; gm->n_words = m[1]; gm->n_bases = m[2]; gm->stranded = m[3];
     return 0;
 }
-
-int graph_dev_recv(dbg_ctx* c, const dbg_transport* tr, GraphDev* g, int32_t peer) {
-    DBuf<uint64_t> meta;
-    ALLOC_OR_FAIL(c, meta, 4);
-    if (tr->recv(tr->self, meta.p, 32, peer, c->stream)) return g2_fail(c, "recv (graph sizes)");
-    uint64_t m[4] = {0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(m, meta.p, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const uint64_t n = m[0], nw = m[1];
+// rank-local: room for a graph of these sizes
+int graph_dev_reserve(dbg_ctx* c, const GraphMeta& gm, GraphDev* g) {
+    const uint64_t n = gm.n_nodes, nw = gm.n_words;
     ALLOC_OR_FAIL(c, g->words, nw + 3); ALLOC_OR_FAIL(c, g->start, n + 1); ALLOC_OR_FAIL(c, g->length, std::max<uint64_t>(n, 1));
     ALLOC_OR_FAIL(c, g->exts, std::max<uint64_t>(n, 1)); ALLOC_OR_FAIL(c, g->data, std::max<uint64_t>(n, 1));
     HIP_TRY(c, hipMemsetAsync(g->words.p + nw, 0, 3 * 8, c->stream));
-    if (nw && tr->recv(tr->self, g->words.p, nw * 8, peer, c->stream)) return g2_fail(c, "recv (sequence words)");
+    return 0;
+}
+int graph_send_data(dbg_ctx* c, ShardComm& X, const GraphDev& g, int32_t peer) {
+    const dbg_transport* tr = X.tr;
+    if (g.n_words && tr->send(tr->self, g.words.p, g.n_words * 8, peer, c->stream)) return X.op_failed("send (sequence words)");
+    if (g.n_nodes) {
+        if (tr->send(tr->self, g.start.p, g.n_nodes * 8, peer, c->stream) || tr->send(tr->self, g.length.p, g.n_nodes * 4, peer, c->stream) ||
+            tr->send(tr->self, g.exts.p, g.n_nodes, peer, c->stream) || tr->send(tr->self, g.data.p, g.n_nodes * 4, peer, c->stream))
+            return X.op_failed("send (node arrays)");
+    }
+    return X.wait_stream(c->stream, "a shard graph to be sent");
+}
+int graph_recv_data(dbg_ctx* c, ShardComm& X, const GraphMeta& gm, GraphDev* g, int32_t peer) {
+    const dbg_transport* tr = X.tr;
+    const uint64_t n = gm.n_nodes, nw = gm.n_words;
+    if (nw && tr->recv(tr->self, g->words.p, nw * 8, peer, c->stream)) return X.op_failed("recv (sequence words)");
     if (n) {
         if (tr->recv(tr->self, g->start.p, n * 8, peer, c->stream) || tr->recv(tr->self, g->length.p, n * 4, peer, c->stream) ||
             tr->recv(tr->self, g->exts.p, n, peer, c->stream) || tr->recv(tr->self, g->data.p, n * 4, peer, c->stream))
-            return g2_fail(c, "recv (node arrays)");
+            return X.op_failed("recv (node arrays)");
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    g->n_nodes = n; g->n_words = nw; g->n_bases = m[2]; g->stranded = (int)m[3]; g->filled = true;
+    DBG_TRY(X.wait_stream(c->stream, "a shard graph of a peer"));
+    g->n_nodes = n; g->n_words = nw; g->n_bases = gm.n_bases; g->stranded = (int)gm.stranded; g->filled = true;
     return 0;
 }
 
@@ -837,32 +858,42 @@ __global__ void __launch_bounds__(256) remap_u32_kernel(uint32_t* __restrict__ d
     if (v < n_map) data[i] = map[v]; else *flag = 1u;
 }
 
-// all_gather of one variable-size host blob per rank (sizes first, then the blobs padded to the largest)
-int gather_blobs(dbg_ctx* c, const dbg_transport* tr, const std::vector<uint8_t>& mine, std::vector<std::vector<uint8_t>>* all) {
-    const uint32_t W = (uint32_t)tr->world;
+// all_gather of one variable-size host blob per rank (sizes first, then the blobs padded to the largest).  `lrc`: this rank's
+// status so far; the ranks agree on it (and on their allocations) between the two steps.
+int gather_blobs(dbg_ctx* c, ShardComm& X, int lrc, const std::vector<uint8_t>& mine, std::vector<std::vector<uint8_t>>* all) {
+    const dbg_transport* tr = X.tr;
+    const uint32_t W = X.W;
     all->assign(W, {});
-    if (W == 1) { (*all)[0] = mine; return 0; }
+    if (W == 1) { (*all)[0] = mine; return lrc; }
     if (!tr->all_gather) return c->fail(161, "sharded compress: the transport lacks all_gather");
-    DBuf<uint64_t> d_sz, d_all;
-    ALLOC_OR_FAIL(c, d_sz, 1); ALLOC_OR_FAIL(c, d_all, W);
+    // (the two size words come out of the status reserve: nothing can fail locally before the first collective)
+    uint64_t* d_sz = X.word.p + 6;
+    DBuf<uint64_t> d_all;
+    if (!lrc && !d_all.alloc(c, W)) lrc = c->fail(101, "sharded compress: no device memory for the class-table sizes");
+    DBG_TRY(X.agree(lrc, "classes (sizes)"));
     const uint64_t sz = mine.size();
-    HIP_TRY(c, hipMemcpyAsync(d_sz.p, &sz, 8, hipMemcpyHostToDevice, c->stream));
-    if (tr->all_gather(tr->self, d_sz.p, d_all.p, 8, c->stream)) return g2_fail(c, "all_gather (class table sizes)");
+    if (hipMemcpyAsync(d_sz, &sz, 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the class-table size"); }
+    if (tr->all_gather(tr->self, d_sz, d_all.p, 8, c->stream)) return X.op_failed("all_gather (class table sizes)");
     std::vector<uint64_t> sizes(W);
-    HIP_TRY(c, hipMemcpyAsync(sizes.data(), d_all.p, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hipMemcpyAsync(sizes.data(), d_all.p, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the class-table sizes"); }
+    DBG_TRY(X.wait_stream(c->stream, "the class-table sizes of the other ranks"));
     uint64_t mx = 0;
     for (uint64_t v : sizes) mx = std::max(mx, v);
     mx = (mx + 7) & ~7ull;
     if (!mx) return 0;
     DBuf<uint8_t> d_mine, d_blobs;
-    ALLOC_OR_FAIL(c, d_mine, mx); ALLOC_OR_FAIL(c, d_blobs, mx * W);
-    HIP_TRY(c, hipMemsetAsync(d_mine.p, 0, mx, c->stream));
-    if (sz) HIP_TRY(c, hipMemcpyAsync(d_mine.p, mine.data(), sz, hipMemcpyHostToDevice, c->stream));
-    if (tr->all_gather(tr->self, d_mine.p, d_blobs.p, mx, c->stream)) return g2_fail(c, "all_gather (class tables)");
+    lrc = [&]() -> int {
+        if (X.inject("classes")) return X.injected("classes");
+        ALLOC_OR_FAIL(c, d_mine, mx); ALLOC_OR_FAIL(c, d_blobs, mx * W);
+        HIP_TRY(c, hipMemsetAsync(d_mine.p, 0, mx, c->stream));
+        if (sz) HIP_TRY(c, hipMemcpyAsync(d_mine.p, mine.data(), sz, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }();
+    DBG_TRY(X.agree(lrc, "classes (tables)"));
+    if (tr->all_gather(tr->self, d_mine.p, d_blobs.p, mx, c->stream)) return X.op_failed("all_gather (class tables)");
     std::vector<uint8_t> flat(mx * W);
-    HIP_TRY(c, hipMemcpyAsync(flat.data(), d_blobs.p, mx * W, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (hipMemcpyAsync(flat.data(), d_blobs.p, mx * W, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the class tables"); }
+    DBG_TRY(X.wait_stream(c->stream, "the class tables of the other ranks"));
     for (uint32_t r = 0; r < W; r++) (*all)[r].assign(flat.begin() + r * mx, flat.begin() + r * mx + sizes[r]);
     return 0;
 }
@@ -877,19 +908,30 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
     if (!table->on_device) return c->fail(162, "dbg_shard_compress_dev needs a device-resident table");
     const uint32_t W = tr ? (uint32_t)tr->world : 1u, me = tr ? (uint32_t)tr->rank : 0u;
     if (W == 0 || me >= W || root < 0 || (uint32_t)root >= W) return c->fail(161, "sharded compress: bad rank / world / root");
-    if (W > 1 && (!tr->send || !tr->recv)) return c->fail(161, "sharded compress: the transport lacks send / recv");
+    if (W > 1 && (!tr->send || !tr->recv || !tr->all_reduce_u64)) return c->fail(161, "sharded compress: the transport lacks send / recv / all_reduce_u64");
     if (reduce != DBG_REDUCE_GATHER && reduce != DBG_REDUCE_TREE) return c->fail(161, "sharded compress: unknown reduce mode");
     if (second_spec < 0) second_spec = spec;
     HIP_TRY(c, hipSetDevice(c->device));
     memset(final_out, 0, sizeof(*final_out));
     if (local_out) memset(local_out, 0, sizeof(*local_out));
     if (classes) memset(classes, 0, sizeof(*classes));
+    // Failure agreement (shard_comm.hpp): rank-local work keeps its status in `lrc`; every phase ends in X.agree() before the
+    // phase's data moves, so that all ranks leave with the same verdict and nobody waits for a graph that will not come.
+    ShardComm X(c, tr);
+    DBG_TRY(X.prepare());
+    int lrc = 0;
+    auto release_outputs = [&]() {
+        if (local_out) { dbg_free_graph(c, local_out); memset(local_out, 0, sizeof(*local_out)); }
+        if (classes) { dbg_free_label_classes(classes); memset(classes, 0, sizeof(*classes)); }
+        dbg_free_graph(c, final_out); memset(final_out, 0, sizeof(*final_out));
+    };
 
-    // ---- this rank's shard: compress_kmers_with_hash on the table of the bins it owns; the graph stays in HBM ----
+    // ---- phase "shard": this rank's compress_kmers_with_hash on the table of the bins it owns; the graph stays in HBM ----
     GraphDev mine;
     dbg_label_classes lc;
     memset(&lc, 0, sizeof(lc));
-    {
+    lrc = [&]() -> int {
+        if (X.inject("shard")) return X.injected("shard");
         dbg_graph hg;
         memset(&hg, 0, sizeof(hg));
         c->graph_sink = &mine;
@@ -902,7 +944,8 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             mine.stranded = stranded ? 1 : 0;
             dbg_free_graph(c, &hg);
         }
-    }
+        return 0;
+    }();
     // ---- label-list classes: one numbering for all ranks (ranks of the sorted distinct lists) ----
     if (table->set_off) {
         std::vector<uint8_t> blob(8 + (lc.n_classes + 1) * 8 + lc.n_set_val * 4);
@@ -910,8 +953,7 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
         if (lc.set_off) memcpy(blob.data() + 8, lc.set_off, (lc.n_classes + 1) * 8);       // (else: the one zero offset the vector already holds)
         if (lc.n_set_val) memcpy(blob.data() + 8 + (lc.n_classes + 1) * 8, lc.set_val, lc.n_set_val * 4);
         std::vector<std::vector<uint8_t>> all;
-        int r = W > 1 ? gather_blobs(c, tr, blob, &all) : 0;
-        if (W == 1) all.assign(1, blob);
+        const int r = gather_blobs(c, X, lrc, blob, &all);                                 // (agrees on `lrc` before anything moves)
         if (r) { dbg_free_label_classes(&lc); return r; }
         typedef std::vector<uint32_t> List;
         std::vector<std::vector<List>> tabs(W);
@@ -928,7 +970,8 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
         glob.erase(std::unique(glob.begin(), glob.end()), glob.end());
         std::vector<uint32_t> remap(tabs[me].size());
         for (size_t i = 0; i < remap.size(); i++) remap[i] = (uint32_t)(std::lower_bound(glob.begin(), glob.end(), tabs[me][i]) - glob.begin());
-        if (mine.n_nodes) {
+        lrc = [&]() -> int {
+            if (!mine.n_nodes) return 0;
             DBuf<uint32_t> d_map, fl;
             ALLOC_OR_FAIL(c, d_map, std::max<size_t>(remap.size(), 1)); ALLOC_OR_FAIL(c, fl, 1);
             HIP_TRY(c, hipMemsetAsync(fl.p, 0, 4, c->stream));
@@ -938,10 +981,11 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             uint32_t bad = 0;
             HIP_TRY(c, hipMemcpyAsync(&bad, fl.p, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (bad) { dbg_free_label_classes(&lc); return c->fail(164, "sharded compress: a node's class id is outside its rank's class table"); }
-        }
+            if (bad) return c->fail(164, "sharded compress: a node's class id is outside its rank's class table");
+            return 0;
+        }();
         dbg_free_label_classes(&lc);
-        if (classes) {
+        if (classes && !lrc) {
             uint64_t nv = 0;
             for (auto& l : glob) nv += l.size();
             classes->n_classes = glob.size(); classes->n_set_val = nv;
@@ -952,54 +996,87 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             classes->set_off[glob.size()] = o;
         }
     }
-    if (local_out) DBG_TRY(graph_dev_to_host(c, mine, local_out));
+    if (local_out && !lrc) lrc = graph_dev_to_host(c, mine, local_out);
+    if (int r = X.agree(lrc, "shard")) { release_outputs(); return r; }
 
     // ---- merge the shard graphs ----
     GraphDev result;
     bool have_result = false;
     if (reduce == DBG_REDUCE_GATHER || W == 1) {
-        if (me != (uint32_t)root) DBG_TRY(graph_dev_send(c, tr, mine, root));
+        // phase "gather (sizes)": the sizes go to root, root reserves room for every shard graph
+        std::vector<GraphDev> got(W);
+        std::vector<GraphMeta> gm(W);
+        if (me != (uint32_t)root) DBG_TRY(graph_send_meta(c, X, mine, root));
         else {
-            std::vector<GraphDev> got(W);
+            for (uint32_t r = 0; r < W; r++) if (r != me) DBG_TRY(graph_recv_meta(c, X, &gm[r], (int32_t)r));
+            lrc = [&]() -> int {
+                if (W > 1 && X.inject("gather")) return X.injected("gather");
+                for (uint32_t r = 0; r < W; r++) if (r != me) DBG_TRY(graph_dev_reserve(c, gm[r], &got[r]));
+                return 0;
+            }();
+        }
+        if (int r = X.agree(lrc, "gather (sizes)")) { release_outputs(); return r; }
+        if (me != (uint32_t)root) DBG_TRY(graph_send_data(c, X, mine, root));
+        else {
             std::vector<GraphDev*> order(W);
             for (uint32_t r = 0; r < W; r++) {
                 if (r == me) order[r] = &mine;
-                else { DBG_TRY(graph_dev_recv(c, tr, &got[r], (int32_t)r)); order[r] = &got[r]; }
+                else { DBG_TRY(graph_recv_data(c, X, gm[r], &got[r], (int32_t)r)); order[r] = &got[r]; }
             }
-            GraphDev comb;
-            DBG_TRY(graph_dev_combine(c, order, &comb));                                       // BaseGraph::combine(shard graphs in shard order), test.rs:468
-            DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result));     // compress_graph, test.rs:469
-            have_result = true;
+            lrc = [&]() -> int {
+                if (X.inject("merge")) return X.injected("merge");
+                GraphDev comb;
+                DBG_TRY(graph_dev_combine(c, order, &comb));                                       // BaseGraph::combine(shard graphs in shard order), test.rs:468
+                DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result));     // compress_graph, test.rs:469
+                return 0;
+            }();
+            have_result = !lrc;
         }
     } else {
-        // binary tree over ranks renumbered so that `root` is 0: at level l, position q with bit l set sends to q - 2^l and leaves
+        // binary tree over ranks renumbered so that `root` is 0: at level l, position q with bit l set sends to q - 2^l and leaves.
+        // Every rank takes part in every level's agreement, whether or not it still holds a graph.
         const uint32_t pos = (me + W - (uint32_t)root) % W;
         bool active = true;
-        for (uint32_t st = 1; st < W && active; st <<= 1) {
-            if (pos & st) {
-                const uint32_t to = ((pos - st) + (uint32_t)root) % W;
-                DBG_TRY(graph_dev_send(c, tr, mine, (int32_t)to));
+        for (uint32_t st = 1; st < W; st <<= 1) {
+            const bool sender = active && (pos & st), receiver = active && !(pos & st) && pos + st < W;
+            const uint32_t to = ((pos - st) + (uint32_t)root) % W, from = ((pos + st) + (uint32_t)root) % W;
+            GraphDev other;
+            GraphMeta gm{0, 0, 0, 0};
+            // (a rank whose own merge failed at the level below still exchanges sizes, so that its partner is not left waiting; the
+            //  status is agreed right after)
+            if (sender) DBG_TRY(graph_send_meta(c, X, mine, (int32_t)to));
+            else if (receiver) {
+                DBG_TRY(graph_recv_meta(c, X, &gm, (int32_t)from));
+                if (!lrc) lrc = (X.inject("tree") && st == 1) ? X.injected("tree") : graph_dev_reserve(c, gm, &other);
+            }
+            if (int r = X.agree(lrc, "tree (sizes)")) { release_outputs(); return r; }
+            if (sender) {
+                DBG_TRY(graph_send_data(c, X, mine, (int32_t)to));
                 graph_dev_clear(&mine);
                 active = false;
-            } else if (pos + st < W) {
-                const uint32_t from = ((pos + st) + (uint32_t)root) % W;
-                GraphDev other, comb, merged;
-                DBG_TRY(graph_dev_recv(c, tr, &other, (int32_t)from));
-                std::vector<GraphDev*> pair{&mine, &other};
-                DBG_TRY(graph_dev_combine(c, pair, &comb));
-                // every merge but the root's last one sees a part of the shards only
-                const bool last = pos == 0 && 2 * st >= W;
-                DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &merged, !last));
-                mine = std::move(merged);
+            } else if (receiver) {
+                DBG_TRY(graph_recv_data(c, X, gm, &other, (int32_t)from));
+                lrc = [&]() -> int {
+                    GraphDev comb, merged;
+                    std::vector<GraphDev*> pair{&mine, &other};
+                    DBG_TRY(graph_dev_combine(c, pair, &comb));
+                    // every merge but the root's last one sees a part of the shards only
+                    const bool last = pos == 0 && 2 * st >= W;
+                    DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &merged, !last));
+                    mine = std::move(merged);
+                    return 0;
+                }();
             }
         }
-        if (pos == 0) {
-            if (W == 1) { GraphDev comb; std::vector<GraphDev*> one{&mine}; DBG_TRY(graph_dev_combine(c, one, &comb)); DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result)); }
-            else result = std::move(mine);
-            have_result = true;
+        if (pos == 0 && !lrc) {
+            if (W == 1) {
+                lrc = [&]() -> int { GraphDev comb; std::vector<GraphDev*> one{&mine}; DBG_TRY(graph_dev_combine(c, one, &comb)); return graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result); }();
+            } else result = std::move(mine);
+            have_result = !lrc;
         }
     }
-    if (have_result) DBG_TRY(graph_dev_to_host(c, result, final_out));
-    else final_out->stranded = stranded ? 1 : 0;
+    if (have_result) lrc = graph_dev_to_host(c, result, final_out);
+    else if (!lrc) final_out->stranded = stranded ? 1 : 0;
+    if (int r = X.agree(lrc, "merge")) { release_outputs(); return r; }
     return 0;
 }

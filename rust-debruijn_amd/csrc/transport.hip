@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <mutex>
+#include <atomic>
 
 namespace {
 
@@ -25,6 +26,9 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    // failure handling (optional symbols: a librccl without them simply offers no poll / abort)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 void set_err(char* err, uint64_t n, const std::string& m) {
@@ -59,6 +63,8 @@ bool load_rccl(const char* path, RcclApi* api, std::string* why) {
     SYM(GetErrorString, "ncclGetErrorString"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
     SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
 #undef SYM
+    *(void**)(&a.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
+    *(void**)(&a.CommAbort) = dlsym(h, "ncclCommAbort");
     cache[key] = a;
     *api = a;
     return true;
@@ -69,6 +75,7 @@ struct RcclTransport {
     RcclApi api;
     ncclComm_t comm;
     std::string last;
+    std::atomic<bool> dead{false};   // aborted (or seen failing): the communicator is gone, every operation fails at once
 };
 
 // No single message above 1 GiB: RCCL transfers of 2 GiB and more were seen to arrive incomplete (round 2), and a message is
@@ -77,6 +84,7 @@ constexpr uint64_t MSG_MAX = 1ull << 30;
 
 int rc(RcclTransport* t, ncclResult_t r, const char* what) {
     if (r == ncclSuccess) return 0;
+    if (r == ncclInProgress) return 0;          // (non-blocking communicators: the operation is queued)
     t->last = std::string(what) + ": " + t->api.GetErrorString(r);
     fprintf(stderr, "[dbg transport rccl] %s\n", t->last.c_str());
     return 1;
@@ -84,17 +92,20 @@ int rc(RcclTransport* t, ncclResult_t r, const char* what) {
 
 int rccl_all_reduce(void* self, uint64_t* buf, uint64_t n, int32_t op, void* stream) {
     RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.load()) return 1;
     if (!n) return 0;
     return rc(t, t->api.AllReduce(buf, buf, (size_t)n, ncclUint64, op == 1 ? ncclMax : ncclSum, t->comm, (hipStream_t)stream), "ncclAllReduce");
 }
 int rccl_all_gather(void* self, const void* send, void* recv, uint64_t bytes, void* stream) {
     RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.load()) return 1;
     if (!bytes) return 0;
     return rc(t, t->api.AllGather(send, recv, (size_t)bytes, ncclUint8, t->comm, (hipStream_t)stream), "ncclAllGather");
 }
 int rccl_all_to_allv(void* self, const void* send, const uint64_t* soff, const uint64_t* sbytes, void* recv, const uint64_t* roff,
                      const uint64_t* rbytes, void* stream) {
     RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.load()) return 1;
     const int W = t->tab.world, me = t->tab.rank;
     // Peers in rotated order (rank + i), every pair's message cut into <= 1 GiB pieces: piece j of all pairs forms one group,
     // so that sends and receives of a group can progress together and both ends cut a pair's bytes the same way.
@@ -120,15 +131,42 @@ int rccl_all_to_allv(void* self, const void* send, const uint64_t* soff, const u
 }
 int rccl_send(void* self, const void* buf, uint64_t bytes, int32_t peer, void* stream) {
     RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.load()) return 1;
     for (uint64_t o = 0; o < bytes; o += MSG_MAX)
         if (rc(t, t->api.Send((const char*)buf + o, (size_t)std::min(MSG_MAX, bytes - o), ncclUint8, peer, t->comm, (hipStream_t)stream), "ncclSend")) return 1;
     return 0;
 }
 int rccl_recv(void* self, void* buf, uint64_t bytes, int32_t peer, void* stream) {
     RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.load()) return 1;
     for (uint64_t o = 0; o < bytes; o += MSG_MAX)
         if (rc(t, t->api.Recv((char*)buf + o, (size_t)std::min(MSG_MAX, bytes - o), ncclUint8, peer, t->comm, (hipStream_t)stream), "ncclRecv")) return 1;
     return 0;
+}
+
+// 0 = healthy.  ncclCommGetAsyncError reports errors RCCL's proxy / network threads met after an operation was queued (a peer
+// that died, a link that failed): the library polls it while it waits for communication.
+int rccl_poll(void* self) {
+    RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.load()) return 1;
+    if (!t->api.CommGetAsyncError) return 0;
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t r = t->api.CommGetAsyncError(t->comm, &st);
+    if (r != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) {
+        t->last = std::string("ncclCommGetAsyncError: ") + t->api.GetErrorString(r != ncclSuccess ? r : st);
+        fprintf(stderr, "[dbg transport rccl] %s\n", t->last.c_str());
+        return 1;
+    }
+    return 0;
+}
+// ncclCommAbort: frees the communicator and makes the kernels RCCL has in flight on this rank give up, so that a host wait on
+// them returns; the peers' operations with this rank then fail (their poll reports it) instead of waiting for ever.  The
+// ncclComm_t is gone afterwards: the host must not destroy it again (dbg_rccl_comm_destroy of an aborted communicator is the
+// caller's to skip -- dbg_transport_aborted tells).
+void rccl_abort(void* self) {
+    RcclTransport* t = (RcclTransport*)self;
+    if (t->dead.exchange(true)) return;
+    if (t->api.CommAbort) (void)t->api.CommAbort(t->comm);
 }
 
 }  // namespace
@@ -147,6 +185,7 @@ extern "C" int dbg_transport_rccl_create(void* nccl_comm, int32_t rank, int32_t 
     t->tab.self = t; t->tab.rank = rank; t->tab.world = world;
     t->tab.all_reduce_u64 = rccl_all_reduce; t->tab.all_gather = rccl_all_gather; t->tab.all_to_allv = rccl_all_to_allv;
     t->tab.send = rccl_send; t->tab.recv = rccl_recv;
+    t->tab.poll = rccl_poll; t->tab.abort = rccl_abort;
     *out = &t->tab;
     return 0;
 }
@@ -215,13 +254,15 @@ struct InprocShared {
     struct Mail { const void* p = nullptr; uint64_t bytes = 0; bool full = false, taken = false; };
     std::vector<std::vector<Mail>> mail;
     int refs = 0;
+    int timeout_s = 300;
+    void fail() { std::lock_guard<std::mutex> lk(mu); broken = true; cv.notify_all(); }
     bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
         if (broken) return false;
         const uint64_t gen = generation;
         if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return true; }
         // a rank that never arrives (its entry point failed) must not hang the others for ever
-        if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen || broken; })) { broken = true; cv.notify_all(); return false; }
+        if (!cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return generation != gen || broken; })) { broken = true; cv.notify_all(); return false; }
         return !broken;
     }
 };
@@ -238,27 +279,31 @@ int ip_all_reduce(void* self, uint64_t* buf, uint64_t n, int32_t op, void* strea
     const int me = t->tab.rank, W = sh->world;
     std::vector<uint64_t>& mine = sh->host[me];
     mine.resize(n);
-    if (n && hipMemcpyAsync(mine.data(), buf, n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return 1;
-    if (ip_sync(stream) || !sh->barrier()) return 1;
+    if (n && hipMemcpyAsync(mine.data(), buf, n * 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); sh->fail(); return 1; }
+    if (ip_sync(stream)) { sh->fail(); return 1; }
+    if (!sh->barrier()) return 1;
     std::vector<uint64_t> acc(n, 0);
     for (int r = 0; r < W; r++) {
         const std::vector<uint64_t>& v = sh->host[r];
-        if (v.size() != n) return 1;                                    // the ranks disagree about the operation
+        if (v.size() != n) { sh->fail(); return 1; }                    // the ranks disagree about the operation
         for (uint64_t i = 0; i < n; i++) acc[i] = op == 1 ? std::max(acc[i], v[i]) : acc[i] + v[i];
     }
     if (!sh->barrier()) return 1;                                       // everybody has read the slots
-    if (n && hipMemcpyAsync(buf, acc.data(), n * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return 1;
-    return ip_sync(stream);                                             // `acc` leaves scope
+    if (n && hipMemcpyAsync(buf, acc.data(), n * 8, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); sh->fail(); return 1; }
+    if (ip_sync(stream)) { sh->fail(); return 1; }                      // `acc` leaves scope
+    return 0;
 }
 int ip_all_gather(void* self, const void* send, void* recv, uint64_t bytes, void* stream) {
     InprocTransport* t = (InprocTransport*)self;
     InprocShared* sh = t->sh;
     const int me = t->tab.rank, W = sh->world;
     sh->ptr[me] = send;
-    if (ip_sync(stream) || !sh->barrier()) return 1;
+    if (ip_sync(stream)) { sh->fail(); return 1; }
+    if (!sh->barrier()) return 1;
     for (int r = 0; r < W; r++)
-        if (bytes && hipMemcpyAsync((char*)recv + (uint64_t)r * bytes, sh->ptr[r], bytes, hipMemcpyDefault, (hipStream_t)stream) != hipSuccess) return 1;
-    if (ip_sync(stream) || !sh->barrier()) return 1;                    // the senders' buffers may change again
+        if (bytes && hipMemcpyAsync((char*)recv + (uint64_t)r * bytes, sh->ptr[r], bytes, hipMemcpyDefault, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); sh->fail(); return 1; }
+    if (ip_sync(stream)) { sh->fail(); return 1; }
+    if (!sh->barrier()) return 1;                                       // the senders' buffers may change again
     return 0;
 }
 int ip_all_to_allv(void* self, const void* send, const uint64_t* soff, const uint64_t* sbytes, void* recv, const uint64_t* roff,
@@ -269,26 +314,30 @@ int ip_all_to_allv(void* self, const void* send, const uint64_t* soff, const uin
     sh->ptr[me] = send;
     sh->off[me].assign(soff, soff + W);
     sh->bytes[me].assign(sbytes, sbytes + W);
-    if (ip_sync(stream) || !sh->barrier()) return 1;
+    if (ip_sync(stream)) { sh->fail(); return 1; }
+    if (!sh->barrier()) return 1;
     for (int i = 0; i < W; i++) {
         const int s = (me + i) % W;
-        if (sh->bytes[s][me] != rbytes[s]) return 1;                    // sender and receiver disagree about the message
-        if (rbytes[s] && hipMemcpyAsync((char*)recv + roff[s], (const char*)sh->ptr[s] + sh->off[s][me], rbytes[s], hipMemcpyDefault, (hipStream_t)stream) != hipSuccess)
-            return 1;
+        if (sh->bytes[s][me] != rbytes[s]) { sh->fail(); return 1; }    // sender and receiver disagree about the message
+        if (rbytes[s] && hipMemcpyAsync((char*)recv + roff[s], (const char*)sh->ptr[s] + sh->off[s][me], rbytes[s], hipMemcpyDefault, (hipStream_t)stream) != hipSuccess) {
+            (void)hipGetLastError(); sh->fail(); return 1;
+        }
     }
-    if (ip_sync(stream) || !sh->barrier()) return 1;
+    if (ip_sync(stream)) { sh->fail(); return 1; }
+    if (!sh->barrier()) return 1;
     return 0;
 }
 int ip_send(void* self, const void* buf, uint64_t bytes, int32_t peer, void* stream) {
     InprocTransport* t = (InprocTransport*)self;
     InprocShared* sh = t->sh;
-    if (peer < 0 || peer >= sh->world || ip_sync(stream)) return 1;
+    if (peer < 0 || peer >= sh->world) return 1;
+    if (ip_sync(stream)) { sh->fail(); return 1; }
     InprocShared::Mail& m = sh->mail[peer][t->tab.rank];
     std::unique_lock<std::mutex> lk(sh->mu);
-    if (!sh->cv.wait_for(lk, std::chrono::seconds(300), [&] { return !m.full || sh->broken; }) || sh->broken) return 1;
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(sh->timeout_s), [&] { return !m.full || sh->broken; }) || sh->broken) { sh->broken = true; sh->cv.notify_all(); return 1; }
     m.p = buf; m.bytes = bytes; m.full = true; m.taken = false;
     sh->cv.notify_all();
-    if (!sh->cv.wait_for(lk, std::chrono::seconds(300), [&] { return m.taken || sh->broken; }) || sh->broken) return 1;   // the receiver has copied
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(sh->timeout_s), [&] { return m.taken || sh->broken; }) || sh->broken) { sh->broken = true; sh->cv.notify_all(); return 1; }   // the receiver has copied
     m.full = false;
     sh->cv.notify_all();
     return 0;
@@ -301,7 +350,7 @@ int ip_recv(void* self, void* buf, uint64_t bytes, int32_t peer, void* stream) {
     const void* src = nullptr;
     {
         std::unique_lock<std::mutex> lk(sh->mu);
-        if (!sh->cv.wait_for(lk, std::chrono::seconds(300), [&] { return (m.full && !m.taken) || sh->broken; }) || sh->broken) return 1;
+        if (!sh->cv.wait_for(lk, std::chrono::seconds(sh->timeout_s), [&] { return (m.full && !m.taken) || sh->broken; }) || sh->broken) { sh->broken = true; sh->cv.notify_all(); return 1; }
         if (m.bytes != bytes) { sh->broken = true; sh->cv.notify_all(); return 1; }
         src = m.p;
     }
@@ -314,6 +363,12 @@ int ip_recv(void* self, void* buf, uint64_t bytes, int32_t peer, void* stream) {
     sh->cv.notify_all();
     return rc;
 }
+int ip_poll(void* self) {
+    InprocShared* sh = ((InprocTransport*)self)->sh;
+    std::lock_guard<std::mutex> lk(sh->mu);
+    return sh->broken ? 1 : 0;
+}
+void ip_abort(void* self) { ((InprocTransport*)self)->sh->fail(); }
 std::mutex g_inproc_mu;
 }  // namespace
 
@@ -325,14 +380,24 @@ extern "C" int dbg_transport_inprocess_create(int32_t world, dbg_transport** out
     sh->off.assign(world, {}); sh->bytes.assign(world, {}); sh->host.assign(world, {});
     sh->mail.assign(world, std::vector<InprocShared::Mail>(world));
     sh->refs = world;
+    if (const char* e = getenv("DBG_INPROC_TIMEOUT_S")) { const int v = atoi(e); if (v > 0) sh->timeout_s = v; }    // (read once, at creation)
     for (int r = 0; r < world; r++) {
         InprocTransport* t = new InprocTransport();
         t->sh = sh;
         t->tab.self = t; t->tab.rank = r; t->tab.world = world;
         t->tab.all_reduce_u64 = ip_all_reduce; t->tab.all_gather = ip_all_gather; t->tab.all_to_allv = ip_all_to_allv;
         t->tab.send = ip_send; t->tab.recv = ip_recv;
+        t->tab.poll = ip_poll; t->tab.abort = ip_abort;
         out[r] = &t->tab;
     }
+    return 0;
+}
+
+// 1 once a table of this library has been aborted / broken (RCCL: the ncclComm_t no longer exists -- do not destroy it again)
+extern "C" int dbg_transport_aborted(const dbg_transport* t) {
+    if (!t || t->self != (const void*)t) return 0;
+    if (t->all_reduce_u64 == rccl_all_reduce) return ((RcclTransport*)t->self)->dead.load() ? 1 : 0;
+    if (t->all_reduce_u64 == ip_all_reduce) return ip_poll(t->self);
     return 0;
 }
 

@@ -40,6 +40,7 @@ class TorchTransport:
         self.name = "torch.distributed/%s%s" % (dist.get_backend(group), " (host-staged)" if self.staged else "")
         self._cbs = (_capi.TR_ALL_REDUCE(self._all_reduce), _capi.TR_ALL_GATHER(self._all_gather),
                      _capi.TR_ALL_TO_ALLV(self._all_to_allv), _capi.TR_SEND(self._send), _capi.TR_RECV(self._recv))
+        # (poll / abort stay NULL: torch.distributed has its own watchdog; the library then waits without a health check)
         self.table = _capi.Transport(None, self.rank, self.world, *self._cbs)
 
     @property
@@ -163,10 +164,12 @@ class RcclTransport:
         lib = _capi.load()
         self.lib = lib
         self.path = (librccl or os.environ.get("DBG_LIBRCCL") or _torch_librccl() or "").encode() or None
-        if rank is None or world is None or bootstrap is None:
+        if rank is None or world is None:
             import torch.distributed as dist
             rank = dist.get_rank(group) if rank is None else rank
             world = dist.get_world_size(group) if world is None else world
+        if bootstrap is None:
+            import torch.distributed as dist
 
             def bootstrap(obj, _g=group):
                 box = [obj]
@@ -204,11 +207,13 @@ class RcclTransport:
         return self._tp.contents
 
     def close(self):
+        aborted = bool(getattr(self, "_tp", None)) and bool(self.lib.dbg_transport_aborted(self._tp))
         if getattr(self, "_tp", None):
             self.lib.dbg_transport_destroy(self._tp)
             self._tp = None
         if getattr(self, "comm", None):
-            self.lib.dbg_rccl_comm_destroy(self.path, self.comm)
+            if not aborted:                                   # (ncclCommAbort has already freed an aborted communicator)
+                self.lib.dbg_rccl_comm_destroy(self.path, self.comm)
             self.comm = None
 
 

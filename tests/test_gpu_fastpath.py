@@ -21,16 +21,13 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["wave", "wg"])
-def force_fast(ctx, request):
-    """every test runs with both counting kernels: the workgroup-per-bin kernel (the default; DBG_COUNT=wg names it: 2048-entry
-    tables shared by eight waves) and the wave-per-bin kernel (DBG_COUNT=wave: small bins, private 256-entry tables,
-    fast_wavecount.hpp -- measured 1.5-1.7x slower in round 3 and kept as an option)"""
+@pytest.fixture(autouse=True)
+def force_fast(ctx):
+    """every test of this file insists on the fast path (the wave-per-bin counting kernel of round 3, which these tests also ran
+    with, was measured 1.5-1.7x slower and left the product in round 5: branch exp-wavecount)"""
     old = ctx.set_option("DBG_PATH", "fast")
-    old_c = ctx.set_option("DBG_COUNT", request.param)
     yield
     ctx.set_option("DBG_PATH", old)
-    ctx.set_option("DBG_COUNT", old_c)
 
 
 def run_fast(ctx, ss, k, summarizer, min_obs, stranded, data_width=0):

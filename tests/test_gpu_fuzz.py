@@ -59,10 +59,10 @@ def draw_case(rng):
         data = alphabet[rng.integers(0, len(alphabet), size=n_reads)]
     min_obs = int(rng.choice([1, 1, 2, 3]))
     report_all = bool(rng.integers(0, 2))
-    # a route knob now and then (all routes must give the same table): the wave-per-bin counting kernel, tiny and huge bins (multi-pass
+    # a route knob now and then (all routes must give the same table): tiny and huge bins (multi-pass
     # tables, slab overflow), no slabs, the three-array sort form, the plain LSD sort, the wave-per-read scanner
-    knobs = [{}, {}, {}, {"DBG_COUNT": "wave"}, {"DBG_FAST_TARGET": "600"}, {"DBG_FAST_TARGET": "50000"}, {"DBG_FAST_NO_SLAB": "1"},
-             {"DBG_NO_REC16": "1"}, {"DBG_NO_HYBRID_SORT": "1"}, {"DBG_SCAN": "wave"}, {"DBG_COUNT": "wave", "DBG_FAST_TARGET": "300"},
+    knobs = [{}, {}, {}, {}, {"DBG_FAST_TARGET": "600"}, {"DBG_FAST_TARGET": "50000"}, {"DBG_FAST_NO_SLAB": "1"},
+             {"DBG_NO_REC16": "1"}, {"DBG_NO_HYBRID_SORT": "1"}, {"DBG_SCAN": "wave"}, {"DBG_FAST_TARGET": "300"},
              {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}, {"DBG_NO_LABEL_GROUPS": "1"}, {"DBG_NO_STRAND_NORM": "1"},
              # (k <= 15: the directly addressed table whatever the input's size -- k >= 9 partitions its k-mer instances, in one batch or in many)
              {"DBG_PATH": "dense"}, {"DBG_PATH": "dense", "DBG_DENSE_BATCH": "3000"}, {"DBG_PATH": "dense", "DBG_DENSE_PART": "0"},
