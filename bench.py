@@ -246,7 +246,7 @@ def main():
         if dom:
             key = 8 if k <= 32 else 16
             rbytes = key + 4                                   # record = key + 4-byte payload in this build
-            pint = 15 if k >= 23 else (13 if k >= 21 else max(4, k - 8))
+            pint = 15 if k >= 30 else (14 if k >= 26 else 13)         # fast_internal_p (fastpath.hip)
             rec_b = 8 * max(2, (2 * (2 * k - pint) + 20 + 63) // 64)   # super-k-mer record bytes (bases + 20 meta bits)
             b_in = (L / 4.0) / (L - k + 1)
             sk_b = n_recs * rec_b / max(n_inst, 1)             # super-k-mer bytes per k-mer instance

@@ -1486,7 +1486,13 @@ __global__ void __launch_bounds__(256) slab_probe_kernel(uint64_t* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------------
-int fast_internal_p(int k) { return k >= 23 ? 15 : (k >= 21 ? 13 : std::max(4, k - 8)); }
+// Length of the internal minimizers.  Longer p-mers mean shorter windows (W = k - p + 1) and so more records per read (density
+// 2 / (W + 1)), shorter ones mean fewer distinct minimizers than bins: hot bins, slabs that overflow, tables re-streamed in passes.
+// Measured at the C2 shape for every p the record layout allows (profiles/r05_p_sweep.json, round 5): 13 bases are the shortest that
+// keep the load of 10^6 bins even (4^13 / 2 = 3.4e7 canonical p-mers), so k <= 25 uses 13 whatever the window -- the earlier rule
+// p = k - 8 for k <= 20 kept windows of nine p-mers and paid for it with 65 536 .. 8e6 distinct minimizers: 1.0 / 5.0 / 23.9
+// Gkmer/s at k = 16 / 18 / 20, now 24.9 / 39.4 / 43.7 -- 26..29 gain 3-8 % with 14, from 30 on 15 wins.
+int fast_internal_p(int k) { return k >= 30 ? 15 : (k >= 26 ? 14 : 13); }
 
 struct FastPlan {
     int k, p, nbw, rw;

@@ -920,6 +920,18 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
     ShardComm X(c, tr);
     DBG_TRY(X.prepare());
     int lrc = 0;
+    // per-phase host time of this rank (DBG_DEBUG: one line per phase on stderr; tools/rehearse_shard.py collects them)
+    const bool dbg_t = c->opt("DBG_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_last = now();
+    auto phase_done = [&](const char* name, uint64_t nodes) {
+        if (!dbg_t) return;
+        (void)hipStreamSynchronize(c->stream);
+        const auto t = now();
+        fprintf(stderr, "[shard_compress] rank=%u phase=%s ms=%.2f nodes=%llu\n", me, name, std::chrono::duration<double, std::milli>(t - t_last).count(),
+                (unsigned long long)nodes);
+        t_last = t;
+    };
     auto release_outputs = [&]() {
         if (local_out) { dbg_free_graph(c, local_out); memset(local_out, 0, sizeof(*local_out)); }
         if (classes) { dbg_free_label_classes(classes); memset(classes, 0, sizeof(*classes)); }
@@ -997,6 +1009,7 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
         }
     }
     if (local_out && !lrc) lrc = graph_dev_to_host(c, mine, local_out);
+    phase_done("shard_compress", mine.n_nodes);
     if (int r = X.agree(lrc, "shard")) { release_outputs(); return r; }
 
     // ---- merge the shard graphs ----
@@ -1023,11 +1036,14 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
                 if (r == me) order[r] = &mine;
                 else { DBG_TRY(graph_recv_data(c, X, gm[r], &got[r], (int32_t)r)); order[r] = &got[r]; }
             }
+            phase_done("gather_transfer", 0);
             lrc = [&]() -> int {
                 if (X.inject("merge")) return X.injected("merge");
                 GraphDev comb;
                 DBG_TRY(graph_dev_combine(c, order, &comb));                                       // BaseGraph::combine(shard graphs in shard order), test.rs:468
+                phase_done("combine", comb.n_nodes);
                 DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &result));     // compress_graph, test.rs:469
+                phase_done("compress_graph", result.n_nodes);
                 return 0;
             }();
             have_result = !lrc;
@@ -1056,13 +1072,16 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
                 active = false;
             } else if (receiver) {
                 DBG_TRY(graph_recv_data(c, X, gm, &other, (int32_t)from));
+                phase_done("tree_transfer", other.n_nodes);
                 lrc = [&]() -> int {
                     GraphDev comb, merged;
                     std::vector<GraphDev*> pair{&mine, &other};
                     DBG_TRY(graph_dev_combine(c, pair, &comb));
+                    phase_done("tree_combine", comb.n_nodes);
                     // every merge but the root's last one sees a part of the shards only
                     const bool last = pos == 0 && 2 * st >= W;
                     DBG_TRY(graph_dev_compress(c, (int)k, stranded, second_spec, &comb, &merged, !last));
+                    phase_done(last ? "tree_compress_graph_last" : "tree_compress_graph_partial", merged.n_nodes);
                     mine = std::move(merged);
                     return 0;
                 }();
@@ -1075,7 +1094,7 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             have_result = !lrc;
         }
     }
-    if (have_result) lrc = graph_dev_to_host(c, result, final_out);
+    if (have_result) { lrc = graph_dev_to_host(c, result, final_out); phase_done("graph_to_host", result.n_nodes); }
     else if (!lrc) final_out->stranded = stranded ? 1 : 0;
     if (int r = X.agree(lrc, "merge")) { release_outputs(); return r; }
     return 0;

@@ -45,6 +45,32 @@ def test_collective_route_full_size_nccl():
     assert d["config"]["valid_kmers_all_ranks"] == 501537896            # the single-call count of this stream (BENCH_r02)
 
 
+@pytest.mark.parametrize("k,reads,summarizer", [(63, 125_000_000, "count"), (51, 75_000_000, "set")])
+def test_collective_route_config4_config5_shares_full_size_nccl(k, reads, summarizer):
+    """One GPU's share of BASELINE configs 4 and 5 (10^9 reads / 8 at k = 63: 4-word records, 20-byte outputs; 6*10^8 / 8 at k = 51 with
+    label sets) through the library's RCCL table on a one-rank communicator with the exchange route forced: layout, compaction,
+    ncclSend / ncclRecv groups and event-ordered rounds at the sizes the 8-GPU runs will have.  Same digest as the plain call."""
+    import json
+    def run(extra):
+        r = subprocess.run(["python", "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-host-boundary", "--compress-reads", "0",
+                            "--digest", "--k", str(k), "--reads", str(reads), "--summarizer", summarizer] + extra, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = run([]), run(["--force-exchange", "--backend", "nccl"])
+    assert a["config"]["kmer_instances_per_step"] == reads * (150 - k + 1)
+    assert a["table_digest"] == b["table_digest"] and a["config"]["valid_kmers_all_ranks"] == b["config"]["valid_kmers_all_ranks"]
+    assert b["exchange"]["transport"].startswith("rccl") and b["exchange"]["rounds"] >= 4
+
+
+def test_rehearsal_tool_small():
+    """tools/rehearse_shard.py (thread-ranks over the in-process transport: both rank-spanning C calls against the single-GPU calls,
+    table digests and an order- and strand-independent graph digest) at a size the suite can afford; the full-size runs are in
+    profiles/r05_second_stage.txt"""
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "rehearse_shard.py"), "--ranks", "3", "--reads-per-rank", "40000"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "rehearsal ok" in r.stdout and r.stdout.count("EQUAL") == 3, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_strong_scaled_baseline_shapes_two_ranks_one_gpu():
     """bench.py --config c4 / c5: BASELINE shapes that name a TOTAL size, split over the ranks (strong scaling).  Two ranks share
     cuda:0 (gloo); a scaled-down total; the tables add up to the single-call table of the same reads and k."""

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Full-size rehearsal of the two rank-spanning C entry points on ONE GPU (round 5; VERDICT r04 item 1 b/c).
+
+N thread-ranks (the library's in-process transport; one dbg_ctx each on cuda:0) share a stream of synthetic reads the way N GPUs
+would: rank r generates reads [r * per, (r + 1) * per) of the stream in HBM, all ranks call dbg_shard_filter_kmers_dev (N owners,
+N rounds by default), then dbg_shard_compress_dev in gather and in tree mode.  Checked against the single-GPU calls over the same
+reads:
+  * the per-rank table digests add up to the digest of dbg_filter_kmers_dev's table (every k-mer lives on exactly one rank),
+  * the root's final graph has the digest of the graph dbg_compress_kmers_with_hash_dev builds from the whole table: an
+    order- and strand-independent sum over nodes of a hash of {canonical first k-mer, canonical last k-mer}, length and data
+    (both graphs are maximal compressions of the same k-mer set, src/compression.rs:291-349, so equal node sets <=> equal digests),
+and the per-phase host times of the second stage (DBG_DEBUG lines of dbg_shard_compress_dev) are collected:
+per-shard compress, transfer, combine, compress_graph -- the reference's flow is src/test.rs:459-470, src/graph.rs:71-100.
+
+    python tools/rehearse_shard.py --ranks 8 --reads-per-rank 12500000 --k 47 [--summarizer count] [--out profiles/r05_second_stage.txt]
+"""
+import argparse
+import ctypes as C
+import importlib
+import io
+import json
+import os
+import re
+import sys
+import tempfile
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+M64 = (1 << 64) - 1
+
+
+def s64(x):
+    x &= M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+def lshr(x, n):
+    """logical right shift of int64 tensors by a python int 1..63"""
+    return (x >> n) & ((1 << (64 - n)) - 1)
+
+
+def rev2_64(x):
+    """reverse the 32 two-bit groups of every int64"""
+    for sh, m in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF)):
+        x = (lshr(x, sh) & m) | ((x & m) << sh)
+    return lshr(x, 32) | (x << 32)
+
+
+def graph_digest(torch, dev, words, start, length, data, k):
+    """order- and strand-independent digest of a BaseGraph's node set (see the module docstring)"""
+    n = len(length)
+    if n == 0:
+        return 0
+    w = torch.from_numpy(words.view("int64")).to(dev)
+    nw = w.numel()
+    st = torch.from_numpy(start.view("int64")).to(dev)
+    ln = torch.from_numpy(length.astype("int64")).to(dev)
+    da = torch.from_numpy(data.astype("int64")).to(dev)
+    SIGN = -(1 << 63)
+
+    def kmer_at(pos):
+        wi = pos >> 5
+        sh = (pos & 31) * 2
+        idx = lambda d: torch.clamp(wi + d, max=nw - 1)
+        w0, w1, w2 = w[idx(0)], w[idx(1)], w[idx(2)]
+        inv = 64 - sh                                              # 2..64
+        z = sh == 0
+        r1 = torch.where(z, torch.zeros_like(w1), (w1 >> torch.clamp(inv, max=63)) & ((torch.ones_like(sh) << sh) - 1))
+        r2 = torch.where(z, torch.zeros_like(w2), (w2 >> torch.clamp(inv, max=63)) & ((torch.ones_like(sh) << sh) - 1))
+        hi = (w0 << sh) | r1
+        lo = (w1 << sh) | r2
+        if 2 * k <= 64:
+            hi = hi & s64(M64 << (64 - 2 * k))
+            lo = torch.zeros_like(lo)
+        elif 2 * k < 128:
+            lo = lo & s64(M64 << (128 - 2 * k))
+        # reverse complement, left-aligned again
+        chi, clo = rev2_64(~lo), rev2_64(~hi)                      # 128-bit reversal of the complement: the k-mer's rc sits in the LOW 2k bits
+        sft = 128 - 2 * k
+        if sft >= 64:
+            rhi, rlo = clo << (sft - 64) if sft > 64 else clo, torch.zeros_like(clo)
+        elif sft == 0:
+            rhi, rlo = chi, clo
+        else:
+            rhi, rlo = (chi << sft) | lshr(clo, 64 - sft), clo << sft
+        less = ((rhi ^ SIGN) < (hi ^ SIGN)) | ((rhi == hi) & ((rlo ^ SIGN) < (lo ^ SIGN)))
+        return torch.where(less, rhi, hi), torch.where(less, rlo, lo)
+
+    def mix(a, b):
+        x = a * s64(0x9E3779B97F4A7C15) + b * s64(0xC2B2AE3D27D4EB4F)
+        x = x ^ lshr(x, 29)
+        x = x * s64(0xD6E8FEB86659FD93)
+        return x ^ lshr(x, 32)
+    fh, fl = kmer_at(st)
+    lh, ll = kmer_at(st + ln - k)
+    ends = mix(fh, fl) + mix(lh, ll)                              # commutative: a node and its reverse complement agree
+    node = mix(ends + ln * s64(0x9FB21C651E98DF25), da + 1)
+    return int(node.sum().item()) & M64
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=8)
+    ap.add_argument("--reads-per-rank", type=int, default=12_500_000)
+    ap.add_argument("--k", type=int, default=47)
+    ap.add_argument("--summarizer", default="count", choices=["count", "set"])
+    ap.add_argument("--rounds", type=int, default=0, help="exchange rounds (0 = the library's default: 8 from four ranks on)")
+    ap.add_argument("--no-compress", action="store_true")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    os.environ.setdefault("DBG_INPROC_TIMEOUT_S", "600")
+    import numpy as np
+    import torch
+    dbg = importlib.import_module("rust-debruijn_amd")
+    capi = importlib.import_module("rust-debruijn_amd._capi")
+    D = importlib.import_module("rust-debruijn_amd.distributed")
+    lib = capi.load()
+    dev = torch.device("cuda", 0)
+    W, per, k, L = args.ranks, args.reads_per_rank, args.k, 150
+    is_set = args.summarizer == "set"
+    total_reads = W * per
+    genome_len = total_reads * L // 30
+    log = io.StringIO()
+
+    def say(*a):
+        line = " ".join(str(x) for x in a)
+        print(line, flush=True)
+        log.write(line + "\n")
+
+    def synth(ctx, n, first):
+        p = dbg.synth_params(n_reads=n, read_len=L, genome_len=genome_len, error_rate=0.001, stranded=False, n_colours=4, first_read=first)
+        nw = lib.dbg_synth_words(C.byref(p))
+        t = dict(words=torch.empty(nw, dtype=torch.int64, device=dev), start=torch.empty(n, dtype=torch.int64, device=dev),
+                 length=torch.empty(n, dtype=torch.int32, device=dev), colour=torch.empty(n, dtype=torch.uint8, device=dev))
+        ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), t["words"].data_ptr(), t["start"].data_ptr(), t["length"].data_ptr(), t["colour"].data_ptr()))
+        torch.cuda.synchronize()
+        ss = capi.SeqSet(t["words"].data_ptr(), nw, t["start"].data_ptr(), t["length"].data_ptr(), None,
+                         t["colour"].data_ptr() if is_set else None, 1 if is_set else 0, n)
+        return ss, t
+
+    spec = dbg.SimpleCompress("saturating_add")
+    say("# rehearse_shard: %d thread-ranks x %d reads (%d in all), k = %d, %s(2), one GPU, in-process transport" % (W, per, total_reads, k, "CountFilterSet" if is_set else "CountFilter"))
+
+    # ---- the single-GPU calls over the same reads ----
+    ctx0 = dbg.Context(0)
+    ss, keep = synth(ctx0, total_reads, 0)
+    fp = capi.FilterParams(k, 0, 1 if is_set else 0, 2, 0, 4)
+    t1 = capi.KmerTable()
+    t0 = time.perf_counter()
+    ctx0.check(lib.dbg_filter_kmers_dev(ctx0.h, C.byref(ss), C.byref(fp), C.byref(t1)))
+    single_filter_s = time.perf_counter() - t0
+    single_digest, single_valid = D.table_digest(t1, dev), int(t1.n)
+    say("single call: %d valid k-mers, table digest %016x, %.3f s (first call of the ctx)" % (single_valid, single_digest, single_filter_s))
+    single_graph_digest = None
+    if not args.no_compress and not is_set:
+        g = capi.Graph()
+        t0 = time.perf_counter()
+        ctx0.check(lib.dbg_compress_kmers_with_hash_dev(ctx0.h, k, 0, spec.kind, t1.n, t1.key_hi, t1.key_lo, t1.exts, None, t1.count, C.byref(g)))
+        single_compress_s = time.perf_counter() - t0
+        arr = lambda ptr, n_, ty: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(max(int(n_), 1),))[:int(n_)]
+        single_graph_digest = graph_digest(torch, dev, arr(g.seq_words, g.n_seq_words, C.c_uint64), arr(g.start, g.n_nodes, C.c_uint64),
+                                           arr(g.length, g.n_nodes, C.c_uint32), arr(g.data, g.n_nodes, C.c_uint32), k)
+        say("single compress_kmers_with_hash (index in HBM): %d unitigs, %d bases, graph digest %016x, %.3f s"
+            % (g.n_nodes, g.seq_len_bases, single_graph_digest, single_compress_s))
+        single_nodes = int(g.n_nodes)
+        lib.dbg_free_graph(ctx0.h, C.byref(g))
+    lib.dbg_free_table(ctx0.h, C.byref(t1))
+    del keep, ss
+    ctx0.close()
+    torch.cuda.empty_cache()
+
+    # ---- the same over W thread-ranks ----
+    arr_t = (C.POINTER(capi.Transport) * W)()
+    assert lib.dbg_transport_inprocess_create(W, arr_t) == 0
+    ctxs = [dbg.Context(0) for _ in range(W)]
+    res = [None] * W
+    err = [None] * W
+
+    def run(fn):
+        def body(r):
+            try:
+                res[r] = fn(r)
+            except BaseException as e:                           # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=body, args=(r,)) for r in range(W)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for r, e in enumerate(err):
+            if e is not None:
+                raise SystemExit("rank %d: %r" % (r, e))
+        return time.perf_counter() - t0
+
+    reads = [synth(ctxs[r], per, r * per) for r in range(W)]
+
+    def do_filter(r):
+        p = capi.ShardParams(k, 0, 1 if is_set else 0, 2, args.rounds, -1, 1, 0)
+        tab, st = capi.KmerTable(), capi.ShardStats()
+        ctxs[r].check(lib.dbg_shard_filter_kmers_dev(ctxs[r].h, arr_t[r], C.byref(reads[r][0]), C.byref(p), C.byref(tab), C.byref(st)))
+        return tab, st
+    secs = run(do_filter)
+    tabs = [x[0] for x in res]
+    stats = [x[1] for x in res]
+    dsum = sum(D.table_digest(t, dev) for t in tabs) & M64
+    vsum = sum(int(t.n) for t in tabs)
+    owned = [int(s.records_owned) for s in stats]
+    say("dbg_shard_filter_kmers_dev x %d ranks: %.3f s wall (all ranks on one GPU), rounds %d, sender merge %d, valid %d, digest sum %016x -> %s"
+        % (W, secs, int(stats[0].n_rounds), int(stats[0].merge_dups), vsum, dsum, "EQUAL to the single call" if (dsum == single_digest and vsum == single_valid) else "MISMATCH"))
+    say("  records owned per rank: min %d max %d (max / mean %.4f); bytes sent per rank: %s"
+        % (min(owned), max(owned), max(owned) / (sum(owned) / W), [int(s.bytes_sent) for s in stats]))
+    ok = dsum == single_digest and vsum == single_valid
+    del reads
+    torch.cuda.empty_cache()
+
+    if not args.no_compress and not is_set:
+        for mode, name in ((0, "gather"), (1, "tree")):
+            for c in ctxs:
+                c.set_option("DBG_DEBUG", "1")
+            # the library writes its phase lines to stderr: capture the process's fd 2 for the duration of the call
+            sys.stderr.flush()
+            tmp = tempfile.TemporaryFile(mode="w+b")
+            saved = os.dup(2)
+            os.dup2(tmp.fileno(), 2)
+
+            def do_compress(r, mode=mode):
+                fin, loc, cl = capi.Graph(), capi.Graph(), capi.LabelClasses()
+                ctxs[r].check(lib.dbg_shard_compress_dev(ctxs[r].h, arr_t[r], k, 0, spec.kind, spec.kind, C.byref(tabs[r]), mode, 0, C.byref(fin), None, C.byref(cl)))
+                return fin
+            try:
+                secs = run(do_compress)
+            finally:
+                sys.stderr.flush()
+                os.dup2(saved, 2)
+                os.close(saved)
+            for c in ctxs:
+                c.set_option("DBG_DEBUG", None)
+            tmp.seek(0)
+            lines = [l for l in tmp.read().decode(errors="replace").splitlines() if l.startswith("[shard_compress]")]
+            tmp.close()
+            fin = res[0]
+            arr = lambda ptr, n_, ty: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(max(int(n_), 1),))[:int(n_)]
+            gd = graph_digest(torch, dev, arr(fin.seq_words, fin.n_seq_words, C.c_uint64), arr(fin.start, fin.n_nodes, C.c_uint64),
+                              arr(fin.length, fin.n_nodes, C.c_uint32), arr(fin.data, fin.n_nodes, C.c_uint32), k)
+            same = gd == single_graph_digest and int(fin.n_nodes) == single_nodes
+            ok = ok and same
+            say("dbg_shard_compress_dev %s x %d ranks: %.3f s wall, %d unitigs, %d bases, graph digest %016x -> %s"
+                % (name, W, secs, fin.n_nodes, fin.seq_len_bases, gd, "EQUAL to the single-GPU graph" if same else "MISMATCH"))
+            ph = {}
+            for l in lines:
+                m = re.match(r"\[shard_compress\] rank=(\d+) phase=(\S+) ms=([\d.]+) nodes=(\d+)", l)
+                if m:
+                    ph.setdefault(m.group(2), []).append((int(m.group(1)), float(m.group(3)), int(m.group(4))))
+            for name2, v in ph.items():
+                root = [x for x in v if x[0] == 0]
+                say("    %-30s ranks %2d  max %9.2f ms  root %9.2f ms  nodes (root) %d" % (name2, len(v), max(x[1] for x in v), root[-1][1] if root else 0.0, root[-1][2] if root else 0))
+            for r in range(W):
+                lib.dbg_free_graph(ctxs[r].h, C.byref(res[r]))
+    for r in range(W):
+        lib.dbg_free_table(ctxs[r].h, C.byref(tabs[r]))
+        ctxs[r].close()
+        lib.dbg_transport_destroy(arr_t[r])
+    say("rehearsal %s" % ("ok" if ok else "FAILED"))
+    if args.out:
+        with open(args.out, "a") as f:
+            f.write(log.getvalue() + "\n")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
