@@ -23,6 +23,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# Random device-scope atomic adds (returning or not, any scope, any counter layout) complete at 2.7e10 per second on this device:
+# tools/micro/atomic_stride.hip, atomic_scope.hip, atomic_noret.hip -> profiles/r04_micro_benchmarks.txt.  The scan reserves one slab
+# slot per super-k-mer record with such an atomic: that rate, not HBM, is its roof.
+ATOMIC_PEAK_PER_S = 2.7e10
 
 
 def alg_bytes_per_kmer(k, read_len, is_set, u_over_n):
@@ -66,6 +70,7 @@ def main():
                          "single-GPU digest over the same reads (tools/check_multirank.sh)")
     ap.add_argument("--no-host-boundary", action="store_true",
                     help="skip the host-pointer measurement (dbg_filter_kmers: host arrays in, host table out -- the reference's own boundary)")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the secondary shapes (k = 31, 63, 24; CountFilter) timed on the same reads")
     ap.add_argument("--compress-reads", type=int, default=-1,
                     help="reads of the stream used for the secondary unitigs/s measurement (0 = skip, -1 = all: BASELINE config 3)")
     args = ap.parse_args()
@@ -296,7 +301,10 @@ def main():
                 r = {"kernel": name, "ms_per_step": round(step_ms, 3), "launches_per_step": a["launches"] / args.steps,
                      "alg_bytes_per_unit": round(per_unit, 2), "units_per_step": units_step,
                      "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                     "traffic_bytes_per_step": None, "measured_gb_per_s": None, "measured_hbm_frac": None, "bound": "hbm"}
+                     "traffic_bytes_per_step": None, "measured_gb_per_s": None, "measured_hbm_frac": None, "bound": "hbm",
+                     # the resource that actually binds the kernel and how much of it is used (frac above is the SURVEY 8(d)
+                     # contract figure -- algorithmic bytes against the HBM roof -- whatever the kernel is bound by)
+                     "bound_resource": None, "bound_frac": None}
                 if ent and step_ms > 0:
                     tb = ent["bytes_per_instance"] * n_inst     # the PMC file is normalised per k-mer instance of the profiled run
                     pl = ent.get("dispatches", 0) / max(tj.get("_steps", 0), 1)
@@ -311,6 +319,22 @@ def main():
                         r["bound"] = "lds/valu"
                     elif r["measured_hbm_frac"] < 0.25:
                         r["bound"] = "valu/latency"
+                if name in ("sk_scan", "sk_scan_long") and n_recs and step_ms > 0:
+                    r["bound_resource"] = "global slot atomics (one returning atomicAdd per super-k-mer record; device rate %.1e/s, tools/micro/atomic_stride.hip)" % ATOMIC_PEAK_PER_S
+                    r["atomics_per_step"] = n_recs
+                    r["bound_frac"] = round(n_recs / (step_ms * 1e-3) / ATOMIC_PEAK_PER_S, 4)
+                    r["bound"] = "atomics"
+                elif ent and ent.get("valu_busy") is not None and r["bound"] != "hbm":
+                    # counters of the same PMC passes as the traffic (hash-guarded by traffic_stale): VALUBusy and the share of CU
+                    # cycles with the LDS busy; neither saturates in bin_count -- it is bound by the dependent LDS / barrier chain
+                    # of a bin at two workgroups per CU -- so the larger of the two is what is reported
+                    r["valu_busy"], r["lds_active"] = ent.get("valu_busy"), ent.get("lds_active")
+                    r["lds_bank_conflict_share"], r["wave_wait_share"] = ent.get("lds_conflict"), ent.get("wave_wait_share")
+                    r["bound_resource"] = "VALU issue (SQ_ACTIVE_INST_VALU*4/1024 SIMDs per cycle) next to a dependent LDS / barrier chain"
+                    r["bound_frac"] = ent.get("valu_busy")
+                elif r["measured_hbm_frac"] is not None:
+                    r["bound_resource"] = "HBM bandwidth (FETCH_SIZE*2 + WRITE_SIZE per second / 8 TB/s)"
+                    r["bound_frac"] = r["measured_hbm_frac"]
                 return r
 
             rows = [row(nm, a) for nm, a in sorted(ktimes.items(), key=lambda kv: -kv[1]["ms"])]
@@ -323,6 +347,14 @@ def main():
                     "alg_bytes_per_unit": d["alg_bytes_per_unit"], "units_per_launch": a["units"] / a["launches"],
                     "avg_launch_ms": round(a["ms"] / a["launches"], 4), "launches_per_step": d["launches_per_step"],
                     "whole_path_alg_frac": round(value * b_alg / HBM_PEAK_GBS, 4),
+                    "whole_path_alg_bytes_per_unit": round(b_alg, 2),
+                    # what THIS design has to move per k-mer instance at the least: the packed reads in, every super-k-mer record
+                    # written once and read once, the valid k-mers' table out (SURVEY 8(d)'s two-touch model prices 17-20 B records
+                    # per instance; super-k-mers carry ~1.6 B) -- and with the three order-restoring passes it actually runs
+                    "design_floor_bytes_per_unit": round(b_in + 2 * sk_b + u_over_n * (key + 3), 2),
+                    "design_traffic_bytes_per_unit": round(b_in + 2 * sk_b + u_over_n * (16 + 3 * 2 * sort_rec + sort_rec + key + 3 + (4 + 4 * 1.5 if is_set else 0)), 2),
+                    "whole_path_measured_bytes_per_unit": (round(sum(r["traffic_bytes_per_step"] or 0 for r in rows) / max(n_inst, 1), 2)
+                                                           if any(r["traffic_bytes_per_step"] for r in rows) else None),
                     "whole_path_measured_hbm_frac": (round(sum(r["traffic_bytes_per_step"] or 0 for r in rows) / (ms_per_step * 1e-3) / 1e9
                                                            / HBM_PEAK_GBS, 4) if any(r["traffic_bytes_per_step"] for r in rows) else None),
                     "note": "achieved/frac: SURVEY 8(d) algorithmic bytes / HIP-event time (the contract figure); measured_*: HBM bytes "
@@ -332,6 +364,36 @@ def main():
                     "kernel_source_sha16": src_sha,
                     "kernels": rows,
                     "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()}}
+        other = None
+        if world == 1 and not args.force_sharded and not args.no_other_shapes:
+            # the shapes the crate is used with day to day, on the same reads (BASELINE configs 4 / 5 per-GPU k, Kmer32's neighbourhood,
+            # the plain counter): two timed steps each after one warm-up, per-kernel ms included
+            other = {}
+            for nm, k2, set2 in (("k31_set", 31, 1), ("k63_set", 63, 1), ("k47_count", 47, 0), ("k24_set", 24, 1)):
+                if k2 == k and bool(set2) == is_set:
+                    continue
+                fp2 = capi.FilterParams(k2, 0, set2, args.min_obs, 0, 4)
+                ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, colour.data_ptr() if set2 else None,
+                                  1 if set2 else 0, reads_per_gpu)
+                kt2, ni2 = {}, 0
+                for rep in range(3):
+                    if rep == 1:
+                        ctx.enable_timing(True)
+                        torch.cuda.synchronize()
+                        o0 = time.perf_counter()
+                    t = capi.KmerTable()
+                    ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss2), C.byref(fp2), C.byref(t)))
+                    ni2, nv2 = t.n_kmer_instances, t.n
+                    lib.dbg_free_table(ctx.h, C.byref(t))
+                    if rep >= 1:
+                        for kt in ctx.timings():
+                            kt2[kt["name"]] = kt2.get(kt["name"], 0.0) + kt["ms"]
+                torch.cuda.synchronize()
+                odt = (time.perf_counter() - o0) / 2
+                ctx.enable_timing(False)
+                kt2.pop("sk_records", None)
+                other[nm] = {"k": k2, "summarizer": "CountFilterSet" if set2 else "CountFilter", "value": round(ni2 / odt / 1e9, 3), "unit": "Gkmer/s",
+                             "ms_per_step": round(odt * 1e3, 3), "valid_kmers": int(nv2), "kernel_ms_per_step": {n_: round(v / 2, 3) for n_, v in kt2.items()}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
             import oracle_lib as O
@@ -467,7 +529,7 @@ def main():
                           "transport": xstats.get("transport"), "transport_fallback": xstats.get("transport_fallback"),
                           "setup_ms_per_step_rank0": round(xstats.get("setup_ms", 0.0) / max(args.steps, 1), 3)} if (world > 1 or args.force_exchange) else None),
             "balance": balance,
-            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
+            "roofline": roof, "other_shapes": other, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
             "host_boundary": hostb, "compress": comp,
         }
     D.close_transports()

@@ -425,7 +425,8 @@ int  dbg_shard_round_cuts(const uint32_t* bounds, uint32_t world, uint32_t bin_g
 typedef struct {
     uint32_t k;
     int32_t  stranded;
-    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (at most 64 distinct labels < 65536 over all ranks) */
+    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (up to 64 distinct labels < 65536 over all ranks on the
+                                   super-k-mer route; larger alphabets and labels up to 2^24 - 1 on the key-range route) */
     uint64_t min_kmer_obs;
     uint32_t n_rounds;          /* exchange rounds; 0 = 4 (8 from 4 ranks on), more when a round's receive buffer would pass 8 GiB */
     int32_t  merge_dups;        /* sender-side duplicate merge: 1 on, 0 off, -1 = the library decides (on at 2 ranks, where one link
@@ -457,7 +458,10 @@ typedef struct {
  * is the table dbg_filter_kmers_dev returns for the concatenated reads.  Collective: every rank calls it with the same
  * parameters.  Scan -> ownership -> slab compaction in (round, destination, bin) order -> pipelined all-to-all rounds on a
  * communication stream ordered against the ctx's stream with events (no host synchronisation per round) -> per-bin counting
- * -> one order-restoring sort.  stats may be NULL. */
+ * -> one order-restoring sort.  Shapes that exchange cannot carry -- k < 16, more than 64 distinct labels over all ranks, labels >=
+ * 65536 -- take the key-range route instead (round 5): ownership by ranges of the canonical k-mer's top byte from the all-reduced
+ * byte histogram, k-mer records exchanged per round, sort + segmented reduce on the owner (the rank-spanning form of the generic
+ * path; SURVEY.md section 8(e) "non-MSP variant"), so the call covers every shape dbg_filter_kmers_dev covers.  stats may be NULL. */
 int  dbg_shard_filter_kmers_dev(dbg_ctx* ctx, const dbg_transport* tr, const dbg_seqset* dev_seqs, const dbg_shard_params* p,
                                 dbg_kmer_table* out_dev, dbg_shard_stats* stats);
 

@@ -128,6 +128,45 @@ __global__ void shift_u64_kernel(const uint64_t* __restrict__ in, uint64_t n, ui
     if (i < n) out[i] = in[i] + add;
 }
 
+// The tables of consecutive key ranges (passes of the generic path, rounds of its rank-spanning form), one after the other: set_off
+// entries of later parts are shifted by the labels before them.  The parts' arrays are released (also on failure).
+int join_reduce_parts(dbg_ctx* c, std::vector<ReduceOut>& parts, bool is_set, bool report_all, ReduceOut* out) {
+    auto free_parts = [&]() {
+        for (auto& r : parts) for (void* q : {(void*)r.key_hi, (void*)r.key_lo, (void*)r.exts, (void*)r.count, (void*)r.set_off, (void*)r.set_val, (void*)r.all_hi, (void*)r.all_lo}) c->dfree(q);
+        parts.clear();
+    };
+    ReduceOut r;
+    if (parts.size() == 1) { *out = parts[0]; parts.clear(); return 0; }
+    for (auto& q : parts) { r.n_valid += q.n_valid; r.n_all += q.n_all; r.n_set_val += q.n_set_val; }
+    DBuf<uint64_t> o_hi, o_lo, o_set_off, all_hi, all_lo;
+    DBuf<uint8_t> o_exts; DBuf<uint16_t> o_count; DBuf<uint32_t> o_set_val;
+    bool ok = o_hi.alloc(c, std::max<uint64_t>(r.n_valid, 1)) && o_lo.alloc(c, std::max<uint64_t>(r.n_valid, 1)) && o_exts.alloc(c, std::max<uint64_t>(r.n_valid, 1));
+    if (is_set) ok = ok && o_set_off.alloc(c, r.n_valid + 1) && o_set_val.alloc(c, std::max<uint64_t>(r.n_set_val, 1));
+    else ok = ok && o_count.alloc(c, std::max<uint64_t>(r.n_valid, 1));
+    if (report_all) ok = ok && all_hi.alloc(c, std::max<uint64_t>(r.n_all, 1)) && all_lo.alloc(c, std::max<uint64_t>(r.n_all, 1));
+    if (!ok) { free_parts(); return c->fail(101, "device allocation failed in the generic path"); }
+    uint64_t ov = 0, oa = 0, os = 0;
+    hipError_t e = hipSuccess;
+    auto cp = [&](void* d, const void* sp, size_t bytes) { if (bytes && e == hipSuccess) e = hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, c->stream); };
+    for (auto& q : parts) {
+        cp(o_hi.p + ov, q.key_hi, q.n_valid * 8); cp(o_lo.p + ov, q.key_lo, q.n_valid * 8); cp(o_exts.p + ov, q.exts, q.n_valid);
+        if (is_set) {
+            cp(o_set_val.p + os, q.set_val, q.n_set_val * 4);
+            if (e == hipSuccess && q.n_valid) { shift_u64_kernel<<<cdiv(q.n_valid, 256), 256, 0, c->stream>>>(q.set_off, q.n_valid, os, o_set_off.p + ov); e = hipGetLastError(); }
+        } else cp(o_count.p + ov, q.count, q.n_valid * 2);
+        if (report_all) { cp(all_hi.p + oa, q.all_hi, q.n_all * 8); cp(all_lo.p + oa, q.all_lo, q.n_all * 8); }
+        ov += q.n_valid; oa += q.n_all; os += q.n_set_val;
+    }
+    if (is_set && e == hipSuccess) e = hipMemcpyAsync(o_set_off.p + r.n_valid, &r.n_set_val, 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free_parts();
+    if (e != hipSuccess) { (void)hipGetLastError(); return c->fail(100, std::string("HIP error while joining the passes: ") + hipGetErrorString(e)); }
+    r.key_hi = o_hi.take(); r.key_lo = o_lo.take(); r.exts = o_exts.take(); r.count = o_count.take();
+    r.set_off = o_set_off.take(); r.set_val = o_set_val.take(); r.all_hi = all_hi.take(); r.all_lo = all_lo.take();
+    *out = r;
+    return 0;
+}
+
 extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out) {
     DBG_TRY(validate_filter(c, ds, p));
     HIP_TRY(c, hipSetDevice(c->device));
@@ -226,36 +265,7 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
     }
     if (rc) { free_parts(); return rc; }
     ReduceOut r;
-    if (parts.size() == 1) r = parts[0];
-    else {
-        // the passes' tables, one after the other (set_off entries of later passes are shifted by the labels before them)
-        for (auto& q : parts) { r.n_valid += q.n_valid; r.n_all += q.n_all; r.n_set_val += q.n_set_val; }
-        DBuf<uint64_t> o_hi, o_lo, o_set_off, all_hi, all_lo;
-        DBuf<uint8_t> o_exts; DBuf<uint16_t> o_count; DBuf<uint32_t> o_set_val;
-        bool ok = o_hi.alloc(c, std::max<uint64_t>(r.n_valid, 1)) && o_lo.alloc(c, std::max<uint64_t>(r.n_valid, 1)) && o_exts.alloc(c, std::max<uint64_t>(r.n_valid, 1));
-        if (is_set) ok = ok && o_set_off.alloc(c, r.n_valid + 1) && o_set_val.alloc(c, std::max<uint64_t>(r.n_set_val, 1));
-        else ok = ok && o_count.alloc(c, std::max<uint64_t>(r.n_valid, 1));
-        if (p->report_all_kmers) ok = ok && all_hi.alloc(c, std::max<uint64_t>(r.n_all, 1)) && all_lo.alloc(c, std::max<uint64_t>(r.n_all, 1));
-        if (!ok) { free_parts(); return c->fail(101, "device allocation failed in the generic path"); }
-        uint64_t ov = 0, oa = 0, os = 0;
-        hipError_t e = hipSuccess;
-        auto cp = [&](void* d, const void* sp, size_t bytes) { if (bytes && e == hipSuccess) e = hipMemcpyAsync(d, sp, bytes, hipMemcpyDeviceToDevice, c->stream); };
-        for (auto& q : parts) {
-            cp(o_hi.p + ov, q.key_hi, q.n_valid * 8); cp(o_lo.p + ov, q.key_lo, q.n_valid * 8); cp(o_exts.p + ov, q.exts, q.n_valid);
-            if (is_set) {
-                cp(o_set_val.p + os, q.set_val, q.n_set_val * 4);
-                if (e == hipSuccess && q.n_valid) { shift_u64_kernel<<<cdiv(q.n_valid, 256), 256, 0, c->stream>>>(q.set_off, q.n_valid, os, o_set_off.p + ov); e = hipGetLastError(); }
-            } else cp(o_count.p + ov, q.count, q.n_valid * 2);
-            if (p->report_all_kmers) { cp(all_hi.p + oa, q.all_hi, q.n_all * 8); cp(all_lo.p + oa, q.all_lo, q.n_all * 8); }
-            ov += q.n_valid; oa += q.n_all; os += q.n_set_val;
-        }
-        if (is_set && e == hipSuccess) e = hipMemcpyAsync(o_set_off.p + r.n_valid, &r.n_set_val, 8, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        free_parts();
-        if (e != hipSuccess) { (void)hipGetLastError(); return c->fail(100, std::string("HIP error while joining the passes: ") + hipGetErrorString(e)); }
-        r.key_hi = o_hi.take(); r.key_lo = o_lo.take(); r.exts = o_exts.take(); r.count = o_count.take();
-        r.set_off = o_set_off.take(); r.set_val = o_set_val.take(); r.all_hi = all_hi.take(); r.all_lo = all_lo.take();
-    }
+    DBG_TRY(join_reduce_parts(c, parts, is_set, p->report_all_kmers != 0, &r));
     if (!has_hi && r.n_valid) HIP_TRY(c, hipMemsetAsync(r.key_hi, 0, r.n_valid * 8, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     table_from_reduce(r, n_kmers, out);

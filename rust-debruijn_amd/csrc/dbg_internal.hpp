@@ -94,6 +94,13 @@ struct ReduceOut {
 };
 int reduce_sorted_records(dbg_ctx* ctx, uint64_t n, RecArrays sorted, bool has_hi, int summarizer, uint64_t min_obs,
                           bool report_all, ReduceOut* out);
+// api.hip: the tables of consecutive key ranges, one after the other (the parts' arrays are released, also on failure)
+int join_reduce_parts(dbg_ctx* ctx, std::vector<ReduceOut>& parts, bool is_set, bool report_all, ReduceOut* out);
+// shard_generic.hip: the rank-spanning form of the generic path -- ownership by ranges of the canonical k-mer's top byte; what
+// dbg_shard_filter_kmers_dev runs for shapes the super-k-mer exchange does not take (k < 16, more than 64 distinct labels, labels
+// >= 65536).  X: the call's failure-agreement state (shard_comm.hpp), passed as an opaque pointer to keep that header out of here.
+int shard_filter_generic(dbg_ctx* ctx, void* shard_comm, const dbg_transport* tr, const dbg_seqset* ds, const dbg_shard_params* p,
+                         uint64_t total_kmers, dbg_kmer_table* out, dbg_shard_stats* stats);
 
 // ---- fastpath.hip : super-k-mer bins + per-bin LDS hash tables --------------------------------
 int filter_kmers_fast(dbg_ctx* ctx, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out,

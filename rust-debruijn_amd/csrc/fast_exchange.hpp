@@ -179,13 +179,16 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         return 0;
     }
     // (argument checks on values every rank holds alike need no agreement)
-    if (p->k < 16 || p->k > 64) return c->fail(140, "sharded counting supports 16 <= k <= 64");
+    if (p->k < 4 || p->k > 64) return c->fail(11, "k must be in 4..=64 (filter.rs:18-23 reads the first 4 bases)");
+    // Shapes the super-k-mer exchange does not take -- k < 16, more than 64 distinct labels over all ranks, labels >= 65536 -- go
+    // the key-range route (shard_generic.hip): decided from values every rank holds alike.  DBG_PATH=generic insists on it.
+    bool key_range_route = p->k < 16 || (c->opt("DBG_PATH") && !strcmp(c->opt("DBG_PATH"), "generic"));
 
     dbg_shard_plan sp;
     memset(&sp, 0, sizeof(sp));
     sp.k = p->k; sp.stranded = p->stranded; sp.summarizer = p->summarizer; sp.min_kmer_obs = p->min_kmer_obs;
     sp.total_kmers = std::max<uint64_t>(total, 1); sp.max_label = max_label;
-    if (is_set && max_label >= 64) {
+    if (is_set && max_label >= 64 && !key_range_route) {
         // ---- phase "labels" ----
         // labels beyond the 64 colours of the counting kernel: a sparse alphabet is mapped to colour indices, the same way on every
         // rank -- the union of the ranks' label sets (a max-reduction of presence flags: the transport has sum and max, no OR)
@@ -196,14 +199,15 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         for (uint32_t v = 0; v < 65536; v++) pres[v] = (bm[v >> 5] >> (v & 31)) & 1u;
         pres[65536] = bm[2048] ? 1 : 0;
         DBG_TRY(X.reduce(pres.data(), 65537, 1, "all_reduce_u64 (label presence)"));
-        if (pres[65536]) return c->fail(141, "sharded CountFilterSet: labels must be < 65536");
         uint32_t nl = 0;
-        for (uint32_t v = 0; v < 65536; v++)
-            if (pres[v]) {
-                if (nl == 64) return c->fail(141, "sharded CountFilterSet: more than 64 distinct labels over all ranks; the sharded path holds 64");
-                sp.labels[nl++] = v;
-            }
-        sp.n_labels = nl;
+        for (uint32_t v = 0; v < 65536; v++) if (pres[v]) { if (nl < 64) sp.labels[nl] = v; nl++; }
+        if (pres[65536] || nl > 64) key_range_route = true;       // labels >= 65536, or more colours than the counting kernel's sets hold
+        else sp.n_labels = nl;
+    }
+    if (key_range_route) {
+        const int r = shard_filter_generic(c, &X, tr, ds, p, total, out, S);
+        S->total_kmers = total; S->local_kmers = n_local;
+        return r;
     }
     // sender-side merge: asked for, or decided above: on at 2 ranks, otherwise the ranks' vote
     int merge = p->merge_dups;

@@ -1,8 +1,8 @@
 """GPU: seeded differential fuzzing of the rank-spanning entry points (dbg_shard_filter_kmers_dev, dbg_shard_compress_dev) against the
 CPU oracle.  The ranks are THREADS of this process -- one dbg_ctx each on the one GPU, connected by the library's in-process transport
 (dbg_transport_inprocess_create; ctypes releases the GIL inside the calls, so the ranks really run side by side and meet in the
-transport's barriers).  Every case draws k (16..64), strandedness, summarizer, min_kmer_obs, the label alphabet (narrow / wide /
-sparse), the number of ranks (1..5), how the reads are split (uneven, a rank may hold nothing), exchange rounds, the sender-side merge
+transport's barriers).  Every case draws k (4..64), strandedness, summarizer, min_kmer_obs, the label alphabet (narrow / wide /
+sparse / up to 2000 labels up to 2^24 - 1), the number of ranks (1..5), how the reads are split (uneven, a rank may hold nothing), exchange rounds, the sender-side merge
 per rank and the ownership rule, and demands:
 
   * the ranks' tables are disjoint and their union, merged by key, is the oracle's filter_kmers over ALL reads, row for row
@@ -59,7 +59,8 @@ def run_ranks(world, fn):
 
 
 def draw(rng):
-    k = int(rng.choice([int(rng.integers(16, 33)), int(rng.integers(33, 49)), int(rng.integers(49, 65)), 47, 63]))
+    # (round 5: k below 16 and label alphabets beyond 64 colours / 65535 take the key-range route of the rank-spanning call)
+    k = int(rng.choice([int(rng.integers(16, 33)), int(rng.integers(33, 49)), int(rng.integers(49, 65)), 47, 63, int(rng.integers(4, 16))]))
     stranded = bool(rng.random() < 0.3)
     kind = int(rng.integers(0, 2))
     world = int(rng.choice([1, 2, 2, 3, 4, 5]))
@@ -86,7 +87,10 @@ def draw(rng):
     if kind:
         width = int(rng.choice([1, 2, 4]))
         alphabet = {0: np.arange(int(rng.integers(1, 24))), 1: np.arange(int(rng.integers(25, 64))),
-                    2: np.sort(rng.choice(np.arange(250 if width == 1 else 60000), size=int(rng.integers(2, 60)), replace=False))}[int(rng.integers(0, 3))]
+                    2: np.sort(rng.choice(np.arange(250 if width == 1 else 60000), size=int(rng.integers(2, 60)), replace=False)),
+                    # more than 64 distinct labels; with 4-byte labels also values beyond 65535 (up to 2^24 - 1)
+                    3: np.sort(rng.choice(np.arange(256 if width == 1 else (65536 if width == 2 else 1 << 24)),
+                                          size=int(rng.integers(65, 250 if width == 1 else 2000)), replace=False))}[int(rng.integers(0, 4))]
         data = alphabet[rng.integers(0, len(alphabet), size=n_reads)]
     # uneven split of the reads over the ranks; now and then a rank holds nothing
     cuts = np.sort(rng.integers(0, n_reads + 1, size=world - 1)) if world > 1 else np.zeros(0, np.int64)

@@ -9,7 +9,7 @@ for v in 2 3 4 5 full; do
   L=$GRAFT_REPO_ROOT/rust-debruijn_amd/_exp/libabl$v.so
   [ $v = full ] && L=$GRAFT_REPO_ROOT/rust-debruijn_amd/libdbg_mi355x.so
   DBG_LIB=$L timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/$v -- \
-    python $GRAFT_REPO_ROOT/bench.py --reads $NR --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0 --no-host-boundary > $OUT/$v.log 2>&1 || tail -n 3 $OUT/$v.log
+    python $GRAFT_REPO_ROOT/bench.py --reads $NR --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0 --no-other-shapes --no-host-boundary > $OUT/$v.log 2>&1 || tail -n 3 $OUT/$v.log
 done
 cd $GRAFT_REPO_ROOT
 python - <<'PY'

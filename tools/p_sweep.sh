@@ -5,7 +5,7 @@ OUT=gpurun_out/${R}_p_sweep.json
 : > $OUT
 for k in $KS; do for p in $PS; do
   if [ $p -gt $((k-3)) ]; then continue; fi
-  DBG_FAST_P=$p timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-boundary --compress-reads 0 --k $k ${READS:+--reads $READS} 2>&1 | grep '^{' | python -c "
+  DBG_FAST_P=$p timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes --k $k ${READS:+--reads $READS} 2>&1 | grep '^{' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(json.dumps({'k': $k, 'p': $p, 'value': d['value'], 'ms_per_step': d['ms_per_step'],

@@ -28,8 +28,13 @@ def newest_per_pass(root):
     return sorted(best.values())
 
 
+SQ = ("SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES")
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in newest_per_pass(root):
     for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] in SQ:
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+            sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
@@ -43,5 +48,21 @@ for k, v in agg.items():
     b = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
     res[k] = {"fetch_kib": v.get("FETCH_SIZE", 0), "write_kib": v.get("WRITE_SIZE", 0), "dispatches": disp[k],
               "bytes_per_instance": b / n_inst}
+    # Occupancy of the units that bind the kernels that are not HBM-bound (the same passes' SQ counters, summed over the kernel's
+    # dispatches).  GRBM_GUI_ACTIVE counts every XCD's busy cycles: / 8 = cycles of the dispatch; 256 CUs, 1024 SIMDs.
+    #   valu_busy   = SQ_ACTIVE_INST_VALU * 4 / 1024 / (GRBM_GUI_ACTIVE / 8)        (rocprof's VALUBusy)
+    #   lds_active  = SQ_LDS_IDX_ACTIVE / (256 * GRBM_GUI_ACTIVE / 8)               (share of CU cycles with the LDS index path busy)
+    #   lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+    q = sq.get(k, {})
+    cyc = q.get("GRBM_GUI_ACTIVE", 0) / 8.0
+    if cyc > 0:
+        if "SQ_ACTIVE_INST_VALU" in q:
+            res[k]["valu_busy"] = round(q["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc, 4)
+        if "SQ_LDS_IDX_ACTIVE" in q:
+            res[k]["lds_active"] = round(q["SQ_LDS_IDX_ACTIVE"] / (256 * cyc), 4)
+            if q["SQ_LDS_IDX_ACTIVE"] > 0 and "SQ_LDS_BANK_CONFLICT" in q:
+                res[k]["lds_conflict"] = round(q["SQ_LDS_BANK_CONFLICT"] / q["SQ_LDS_IDX_ACTIVE"], 4)
+        if "SQ_WAIT_ANY" in q and q.get("SQ_WAVE_CYCLES", 0) > 0:
+            res[k]["wave_wait_share"] = round(q["SQ_WAIT_ANY"] / q["SQ_WAVE_CYCLES"], 4)
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: round(v["bytes_per_instance"], 3) for k, v in res.items() if isinstance(v, dict)}, indent=1))

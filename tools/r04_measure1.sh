@@ -17,7 +17,7 @@ for v in 2 3 4 5 full; do
   L=$R/rust-debruijn_amd/_exp/libabl$v.so
   [ $v = full ] && L=$R/rust-debruijn_amd/libdbg_mi355x.so
   DBG_LIB=$L timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $O/lds_$v -- \
-    python $R/bench.py --reads $NR --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0 --no-host-boundary > $O/lds_$v.log 2>&1 || tail -n 3 $O/lds_$v.log
+    python $R/bench.py --reads $NR --steps 1 --warmup 0 --no-cpu-baseline --compress-reads 0 --no-other-shapes --no-host-boundary > $O/lds_$v.log 2>&1 || tail -n 3 $O/lds_$v.log
 done
 cd $R
 python - <<'PY'

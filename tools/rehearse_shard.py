@@ -8,7 +8,9 @@ reads:
   * the per-rank table digests add up to the digest of dbg_filter_kmers_dev's table (every k-mer lives on exactly one rank),
   * the root's final graph has the digest of the graph dbg_compress_kmers_with_hash_dev builds from the whole table: an
     order- and strand-independent sum over nodes of a hash of {canonical first k-mer, canonical last k-mer}, length and data
-    (both graphs are maximal compressions of the same k-mer set, src/compression.rs:291-349, so equal node sets <=> equal digests),
+    (both graphs are maximal compressions of the same k-mer set, src/compression.rs:291-349, so equal node sets <=> equal digests;
+    the single-GPU side censors the table first -- remove_censored_exts, src/filter.rs:238-306 -- because compress_graph's fix_exts
+    drops the extensions towards filtered k-mers on the sharded side),
 and the per-phase host times of the second stage (DBG_DEBUG lines of dbg_shard_compress_dev) are collected:
 per-shard compress, transfer, combine, compress_graph -- the reference's flow is src/test.rs:459-470, src/graph.rs:71-100.
 
@@ -157,6 +159,13 @@ def main():
     say("single call: %d valid k-mers, table digest %016x, %.3f s (first call of the ctx)" % (single_valid, single_digest, single_filter_s))
     single_graph_digest = None
     if not args.no_compress and not is_set:
+        # The sharded flow ends in compress_graph, whose fix_exts (src/graph.rs:337-377, src/compression.rs:309, :331) drops every
+        # extension that leads to no node -- the hanging Exts towards k-mers the filter removed.  The single-GPU counterpart of that
+        # is the pipeline real callers run: filter_kmers -> remove_censored_exts (src/filter.rs:238-306) -> compress_kmers_with_hash.
+        # (Without the censoring step the plain compress stops at every such hanging extension: 1.9e7 unitigs instead of 1.3e5 here.)
+        t0 = time.perf_counter()
+        ctx0.check(lib.dbg_remove_censored_exts(ctx0.h, k, 0, C.byref(t1), 0))
+        censor_s = time.perf_counter() - t0
         g = capi.Graph()
         t0 = time.perf_counter()
         ctx0.check(lib.dbg_compress_kmers_with_hash_dev(ctx0.h, k, 0, spec.kind, t1.n, t1.key_hi, t1.key_lo, t1.exts, None, t1.count, C.byref(g)))
@@ -164,8 +173,8 @@ def main():
         arr = lambda ptr, n_, ty: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(max(int(n_), 1),))[:int(n_)]
         single_graph_digest = graph_digest(torch, dev, arr(g.seq_words, g.n_seq_words, C.c_uint64), arr(g.start, g.n_nodes, C.c_uint64),
                                            arr(g.length, g.n_nodes, C.c_uint32), arr(g.data, g.n_nodes, C.c_uint32), k)
-        say("single compress_kmers_with_hash (index in HBM): %d unitigs, %d bases, graph digest %016x, %.3f s"
-            % (g.n_nodes, g.seq_len_bases, single_graph_digest, single_compress_s))
+        say("single remove_censored_exts %.3f s + compress_kmers_with_hash (index in HBM): %d unitigs, %d bases, graph digest %016x, %.3f s"
+            % (censor_s, g.n_nodes, g.seq_len_bases, single_graph_digest, single_compress_s))
         single_nodes = int(g.n_nodes)
         lib.dbg_free_graph(ctx0.h, C.byref(g))
     lib.dbg_free_table(ctx0.h, C.byref(t1))

@@ -11,7 +11,7 @@ timeout 600 python tools/bench_colours.py 4 24 40 64 100 250 > gpurun_out/${R}_c
 : > gpurun_out/${R}_generic_dense.txt
 for a in "--k 47 --reads 10000000:generic" "--k 15 --reads 20000000:dense" "--k 11 --reads 20000000:dense" "--k 8 --reads 20000000:dense" "--k 15 --reads 20000000:generic"; do
   args=${a%%:*}; path=${a##*:}
-  DBG_PATH=$path timeout 300 python bench.py $args --no-cpu-baseline --no-host-boundary --compress-reads 0 2>/dev/null | grep '^{' | python -c "
+  DBG_PATH=$path timeout 300 python bench.py $args --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes 2>/dev/null | grep '^{' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(json.dumps({'args': '$args', 'path': '$path', 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'valid': d['config']['valid_kmers_rank0'], 'kernel_ms_per_step': d['roofline']['kernel_ms_per_step']}))" >> gpurun_out/${R}_generic_dense.txt

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/trace_fx
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_fx -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-boundary --compress-reads 0 --force-exchange --backend nccl > $GRAFT_REPO_ROOT/gpurun_out/trace_fx.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace_fx -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes --force-exchange --backend nccl > $GRAFT_REPO_ROOT/gpurun_out/trace_fx.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, glob
