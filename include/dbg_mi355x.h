@@ -95,6 +95,12 @@ typedef struct {
     uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero).  Otherwise IGNORED: in the
                                    reference it only sets the number of bucket-range passes (filter.rs:156-168), never the
                                    result; here the device decides its own passes from free HBM */
+    uint32_t compact_sets;      /* dbg_filter_kmers (host tables) with CountFilterSet, opt-in (round 5): return the CSR in the narrowest
+                                   element types that hold it -- set_off as uint32_t[n + 1] when n_set_val < 2^32, set_val in the
+                                   width of D1 (data_width of the input: uint8_t / uint16_t / uint32_t) -- and say so in
+                                   dbg_kmer_table.set_off_width / set_val_width.  The table crosses PCIe: at BASELINE configs[1] the
+                                   CSR is 7.4 GB as u64 / u32 and 2.9 GB compact.  0 = the plain u64 / u32 form.  Device tables
+                                   (the _dev calls) are always plain */
 } dbg_filter_params;
 
 /* The vectors the reference hands to BoomHashMap2::new (filter.rs:227-230), i.e. ascending
@@ -115,6 +121,9 @@ typedef struct {
     uint32_t  n_passes;         /* passes over the input the device needed (1 unless the input was streamed in several
                                    prefix ranges); unrelated to memory_size */
     int32_t   on_device;        /* 1 when the arrays are device pointers */
+    uint32_t  set_off_width;    /* bytes per set_off element: 0 or 8 = uint64_t (the declared type); 4 = the array is uint32_t[n + 1] */
+    uint32_t  set_val_width;    /* bytes per set_val element: 0 or 4 = uint32_t; 1 / 2 = the array is uint8_t / uint16_t[n_set_val]
+                                   (only tables asked for with dbg_filter_params.compact_sets carry narrow arrays) */
 } dbg_kmer_table;
 
 int  dbg_filter_kmers(dbg_ctx* ctx, const dbg_seqset* host_seqs, const dbg_filter_params* p, dbg_kmer_table* out_host);

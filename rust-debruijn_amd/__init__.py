@@ -363,8 +363,11 @@ def _table_from_c(t, k):
     out.key_lo = _copy(t.key_lo, n, np.uint64)
     out.exts = _copy(t.exts, n, np.uint8)
     out.count = _copy(t.count, n, np.uint16) if t.count else None
-    out.set_off = _copy(t.set_off, n + 1, np.uint64) if t.set_off else None
-    out.set_val = _copy(t.set_val, t.n_set_val, np.uint32) if t.set_off else None
+    # (compact tables -- dbg_filter_params.compact_sets -- carry narrow CSR arrays: widened here, the mirror's tables are plain)
+    ow = {0: np.uint64, 8: np.uint64, 4: np.uint32}[int(getattr(t, "set_off_width", 0))]
+    vw = {0: np.uint32, 4: np.uint32, 2: np.uint16, 1: np.uint8}[int(getattr(t, "set_val_width", 0))]
+    out.set_off = _copy(t.set_off, n + 1, ow).astype(np.uint64) if t.set_off else None
+    out.set_val = _copy(t.set_val, t.n_set_val, vw).astype(np.uint32) if t.set_off else None
     out.all_hi = _copy(t.all_hi, t.n_all, np.uint64)
     out.all_lo = _copy(t.all_lo, t.n_all, np.uint64)
     out.n_kmer_instances = t.n_kmer_instances
@@ -375,15 +378,17 @@ def _table_from_c(t, k):
 # ------------------------------------------------------------------------------------------------
 # the reference's functions
 # ------------------------------------------------------------------------------------------------
-def filter_kmers(seqs, summarizer, stranded, report_all_kmers, memory_size, k, ctx=None):
+def filter_kmers(seqs, summarizer, stranded, report_all_kmers, memory_size, k, ctx=None, compact_sets=False):
     """filter_kmers::<K, V, D1, DS, S> (src/filter.rs:139-231).
 
     seqs: HostSeqs or an iterable of (bases, Exts, d).  Returns (KmerTable, all_kmers) where
-    all_kmers is the list of every observed k-mer (ascending) iff report_all_kmers, else []."""
+    all_kmers is the list of every observed k-mer (ascending) iff report_all_kmers, else [].
+    compact_sets: ask the library for the narrow CSR of a CountFilterSet table (dbg_filter_params.compact_sets); the mirror
+    widens it again, so the result is the same table."""
     ctx = ctx or default_context()
     hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples(seqs)
     p = _capi.FilterParams(k, int(bool(stranded)), summarizer.kind, summarizer.min_kmer_obs,
-                           int(bool(report_all_kmers)), int(memory_size))
+                           int(bool(report_all_kmers)), int(memory_size), int(bool(compact_sets)))
     cs = hs.c_struct()
     t = _capi.KmerTable()
     ctx.check(ctx.lib.dbg_filter_kmers(ctx.h, C.byref(cs), C.byref(p), C.byref(t)))

@@ -18,14 +18,15 @@ class SeqSet(C.Structure):
 
 class FilterParams(C.Structure):
     _fields_ = [("k", C.c_uint32), ("stranded", C.c_int32), ("summarizer", C.c_int32), ("min_kmer_obs", C.c_uint64),
-                ("report_all_kmers", C.c_int32), ("memory_size", C.c_uint64)]
+                ("report_all_kmers", C.c_int32), ("memory_size", C.c_uint64), ("compact_sets", C.c_uint32)]
 
 
 class KmerTable(C.Structure):
     _fields_ = [("n", C.c_uint64), ("key_hi", C.c_void_p), ("key_lo", C.c_void_p), ("exts", C.c_void_p),
                 ("count", C.c_void_p), ("set_off", C.c_void_p), ("set_val", C.c_void_p), ("n_set_val", C.c_uint64),
                 ("n_all", C.c_uint64), ("all_hi", C.c_void_p), ("all_lo", C.c_void_p),
-                ("n_kmer_instances", C.c_uint64), ("n_passes", C.c_uint32), ("on_device", C.c_int32)]
+                ("n_kmer_instances", C.c_uint64), ("n_passes", C.c_uint32), ("on_device", C.c_int32),
+                ("set_off_width", C.c_uint32), ("set_val_width", C.c_uint32)]
 
 
 class MspParams(C.Structure):

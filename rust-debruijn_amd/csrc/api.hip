@@ -384,6 +384,13 @@ extern "C" void dbg_seqset_free_device(dbg_ctx* c, dbg_seqset* dev) {
     memset(dev, 0, sizeof(*dev));
 }
 
+// compact CSR of a host table (dbg_filter_params.compact_sets): offsets and labels narrowed on the device, before they cross PCIe
+template <class T>
+__global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict__ in64, const uint32_t* __restrict__ in32, uint64_t n, T* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (T)(in64 ? in64[i] : (uint64_t)in32[i]);
+}
+
 extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filter_params* p, dbg_kmer_table* out) {
     DBG_TRY(validate_filter(c, hs, p));
     DBG_TRY(check_host_seqset(c, hs));
@@ -392,7 +399,43 @@ extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filt
     DBG_TRY(upload_seqset(c, hs, &d));
     dbg_kmer_table dev;
     DBG_TRY(dbg_filter_kmers_dev(c, &d.view, p, &dev));
-    int r = dbg_table_to_host(c, &dev, out);
+    d.words.release(); d.start.release(); d.length.release(); d.exts.release(); d.data.release();     // (the reads are no longer needed: room for the copies below)
+    int r = 0;
+    if (p->compact_sets && dev.set_off) {
+        const uint32_t ow = dev.n_set_val < (1ull << 32) ? 4u : 8u;
+        const uint32_t vw = hs->data && (hs->data_width == 1 || hs->data_width == 2) ? hs->data_width : 4u;
+        DBuf<uint32_t> off32, val32;
+        DBuf<uint16_t> val16;
+        DBuf<uint8_t> val8;
+        r = [&]() -> int {
+            const uint64_t no = dev.n + 1, nv = dev.n_set_val;
+            if (ow == 4) {
+                ALLOC_OR_FAIL(c, off32, no);
+                narrow_kernel<uint32_t><<<cdiv(no, 256), 256, 0, c->stream>>>(dev.set_off, nullptr, no, off32.p);
+                LAUNCH_CHECK(c, "narrow_set_off");
+            }
+            if (vw == 1 && nv) { ALLOC_OR_FAIL(c, val8, nv); narrow_kernel<uint8_t><<<cdiv(nv, 256), 256, 0, c->stream>>>(nullptr, dev.set_val, nv, val8.p); LAUNCH_CHECK(c, "narrow_set_val"); }
+            if (vw == 2 && nv) { ALLOC_OR_FAIL(c, val16, nv); narrow_kernel<uint16_t><<<cdiv(nv, 256), 256, 0, c->stream>>>(nullptr, dev.set_val, nv, val16.p); LAUNCH_CHECK(c, "narrow_set_val"); }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            // the plain columns leave as they are; the CSR leaves narrow
+            dbg_kmer_table plain = dev;
+            plain.set_off = nullptr; plain.set_val = nullptr;
+            DBG_TRY(dbg_table_to_host(c, &plain, out));
+            out->n_set_val = nv;
+            const size_t ob = (size_t)no * ow, vb = (size_t)std::max<uint64_t>(nv, 1) * vw;
+            out->set_off = (uint64_t*)ctx_halloc(c, ob);
+            out->set_val = (uint32_t*)ctx_halloc(c, vb);
+            if (!out->set_off || !out->set_val) { dbg_free_table(c, out); return c->fail(101, "host allocation of the compact CSR failed"); }
+            hipStream_t s2 = c->get_copy_stream() ? c->get_copy_stream() : c->stream;
+            HIP_TRY(c, hipMemcpyAsync(out->set_off, ow == 4 ? (const void*)off32.p : (const void*)dev.set_off, ob, hipMemcpyDeviceToHost, c->stream));
+            if (nv) HIP_TRY(c, hipMemcpyAsync(out->set_val, vw == 1 ? (const void*)val8.p : (vw == 2 ? (const void*)val16.p : (const void*)dev.set_val), (size_t)nv * vw, hipMemcpyDeviceToHost, s2));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (s2 != c->stream) HIP_TRY(c, hipStreamSynchronize(s2));
+            out->set_off_width = ow; out->set_val_width = vw;
+            return 0;
+        }();
+        if (r) dbg_free_table(c, out);
+    } else r = dbg_table_to_host(c, &dev, out);
     dbg_free_table(c, &dev);
     return r;
 }

@@ -358,7 +358,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     uint64_t max_recv = 0, owned = 0;
     DBuf<uint64_t> seg, recs, ovf_base, rbuf[2];
     EventSet events(c);
-    std::vector<hipEvent_t> ev_done(R), ev_a(R), ev_b(R), ev_w0(R), ev_w1(R);
+    std::vector<hipEvent_t> ev_done(R), ev_a(R), ev_b(R), ev_w0(R), ev_w1(R), ev_counted(R);
     std::unique_ptr<FastCountState> cs(new FastCountState());
     auto compact_round = [&](uint32_t r, hipStream_t stream) -> int {
         for (uint32_t d = 0; d < W; d++) {
@@ -436,7 +436,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         if (X.inject("rbuf")) return X.injected("rbuf");
         ALLOC_OR_FAIL(c, rbuf[0], std::max<uint64_t>(max_recv * rw, 1));
         if (R > 1) ALLOC_OR_FAIL(c, rbuf[1], std::max<uint64_t>(max_recv * rw, 1));
-        for (uint32_t r = 0; r < R; r++) { ev_done[r] = events.get(); ev_a[r] = events.get(); ev_b[r] = events.get(); ev_w0[r] = events.get(); ev_w1[r] = events.get(); }
+        for (uint32_t r = 0; r < R; r++) { ev_done[r] = events.get(); ev_a[r] = events.get(); ev_b[r] = events.get(); ev_w0[r] = events.get(); ev_w1[r] = events.get(); ev_counted[r] = events.get(); }
         if (X.inject("count_begin")) return X.injected("count_begin");
         return fast_count_begin(c, pl, p->min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get());
     }();
@@ -458,6 +458,9 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         // this round's part of the send buffer, in stream order before its messages.  (A launch failure here is local: the messages
         // still go out -- with whatever the buffer holds -- so that no peer waits for them; the status is agreed after the rounds.)
         if (r) { const int e = compact_round(r, xs); if (e && !lrc) lrc = e; }
+        // receive buffer r & 1 was last read by the counting of round r - 2: its messages wait for that kernel IN STREAM ORDER (an
+        // event recorded behind it on the ctx stream) -- not merely because the host happens to have waited for its result
+        if (r >= 2 && hipStreamWaitEvent(xs, ev_counted[r - 2], 0) != hipSuccess) { (void)hipGetLastError(); return tr_rc = X.op_failed("hipStreamWaitEvent in front of all_to_allv"); }
         (void)hipEventRecord(ev_w0[r], xs);
         XTimer th;
         const int e = W > 1 ? tr->all_to_allv(tr->self, recs.p, soff.data(), sby.data(), rbuf[r & 1].p, roff.data(), rby.data(), xs) : 0;
@@ -472,9 +475,8 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     // their receives -- and only stops counting; the status is agreed after the last round.
     if (launch(0)) return tr_rc;
     for (uint32_t r = 0; r < R; r++) {
-        // buffer (r + 1) & 1 was last read by the counting of round r - 1, which has completed (fast_count_bins returns after its
-        // launch has finished: its read-back of the output size is a host wait), so round r + 1 may go on the wire now and travels
-        // while round r is counted
+        // buffer (r + 1) & 1 was last read by the counting of round r - 1: launch() orders round r + 1's messages behind that kernel
+        // with ev_counted[r - 1]; round r + 1 goes on the wire now and travels while round r is counted
         if (r + 1 < R && launch(r + 1)) break;
         // the host waits for round r's records itself, with a deadline and an eye on the communicator: the ctx stream is idle here, so
         // this wait IS the exchange time the counting could not hide
@@ -490,6 +492,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
             lrc = fast_count_bins(c, cs.get(), recs.p, rbuf[r & 1].p, 1, seg.p + tab_off[r], seg.p + tab_off[r] + 1, W, (uint64_t)nbc + 1, nbc / NCLS,
                                   std::max<uint64_t>(n_local, 1) / R, 0);
         else (void)hipStreamSynchronize(c->stream);
+        (void)hipEventRecord(ev_counted[r], c->stream);           // (also behind a re-launch after an output buffer grew: the last one counts)
     }
     if (tr_rc) { (void)hipStreamSynchronize(c->stream); return tr_rc; }
     DBG_TRY(X.wait_stream(xs, "the last exchange round"));

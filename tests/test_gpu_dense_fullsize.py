@@ -12,8 +12,10 @@ Everything is compared on the device (torch views over the library's device arra
 import ctypes as C
 import os
 
+import numpy as np
 import pytest
 
+import oracle_lib as O
 from pkg import dbg
 from test_gpu_fullsize import dev_view
 
@@ -45,11 +47,11 @@ def env():
     torch.cuda.empty_cache()
 
 
-def run(e, k, summarizer, min_obs, **opts):
+def run(e, k, summarizer, min_obs, n_reads=None, **opts):
     capi, ctx, lib = e["capi"], e["ctx"], e["lib"]
     is_set = summarizer == 1
     ss = capi.SeqSet(e["words"].data_ptr(), e["nw"], e["start"].data_ptr(), e["length"].data_ptr(), None,
-                     e["colour"].data_ptr() if is_set else None, 1 if is_set else 0, N_READS)
+                     e["colour"].data_ptr() if is_set else None, 1 if is_set else 0, N_READS if n_reads is None else n_reads)
     fp = capi.FilterParams(k, 0, summarizer, min_obs, 0, 4)
     t = capi.KmerTable()
     with ctx.options(DBG_PATH="dense", **opts):
@@ -105,3 +107,31 @@ def test_dense_fullsize_label_sets(env, k):
     assert counted.n == part.n and e["torch"].equal(dev_view(counted.key_lo, counted.n), dev_view(part.key_lo, part.n))
     for t in (part, atomic, counted):
         lib.dbg_free_table(ctx.h, C.byref(t))
+
+
+@pytest.mark.parametrize("k,summarizer", [(11, 0), (15, 0), (12, 1), (15, 1)])
+def test_dense_fullsize_prefix_bit_exact(env, k, summarizer):
+    """A prefix of the SAME full-size stream against the oracle, row for row (round 5; the tests above compare the dense path's
+    forms with one another): the partitioned form in one batch and in many (DBG_DENSE_BATCH), and the device-atomic form --
+    keys, Exts, counts / label lists of filter_kmers (src/filter.rs:139-231) over reads [0, m)."""
+    e = env
+    capi, lib, ctx = e["capi"], e["lib"], e["ctx"]
+    m = min(100_000, N_READS)
+    hs = dbg.synth_reads_host(n_reads=m, read_len=L, genome_len=N_READS * L // 30, error_rate=0.001, stranded=False, n_colours=4)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if summarizer else None, 1 if summarizer else 0), k,
+                          O.COUNT_FILTER_SET if summarizer else O.COUNT_FILTER, 1, stranded=False)
+    as_np = lambda p, ct, cnt: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(max(cnt, 1),))[:cnt].copy()
+    for opts in ({}, {"DBG_DENSE_BATCH": "3000000"}, {"DBG_DENSE_PART": "0", "DBG_DENSE_RANGES": "0"}):
+        t = run(e, k, summarizer, 1, n_reads=m, **opts)
+        h = capi.KmerTable()
+        ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))
+        lib.dbg_free_table(ctx.h, C.byref(t))
+        n = int(h.n)
+        assert n == want.n, opts
+        assert np.array_equal(as_np(h.key_lo, C.c_uint64, n), want.key_lo) and np.array_equal(as_np(h.exts, C.c_uint8, n), want.exts), opts
+        if summarizer:
+            assert np.array_equal(as_np(h.set_off, C.c_uint64, n + 1), want.set_off), opts
+            assert np.array_equal(as_np(h.set_val, C.c_uint32, int(h.n_set_val)), want.set_val), opts
+        else:
+            assert np.array_equal(as_np(h.count, C.c_uint16, n), want.count), opts
+        lib.dbg_free_table(ctx.h, C.byref(h))

@@ -8,7 +8,7 @@ import pytest
 
 import oracle_lib as O
 import refgen as R
-from pkg import dbg
+from pkg import dbg, capi
 
 pytestmark = pytest.mark.gpu
 
@@ -91,6 +91,35 @@ def test_count_filter_set_parity(ctx, k, width):
     data = rng.integers(0, 4 if width == 1 else 3000, size=len(seqs))
     ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=width)
     run_both(ctx, ss, k, O.COUNT_FILTER_SET, 2, False, report_all=True, data_width=width)
+
+
+@pytest.mark.parametrize("k,width,n_labels", [(47, 1, 4), (31, 2, 3000), (51, 4, 70000), (12, 1, 40)])
+def test_compact_label_sets_at_the_host_boundary(ctx, k, width, n_labels):
+    """dbg_filter_params.compact_sets (round 5): the host table's CSR arrives with set_off as u32 and set_val in the width of D1 --
+    the same lists as the plain form and the oracle's (src/filter.rs:85-100), fewer bytes over PCIe."""
+    import ctypes as C
+    rng = np.random.default_rng(900 + k + width)
+    seqs = random_reads(rng, 500, 2500, 150, False)
+    data = rng.integers(0, n_labels, size=len(seqs))
+    ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=width)
+    want = O.filter_kmers(ss, k, O.COUNT_FILTER_SET, 2, stranded=False)
+    hs = to_host_seqs(ss, width)
+    got, _ = dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=k, ctx=ctx, compact_sets=True)
+    assert_tables_equal(got, want, True)
+    # the raw C table really is narrow
+    cs, t = hs.c_struct(), capi.KmerTable()
+    p = capi.FilterParams(k, 0, 1, 2, 0, 4, 1)
+    ctx.check(ctx.lib.dbg_filter_kmers(ctx.h, C.byref(cs), C.byref(p), C.byref(t)))
+    assert (t.set_off_width, t.set_val_width) == (4, width) and t.n == want.n and t.n_set_val == len(want.set_val)
+    off = np.ctypeslib.as_array(C.cast(t.set_off, C.POINTER(C.c_uint32)), shape=(t.n + 1,))
+    val = np.ctypeslib.as_array(C.cast(t.set_val, C.POINTER({1: C.c_uint8, 2: C.c_uint16, 4: C.c_uint32}[width])), shape=(max(int(t.n_set_val), 1),))[:int(t.n_set_val)]
+    assert np.array_equal(off, want.set_off) and np.array_equal(val.astype(np.uint32), want.set_val)
+    ctx.lib.dbg_free_table(ctx.h, C.byref(t))
+    # CountFilter ignores the flag; the plain form stays what it was
+    p0 = capi.FilterParams(k, 0, 1, 2, 0, 4, 0)
+    ctx.check(ctx.lib.dbg_filter_kmers(ctx.h, C.byref(cs), C.byref(p0), C.byref(t)))
+    assert (t.set_off_width, t.set_val_width) == (0, 0)
+    ctx.lib.dbg_free_table(ctx.h, C.byref(t))
 
 
 def test_ragged_empty_and_boundary_exts(ctx):
