@@ -39,8 +39,8 @@ extern "C" void dbg_ctx_destroy(dbg_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     c->t_clear();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
-    for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
+    for (auto& kv : c->free_blocks) c->raw_free(kv.second);
+    for (auto& kv : c->live_blocks) c->raw_free(kv.first);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -278,9 +278,10 @@ extern "C" int dbg_table_to_host(dbg_ctx* c, const dbg_kmer_table* d, dbg_kmer_t
     h->on_device = 0;
     h->key_hi = h->key_lo = h->set_off = h->all_hi = h->all_lo = nullptr;
     h->exts = nullptr; h->count = nullptr; h->set_val = nullptr;
-    // the arrays leave on two streams (both directions of PCIe stay busy with one copy each at most, but a second stream
-    // hides the gaps between copies); destinations are pinned blocks of the ctx pool
-    hipStream_t st[2] = {c->stream, c->get_copy_stream() ? c->get_copy_stream() : c->stream};
+    // the arrays leave one after the other on ONE stream: a single device-to-host copy runs at 57 GB/s, two in flight on two
+    // streams share the link at 47 GB/s in all (tools/micro/pcie_bw.hip, profiles/r05_pcie_bw.txt; rounds 2-4 used two streams);
+    // destinations are pinned blocks of the ctx pool
+    hipStream_t st[2] = {c->stream, c->stream};
     int which = 0;
     hipError_t e = hipSuccess;
 #define CP(field, T, cnt)                                                                             \
@@ -426,7 +427,7 @@ extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filt
             out->set_off = (uint64_t*)ctx_halloc(c, ob);
             out->set_val = (uint32_t*)ctx_halloc(c, vb);
             if (!out->set_off || !out->set_val) { dbg_free_table(c, out); return c->fail(101, "host allocation of the compact CSR failed"); }
-            hipStream_t s2 = c->get_copy_stream() ? c->get_copy_stream() : c->stream;
+            hipStream_t s2 = c->stream;                                  // (one copy at a time: see dbg_table_to_host)
             HIP_TRY(c, hipMemcpyAsync(out->set_off, ow == 4 ? (const void*)off32.p : (const void*)dev.set_off, ob, hipMemcpyDeviceToHost, c->stream));
             if (nv) HIP_TRY(c, hipMemcpyAsync(out->set_val, vw == 1 ? (const void*)val8.p : (vw == 2 ? (const void*)val16.p : (const void*)dev.set_val), (size_t)nv * vw, hipMemcpyDeviceToHost, s2));
             HIP_TRY(c, hipStreamSynchronize(c->stream));

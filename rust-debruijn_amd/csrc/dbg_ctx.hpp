@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include "../../include/dbg_mi355x.h"
@@ -30,7 +31,7 @@ struct dbg_state_slot {
 static const char* const DBG_OPTION_NAMES[] = {
     "DBG_PATH", "DBG_COMPRESS", "DBG_FAST_TARGET", "DBG_FAST_NT", "DBG_FAST_TABLE", "DBG_NO_HYBRID_SORT", "DBG_NO_REC16",
     "DBG_FAST_NO_SLAB", "DBG_DEBUG", "DBG_UNITIG_NO_WALK", "DBG_UNITIG_NO_CHAINS", "DBG_NO_KEY_RECORDS", "DBG_NO_NODE_RECORDS",
-    "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_SLAB_PROBE", "DBG_NO_LABEL_GROUPS", "DBG_NO_STRAND_NORM", "DBG_SHARD_MERGE", "DBG_LINKS", "DBG_DENSE_RANGES", "DBG_CHAIN_WALKS", "DBG_DENSE_PART", "DBG_DENSE_BATCH", "DBG_DENSE_L1", "DBG_DENSE_RAW",
+    "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_SLAB_VMM", "DBG_NO_LABEL_GROUPS", "DBG_NO_STRAND_NORM", "DBG_SHARD_MERGE", "DBG_LINKS", "DBG_DENSE_RANGES", "DBG_CHAIN_WALKS", "DBG_DENSE_PART", "DBG_DENSE_BATCH", "DBG_DENSE_L1", "DBG_DENSE_RAW",
     "DBG_FAIL_AT", "DBG_COMM_TIMEOUT_S", "DBG_SHARD_MERGE_COST_MS"};   // (the last two: fault injection and the bound on communication waits of the rank-spanning calls, shard_comm.hpp)   // (DBG_MSP: wave | twopass)
 
 struct dbg_ctx {
@@ -109,22 +110,75 @@ struct dbg_ctx {
     void dfree(void* p) {
         if (!p) return;
         auto it = live_blocks.find(p);
-        if (it == live_blocks.end()) { (void)hipFree(p); return; }
+        if (it == live_blocks.end()) { raw_free(p); return; }
         free_blocks.insert({it->second, p});
         live_blocks.erase(it);
     }
-    // blocks that lost the placement probe of the slab allocation (fastpath.hip): they serve the rest of the call from the pool and
-    // go back to the driver when it ends -- hoarding them is what makes the next allocator on the GPU run out
-    std::vector<void*> spare_blocks;
-    void drop_spares() {
-        for (void* q : spare_blocks)
-            for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it)
-                if (it->second == q) { (void)hipFree(q); pooled_bytes -= it->first; free_blocks.erase(it); break; }
-        spare_blocks.clear();
+    // Blocks of several GB that are written at random (the scan's slabs): ONE virtual range mapped from physical handles of 2 GB
+    // (hipMemCreate / hipMemMap).  Round 5 measured why (profiles/r05_slab_modes.txt, r05_slab_vmm_probe.txt): a 26 GB hipMalloc --
+    // and a 26 GB range mapped from a single handle -- comes in two kinds, 5.8 or 7.0-7.5 ms for the same 1.3e8 random 24-byte writes,
+    // the slow kind stalling on DRAM write credits at the L2 with identical traffic; the same range mapped from 13 handles of 2 GB
+    // (or 104 of 256 MB) is always of the fast kind (5.6-5.85 ms).  Such blocks join the pool like any other (live_blocks /
+    // free_blocks); only their release differs (raw_free).
+    struct VmmBlock { size_t bytes; std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> pieces; };
+    std::map<void*, VmmBlock> vmm_blocks;
+    void vmm_release(void* va, VmmBlock& b, size_t mapped) {
+        size_t o = 0;
+        for (auto& pc : b.pieces) {
+            if (o < mapped) (void)hipMemUnmap((char*)va + o, pc.second);
+            (void)hipMemRelease(pc.first);
+            o += pc.second;
+        }
+        (void)hipMemAddressFree(va, b.bytes);
+        (void)hipGetLastError();
+    }
+    void* dalloc_pieces(size_t bytes, size_t piece = 2ull << 30) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        auto it = free_blocks.lower_bound(bytes);                    // a pooled block of this size (a slab of an earlier call) first
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+            void* p = it->second;
+            live_blocks[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return nullptr; }
+        piece = (piece + gran - 1) / gran * gran;
+        const size_t total = (bytes + gran - 1) / gran * gran;
+        void* va = nullptr;
+        if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        VmmBlock b{total, {}};
+        size_t mapped = 0;
+        bool ok = true;
+        for (size_t o = 0; o < total && ok; o += piece) {
+            const size_t n = std::min(piece, total - o);
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, n, &prop, 0) != hipSuccess) { ok = false; break; }
+            b.pieces.push_back({h, n});
+            if (hipMemMap((char*)va + o, n, 0, h, 0) != hipSuccess) { ok = false; break; }
+            mapped = o + n;
+        }
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice; acc.location.id = device; acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (ok && hipMemSetAccess(va, total, &acc, 1) != hipSuccess) ok = false;
+        if (!ok) { (void)hipGetLastError(); vmm_release(va, b, mapped); return nullptr; }
+        vmm_blocks[va] = std::move(b);
+        live_blocks[va] = total;
+        pooled_bytes += total;
+        return va;
+    }
+    // give a block back to the driver, whichever way it was obtained
+    void raw_free(void* p) {
+        auto it = vmm_blocks.find(p);
+        if (it == vmm_blocks.end()) { (void)hipFree(p); return; }
+        vmm_release(p, it->second, it->second.bytes);
+        vmm_blocks.erase(it);
     }
     void trim() {
         (void)hipStreamSynchronize(stream);
-        for (auto& kv : free_blocks) { (void)hipFree(kv.second); pooled_bytes -= kv.first; }
+        for (auto& kv : free_blocks) { raw_free(kv.second); pooled_bytes -= kv.first; }
         free_blocks.clear();
     }
     hipEvent_t get_event() {

@@ -509,7 +509,6 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         if (r) wire_ms += std::max<double>(wire, host_ms[r] > 1.0 ? host_ms[r] : 0.0);
     }
     sc.slab.release(); sc.cursor.release(); off.release(); ovf_base.release();
-    c->drop_spares();
     recs.release(); rbuf[0].release(); rbuf[1].release(); seg.release();
 
     // ---- phase "finish": one order-restoring sort of everything counted ----

@@ -1469,18 +1469,6 @@ __global__ void __launch_bounds__(256) max_label_kernel(const void* data, uint32
     if (threadIdx.x == 0) { uint32_t m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3])); if (m) atomicMax(out, m); }
 }
 
-// Placement probe for the slab block (see slab_alloc_probed): the scan's memory pattern -- random record-sized writes over the
-// whole block -- timed on the block itself.
-__global__ void __launch_bounds__(256) slab_probe_kernel(uint64_t* __restrict__ slab, uint64_t n_rec, uint32_t per_thread) {
-    uint32_t h = fmix32(blockIdx.x * 1024u + threadIdx.x + 1u);
-    for (uint32_t i = 0; i < per_thread; i++) {
-        h = fmix32(h + i);
-        const uint32_t h2 = fmix32(h ^ 0x9E3779B9u);
-        const uint64_t r = (uint64_t)(((unsigned __int128)(((uint64_t)h << 32) | h2) * n_rec) >> 64);
-        uint64_t* o = slab + r * 3;
-        o[0] = h; o[1] = h2; o[2] = i;
-    }
-}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1628,58 +1616,28 @@ int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out) {
     return 0;
 }
 
-// The slabs are ~26 GB written 24 bytes at a time at random addresses, and how fast that goes depends on WHICH physical memory the
-// driver hands out: blocks of the same size allocated side by side in one process take 5.9, 7.0 or 7.4 ms for the same 1.3e8 random
-// writes, reproducibly per block (tools/micro/slab_probe2.hip), and the scan follows (30.5 against 35 ms).  So a freshly
-// allocated slab block is not taken as it comes: up to three more candidates are allocated next to it (memory permitting), each is
-// timed with the scan's own write pattern (~2 ms) until one of the fast kind is in hand; the others serve the rest of the call and
-// then go back to the driver.  Once per ctx and block size (the pool keeps the chosen block); DBG_SLAB_PROBE=0 turns it off.
-static float slab_probe_ms(dbg_ctx* c, uint64_t* p, size_t words) {
-    hipEvent_t a = c->get_event(), b = c->get_event();
-    float best = 1e30f;
-    for (int rep = 0; rep < 2; rep++) {
-        (void)hipEventRecord(a, c->stream);
-        slab_probe_kernel<<<256 * 16 * 2, 256, 0, c->stream>>>(p, words / 3, 16);         // 3.4e7 records
-        (void)hipEventRecord(b, c->stream);
-        if (hipEventSynchronize(b) != hipSuccess) { (void)hipGetLastError(); best = 1e30f; break; }
-        float ms = 1e30f;
-        if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms < best) best = ms;
-    }
-    c->event_pool.push_back(a); c->event_pool.push_back(b);
-    return best;
-}
-static bool slab_alloc_probed(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words) {
-    const size_t pooled_before = c->pooled_bytes;
-    if (!slab->alloc(c, words)) return false;
+// The slabs are ~26 GB written 24 bytes at a time at random addresses, and how fast that goes depends on how the block is backed: a
+// plain 26 GB hipMalloc comes in two kinds -- 5.8 or 7.0-7.5 ms for the same 1.3e8 random writes, reproducibly per block, the scan
+// 30.5 or 35 ms -- and the slow kind stalls on DRAM write credits at the L2 with the same requests and hit rates
+// (profiles/r05_slab_modes.txt).  Rounds 3-4 worked around it by timing up to four candidate blocks (slab_probe_kernel); round 5
+// found the cure: the same virtual range mapped from physical handles of 256 MB or 2 GB is always of the fast kind
+// (profiles/r05_slab_vmm_probe.txt, tools/micro/slab_probe5.hip; k = 31 over nine processes: scan 59.0-59.5 ms with 256 MB
+// handles, 59.3-62.3 with 2 GB, 58.8-63.3 plain -- profiles/r05_k31_vmm_ab.txt), so slabs of 4 GB and more are allocated that way
+// (dbg_ctx::dalloc_pieces; DBG_SLAB_VMM=0: plain pool blocks, as smaller slabs always are).
+static bool slab_alloc(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words) {
     const size_t bytes = words * 8;
-    const bool fresh = c->pooled_bytes != pooled_before;             // not a block the pool already held (and had selected)
-    const char* knob = c->opt("DBG_SLAB_PROBE");
-    if (!fresh || bytes < (4ull << 30) || (knob && !strcmp(knob, "0"))) return true;
-    auto it = c->live_blocks.find(slab->p);
-    if (it == c->live_blocks.end()) return true;
-    const size_t blk = it->second;                                   // (rounded-up size the pool booked)
-    (void)hipStreamSynchronize(c->stream);
-    float best = slab_probe_ms(c, slab->p, words), worst = best;
-    const int extra = knob ? std::max(0, atoi(knob) - 1) : 3;
-    for (int i = 0; i < extra; i++) {
-        if (best < worst * 0.9f) break;                              // the two modes are ~20 % apart: a block of the fast kind is in hand
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
-        if (free_b < 3 * blk) break;                                 // the rest of the call still needs room
-        void* q = c->dalloc(blk);                                    // (fresh from the driver: the pool held no block of this size)
-        if (!q) break;
-        const float t = slab_probe_ms(c, (uint64_t*)q, words);
-        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] slab candidate %d: %.2f ms (best so far %.2f)\n", i + 1, t, best);
-        worst = std::max(worst, t);
-        void* loser = q;
-        if (t < best * 0.97f) { loser = slab->p; slab->p = (uint64_t*)q; best = t; }     // clearly better: the two blocks swap roles
-        // The loser serves the rest of this call from the pool (the counting output is a block of about this size) and goes back to
-        // the driver when the call ends (drop_spares).  Not now: a hipMalloc that follows a large hipFree was seen to wait seconds
-        // for the driver's deferred release.
-        c->dfree(loser);
-        c->spare_blocks.push_back(loser);
+    const char* knob = c->opt("DBG_SLAB_VMM");
+    if (bytes >= (4ull << 30) && !(knob && !strcmp(knob, "0"))) {
+        (void)hipStreamSynchronize(c->stream);                           // (a pooled block may still be in use by queued work of its previous owner)
+        const size_t piece = knob && atoll(knob) > 0 ? (size_t)atoll(knob) << 20 : (size_t)256 << 20;    // (DBG_SLAB_VMM=<MB per handle>: measurements)
+        if (void* p = c->dalloc_pieces(bytes, piece)) {
+            slab->release();
+            slab->ctx = c; slab->p = (uint64_t*)p; slab->n = words;
+            return true;
+        }
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] slab of %zu bytes: no piecewise mapping, plain allocation\n", bytes);
     }
-    return true;
+    return slab->alloc(c, words);
 }
 
 // scan: super-k-mer records in read order + bin histogram
@@ -1705,7 +1663,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
         if (const char* e = c->opt("DBG_SLAB_CAP")) st->slab_cap = (uint32_t)std::max(4, atoi(e)) & ~3u;      // measurement: records per slab
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc_probed(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
+        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
         else {
             // not enough memory for slabs (1.3x the records + slack): every record takes the read-order buffer and the
             // scatter pass instead -- slab capacity 0 routes them all there
@@ -2263,7 +2221,6 @@ static int fast_run(dbg_ctx* c, const SeqDev& s, FastPlan pl, uint64_t min_obs, 
                                      n_recs_total, (unsigned long long)st.n_recs);
     const int rc_count = fast_count(c, pl, min_obs, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, st.n_recs ? 2u : 1u, (uint64_t)nb,
                                     pl.nbins, n_kmers, n_recs_total, out, report_all, keep_masks);
-    c->drop_spares();
     return rc_count;
 }
 
@@ -2460,7 +2417,6 @@ static int shard_scatter_core(dbg_ctx* c, FastScan* st, const uint64_t* bin_off_
     st->slab.release(); st->cursor.release();
     DBG_TRY(fast_scatter(c, st, ovf_base.p, recs_out_dev));           // records that did not fit their slab go behind it
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->drop_spares();
     return 0;
 }
 

@@ -24,16 +24,20 @@ constexpr size_t STAGE_CHUNK = 16u << 20;       // bytes per staging buffer
 constexpr size_t STAGE_MIN = 8u << 20;          // smaller transfers take the plain copy
 
 struct UploadLane {
-    hipStream_t st = nullptr;
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
 };
 struct Stager {
     std::vector<UploadLane> lanes;
+    // ONE stream carries all the DMA: two host-to-device copies in flight on two streams share the link at 47 GB/s in all, one
+    // after the other they run at 57 (tools/micro/pcie_bw.hip, profiles/r05_pcie_bw.txt); the lanes' threads only fill the pinned
+    // buffers (8 threads copy pageable memory at ~97 GB/s) and queue their copies here, one at a time
+    hipStream_t dma = nullptr;
+    std::mutex mu;
     ~Stager() {
+        if (dma) (void)hipStreamDestroy(dma);
         for (auto& l : lanes) {
             for (int b = 0; b < 2; b++) { if (l.buf[b]) (void)hipHostFree(l.buf[b]); if (l.ev[b]) (void)hipEventDestroy(l.ev[b]); }
-            if (l.st) (void)hipStreamDestroy(l.st);
         }
     }
 };
@@ -56,9 +60,8 @@ Stager* get_stager(dbg_ctx* c) {
     Stager* s = new Stager();
     const unsigned nt = host_threads();
     s->lanes.resize(nt);
-    bool ok = true;
+    bool ok = hipStreamCreateWithFlags(&s->dma, hipStreamNonBlocking) == hipSuccess;
     for (auto& l : s->lanes) {
-        ok = ok && hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) == hipSuccess;
         for (int b = 0; b < 2 && ok; b++)
             ok = hipHostMalloc(&l.buf[b], STAGE_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming) == hipSuccess;
     }
@@ -97,15 +100,16 @@ int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs) {
             const int b = it & 1;
             if (it >= 2 && hipEventSynchronize(l->ev[b]) != hipSuccess) { err = 1; break; }       // the buffer's previous DMA is done
             memcpy(l->buf[b], chunks[i].src, chunks[i].n);
-            if (hipMemcpyAsync(chunks[i].dst, l->buf[b], chunks[i].n, hipMemcpyHostToDevice, l->st) != hipSuccess ||
-                hipEventRecord(l->ev[b], l->st) != hipSuccess) { err = 1; break; }
+            std::lock_guard<std::mutex> g(s->mu);
+            if (hipMemcpyAsync(chunks[i].dst, l->buf[b], chunks[i].n, hipMemcpyHostToDevice, s->dma) != hipSuccess ||
+                hipEventRecord(l->ev[b], s->dma) != hipSuccess) { err = 1; break; }
         }
-        if (hipStreamSynchronize(l->st) != hipSuccess) err = 1;
     };
     std::vector<std::thread> th;
     for (size_t t = 1; t < s->lanes.size(); t++) th.emplace_back(work, &s->lanes[t]);
     work(&s->lanes[0]);
     for (auto& t : th) t.join();
+    if (hipStreamSynchronize(s->dma) != hipSuccess) err = 1;
     if (err) { (void)hipGetLastError(); return c->fail(100, "HIP error in the staged host-to-device upload"); }
     return 0;
 }
