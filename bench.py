@@ -276,9 +276,10 @@ def main():
             # of the kernel sources it was measured on, and a file from other sources is reported as stale
             hsrc = hashlib.sha256()
             cdir = os.path.join(ROOT, "rust-debruijn_amd", "csrc")
-            for f_ in sorted(os.listdir(cdir)):
-                if f_.endswith((".hip", ".hpp")):
-                    hsrc.update(f_.encode()); hsrc.update(open(os.path.join(cdir, f_), "rb").read())
+            # (the files that hold the kernels of the timed path; host-side files -- api, transports, graph, the rank-spanning flows --
+            #  do not change what the counters measured.  tools/pmc_traffic.py hashes the same list)
+            for f_ in ("dbg_device.hpp", "dbg_msp_device.hpp", "fast_manylabels.hpp", "fastpath.hip", "radix.hip", "scan.hip"):
+                hsrc.update(f_.encode()); hsrc.update(open(os.path.join(cdir, f_), "rb").read())
             src_sha = hsrc.hexdigest()[:16]
             traffic_stale = bool(tj) and tj.get("_kernel_source_sha16") != src_sha
             pmc_name = {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
@@ -445,10 +446,11 @@ def main():
             # bench workload.  First call of each kind warms the ctx's pinned result pool (hipHostMalloc is slow), second is timed.
             hw, hst, hl, hc = words.cpu().numpy(), start.cpu().numpy(), length.cpu().numpy(), colour.cpu().numpy()
             hostb = {}
-            for kind, setk in (("CountFilter", 0), ("CountFilterSet", 1)):
+            # (CountFilterSet_compact: dbg_filter_params.compact_sets -- the CSR crosses PCIe as u32 offsets + u8 labels)
+            for kind, setk, compact in (("CountFilter", 0, 0), ("CountFilterSet", 1, 0), ("CountFilterSet_compact", 1, 1)):
                 hss = capi.SeqSet(hw.ctypes.data, nw, hst.ctypes.data, hl.ctypes.data, None, hc.ctypes.data if setk else None, 1 if setk else 0,
                                   reads_per_gpu)
-                hfp = capi.FilterParams(k, 0, setk, args.min_obs, 0, 4)
+                hfp = capi.FilterParams(k, 0, setk, args.min_obs, 0, 4, compact)
                 for rep in range(2):
                     ht = capi.KmerTable()
                     torch.cuda.synchronize()
@@ -456,13 +458,17 @@ def main():
                     ctx.check(lib.dbg_filter_kmers(ctx.h, C.byref(hss), C.byref(hfp), C.byref(ht)))
                     hdt = time.perf_counter() - h0
                     b_in = hw.nbytes + hst.nbytes + hl.nbytes + (hc.nbytes if setk else 0)
-                    b_out = ht.n * 17 + ((ht.n + 1) * 8 + ht.n_set_val * 4 if setk else ht.n * 2)
+                    b_out = ht.n * 17 + ((ht.n + 1) * (ht.set_off_width or 8) + ht.n_set_val * (ht.set_val_width or 4) if setk else ht.n * 2)
                     n_i = ht.n_kmer_instances
                     lib.dbg_free_table(ctx.h, C.byref(ht))
                 hostb[kind] = {"value": round(n_i / hdt / 1e9, 3), "unit": "Gkmer/s", "seconds": round(hdt, 4),
                                "gb_host_to_device": round(b_in / 1e9, 2), "gb_device_to_host": round(b_out / 1e9, 2),
                                "pcie_gb_per_s": round((b_in + b_out) / hdt / 1e9, 1)}
             hostb["boundary"] = "dbg_filter_kmers: pageable host arrays in, host table out (pinned result pool of the ctx, warm)"
+            # one pinned copy runs at 57 GB/s in either direction and the two directions do not add up (tools/micro/pcie_bw.hip,
+            # profiles/r05_pcie_bw.txt): the bytes above over that rate, plus the kernels that cannot run under a copy (everything but
+            # the scan), is what this boundary can reach on this link
+            hostb["pcie_bound_note"] = "(GB in + GB out) / 57 GB/s + ~0.08 s of kernels that no copy can hide"
             del hw, hst, hl, hc
         comp = None
         if args.compress_reads and world == 1:

@@ -1,5 +1,6 @@
 // extern "C" boundary: context management and filter_kmers (src/filter.rs:139-231).
 #include "dbg_internal.hpp"
+#include <thread>
 #include <algorithm>
 #include <cstdlib>
 #include <atomic>
@@ -394,10 +395,19 @@ __global__ void __launch_bounds__(256) narrow_kernel(const uint64_t* __restrict_
 
 extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filter_params* p, dbg_kmer_table* out) {
     DBG_TRY(validate_filter(c, hs, p));
-    DBG_TRY(check_host_seqset(c, hs));
     HIP_TRY(c, hipSetDevice(c->device));
     DevSeqSet d;
-    DBG_TRY(upload_seqset(c, hs, &d));
+    {
+        // the bounds / label checks of the caller's arrays (a pass over start[] and length[] on the host threads) run next to the
+        // upload -- copying unchecked arrays is harmless, running kernels on them is not: the check is joined before anything is launched
+        int check_rc = 0;
+        std::string check_err;
+        std::thread checker([&] { dbg_ctx tmp; check_rc = check_host_seqset(&tmp, hs); check_err = tmp.err; });
+        const int up = upload_seqset(c, hs, &d);
+        checker.join();
+        if (check_rc) return c->fail(check_rc, check_err);
+        DBG_TRY(up);
+    }
     dbg_kmer_table dev;
     DBG_TRY(dbg_filter_kmers_dev(c, &d.view, p, &dev));
     d.words.release(); d.start.release(); d.length.release(); d.exts.release(); d.data.release();     // (the reads are no longer needed: room for the copies below)

@@ -123,7 +123,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     const uint32_t W = tr ? (uint32_t)tr->world : 1u, me = tr ? (uint32_t)tr->rank : 0u;
     if (W == 0 || me >= W) return c->fail(161, "sharded flow: bad transport (rank / world)");
     if (W > 64) return c->fail(161, "sharded flow: at most 64 ranks (one record segment per source rank in the counting kernel)");
-    if (tr && W > 1 && (!tr->all_reduce_u64 || !tr->all_to_allv)) return c->fail(161, "sharded flow: the transport lacks all_reduce_u64 / all_to_allv");
+    if (tr && (W > 1 || p->force_exchange) && (!tr->all_reduce_u64 || !tr->all_to_allv)) return c->fail(161, "sharded flow: the transport lacks all_reduce_u64 / all_to_allv");
     dbg_shard_stats st_local;
     dbg_shard_stats* S = stats ? stats : &st_local;
     memset(S, 0, sizeof(*S));
@@ -341,7 +341,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     c->t_end();
 
     // ---- per-bin counts of my bins from every source ----
-    if (W > 1) {
+    if (X.live) {
         std::vector<uint64_t> soff(W), sby(W), roff(W), rby(W);
         for (uint32_t d = 0; d < W; d++) {
             soff[d] = (uint64_t)bounds[d] * 4; sby[d] = d == me ? 0 : (uint64_t)(bounds[d + 1] - bounds[d]) * 4;
@@ -463,7 +463,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         if (r >= 2 && hipStreamWaitEvent(xs, ev_counted[r - 2], 0) != hipSuccess) { (void)hipGetLastError(); return tr_rc = X.op_failed("hipStreamWaitEvent in front of all_to_allv"); }
         (void)hipEventRecord(ev_w0[r], xs);
         XTimer th;
-        const int e = W > 1 ? tr->all_to_allv(tr->self, recs.p, soff.data(), sby.data(), rbuf[r & 1].p, roff.data(), rby.data(), xs) : 0;
+        const int e = X.live ? tr->all_to_allv(tr->self, recs.p, soff.data(), sby.data(), rbuf[r & 1].p, roff.data(), rby.data(), xs) : 0;
         host_ms[r] = th.ms();
         if (e) return tr_rc = X.op_failed("all_to_allv (records)");
         (void)hipEventRecord(ev_w1[r], xs);

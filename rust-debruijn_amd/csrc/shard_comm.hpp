@@ -90,7 +90,7 @@ struct ShardComm {
 
     // MAX all-reduce of a few host values over the ranks, ordered on the ctx stream
     int reduce(uint64_t* vals, uint32_t n, int op, const char* what) {
-        if (!live || W <= 1) return 0;
+        if (!live) return 0;                // (a forced one-rank exchange goes through the transport like any other: its calls are the point)
         DBuf<uint64_t> big;
         uint64_t* d = word.p;
         if (n > WORDS) { if (!big.alloc(c, n)) { abort(); return c->fail(101, std::string("rank-spanning call: no device memory for ") + what); } d = big.p; }
@@ -104,7 +104,7 @@ struct ShardComm {
     // values max-reduced in the same message (what the phase has to agree on anyway).  Returns 0, or the largest error code of
     // any rank -- on every rank -- with dbg_last_error naming the phase and the rank.
     int agree(int local_rc, const char* phase, uint64_t* extra = nullptr, uint32_t n_extra = 0) {
-        if (!live || W <= 1) return local_rc;
+        if (!live) return local_rc;
         uint64_t v[WORDS] = {0};
         if (n_extra + 1 > WORDS) return c->fail(10, "agree: too many values");
         v[0] = local_rc ? (((uint64_t)(uint32_t)local_rc << 16) | (uint64_t)(me + 1)) : 0;

@@ -63,7 +63,7 @@ int shard_filter_generic(dbg_ctx* c, void* shard_comm, const dbg_transport* tr, 
     DBG_TRY(X.agree(lrc, "histogram", inv_pm, 1));
     pass_max = ~inv_pm[0];
     std::vector<uint64_t> hall((size_t)256 * W, 0);
-    if (W > 1) {
+    if (X.live && tr->all_gather) {
         if (tr->all_gather(tr->self, d_hist.p, d_all.p, 256 * 8, c->stream)) return X.op_failed("all_gather (top-byte histograms)");
         if (hipMemcpyAsync(hall.data(), d_all.p, hall.size() * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the histograms"); }
     } else if (hipMemcpyAsync(hall.data(), d_hist.p, 256 * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { (void)hipGetLastError(); return X.op_failed("copy of the histogram"); }
@@ -140,7 +140,7 @@ int shard_filter_generic(dbg_ctx* c, void* shard_comm, const dbg_transport* tr, 
             return 0;
         }();
         if (int r = X.agree(lrc, "extract")) { free_parts(); return r; }
-        if (W > 1) {
+        if (X.live) {
             std::vector<uint64_t> so(W), sb(W), ro(W), rb(W);
             auto xchg = [&](const void* sp, void* rp, uint32_t width, const char* what) -> int {
                 for (uint32_t d = 0; d < W; d++) {

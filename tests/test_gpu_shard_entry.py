@@ -134,3 +134,32 @@ def test_shard_compress_entry_world1(ctx, rccl1, k, kind, mode):
         ctx.lib.dbg_free_table(ctx.h, C.byref(tab))
     finally:
         ctx.set_option("DBG_COMPRESS", old)
+
+
+def test_rccl_table_poll_and_abort_world1(ctx):
+    """round 5: the RCCL table's failure handling on a real communicator -- poll is ncclCommGetAsyncError (healthy: 0), abort is
+    ncclCommAbort: afterwards every operation of the table fails at once, dbg_transport_aborted says so (the host must not destroy
+    the ncclComm_t again), and a rank-spanning call over the dead table returns an error instead of hanging"""
+    import torch
+    tr = T.RcclTransport(0, rank=0, world=1, bootstrap=lambda x: x)
+    try:
+        tab = tr.table
+        assert tab.poll(tab.self) == 0 and ctx.lib.dbg_transport_aborted(tr.ptr) == 0
+        a = torch.arange(16, dtype=torch.int64, device=torch.device("cuda", 0))
+        torch.cuda.synchronize()
+        assert tab.all_reduce_u64(tab.self, a.data_ptr(), 16, 0, None) == 0
+        torch.cuda.synchronize()
+        tab.abort(tab.self)
+        assert ctx.lib.dbg_transport_aborted(tr.ptr) == 1 and tab.poll(tab.self) != 0
+        assert tab.all_reduce_u64(tab.self, a.data_ptr(), 16, 0, None) != 0
+        tab.abort(tab.self)                                       # idempotent
+        hs = dbg.synth_reads_host(n_reads=2000, read_len=150, error_rate=0.002, stranded=False, n_colours=3)
+        dev, hc = capi.SeqSet(), hs.c_struct()
+        ctx.check(ctx.lib.dbg_seqset_to_device(ctx.h, C.byref(hc), C.byref(dev)))
+        p = capi.ShardParams(47, 0, 0, 2, 2, 0, 1, 1)             # force_exchange: the collective route over the dead table
+        tab_out, st = capi.KmerTable(), capi.ShardStats()
+        rc = ctx.lib.dbg_shard_filter_kmers_dev(ctx.h, tr.ptr, C.byref(dev), C.byref(p), C.byref(tab_out), C.byref(st))
+        ctx.lib.dbg_seqset_free_device(ctx.h, C.byref(dev))
+        assert rc != 0 and tab_out.n == 0
+    finally:
+        tr.close()                                                # (skips ncclCommDestroy: the communicator is gone)

@@ -10,9 +10,8 @@ def kernel_source_sha():
     measured on other kernels as stale (.git does not travel to the GPU box, so a commit id is not available there)"""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-debruijn_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("dbg_device.hpp", "dbg_msp_device.hpp", "fast_manylabels.hpp", "fastpath.hip", "radix.hip", "scan.hip"):   # = bench.py's list
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 n_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 2          # bench steps the counter passes ran (tools/pmc_round.sh)
