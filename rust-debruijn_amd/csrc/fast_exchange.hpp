@@ -114,118 +114,36 @@ struct EventSet {
 
 }  // namespace
 
-extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, const dbg_seqset* ds, const dbg_shard_params* p,
-                                          dbg_kmer_table* out, dbg_shard_stats* stats) {
-    if (!c) return 1;
-    if (!ds || !p || !out) return c->fail(10, "null argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    XTimer t_setup;
-    const uint32_t W = tr ? (uint32_t)tr->world : 1u, me = tr ? (uint32_t)tr->rank : 0u;
-    if (W == 0 || me >= W) return c->fail(161, "sharded flow: bad transport (rank / world)");
-    if (W > 64) return c->fail(161, "sharded flow: at most 64 ranks (one record segment per source rank in the counting kernel)");
-    if (tr && (W > 1 || p->force_exchange) && (!tr->all_reduce_u64 || !tr->all_to_allv)) return c->fail(161, "sharded flow: the transport lacks all_reduce_u64 / all_to_allv");
-    dbg_shard_stats st_local;
-    dbg_shard_stats* S = stats ? stats : &st_local;
-    memset(S, 0, sizeof(*S));
-    memset(out, 0, sizeof(*out));
-    const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
-    const bool collective = W > 1 || (p->force_exchange && tr);
-    // Failure agreement (shard_comm.hpp): every phase below runs its rank-local work to the end with the status kept in `lrc`, and
-    // ends in X.agree() before the phase's data moves; all ranks leave with the same verdict.
-    ShardComm X(c, tr, collective);
-    DBG_TRY(X.prepare());
+namespace {
+// what one exchange + count run needs beyond the plan
+struct XRun {
+    uint32_t n_rounds = 0;
+    bool balance = true;
+    int merge = 0;
+    uint64_t n_local = 0, n_max = 0, total = 0;
+    std::vector<uint32_t>* bounds_io = nullptr;         // empty: ownership is derived here (and returned); filled: used as it is
+    DBuf<unsigned long long>* keep_masks = nullptr;     // label-group runs
+    int lrc_in = 0;                                     // status of the rank-local work done before the run
+    bool main_run = true;                               // the call's own table (timing records cleared, merge statistics kept)
+};
+
+// scan -> ownership -> layout -> pipelined exchange rounds -> count -> sort, over the plan sp (see the header of this file)
+int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const dbg_seqset* ds, dbg_shard_plan sp, const XRun& o,
+                       dbg_kmer_table* out, dbg_shard_stats* S, const XTimer& t_setup) {
+    const uint32_t W = X.W, me = X.me;
+    const uint64_t n_local = o.n_local, n_max = o.n_max;
     int lrc = 0;
-
-    // ---- phase "count": global quantities every rank must agree on ----
-    uint64_t n_local = 0;
-    uint32_t my_max_label = 0;
-    lrc = [&]() -> int {
-        if (X.inject("count")) return X.injected("count");
-        DBG_TRY(dbg_count_kmer_instances_dev(c, ds, p->k, &n_local));
-        if (is_set) DBG_TRY(dbg_seqset_max_label_dev(c, ds, &my_max_label));
-        return 0;
-    }();
-    if (lrc) { n_local = 0; my_max_label = 0; }
-    // The sender-side merge, when the library is to decide (merge_dups = -1), is decided by ALL ranks together -- a vote from what
-    // each ctx measured in its previous call, max-reduced with the other global quantities -- and it is re-evaluated every call:
-    //   last call without the merge: on, if the exchange time the counting could not hide (beyond the first round, which is always
-    //     exposed) exceeded what the merge costs;
-    //   last call with the merge: it stays on while the wire time it saved -- wire time x (records before / after the merge - 1), all
-    //     of which would have been exposed on top of what already was -- still exceeds its cost.
-    uint64_t vote = 0;
-    if (p->merge_dups < 0 && !c->opt("DBG_SHARD_MERGE") && W != 2 && c->shard_last_valid) {
-        double cost = c->shard_last_merge_cost_ms;
-        if (const char* e = c->opt("DBG_SHARD_MERGE_COST_MS")) cost = atof(e);      // (tests: what the merge is taken to cost)
-        if (!c->shard_last_merge) vote = c->shard_last_exposed_ms > cost ? 1 : 0;
-        else {
-            const double ratio = std::max(1.0, c->shard_last_merge_ratio);
-            vote = c->shard_last_exposed_ms + c->shard_last_wire_ms * (ratio - 1.0) > cost ? 1 : 0;
-        }
-    }
-    uint64_t mx3[3] = {n_local, my_max_label, vote};
-    DBG_TRY(X.agree(lrc, "count", mx3, 3));
-    uint64_t sum1[1] = {n_local};
-    DBG_TRY(X.reduce(sum1, 1, 0, "all_reduce_u64 (k-mer instances)"));
-    const uint64_t total = sum1[0], n_max = mx3[0];
-    const uint32_t max_label = (uint32_t)mx3[1];
-    vote = mx3[2];
-    S->total_kmers = total; S->local_kmers = n_local;
-
-    if (!collective) {
-        // one rank: the sharded table is the whole table
-        dbg_filter_params fp{p->k, p->stranded, p->summarizer, p->min_kmer_obs, 0, 4};
-        DBG_TRY(dbg_filter_kmers_dev(c, ds, &fp, out));
-        S->n_rounds = 0; S->setup_ms = 0.0;
-        return 0;
-    }
-    // (argument checks on values every rank holds alike need no agreement)
-    if (p->k < 4 || p->k > 64) return c->fail(11, "k must be in 4..=64 (filter.rs:18-23 reads the first 4 bases)");
-    // Shapes the super-k-mer exchange does not take -- k < 16, more than 64 distinct labels over all ranks, labels >= 65536 -- go
-    // the key-range route (shard_generic.hip): decided from values every rank holds alike.  DBG_PATH=generic insists on it.
-    bool key_range_route = p->k < 16 || (c->opt("DBG_PATH") && !strcmp(c->opt("DBG_PATH"), "generic"));
-
-    dbg_shard_plan sp;
-    memset(&sp, 0, sizeof(sp));
-    sp.k = p->k; sp.stranded = p->stranded; sp.summarizer = p->summarizer; sp.min_kmer_obs = p->min_kmer_obs;
-    sp.total_kmers = std::max<uint64_t>(total, 1); sp.max_label = max_label;
-    if (is_set && max_label >= 64 && !key_range_route) {
-        // ---- phase "labels" ----
-        // labels beyond the 64 colours of the counting kernel: a sparse alphabet is mapped to colour indices, the same way on every
-        // rank -- the union of the ranks' label sets (a max-reduction of presence flags: the transport has sum and max, no OR)
-        std::vector<uint32_t> bm(2049, 0u);
-        lrc = X.inject("labels") ? X.injected("labels") : dbg_seqset_label_bitmap_dev(c, ds, bm.data());
-        DBG_TRY(X.agree(lrc, "labels"));
-        std::vector<uint64_t> pres(65537);
-        for (uint32_t v = 0; v < 65536; v++) pres[v] = (bm[v >> 5] >> (v & 31)) & 1u;
-        pres[65536] = bm[2048] ? 1 : 0;
-        DBG_TRY(X.reduce(pres.data(), 65537, 1, "all_reduce_u64 (label presence)"));
-        uint32_t nl = 0;
-        for (uint32_t v = 0; v < 65536; v++) if (pres[v]) { if (nl < 64) sp.labels[nl] = v; nl++; }
-        if (pres[65536] || nl > 64) key_range_route = true;       // labels >= 65536, or more colours than the counting kernel's sets hold
-        else sp.n_labels = nl;
-    }
-    if (key_range_route) {
-        const int r = shard_filter_generic(c, &X, tr, ds, p, total, out, S);
-        S->total_kmers = total; S->local_kmers = n_local;
-        return r;
-    }
-    // sender-side merge: asked for, or decided above (DESIGN.md section 5): on at 2 ranks, otherwise the ranks' vote
-    int merge = p->merge_dups;
-    if (merge < 0) {
-        if (const char* e = c->opt("DBG_SHARD_MERGE")) merge = atoi(e) != 0;
-        else if (W == 2) merge = 1;
-        else merge = vote ? 1 : 0;
-    }
-    sp.merge_dups = merge ? 1u : 0u;
-
+    sp.merge_dups = o.merge ? 1u : 0u;
     // ---- phase "scan": plan, scan (+ merge), record histogram of the coarse bin groups ----
     FastPlan pl;
     FastScan sc;
     uint32_t nb = 0, rw = 0, f = 1, ng = 0;
-    const bool balance = p->balance != 0 && W > 1;
+    const bool given = o.bounds_io && !o.bounds_io->empty();       // ownership handed in (label-group runs: the bounds of the first run)
+    const bool balance = o.balance && W > 1 && !given;
     DBuf<uint64_t> gh;
-    c->t_clear();
+    if (o.main_run) c->t_clear();
     lrc = [&]() -> int {
+        if (o.lrc_in) return o.lrc_in;                              // (rank-local work before this run failed: c->err holds its message)
         DBG_TRY(plan_from(c, &sp, &pl));
         nb = pl.nbins * NCLS; rw = (uint32_t)pl.rw;
         if (X.inject("scan")) return X.injected("scan");
@@ -246,7 +164,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     }();
     DBG_TRY(X.agree(lrc, "scan"));
     sp.n_bins = nb; sp.rec_words = rw; sp.bin_group = NCLS;
-    S->n_bins = nb; S->merge_dups = merge;
+    S->n_bins = nb; S->merge_dups = o.merge;
     hipStream_t xs = c->get_comm_stream();
 
     // ---- ownership ----
@@ -262,12 +180,16 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         for (uint32_t r = 0; r <= W; r++) bounds[r] = (uint32_t)std::min<uint64_t>((uint64_t)bounds[r] * f, nb);
         bounds[W] = nb;
         gh.release();
+    } else if (given) {
+        if (o.bounds_io->size() != W + 1 || (*o.bounds_io)[W] != nb) return c->fail(162, "sharded flow: ownership bounds of another bin space");
+        bounds = *o.bounds_io;
     } else if (dbg_shard_owner_bounds(nullptr, nb, NCLS, W, bounds.data())) return c->fail(162, "sharded flow: ownership bounds");
+    if (o.bounds_io) *o.bounds_io = bounds;
     S->balanced = balance ? 1 : 0;
     S->owned_lo = bounds[me]; S->owned_hi = bounds[me + 1];
 
     // ---- rounds ----
-    uint32_t n_rounds = p->n_rounds;
+    uint32_t n_rounds = o.n_rounds;
     if (!n_rounds) {
         // Rounds are the unit of overlap (round c + 1 travels while round c is counted) and of receive-buffer memory (two buffers of
         // one round's incoming records); the transport itself keeps every message under 1 GiB.  Four rounds leave a quarter of the
@@ -438,7 +360,9 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         if (R > 1) ALLOC_OR_FAIL(c, rbuf[1], std::max<uint64_t>(max_recv * rw, 1));
         for (uint32_t r = 0; r < R; r++) { ev_done[r] = events.get(); ev_a[r] = events.get(); ev_b[r] = events.get(); ev_w0[r] = events.get(); ev_w1[r] = events.get(); ev_counted[r] = events.get(); }
         if (X.inject("count_begin")) return X.injected("count_begin");
-        return fast_count_begin(c, pl, p->min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get());
+        DBG_TRY(fast_count_begin(c, pl, sp.min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get()));
+        cs->keep_masks = o.keep_masks;                              // (label-group runs: the sorted 64-bit masks instead of a CSR)
+        return 0;
     }();
     DBG_TRY(X.agree(lrc, "tables"));
     S->records_owned = owned;
@@ -519,13 +443,272 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         if (!lrc) { dbg_free_table(c, out); memset(out, 0, sizeof(*out)); }    // this rank's table is of no use without the others'
         return arc;
     }
-    out->n_kmer_instances = total;
+    out->n_kmer_instances = o.total;
+    if (!o.main_run) return 0;
     // what the next call's merge vote looks at: exposed and wire time beyond the first round (always exposed), the merge's cost and
     // what it removed
-    c->shard_last_valid = true; c->shard_last_merge = merge != 0;
+    c->shard_last_valid = true; c->shard_last_merge = o.merge != 0;
     c->shard_last_exposed_ms = S->exposed_ms - S->exposed_ms_round[0];
     c->shard_last_wire_ms = wire_ms;
     c->shard_last_merge_ratio = n_recs ? (double)(n_recs + sc.n_merged_away) / (double)n_recs : 1.0;
     c->shard_last_merge_cost_ms = 10.0 * (double)n_local / 1.04e10;         // slab_merge: ~9-10 ms per 10^8 reads of 150 bases
     return 0;
+}
+}  // namespace
+
+namespace {
+// CountFilterSet with 65 .. 1024 distinct labels over all ranks (round 5): the label groups of fast_manylabels.hpp across ranks.
+// One CountFilter run gives every owner the valid k-mers of its bins (validity counts observations over all labels,
+// src/filter.rs:85-100); then, per group of 64 labels, one more run over the reads of that group alone -- min_kmer_obs = 1, the
+// WIDE colour layout, the sorted 64-bit masks kept -- in the SAME bin space with the SAME ownership bounds, so that a k-mer's group
+// masks arrive at the rank that holds it in T; the masks are joined into T's rows by key and the label lists written from the rows.
+// The groups' reads are selected by permuting the reads' metadata (start, length, Exts, colour inside the group); the packed bases
+// stay where they are.  Every run agrees on its own status; the rank-local steps between the runs hand theirs to the next run.
+int shard_filter_label_groups(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const dbg_seqset* ds, const dbg_shard_params* p,
+                              dbg_shard_plan sp, XRun o, const std::vector<uint32_t>& labels, dbg_kmer_table* out, dbg_shard_stats* S,
+                              const XTimer& t_setup) {
+    const uint32_t nd = (uint32_t)labels.size(), G = (nd + 63) / 64;
+    SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
+    // 1. the valid k-mers of the bins this rank owns.  Bins of half the usual size: the groups' tables (WIDE layout, 1024 entries)
+    //    see the same bins, each with up to all of a bin's distinct k-mers
+    dbg_shard_plan spA = sp;
+    spA.summarizer = DBG_COUNT_FILTER; spA.n_labels = 0; spA.max_label = 0; spA.n_bins = 0;
+    {
+        FastPlan pl;
+        DBG_TRY(plan_from(c, &spA, &pl));                            // (the same arguments on every rank: the same outcome)
+        spA.n_bins = (uint32_t)std::min<uint64_t>((uint64_t)pl.nbins * 2, (1ull << 23) - 1) * NCLS;
+    }
+    std::vector<uint32_t> bounds;
+    XRun oa = o;
+    oa.bounds_io = &bounds;
+    dbg_kmer_table T;
+    memset(&T, 0, sizeof(T));
+    DBG_TRY(shard_exchange_run(c, X, tr, ds, spA, oa, &T, S, t_setup));
+    struct TableGuard { dbg_ctx* c; dbg_kmer_table* t; ~TableGuard() { dbg_free_table(c, t); } } guard_T{c, &T};
+    const uint32_t nv = (uint32_t)T.n;
+
+    // 2. this rank's reads by label group (rank-local; its status travels with the first group's run)
+    DBuf<uint8_t> d_group, d_colour, p_exts, p_colour;
+    DBuf<uint32_t> d_labels, blk_counts, p_length;
+    DBuf<uint64_t> blk_off, p_start;
+    DBuf<unsigned long long> masks;
+    std::vector<uint64_t> g_off(G + 1, 0);
+    int lrc = [&]() -> int {
+        if (X.inject("groups")) return X.injected("groups");
+        const uint32_t top = labels.back();
+        std::vector<uint8_t> h_group((size_t)top + 1, 0), h_colour((size_t)top + 1, 0);
+        for (uint32_t i = 0; i < nd; i++) { h_group[labels[i]] = (uint8_t)(i / 64); h_colour[labels[i]] = (uint8_t)(i % 64); }
+        const uint32_t nblk = cdiv(std::max<uint64_t>(s.n, 1), ML_BLOCK_READS);
+        ALLOC_OR_FAIL(c, d_group, (size_t)top + 1); ALLOC_OR_FAIL(c, d_colour, (size_t)top + 1); ALLOC_OR_FAIL(c, d_labels, (size_t)G * 64);
+        ALLOC_OR_FAIL(c, blk_counts, (size_t)G * nblk); ALLOC_OR_FAIL(c, blk_off, (size_t)G * nblk + 1);
+        ALLOC_OR_FAIL(c, p_start, std::max<uint64_t>(s.n, 1)); ALLOC_OR_FAIL(c, p_length, std::max<uint64_t>(s.n, 1)); ALLOC_OR_FAIL(c, p_colour, std::max<uint64_t>(s.n, 1));
+        if (s.exts) ALLOC_OR_FAIL(c, p_exts, std::max<uint64_t>(s.n, 1));
+        std::vector<uint32_t> h_labels((size_t)G * 64, 0);
+        std::copy(labels.begin(), labels.end(), h_labels.begin());
+        HIP_TRY(c, hipMemcpyAsync(d_group.p, h_group.data(), h_group.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_colour.p, h_colour.data(), h_colour.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_labels.p, h_labels.data(), h_labels.size() * 4, hipMemcpyHostToDevice, c->stream));
+        if (s.n) {
+            c->t_begin("label_groups", s.n);
+            ml_group_count_kernel<<<nblk, 256, 0, c->stream>>>(s.data, s.data_width, s.n, d_group.p, G, blk_counts.p, nblk);
+            c->t_end();
+            LAUNCH_CHECK(c, "ml_group_count");
+            DBG_TRY(scan_exclusive_u32_u64(c, blk_counts.p, blk_off.p, (uint64_t)G * nblk));
+            ml_group_scatter_kernel<<<nblk, 256, 0, c->stream>>>(s.data, s.data_width, s.n, d_group.p, d_colour.p, blk_off.p, nblk, s.start, s.length, s.exts,
+                                                                p_start.p, p_length.p, p_exts.p, p_colour.p);
+            LAUNCH_CHECK(c, "ml_group_scatter");
+            for (uint32_t g = 0; g < G; g++) HIP_TRY(c, hipMemcpyAsync(&g_off[g], blk_off.p + (size_t)g * nblk, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));              // (also: the host tables above leave scope only after their copies)
+        g_off[G] = s.n;
+        if (!s.n) for (uint32_t g = 0; g < G; g++) g_off[g] = 0;
+        ALLOC_OR_FAIL(c, masks, std::max<size_t>((size_t)nv * G, 1));
+        HIP_TRY(c, hipMemsetAsync(masks.p, 0, std::max<size_t>((size_t)nv * G, 1) * 8, c->stream));
+        return 0;
+    }();
+
+    // 3. one 64-colour run per group over all ranks, joined into the rows of masks
+    for (uint32_t g = 0; g < G; g++) {
+        const uint64_t a = lrc ? 0 : g_off[g], n_g = lrc ? 0 : g_off[g + 1] - a;
+        dbg_seqset dg = *ds;
+        dg.start = p_start.p ? p_start.p + a : ds->start; dg.length = p_length.p ? p_length.p + a : ds->length;
+        dg.exts = s.exts && p_exts.p ? p_exts.p + a : nullptr;
+        dg.data = p_colour.p ? (const void*)(p_colour.p + a) : nullptr; dg.data_width = 1; dg.n_seqs = n_g;
+        uint64_t nk_g = 0;
+        if (!lrc && n_g) lrc = dbg_count_kmer_instances_dev(c, &dg, p->k, &nk_g);
+        dbg_shard_plan spg = sp;
+        spg.summarizer = DBG_COUNT_FILTER_SET; spg.max_label = 63; spg.n_labels = 0; spg.n_bins = spA.n_bins; spg.min_kmer_obs = 1;
+        XRun og = o;
+        og.bounds_io = &bounds; og.lrc_in = lrc; og.main_run = false; og.n_local = nk_g;
+        DBuf<unsigned long long> msk;
+        og.keep_masks = &msk;
+        dbg_kmer_table Tg;
+        memset(&Tg, 0, sizeof(Tg));
+        dbg_shard_stats Sg;
+        memset(&Sg, 0, sizeof(Sg));
+        const int rc = shard_exchange_run(c, X, tr, &dg, spg, og, &Tg, &Sg, t_setup);
+        TableGuard guard_g{c, &Tg};
+        if (rc) return rc;                                         // (agreed inside the run: every rank is here)
+        S->bytes_sent += Sg.bytes_sent; S->exposed_ms += Sg.exposed_ms; S->records_scanned += Sg.records_scanned; S->records_owned += Sg.records_owned;
+        lrc = [&]() -> int {
+            if (X.inject("join") && g == G - 1) return X.injected("join");
+            if (Tg.n && nv) {
+                c->t_begin("label_join", nv);
+                ml_join_kernel<<<cdiv(nv, ML_JOIN_TILE), 256, 0, c->stream>>>(T.key_hi, T.key_lo, nv, Tg.key_hi, Tg.key_lo, msk.p, (uint32_t)Tg.n, masks.p, G, g);
+                c->t_end();
+                LAUNCH_CHECK(c, "ml_join");
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream));          // T_g and its masks are released at the end of this iteration
+            return 0;
+        }();
+    }
+
+    // 4. label lists (rank-local), then the call's last agreement
+    DBuf<uint32_t> setn, set_val;
+    DBuf<uint64_t> set_off;
+    uint64_t n_setval = 0;
+    if (!lrc) lrc = [&]() -> int {
+        ALLOC_OR_FAIL(c, setn, std::max<uint32_t>(nv, 1)); ALLOC_OR_FAIL(c, set_off, (size_t)nv + 1);
+        if (nv) {
+            ml_setn_kernel<<<cdiv(nv, 256), 256, 0, c->stream>>>(masks.p, nv, G, setn.p);
+            LAUNCH_CHECK(c, "ml_setn");
+            DBG_TRY(scan_exclusive_u32_u64(c, setn.p, set_off.p, nv));
+            HIP_TRY(c, hipMemcpyAsync(&n_setval, set_off.p + nv, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else HIP_TRY(c, hipMemsetAsync(set_off.p, 0, 8, c->stream));
+        ALLOC_OR_FAIL(c, set_val, std::max<uint64_t>(n_setval, 1));
+        if (nv) {
+            c->t_begin("set_csr", nv);
+            ml_csr_kernel<<<cdiv(nv, 256), 256, 0, c->stream>>>(masks.p, nv, G, set_off.p, d_labels.p, set_val.p);   // a wave per 64 keys
+            c->t_end();
+            LAUNCH_CHECK(c, "ml_csr");
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }();
+    DBG_TRY(X.agree(lrc, "label lists"));
+    *out = T;
+    memset(&T, 0, sizeof(T));                                      // ownership of T's arrays moves to *out
+    if (out->count) { c->dfree(out->count); out->count = nullptr; }
+    out->set_off = set_off.take(); out->set_val = set_val.take(); out->n_set_val = n_setval;
+    out->n_passes = 1 + G;
+    return 0;
+}
+}  // namespace
+extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, const dbg_seqset* ds, const dbg_shard_params* p,
+                                          dbg_kmer_table* out, dbg_shard_stats* stats) {
+    if (!c) return 1;
+    if (!ds || !p || !out) return c->fail(10, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    XTimer t_setup;
+    const uint32_t W = tr ? (uint32_t)tr->world : 1u, me = tr ? (uint32_t)tr->rank : 0u;
+    if (W == 0 || me >= W) return c->fail(161, "sharded flow: bad transport (rank / world)");
+    if (W > 64) return c->fail(161, "sharded flow: at most 64 ranks (one record segment per source rank in the counting kernel)");
+    if (tr && (W > 1 || p->force_exchange) && (!tr->all_reduce_u64 || !tr->all_to_allv)) return c->fail(161, "sharded flow: the transport lacks all_reduce_u64 / all_to_allv");
+    dbg_shard_stats st_local;
+    dbg_shard_stats* S = stats ? stats : &st_local;
+    memset(S, 0, sizeof(*S));
+    memset(out, 0, sizeof(*out));
+    const bool is_set = p->summarizer == DBG_COUNT_FILTER_SET;
+    const bool collective = W > 1 || (p->force_exchange && tr);
+    // Failure agreement (shard_comm.hpp): every phase below runs its rank-local work to the end with the status kept in `lrc`, and
+    // ends in X.agree() before the phase's data moves; all ranks leave with the same verdict.
+    ShardComm X(c, tr, collective);
+    DBG_TRY(X.prepare());
+    int lrc = 0;
+
+    // ---- phase "count": global quantities every rank must agree on ----
+    uint64_t n_local = 0;
+    uint32_t my_max_label = 0;
+    lrc = [&]() -> int {
+        if (X.inject("count")) return X.injected("count");
+        DBG_TRY(dbg_count_kmer_instances_dev(c, ds, p->k, &n_local));
+        if (is_set) DBG_TRY(dbg_seqset_max_label_dev(c, ds, &my_max_label));
+        return 0;
+    }();
+    if (lrc) { n_local = 0; my_max_label = 0; }
+    // The sender-side merge, when the library is to decide (merge_dups = -1), is decided by ALL ranks together -- a vote from what
+    // each ctx measured in its previous call, max-reduced with the other global quantities -- and it is re-evaluated every call:
+    //   last call without the merge: on, if the exchange time the counting could not hide (beyond the first round, which is always
+    //     exposed) exceeded what the merge costs;
+    //   last call with the merge: it stays on while the wire time it saved -- wire time x (records before / after the merge - 1), all
+    //     of which would have been exposed on top of what already was -- still exceeds its cost.
+    uint64_t vote = 0;
+    if (p->merge_dups < 0 && !c->opt("DBG_SHARD_MERGE") && W != 2 && c->shard_last_valid) {
+        double cost = c->shard_last_merge_cost_ms;
+        if (const char* e = c->opt("DBG_SHARD_MERGE_COST_MS")) cost = atof(e);      // (tests: what the merge is taken to cost)
+        if (!c->shard_last_merge) vote = c->shard_last_exposed_ms > cost ? 1 : 0;
+        else {
+            const double ratio = std::max(1.0, c->shard_last_merge_ratio);
+            vote = c->shard_last_exposed_ms + c->shard_last_wire_ms * (ratio - 1.0) > cost ? 1 : 0;
+        }
+    }
+    uint64_t mx3[3] = {n_local, my_max_label, vote};
+    DBG_TRY(X.agree(lrc, "count", mx3, 3));
+    uint64_t sum1[1] = {n_local};
+    DBG_TRY(X.reduce(sum1, 1, 0, "all_reduce_u64 (k-mer instances)"));
+    const uint64_t total = sum1[0], n_max = mx3[0];
+    const uint32_t max_label = (uint32_t)mx3[1];
+    vote = mx3[2];
+    S->total_kmers = total; S->local_kmers = n_local;
+
+    if (!collective) {
+        // one rank: the sharded table is the whole table
+        dbg_filter_params fp{p->k, p->stranded, p->summarizer, p->min_kmer_obs, 0, 4};
+        DBG_TRY(dbg_filter_kmers_dev(c, ds, &fp, out));
+        S->n_rounds = 0; S->setup_ms = 0.0;
+        return 0;
+    }
+    // (argument checks on values every rank holds alike need no agreement)
+    if (p->k < 4 || p->k > 64) return c->fail(11, "k must be in 4..=64 (filter.rs:18-23 reads the first 4 bases)");
+    // Shapes the super-k-mer exchange does not take -- k < 16, more than 64 distinct labels over all ranks, labels >= 65536 -- go
+    // the key-range route (shard_generic.hip): decided from values every rank holds alike.  DBG_PATH=generic insists on it.
+    bool key_range_route = p->k < 16 || (c->opt("DBG_PATH") && !strcmp(c->opt("DBG_PATH"), "generic"));
+    bool label_groups = false;
+    std::vector<uint32_t> label_list;                            // the distinct labels of all ranks, ascending (labels >= 64 only)
+
+    dbg_shard_plan sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.k = p->k; sp.stranded = p->stranded; sp.summarizer = p->summarizer; sp.min_kmer_obs = p->min_kmer_obs;
+    sp.total_kmers = std::max<uint64_t>(total, 1); sp.max_label = max_label;
+    if (is_set && max_label >= 64 && !key_range_route) {
+        // ---- phase "labels" ----
+        // labels beyond the 64 colours of the counting kernel: a sparse alphabet is mapped to colour indices, the same way on every
+        // rank -- the union of the ranks' label sets (a max-reduction of presence flags: the transport has sum and max, no OR)
+        std::vector<uint32_t> bm(2049, 0u);
+        lrc = X.inject("labels") ? X.injected("labels") : dbg_seqset_label_bitmap_dev(c, ds, bm.data());
+        DBG_TRY(X.agree(lrc, "labels"));
+        std::vector<uint64_t> pres(65537);
+        for (uint32_t v = 0; v < 65536; v++) pres[v] = (bm[v >> 5] >> (v & 31)) & 1u;
+        pres[65536] = bm[2048] ? 1 : 0;
+        DBG_TRY(X.reduce(pres.data(), 65537, 1, "all_reduce_u64 (label presence)"));
+        uint32_t nl = 0;
+        for (uint32_t v = 0; v < 65536; v++) if (pres[v]) { if (nl < 64) sp.labels[nl] = v; nl++; label_list.push_back(v); }
+        // 65 .. 1024 distinct labels (all < 65536): label groups of 64, as on one GPU (fast_manylabels.hpp); beyond that, or labels
+        // >= 65536, or a threshold the u16 counts cannot decide: the key-range route
+        label_groups = !pres[65536] && nl > 64 && nl <= 64u * ML_MAX_GROUPS && p->min_kmer_obs <= 65535 && !c->opt("DBG_NO_LABEL_GROUPS");
+        if (pres[65536] || (nl > 64 && !label_groups)) key_range_route = true;
+        else if (nl <= 64) sp.n_labels = nl;
+    }
+    if (key_range_route) {
+        const int r = shard_filter_generic(c, &X, tr, ds, p, total, out, S);
+        S->total_kmers = total; S->local_kmers = n_local;
+        return r;
+    }
+    // sender-side merge: asked for, or decided above (DESIGN.md section 5): on at 2 ranks, otherwise the ranks' vote
+    int merge = p->merge_dups;
+    if (merge < 0) {
+        if (const char* e = c->opt("DBG_SHARD_MERGE")) merge = atoi(e) != 0;
+        else if (W == 2) merge = 1;
+        else merge = vote ? 1 : 0;
+    }
+    sp.merge_dups = merge ? 1u : 0u;
+
+
+    std::vector<uint32_t> labels_all;
+    for (uint32_t v = 0; v < (uint32_t)label_list.size(); v++) labels_all.push_back(label_list[v]);
+    XRun o;
+    o.n_rounds = p->n_rounds; o.balance = p->balance != 0; o.merge = merge; o.n_local = n_local; o.n_max = n_max; o.total = total;
+    if (label_groups) return shard_filter_label_groups(c, X, tr, ds, p, sp, o, labels_all, out, S, t_setup);
+    return shard_exchange_run(c, X, tr, ds, sp, o, out, S, t_setup);
 }

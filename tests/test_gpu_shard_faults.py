@@ -61,7 +61,7 @@ def run_ranks(world, fn, timeout=120.0):
     return out, time.perf_counter() - t0
 
 
-def make_reads(seed, k, n_reads=900, kind=0):
+def make_reads(seed, k, n_reads=900, kind=0, n_labels=5):
     rng = np.random.default_rng(seed)
     genome = R.random_dna(rng, 6000)
     seqs = []
@@ -74,14 +74,14 @@ def make_reads(seed, k, n_reads=900, kind=0):
         if rng.random() < 0.5:
             s = R.revcomp_bytes(s)
         seqs.append(s.astype(np.uint8))
-    data = rng.integers(0, 5, size=n_reads) if kind else None
+    data = rng.integers(0, n_labels, size=n_reads) if kind else None
     return seqs, data
 
 
 class Job:
     """world contexts + one in-process group, kept across calls (the point: they stay usable after an agreed failure)"""
 
-    def __init__(self, world, k, kind, seed):
+    def __init__(self, world, k, kind, seed, n_labels=5, n_reads=900):
         self.world, self.k, self.kind = world, k, kind
         self.lib = capi.load()
         self.keep = make_group(world)
@@ -89,14 +89,14 @@ class Job:
         self.ctxs = [dbg.Context(0) for _ in range(world)]
         for c in self.ctxs:
             c.set_option("DBG_COMPRESS", "device")
-        self.seqs, self.data = make_reads(seed, k, kind=kind)
+        self.seqs, self.data = make_reads(seed, k, n_reads=n_reads, kind=kind, n_labels=n_labels)
         n = len(self.seqs)
         self.bounds = [n * r // world for r in range(world + 1)]
         self.devs = []
         for r in range(world):
             lo, hi = self.bounds[r], self.bounds[r + 1]
-            ss_o = O.SeqSet.from_byte_seqs(self.seqs[lo:hi], data=(self.data[lo:hi] if kind else None), sizeof_d1=1 if kind else 0)
-            hs = dbg.HostSeqs(ss_o.words, ss_o.start, ss_o.length, None, ss_o.data if kind else None, 1 if kind else 0)
+            ss_o = O.SeqSet.from_byte_seqs(self.seqs[lo:hi], data=(self.data[lo:hi] if kind else None), sizeof_d1=2 if kind else 0)
+            hs = dbg.HostSeqs(ss_o.words, ss_o.start, ss_o.length, None, ss_o.data if kind else None, 2 if kind else 0)
             dev, hc = capi.SeqSet(), hs.c_struct()
             self.ctxs[r].check(self.lib.dbg_seqset_to_device(self.ctxs[r].h, C.byref(hc), C.byref(dev)))
             self.devs.append(dev)
@@ -131,12 +131,12 @@ class Job:
         return rc, g, err
 
     def oracle_table(self):
-        ss = O.SeqSet.from_byte_seqs(self.seqs, data=self.data if self.kind else None, sizeof_d1=1 if self.kind else 0)
+        ss = O.SeqSet.from_byte_seqs(self.seqs, data=self.data if self.kind else None, sizeof_d1=2 if self.kind else 0)
         return O.filter_kmers(ss, self.k, O.COUNT_FILTER_SET if self.kind else O.COUNT_FILTER, 2, stranded=False)
 
     def check_tables(self, tabs):
         want = self.oracle_table()
-        hi, lo, cnt = [], [], []
+        hi, lo, cnt, sets = [], [], [], []
         for r, t in enumerate(tabs):
             h = capi.KmerTable()
             self.ctxs[r].check(self.lib.dbg_table_to_host(self.ctxs[r].h, C.byref(t), C.byref(h)))
@@ -145,11 +145,15 @@ class Job:
             hi.append(th.key_hi); lo.append(th.key_lo)
             if not self.kind:
                 cnt.append(th.count)
+            else:
+                sets += [tuple(int(x) for x in th.set_val[int(th.set_off[i]):int(th.set_off[i + 1])]) for i in range(len(th.key_lo))]
         hi, lo = np.concatenate(hi), np.concatenate(lo)
         o = np.lexsort((lo, hi))
         assert len(hi) == want.n and np.array_equal(hi[o], want.key_hi) and np.array_equal(lo[o], want.key_lo)
         if not self.kind:
             assert np.array_equal(np.concatenate(cnt)[o], want.count)
+        else:
+            assert [sets[i] for i in o] == [tuple(int(x) for x in want.set_val[int(want.set_off[i]):int(want.set_off[i + 1])]) for i in range(want.n)]
 
     def close(self):
         for r, c in enumerate(self.ctxs):
@@ -159,11 +163,18 @@ class Job:
             self.lib.dbg_transport_destroy(self.keep[r])
 
 
-@pytest.mark.parametrize("world,k,kind", [(3, 31, 0), (2, 47, 1)])
-def test_injected_failure_in_shard_filter_fails_all_ranks_together(world, k, kind):
-    job = Job(world, k, kind, seed=5100 + world)
+@pytest.mark.parametrize("world,k,kind,n_labels", [(3, 31, 0, 5), (2, 47, 1, 5), (3, 33, 1, 150), (2, 12, 1, 5), (3, 40, 1, 60000)])
+def test_injected_failure_in_shard_filter_fails_all_ranks_together(world, k, kind, n_labels):
+    """(the last three shapes: label groups -- 150 distinct labels, one CountFilter run + three group runs, failures in the
+    rank-local steps between the runs included -- and the key-range route for k < 16 and for > 1024 distinct labels)"""
+    job = Job(world, k, kind, seed=5100 + world, n_labels=n_labels, n_reads=2600 if n_labels > 1024 else 900)
+    sites = FILTER_SITES
+    if n_labels == 150:
+        sites = ["count", "labels", "scan", "groups", "round", "join", "finish"]
+    elif k < 16 or n_labels > 1024:
+        sites = ["count", "histogram", "extract", "reduce"]
     try:
-        for i, site in enumerate(FILTER_SITES):
+        for i, site in enumerate(sites):
             victim = i % world
             job.set_fault("%s:%d" % (site, victim))
             res, secs = run_ranks(world, lambda r: job.filter_raw(r), timeout=60.0)

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--k", type=int, default=47)
     ap.add_argument("--summarizer", default="count", choices=["count", "set"])
     ap.add_argument("--rounds", type=int, default=0, help="exchange rounds (0 = the library's default: 8 from four ranks on)")
+    ap.add_argument("--colours", type=int, default=4, help="distinct D1 labels of the synthetic reads (read index mod colours; at most 255)")
+    ap.add_argument("--no-label-groups", action="store_true", help="DBG_NO_LABEL_GROUPS=1 on every ctx: 65..1024 labels take the key-range route")
     ap.add_argument("--no-compress", action="store_true")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -134,7 +136,7 @@ def main():
         log.write(line + "\n")
 
     def synth(ctx, n, first):
-        p = dbg.synth_params(n_reads=n, read_len=L, genome_len=genome_len, error_rate=0.001, stranded=False, n_colours=4, first_read=first)
+        p = dbg.synth_params(n_reads=n, read_len=L, genome_len=genome_len, error_rate=0.001, stranded=False, n_colours=args.colours, first_read=first)
         nw = lib.dbg_synth_words(C.byref(p))
         t = dict(words=torch.empty(nw, dtype=torch.int64, device=dev), start=torch.empty(n, dtype=torch.int64, device=dev),
                  length=torch.empty(n, dtype=torch.int32, device=dev), colour=torch.empty(n, dtype=torch.uint8, device=dev))
@@ -145,7 +147,8 @@ def main():
         return ss, t
 
     spec = dbg.SimpleCompress("saturating_add")
-    say("# rehearse_shard: %d thread-ranks x %d reads (%d in all), k = %d, %s(2), one GPU, in-process transport" % (W, per, total_reads, k, "CountFilterSet" if is_set else "CountFilter"))
+    say("# rehearse_shard: %d thread-ranks x %d reads (%d in all), k = %d, %s(2), %d labels%s, one GPU, in-process transport"
+        % (W, per, total_reads, k, "CountFilterSet" if is_set else "CountFilter", args.colours, " (label groups off)" if args.no_label_groups else ""))
 
     # ---- the single-GPU calls over the same reads ----
     ctx0 = dbg.Context(0)
@@ -186,6 +189,9 @@ def main():
     arr_t = (C.POINTER(capi.Transport) * W)()
     assert lib.dbg_transport_inprocess_create(W, arr_t) == 0
     ctxs = [dbg.Context(0) for _ in range(W)]
+    if args.no_label_groups:
+        for c_ in ctxs:
+            c_.set_option("DBG_NO_LABEL_GROUPS", "1")
     res = [None] * W
     err = [None] * W
 
