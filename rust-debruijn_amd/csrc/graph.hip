@@ -25,6 +25,14 @@ struct EndIndex {            // sorted terminal k-mers of one side + owning node
     const uint64_t* lo;
     const uint32_t* node;
     uint32_t n;
+    // round 5: what the k-mer link builder has had since round 1 (compress.hip).  A plain binary search over 4.4e7 end k-mers is 26
+    // dependent steps of two random cache lines each (hi and lo arrays), and fix_exts runs up to 16 searches per node: 60 ms each
+    // for fix_exts and the node links at config 3's 4.4e7 shard-graph nodes, 15x the per-element cost of link_kernel.  With a prefix
+    // index (pidx[p] = first position whose top pbits key bits are >= p: buckets of ~2 keys) over 16-byte {lo, hi} records a search
+    // is one index line + one or two record lines.
+    const ulonglong2* rec = nullptr;
+    const uint32_t* pidx = nullptr;
+    int pbits = 0, key_bits = 0;
 };
 
 // (the node words carry two zero words of slack -- dev_graph_build -- so the k-mer fetches need no clamp)
@@ -32,12 +40,39 @@ constexpr uint64_t NO_CLAMP = ~0ull;
 __device__ __forceinline__ K128 ekey(const EndIndex& t, uint32_t i) { return K128{t.hi ? t.hi[i] : 0ull, t.lo[i]}; }
 __device__ __forceinline__ int64_t search_kmer(const EndIndex& t, K128 q) {          // graph.rs:243-249
     uint32_t lo = 0, hi = t.n;
+    if (t.pidx) {
+        const uint32_t p = (uint32_t)k128_shr(q, t.key_bits - t.pbits).lo;
+        lo = t.pidx[p]; hi = t.pidx[p + 1];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const ulonglong2 r = t.rec[mid];
+            if (k128_lt(K128{r.y, r.x}, q)) lo = mid + 1; else hi = mid;
+        }
+        if (lo < t.n) { const ulonglong2 r = t.rec[lo]; if (r.y == q.hi && r.x == q.lo) return (int64_t)t.node[lo]; }
+        return -1;
+    }
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
         if (k128_lt(ekey(t, mid), q)) lo = mid + 1; else hi = mid;
     }
     if (lo < t.n && k128_eq(ekey(t, lo), q)) return (int64_t)t.node[lo];
     return -1;
+}
+// records + prefix index of a sorted end-k-mer array: position i packs its key and fills the index entries of every prefix in
+// (prefix(key[i-1]), prefix(key[i])]; position n closes the index
+__global__ void __launch_bounds__(256) end_index_pack_kernel(const uint64_t* __restrict__ hi, const uint64_t* __restrict__ lo, uint32_t n, int key_bits, int pbits,
+                                                              ulonglong2* __restrict__ rec, uint32_t* __restrict__ pidx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const uint32_t np = 1u << pbits;
+    uint32_t plo = 0, phi = np;
+    if (i < n) {
+        const K128 key{hi ? hi[i] : 0ull, lo[i]};
+        rec[i] = make_ulonglong2(key.lo, key.hi);
+        phi = (uint32_t)k128_shr(key, key_bits - pbits).lo;
+    }
+    if (i > 0) plo = (uint32_t)k128_shr(K128{hi ? hi[i - 1] : 0ull, lo[i - 1]}, key_bits - pbits).lo + 1u;
+    for (uint64_t q = plo; q <= phi; q++) pidx[q] = i;
 }
 
 struct Link { int64_t node; int side; int flip; };
@@ -224,7 +259,8 @@ void graph_out(const HostBits& seq, const std::vector<uint64_t>& st, const std::
 // Device-resident DebruijnGraph index (finish, graph.rs:116-142) + fix_exts / links on it.
 struct DevGraph {
     DBuf<uint64_t> words, start, f_hi, f_lo, l_hi, l_lo, t_hi, t_lo;
-    DBuf<uint32_t> length, f_id, l_id, t_id, data;
+    DBuf<uint32_t> length, f_id, l_id, t_id, data, f_pidx, l_pidx;
+    DBuf<ulonglong2> f_rec, l_rec;
     DBuf<uint8_t> exts;
     EndIndex left{nullptr, nullptr, nullptr, 0}, right{nullptr, nullptr, nullptr, 0};
     uint32_t n = 0;
@@ -272,6 +308,22 @@ int dev_graph_index(dbg_ctx* c, int k, DevGraph* d) {
     if (in_b) { std::swap(d->l_hi, d->t_hi); std::swap(d->l_lo, d->t_lo); std::swap(d->l_id, d->t_id); }
     d->left = EndIndex{has_hi ? d->f_hi.p : nullptr, d->f_lo.p, d->f_id.p, n};
     d->right = EndIndex{has_hi ? d->l_hi.p : nullptr, d->l_lo.p, d->l_id.p, n};
+    // prefix index + packed records for graphs that are worth it (DBG_PIDX_BITS=0: plain binary searches, for A/B runs); if the
+    // memory is not to be had the plain search serves
+    const char* knob = c->opt("DBG_PIDX_BITS");
+    if (n >= 64 && !(knob && !strcmp(knob, "0"))) {
+        int pb = 8;
+        while (pb < 27 && pb < 2 * k && (n >> pb) > 2) pb++;
+        if (d->f_rec.alloc(c, n) && d->l_rec.alloc(c, n) && d->f_pidx.alloc(c, ((size_t)1 << pb) + 1) && d->l_pidx.alloc(c, ((size_t)1 << pb) + 1)) {
+            c->t_begin("graph_end_index", n);
+            end_index_pack_kernel<<<cdiv((uint64_t)n + 1, 256), 256, 0, c->stream>>>(d->left.hi, d->left.lo, n, 2 * k, pb, d->f_rec.p, d->f_pidx.p);
+            end_index_pack_kernel<<<cdiv((uint64_t)n + 1, 256), 256, 0, c->stream>>>(d->right.hi, d->right.lo, n, 2 * k, pb, d->l_rec.p, d->l_pidx.p);
+            c->t_end();
+            LAUNCH_CHECK(c, "end_index_pack");
+            d->left.rec = d->f_rec.p; d->left.pidx = d->f_pidx.p; d->left.pbits = pb; d->left.key_bits = 2 * k;
+            d->right.rec = d->l_rec.p; d->right.pidx = d->l_pidx.p; d->right.pbits = pb; d->right.key_bits = 2 * k;
+        } else { d->f_rec.release(); d->l_rec.release(); d->f_pidx.release(); d->l_pidx.release(); }
+    }
     return 0;
 }
 

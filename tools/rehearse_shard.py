@@ -247,6 +247,7 @@ def main():
                 fin, loc, cl = capi.Graph(), capi.Graph(), capi.LabelClasses()
                 ctxs[r].check(lib.dbg_shard_compress_dev(ctxs[r].h, arr_t[r], k, 0, spec.kind, spec.kind, C.byref(tabs[r]), mode, 0, C.byref(fin), None, C.byref(cl)))
                 return fin
+            ctxs[0].enable_timing(True)
             try:
                 secs = run(do_compress)
             finally:
@@ -274,6 +275,9 @@ def main():
             for name2, v in ph.items():
                 root = [x for x in v if x[0] == 0]
                 say("    %-30s ranks %2d  max %9.2f ms  root %9.2f ms  nodes (root) %d" % (name2, len(v), max(x[1] for x in v), root[-1][1] if root else 0.0, root[-1][2] if root else 0))
+            kt = sorted(ctxs[0].timings(), key=lambda t: -t["ms"])
+            ctxs[0].enable_timing(False)
+            say("    root's kernels (HIP events, ms): " + ", ".join("%s %.1f" % (t["name"], t["ms"]) for t in kt[:14]))
             for r in range(W):
                 lib.dbg_free_graph(ctxs[r].h, C.byref(res[r]))
     for r in range(W):
