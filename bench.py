@@ -447,7 +447,7 @@ def main():
             hw, hst, hl, hc = words.cpu().numpy(), start.cpu().numpy(), length.cpu().numpy(), colour.cpu().numpy()
             hostb = {}
             # (CountFilterSet_compact: dbg_filter_params.compact_sets -- the CSR crosses PCIe as u32 offsets + u8 labels)
-            for kind, setk, compact in (("CountFilter", 0, 0), ("CountFilterSet", 1, 0), ("CountFilterSet_compact", 1, 1)):
+            for kind, setk, compact in (("CountFilter", 0, 0), ("CountFilterSet", 1, 0), ("CountFilterSet_compact", 1, 3)):
                 hss = capi.SeqSet(hw.ctypes.data, nw, hst.ctypes.data, hl.ctypes.data, None, hc.ctypes.data if setk else None, 1 if setk else 0,
                                   reads_per_gpu)
                 hfp = capi.FilterParams(k, 0, setk, args.min_obs, 0, 4, compact)

@@ -95,12 +95,14 @@ typedef struct {
     uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero).  Otherwise IGNORED: in the
                                    reference it only sets the number of bucket-range passes (filter.rs:156-168), never the
                                    result; here the device decides its own passes from free HBM */
-    uint32_t compact_sets;      /* dbg_filter_kmers (host tables) with CountFilterSet, opt-in (round 5): return the CSR in the narrowest
-                                   element types that hold it -- set_off as uint32_t[n + 1] when n_set_val < 2^32, set_val in the
-                                   width of D1 (data_width of the input: uint8_t / uint16_t / uint32_t) -- and say so in
-                                   dbg_kmer_table.set_off_width / set_val_width.  The table crosses PCIe: at BASELINE configs[1] the
-                                   CSR is 7.4 GB as u64 / u32 and 2.9 GB compact.  0 = the plain u64 / u32 form.  Device tables
-                                   (the _dev calls) are always plain */
+    uint32_t compact_sets;      /* dbg_filter_kmers (host tables), opt-in bit flags (round 5) -- the table crosses PCIe, so bytes are time:
+                                   1: CountFilterSet: return the CSR in the narrowest element types that hold it -- set_off as
+                                      uint32_t[n + 1] when n_set_val < 2^32, set_val in the width of D1 (data_width of the input:
+                                      uint8_t / uint16_t / uint32_t) -- and say so in dbg_kmer_table.set_off_width / set_val_width
+                                      (BASELINE configs[1]: 7.4 GB as u64 / u32, 2.9 GB compact);
+                                   2: k <= 32: key_hi comes back NULL instead of n zeros (8 bytes per k-mer: 4 GB at configs[1]'s
+                                      size; IntKmer<u64> callers never read it).
+                                   0 = the plain form.  Device tables (the _dev calls) are always plain */
 } dbg_filter_params;
 
 /* The vectors the reference hands to BoomHashMap2::new (filter.rs:227-230), i.e. ascending

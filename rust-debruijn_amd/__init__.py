@@ -359,7 +359,7 @@ def _copy(ptr, n, dtype):
 def _table_from_c(t, k):
     out = KmerTable(k)
     n = t.n
-    out.key_hi = _copy(t.key_hi, n, np.uint64)
+    out.key_hi = _copy(t.key_hi, n, np.uint64) if t.key_hi else np.zeros(n, np.uint64)     # (compact flag 2: no key_hi for k <= 32)
     out.key_lo = _copy(t.key_lo, n, np.uint64)
     out.exts = _copy(t.exts, n, np.uint8)
     out.count = _copy(t.count, n, np.uint16) if t.count else None
@@ -388,7 +388,7 @@ def filter_kmers(seqs, summarizer, stranded, report_all_kmers, memory_size, k, c
     ctx = ctx or default_context()
     hs = seqs if isinstance(seqs, HostSeqs) else HostSeqs.from_tuples(seqs)
     p = _capi.FilterParams(k, int(bool(stranded)), summarizer.kind, summarizer.min_kmer_obs,
-                           int(bool(report_all_kmers)), int(memory_size), int(bool(compact_sets)))
+                           int(bool(report_all_kmers)), int(memory_size), int(compact_sets))
     cs = hs.c_struct()
     t = _capi.KmerTable()
     ctx.check(ctx.lib.dbg_filter_kmers(ctx.h, C.byref(cs), C.byref(p), C.byref(t)))

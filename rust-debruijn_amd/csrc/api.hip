@@ -1,6 +1,7 @@
 // extern "C" boundary: context management and filter_kmers (src/filter.rs:139-231).
 #include "dbg_internal.hpp"
 #include <thread>
+#include <chrono>
 #include <algorithm>
 #include <cstdlib>
 #include <atomic>
@@ -180,6 +181,7 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
 
     uint64_t n_kmers = 0;
     DBG_TRY(kmer_total(c, s, k, &n_kmers));                  // the fast path needs the total only
+    if (k < 16) DBG_TRY(c->wait_all_reads());                // (host-boundary calls: only the fast path's scan takes the reads as they arrive)
     {   // short k-mers: directly addressed tables (densepath.hip); DBG_PATH=dense insists on it
         const char* force = c->opt("DBG_PATH");
         const bool want_dense = !force || !strcmp(force, "auto") || !strcmp(force, "dense");
@@ -200,6 +202,7 @@ extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_
             if (force && !strcmp(force, "fast") && n_kmers) return c->fail(21, "DBG_PATH=fast but the fast path does not support this call shape");
         }
     }
+    DBG_TRY(c->wait_all_reads());
     DBuf<uint32_t> kcount;                                   // per-sequence counts and offsets: the generic path writes one record per k-mer
     DBuf<uint64_t> koff;
     ALLOC_OR_FAIL(c, kcount, std::max<uint64_t>(s.n, 1));
@@ -321,14 +324,15 @@ struct DevSeqSet {
     DBuf<uint8_t> exts, data;
     dbg_seqset view;
 };
-int upload_seqset(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d) {
+// words_too = false: everything but the packed words (the caller streams those in chunks of reads, dbg_filter_kmers)
+static int upload_seqset_parts(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d, bool words_too) {
     uint64_t n = hs->n_seqs;
     // the device kernels never read past the last word a sequence touches, so n_words suffices
     ALLOC_OR_FAIL(c, d->words, std::max<uint64_t>(hs->n_words, 1));
     ALLOC_OR_FAIL(c, d->start, std::max<uint64_t>(n, 1));
     ALLOC_OR_FAIL(c, d->length, std::max<uint64_t>(n, 1));
     std::vector<UploadJob> jobs;
-    jobs.push_back({d->words.p, hs->words, (size_t)hs->n_words * 8});
+    if (words_too) jobs.push_back({d->words.p, hs->words, (size_t)hs->n_words * 8});
     jobs.push_back({d->start.p, hs->start, (size_t)n * 8});
     jobs.push_back({d->length.p, hs->length, (size_t)n * 4});
     d->view = *hs;
@@ -346,19 +350,48 @@ int upload_seqset(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d) {
     }
     return staged_upload(c, jobs);
 }
+int upload_seqset(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d) { return upload_seqset_parts(c, hs, d, true); }
 
-static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs) {
+// chunk_end (may be null): [n_chunks] receives, for the reads [n * g / n_chunks, n * (g + 1) / n_chunks), the largest end base of a
+// read of that or an earlier chunk; *monotone = the reads' start offsets never decrease (PackedDnaStringSet::add appends, so they do
+// not in practice): then the words a chunk of reads needs are a prefix of the array
+static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs, uint32_t n_chunks = 0, uint64_t* chunk_end = nullptr, bool* monotone = nullptr) {
     // bounds + D1 range checks that would be undefined behaviour on the device (on the host threads the container is granted)
     std::atomic<int> bad{0};
+    std::vector<std::atomic<uint64_t>> cend(n_chunks);
+    for (auto& v : cend) v = 0;
+    std::vector<uint64_t> upto(n_chunks);                            // chunk g = reads [upto[g - 1], upto[g])
+    for (uint32_t g = 0; g < n_chunks; g++) upto[g] = (uint64_t)(((unsigned __int128)hs->n_seqs * (g + 1)) / n_chunks);
     host_parallel_ranges(hs->n_seqs, [&](uint64_t a, uint64_t b, unsigned) {
         int f = 0;
+        uint64_t prev = a ? hs->start[a - 1] : 0, far = 0;
+        uint32_t g = 0;
+        while (n_chunks && g + 1 < n_chunks && a >= upto[g]) g++;
+        auto flush = [&]() {
+            if (!n_chunks || !far) return;
+            uint64_t cur = cend[g].load(std::memory_order_relaxed);
+            while (far > cur && !cend[g].compare_exchange_weak(cur, far, std::memory_order_relaxed)) {}
+            far = 0;
+        };
         for (uint64_t i = a; i < b; i++) {
-            const uint64_t end = hs->start[i] + hs->length[i];
+            const uint64_t st = hs->start[i], end = st + hs->length[i];
             if ((end + 31) / 32 > hs->n_words && hs->length[i]) f |= 1;
             if (hs->data && hs->data_width == 4 && ((const uint32_t*)hs->data)[i] >= (1u << 24)) f |= 2;
+            if (n_chunks) {
+                if (i >= upto[g]) { flush(); while (g + 1 < n_chunks && i >= upto[g]) g++; }
+                if (st < prev) f |= 4;
+                prev = st;
+                far = end > far ? end : far;
+            }
         }
+        flush();
         if (f) bad |= f;
     });
+    if (n_chunks) {
+        uint64_t run = 0;
+        for (uint32_t g = 0; g < n_chunks; g++) { run = std::max<uint64_t>(run, cend[g]); chunk_end[g] = run; }
+        *monotone = !(bad & 4);
+    }
     if (bad & 1) return c->fail(16, "sequence runs past n_words");
     if (bad & 2) return c->fail(17, "D1 values must be < 2^24");
     return 0;
@@ -397,22 +430,80 @@ extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filt
     DBG_TRY(validate_filter(c, hs, p));
     HIP_TRY(c, hipSetDevice(c->device));
     DevSeqSet d;
+    dbg_kmer_table dev;
+    bool counted = false;
+    const bool dbg_t = c->opt("DBG_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg_t) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host boundary] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
+    // Large inputs on the fast path: the packed words (three quarters of the input bytes) are uploaded in chunks of reads by a
+    // helper thread while the scan runs over the chunks that have arrived (dbg_ctx::read_gates; fast_scan launches once per
+    // chunk) -- the scan's ~30 ms per 10^8 reads disappear under the upload.  Everything else waits for the last chunk.
+    constexpr uint32_t N_GATES = 8;
+    const char* hmode = c->opt("DBG_HOST_STAGING");
+    const bool chunked = (size_t)hs->n_words * 8 >= (256u << 20) && hs->n_seqs >= 4096 && p->k >= 16 && !(hmode && (!strcmp(hmode, "off") || !strcmp(hmode, "whole"))) &&
+                         !(c->opt("DBG_PATH") && strcmp(c->opt("DBG_PATH"), "auto") && strcmp(c->opt("DBG_PATH"), "fast"));
     {
         // the bounds / label checks of the caller's arrays (a pass over start[] and length[] on the host threads) run next to the
         // upload -- copying unchecked arrays is harmless, running kernels on them is not: the check is joined before anything is launched
         int check_rc = 0;
         std::string check_err;
-        std::thread checker([&] { dbg_ctx tmp; check_rc = check_host_seqset(&tmp, hs); check_err = tmp.err; });
-        const int up = upload_seqset(c, hs, &d);
+        uint64_t chunk_end[N_GATES];
+        bool monotone = false;
+        std::thread checker([&] { dbg_ctx tmp; check_rc = check_host_seqset(&tmp, hs, chunked ? N_GATES : 0, chunk_end, &monotone); check_err = tmp.err; });
+        const int up = upload_seqset_parts(c, hs, &d, !chunked);
+        lap(chunked ? "upload (all but the words)" : "upload");
         checker.join();
+        lap("input checks (joined)");
         if (check_rc) return c->fail(check_rc, check_err);
         DBG_TRY(up);
+        if (chunked && !monotone) {                                  // (reads out of order: the whole array first, as for small inputs)
+            std::vector<UploadJob> jobs{{d.words.p, hs->words, (size_t)hs->n_words * 8}};
+            DBG_TRY(staged_upload(c, jobs));
+        } else if (chunked) {
+            dbg_read_gates gates;
+            for (uint32_t g = 0; g < N_GATES; g++) gates.upto.push_back((uint64_t)(((unsigned __int128)hs->n_seqs * (g + 1)) / N_GATES));
+            staged_upload_prepare(c);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));             // (the words block may still be in use by queued work of its previous owner)
+            uint64_t* dw = d.words.p;
+            std::thread uploader([&, dw] {
+                (void)hipSetDevice(c->device);
+                uint64_t done_words = 0;
+                for (uint32_t g = 0; g < N_GATES; g++) {
+                    // chunk g's reads end at base chunk_end[g]: the words up to there (the last chunk: everything, padding included)
+                    const uint64_t upto_w = g + 1 == N_GATES ? hs->n_words : std::min<uint64_t>(hs->n_words, (chunk_end[g] + 31) / 32 + 1);
+                    if (upto_w > done_words) {
+                        std::string err;
+                        std::vector<UploadJob> jobs{{dw + done_words, hs->words + done_words, (size_t)(upto_w - done_words) * 8}};
+                        if (int e = staged_upload_quiet(c, jobs, &err)) { gates.publish(g, e, err); return; }
+                        done_words = upto_w;
+                    }
+                    gates.publish(g + 1);
+                }
+            });
+            c->read_gates = &gates;
+            const int r = dbg_filter_kmers_dev(c, &d.view, p, &dev);
+            c->read_gates = nullptr;
+            lap("filter (gated on the upload)");
+            uploader.join();
+            lap("uploader joined");
+            if (r) return r;
+            if (gates.err) { dbg_free_table(c, &dev); return c->fail(gates.err, gates.msg); }
+            counted = true;
+        }
     }
-    dbg_kmer_table dev;
-    DBG_TRY(dbg_filter_kmers_dev(c, &d.view, p, &dev));
+    if (!counted) { DBG_TRY(dbg_filter_kmers_dev(c, &d.view, p, &dev)); lap("filter"); }
     d.words.release(); d.start.release(); d.length.release(); d.exts.release(); d.data.release();     // (the reads are no longer needed: room for the copies below)
     int r = 0;
-    if (p->compact_sets && dev.set_off) {
+    if ((p->compact_sets & 2u) && p->k <= 32 && dev.key_hi) {        // k <= 32: key_hi is all zeros -- 8 bytes per k-mer that need not cross PCIe
+        c->dfree(dev.key_hi);
+        dev.key_hi = nullptr;
+    }
+    if ((p->compact_sets & 1u) && dev.set_off) {
         const uint32_t ow = dev.n_set_val < (1ull << 32) ? 4u : 8u;
         const uint32_t vw = hs->data && (hs->data_width == 1 || hs->data_width == 2) ? hs->data_width : 4u;
         DBuf<uint32_t> off32, val32;
@@ -447,6 +538,7 @@ extern "C" int dbg_filter_kmers(dbg_ctx* c, const dbg_seqset* hs, const dbg_filt
         }();
         if (r) dbg_free_table(c, out);
     } else r = dbg_table_to_host(c, &dev, out);
+    lap("table to the host");
     dbg_free_table(c, &dev);
     return r;
 }

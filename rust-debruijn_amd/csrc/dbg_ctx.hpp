@@ -6,6 +6,8 @@
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <mutex>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include "../../include/dbg_mi355x.h"
@@ -34,8 +36,37 @@ static const char* const DBG_OPTION_NAMES[] = {
     "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_SLAB_VMM", "DBG_NO_LABEL_GROUPS", "DBG_NO_STRAND_NORM", "DBG_SHARD_MERGE", "DBG_LINKS", "DBG_DENSE_RANGES", "DBG_CHAIN_WALKS", "DBG_DENSE_PART", "DBG_DENSE_BATCH", "DBG_DENSE_L1", "DBG_DENSE_RAW",
     "DBG_FAIL_AT", "DBG_COMM_TIMEOUT_S", "DBG_SHARD_MERGE_COST_MS"};   // (the last two: fault injection and the bound on communication waits of the rank-spanning calls, shard_comm.hpp)   // (DBG_MSP: wave | twopass)
 
+// Reads whose packed words are still on their way to the device (dbg_filter_kmers: the upload of the caller's words runs in chunks
+// of reads next to the scan of the chunks that have arrived, api.hip).  Chunk g is complete once reads [0, upto[g]) have their words
+// in HBM.  Everything that reads the words of all sequences waits for the last gate first (dbg_ctx::wait_all_reads).
+struct dbg_read_gates {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint64_t> upto;
+    size_t ready = 0;
+    int err = 0;
+    std::string msg;
+    void publish(size_t n_ready, int e = 0, const std::string& m = std::string()) {
+        std::lock_guard<std::mutex> g(mu);
+        if (n_ready > ready) ready = n_ready;
+        if (e && !err) { err = e; msg = m; }
+        cv.notify_all();
+    }
+    int wait(size_t g) {                                   // until chunk g is complete (or the upload failed)
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ready > g || err; });
+        return err;
+    }
+};
+
 struct dbg_ctx {
     int device = 0;
+    dbg_read_gates* read_gates = nullptr;
+    int wait_all_reads() {
+        if (!read_gates || read_gates->upto.empty()) return 0;
+        const int e = read_gates->wait(read_gates->upto.size() - 1);
+        return e ? fail(e, read_gates->msg) : 0;
+    }
     std::map<std::string, std::string> opts;
     const char* opt(const char* name) const {
         auto it = opts.find(name);

@@ -20,6 +20,8 @@ static inline void* dbg_host_alloc(size_t bytes) {
 #include <vector>
 struct UploadJob { void* dst; const void* src; size_t bytes; };
 int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs);            // complete on return
+void staged_upload_prepare(dbg_ctx* c);                                       // (see hostio.hip: uploads from a helper thread)
+int staged_upload_quiet(dbg_ctx* c, const std::vector<UploadJob>& jobs, std::string* err);
 void host_parallel_ranges(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)>& fn);
 unsigned host_parallel_width();
 void* ctx_halloc(dbg_ctx* c, size_t bytes);                                  // result array: pinned block from the ctx pool (malloc when small)

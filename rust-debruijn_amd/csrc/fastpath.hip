@@ -1640,6 +1640,8 @@ static bool slab_alloc(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words) {
     return slab->alloc(c, words);
 }
 
+static bool lane_scan_wanted(dbg_ctx* c) { return !(c->opt("DBG_SCAN") && !strcmp(c->opt("DBG_SCAN"), "wave")); }
+
 // scan: super-k-mer records in read order + bin histogram
 static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n_kmers, FastScan* st, bool direct = false) {
     st->pl = pl; st->n_kmers = n_kmers;
@@ -1684,22 +1686,46 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         if (direct) HIP_TRY(c, hipMemsetAsync(st->cursor.p, 0, (size_t)nbins * 4, c->stream));
         // reads of up to SCAN_LANE_MAX bases: lane-per-read kernel; it flags longer reads, which the wave-per-read kernel then
         // takes (DBG_SCAN=wave: everything through the wave-per-read kernel)
-        const bool lane_scan = !(c->opt("DBG_SCAN") && !strcmp(c->opt("DBG_SCAN"), "wave"));
+        const bool lane_scan = lane_scan_wanted(c);
         unsigned long long cur = 0;
         uint32_t sfl[2] = {0, 0};
-#define SCAN_ARGS sd, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p, st->slab.p, st->slab_cap, st->cursor.p
+        SeqDev cur_reads = sd;                                   // (the reads of one launch: all of them, or one chunk of a gated upload)
+#define SCAN_ARGS cur_reads, cfg, st->hist.p, st->tmp_recs.p, st->tmp_bin.p, tmp_cursor.p, tmp_cap, sflags.p, st->slab.p, st->slab_cap, st->cursor.p
+        // Host-boundary calls upload the packed words in chunks of reads next to this scan (dbg_ctx::read_gates, api.hip): the first
+        // attempt of the lane scan launches once per chunk as the chunks arrive; everything else needs all reads
+        dbg_read_gates* gates = (lane_scan_wanted(c) && direct && attempt == 0 && c->read_gates && c->read_gates->upto.size() > 1) ? c->read_gates : nullptr;
+        if (!gates) DBG_TRY(c->wait_all_reads());
         if (lane_scan) {
             const uint32_t W = (uint32_t)(k - p + 1);
 #ifndef DBG_SCAN_LDS_PAD
 #define DBG_SCAN_LDS_PAD 0
 #endif
             const size_t lds = (size_t)scan_lane_lds_words(W) * sizeof(uint32_t) + DBG_SCAN_LDS_PAD;
-            const uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 63) / 64, 256ull * 16 * 4));
+            uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 63) / 64, 256ull * 16 * 4));
             c->t_begin("sk_scan", n_kmers);
 #define SCANL(NBW_, D_) do { HIP_TRY(c, hipFuncSetAttribute((const void*)sk_scan_lane_kernel<NBW_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             sk_scan_lane_kernel<NBW_, D_><<<lane_blocks, 64, lds, c->stream>>>(SCAN_ARGS); } while (0)
-            if (direct) { if (nbw == 2) SCANL(2, true); else if (nbw == 3) SCANL(3, true); else SCANL(4, true); }
-            else { if (nbw == 2) SCANL(2, false); else if (nbw == 3) SCANL(3, false); else SCANL(4, false); }
+#define SCANL_GO() do { if (direct) { if (nbw == 2) SCANL(2, true); else if (nbw == 3) SCANL(3, true); else SCANL(4, true); } \
+            else { if (nbw == 2) SCANL(2, false); else if (nbw == 3) SCANL(3, false); else SCANL(4, false); } } while (0)
+            if (!gates) SCANL_GO();
+            else {
+                uint64_t r0 = 0;
+                for (size_t g = 0; g < gates->upto.size(); g++) {
+                    if (const int e = gates->wait(g)) { c->t_end(); return c->fail(e, gates->msg); }
+                    const uint64_t r1 = std::min<uint64_t>(gates->upto[g], s.n);
+                    if (r1 <= r0) continue;
+                    cur_reads = sd;
+                    cur_reads.start += r0; cur_reads.length += r0; cur_reads.n = r1 - r0;
+                    if (cur_reads.exts) cur_reads.exts += r0;
+                    if (cur_reads.data) cur_reads.data = (const uint8_t*)cur_reads.data + r0 * cur_reads.data_width;
+                    lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((cur_reads.n + 63) / 64, 256ull * 16 * 4));
+                    SCANL_GO();
+                    LAUNCH_CHECK(c, "sk_scan_lane");
+                    r0 = r1;
+                }
+                cur_reads = sd;
+            }
+#undef SCANL_GO
 #undef SCANL
             c->t_end();
             LAUNCH_CHECK(c, "sk_scan_lane");
@@ -2242,6 +2268,7 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok, &many));
         if (!ok) {
             if (many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS")) return 0;
+            DBG_TRY(c->wait_all_reads());
             return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
         }
     }

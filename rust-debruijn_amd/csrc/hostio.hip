@@ -71,15 +71,19 @@ Stager* get_stager(dbg_ctx* c) {
 }
 }  // namespace
 
-// host -> device copies of several arrays, complete on return
-int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs) {
+// host -> device copies of several arrays, complete on return.  drain = false: the destinations are known to be idle (a buffer
+// nothing has touched yet) and the ctx stream may be busy with other work (the scan of reads that have already arrived): it is not
+// waited for, and errors are reported through *err only -- the caller is a helper thread that must not write the ctx's error slot.
+static int staged_upload_impl(dbg_ctx* c, const std::vector<UploadJob>& jobs, bool drain, std::string* err) {
     size_t total = 0;
     for (auto& j : jobs) total += j.bytes;
     const char* mode = c->opt("DBG_HOST_STAGING");            // "off": plain copies (for A/B measurements)
-    Stager* s = (total >= STAGE_MIN && !(mode && !strcmp(mode, "off"))) ? get_stager(c) : nullptr;
+    Stager* s = (total >= STAGE_MIN && !(mode && !strcmp(mode, "off"))) ? (drain ? get_stager(c) : static_cast<Stager*>(c->stager.p)) : nullptr;
+    auto bad = [&](const char* what) { (void)hipGetLastError(); *err = what; return 100; };
     if (!s) {
-        for (auto& j : jobs) if (j.bytes) HIP_TRY(c, hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipStream_t st = drain ? c->stream : (c->copy_stream ? c->copy_stream : c->stream);
+        for (auto& j : jobs) if (j.bytes && hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyHostToDevice, st) != hipSuccess) return bad("HIP error in a host-to-device copy");
+        if (hipStreamSynchronize(st) != hipSuccess) return bad("HIP error in a host-to-device copy");
         return 0;
     }
     struct Chunk { char* dst; const char* src; size_t n; };
@@ -87,32 +91,41 @@ int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs) {
     for (auto& j : jobs)
         for (size_t o = 0; o < j.bytes; o += STAGE_CHUNK) chunks.push_back({(char*)j.dst + o, (const char*)j.src + o, std::min(STAGE_CHUNK, j.bytes - o)});
     // the destinations are pool blocks that c->stream may still be using under their previous owner (the pool hands blocks out
-    // assuming same-stream ordering): nothing is written from the lanes' streams before c->stream has drained
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // assuming same-stream ordering): nothing is written from the DMA stream before c->stream has drained
+    if (drain && hipStreamSynchronize(c->stream) != hipSuccess) return bad("HIP error while draining the stream");
     std::atomic<size_t> next{0};
-    std::atomic<int> err{0};
+    std::atomic<int> e{0};
     const int device = c->device;
     auto work = [&](UploadLane* l) {
-        if (hipSetDevice(device) != hipSuccess) { err = 1; return; }
+        if (hipSetDevice(device) != hipSuccess) { e = 1; return; }
         for (unsigned it = 0;; it++) {
             const size_t i = next.fetch_add(1);
-            if (i >= chunks.size() || err) break;
+            if (i >= chunks.size() || e) break;
             const int b = it & 1;
-            if (it >= 2 && hipEventSynchronize(l->ev[b]) != hipSuccess) { err = 1; break; }       // the buffer's previous DMA is done
+            if (it >= 2 && hipEventSynchronize(l->ev[b]) != hipSuccess) { e = 1; break; }       // the buffer's previous DMA is done
             memcpy(l->buf[b], chunks[i].src, chunks[i].n);
             std::lock_guard<std::mutex> g(s->mu);
             if (hipMemcpyAsync(chunks[i].dst, l->buf[b], chunks[i].n, hipMemcpyHostToDevice, s->dma) != hipSuccess ||
-                hipEventRecord(l->ev[b], s->dma) != hipSuccess) { err = 1; break; }
+                hipEventRecord(l->ev[b], s->dma) != hipSuccess) { e = 1; break; }
         }
     };
     std::vector<std::thread> th;
     for (size_t t = 1; t < s->lanes.size(); t++) th.emplace_back(work, &s->lanes[t]);
     work(&s->lanes[0]);
     for (auto& t : th) t.join();
-    if (hipStreamSynchronize(s->dma) != hipSuccess) err = 1;
-    if (err) { (void)hipGetLastError(); return c->fail(100, "HIP error in the staged host-to-device upload"); }
+    if (hipStreamSynchronize(s->dma) != hipSuccess) e = 1;
+    if (e) return bad("HIP error in the staged host-to-device upload");
     return 0;
 }
+int staged_upload(dbg_ctx* c, const std::vector<UploadJob>& jobs) {
+    std::string err;
+    const int r = staged_upload_impl(c, jobs, true, &err);
+    return r ? c->fail(r, err) : 0;
+}
+// for a helper thread next to a call that is using the ctx: see staged_upload_impl.  staged_upload_prepare (on the ctx's own
+// thread, before the helper starts) makes sure the staging ring exists, so that the helper only reads the ctx
+void staged_upload_prepare(dbg_ctx* c) { (void)get_stager(c); (void)c->get_copy_stream(); }
+int staged_upload_quiet(dbg_ctx* c, const std::vector<UploadJob>& jobs, std::string* err) { return staged_upload_impl(c, jobs, false, err); }
 
 // parallel for over [0, n) in contiguous ranges on the host threads the container is granted
 void host_parallel_ranges(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)>& fn) {

@@ -104,13 +104,15 @@ def test_compact_label_sets_at_the_host_boundary(ctx, k, width, n_labels):
     ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=width)
     want = O.filter_kmers(ss, k, O.COUNT_FILTER_SET, 2, stranded=False)
     hs = to_host_seqs(ss, width)
-    got, _ = dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=k, ctx=ctx, compact_sets=True)
+    got, _ = dbg.filter_kmers(hs, dbg.CountFilterSet(2), False, False, 4, k=k, ctx=ctx, compact_sets=3)
     assert_tables_equal(got, want, True)
+    got, _ = dbg.filter_kmers(hs, dbg.CountFilter(2), False, False, 4, k=k, ctx=ctx, compact_sets=2)        # flag 2: key_hi omitted for k <= 32
+    assert_tables_equal(got, O.filter_kmers(ss, k, O.COUNT_FILTER, 2, stranded=False), False)
     # the raw C table really is narrow
     cs, t = hs.c_struct(), capi.KmerTable()
     p = capi.FilterParams(k, 0, 1, 2, 0, 4, 1)
     ctx.check(ctx.lib.dbg_filter_kmers(ctx.h, C.byref(cs), C.byref(p), C.byref(t)))
-    assert (t.set_off_width, t.set_val_width) == (4, width) and t.n == want.n and t.n_set_val == len(want.set_val)
+    assert (t.set_off_width, t.set_val_width) == (4, width) and t.n == want.n and t.n_set_val == len(want.set_val) and t.key_hi
     off = np.ctypeslib.as_array(C.cast(t.set_off, C.POINTER(C.c_uint32)), shape=(t.n + 1,))
     val = np.ctypeslib.as_array(C.cast(t.set_val, C.POINTER({1: C.c_uint8, 2: C.c_uint16, 4: C.c_uint32}[width])), shape=(max(int(t.n_set_val), 1),))[:int(t.n_set_val)]
     assert np.array_equal(off, want.set_off) and np.array_equal(val.astype(np.uint32), want.set_val)

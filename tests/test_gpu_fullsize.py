@@ -540,3 +540,47 @@ def test_fullsize_label_groups(env):
                           O.COUNT_FILTER_SET, 1, stranded=False)
     assert n == want.n and np.array_equal(g_hi, want.key_hi) and np.array_equal(g_lo, want.key_lo) and np.array_equal(g_ex, want.exts)
     assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)
+
+
+@only_c2
+def test_fullsize_host_boundary_equals_device_call(env):
+    """dbg_filter_kmers (round 5: the caller's packed words are uploaded in chunks of reads while the scan already runs over the chunks
+    that have arrived -- dbg_ctx::read_gates; plain and compact host tables) against dbg_filter_kmers_dev over the same reads:
+    keys, Exts, counts / label lists equal element for element.  Also with the reads' start offsets NOT monotone (two halves
+    swapped: the whole-array upload), and with DBG_HOST_STAGING=whole (no chunking)."""
+    e = env
+    capi, lib, ctx, torch = e["capi"], e["lib"], e["ctx"], e["torch"]
+    K, N = e["k"], min(e["n_reads"], 30_000_000)                     # 1.1 GB of packed words: chunked (>= 256 MB), three calls in seconds
+    hw = e["words"].cpu().numpy()
+    hst, hl, hc = e["start"][:N].cpu().numpy(), e["length"][:N].cpu().numpy(), e["colour"][:N].cpu().numpy()
+    for summarizer, compact, swap, mode in ((0, 0, False, None), (1, 3, False, None), (0, 0, True, None), (1, 0, False, "whole")):
+        want = run_filter(e, 0, N, summarizer, 2)
+        st, ln, co = hst, hl, hc
+        if swap:                                                     # the same reads, second half first: a permutation of the input
+            h = N // 2
+            st, ln, co = np.concatenate([hst[h:], hst[:h]]), np.concatenate([hl[h:], hl[:h]]), np.concatenate([hc[h:], hc[:h]])
+        hs = capi.SeqSet(hw.ctypes.data, e["nw"], st.ctypes.data, ln.ctypes.data, None, co.ctypes.data if summarizer else None, 1 if summarizer else 0, N)
+        fp = capi.FilterParams(K, 0, summarizer, 2, 0, 4, compact)
+        got = capi.KmerTable()
+        old = ctx.set_option("DBG_HOST_STAGING", mode)
+        try:
+            ctx.check(lib.dbg_filter_kmers(ctx.h, C.byref(hs), C.byref(fp), C.byref(got)))
+        finally:
+            ctx.set_option("DBG_HOST_STAGING", old)
+        n = int(got.n)
+        assert n == int(want.n) and n > 0
+        host = lambda ptr, cnt, ct: torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(cnt,))).cuda()
+        assert torch.equal(host(got.key_lo, n, C.c_int64), dev_view(want.key_lo, n))
+        assert torch.equal(host(got.key_hi, n, C.c_int64), dev_view(want.key_hi, n))
+        assert torch.equal(host(got.exts, n, C.c_uint8), dev_view(want.exts, n, "|u1"))
+        if summarizer:
+            nv = int(got.n_set_val)
+            assert nv == int(want.n_set_val)
+            ow, vw = (C.c_int32, C.c_uint8) if compact else (C.c_int64, C.c_int32)
+            assert (got.set_off_width, got.set_val_width) == ((4, 1) if compact else (0, 0))
+            assert torch.equal(host(got.set_off, n + 1, ow).to(torch.int64), dev_view(want.set_off, n + 1))
+            assert torch.equal(host(got.set_val, nv, vw).to(torch.int64), dev_view(want.set_val, nv, "<i4").to(torch.int64))
+        else:
+            assert torch.equal(host(got.count, n, C.c_int16), dev_view(want.count, n, "<i2"))
+        lib.dbg_free_table(ctx.h, C.byref(got))
+        lib.dbg_free_table(ctx.h, C.byref(want))
