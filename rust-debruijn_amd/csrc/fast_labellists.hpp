@@ -1,0 +1,735 @@
+// CountFilterSet over ANY label alphabet on the fast path (round 5; included by fastpath.hip).
+//
+// The colour masks of the counting kernel hold 64 labels; label groups (fast_manylabels.hpp) stretch that to 1024 at one pass per 64
+// labels; everything beyond -- thousands of sample / transcript ids, labels >= 65536 -- used to take the generic path (sort every
+// k-mer instance: ~4 Gkmer/s).  CountFilterSet::summarize (filter.rs:85-100) collects the labels of a k-mer's observations, sorts
+// and de-duplicates them; here that happens bin by bin, next to the LDS hash table that already groups the bin's k-mers:
+//   * the scan writes every record's full D1 label into a side array at the record's index (FastCfg::lab_slab / lab_tmp);
+//   * bin_labels_kernel, one workgroup per bin, streams the bin's records TWICE:
+//       A  count: k-mer -> table slot, count, Exts (the probing scheme of bin_count_kernel);
+//       B  validity (filter.rs:88 compares the unsaturated number of observations) and an exclusive scan of the valid slots'
+//          counts: every valid k-mer owns a segment of `count` labels in the bin's stretch of the label buffer (one global atomic
+//          per bin reserves the stretch);
+//       C  append: every instance of a valid k-mer stores its read's label at the next free place of its segment (LDS cursor);
+//       D  every segment is sorted and de-duplicated in place: segments of up to 64 labels -- packed several to a wavefront --
+//          by a bitonic network over (segment, label) in registers, longer ones by a wave-level network over the segment itself;
+//       E  emit (key, position) records for the order-restoring sort, and {segment offset, labels, Exts} at that position;
+//   * after the sort the lists are copied into CSR order (ll_meta_kernel, ll_csr_kernel).
+// One pass whatever the alphabet; labels are compared as the u32 values they are (no colour map).  Tables that overflow are
+// re-streamed in hash-selected passes like bin_count_kernel's.
+#pragma once
+
+struct ListOut {
+    uint32_t* lab;                      // label segments
+    uint64_t cap;
+    unsigned long long* cursor;
+};
+
+__device__ __forceinline__ uint64_t ll_range_mask(uint32_t start, uint32_t len) {      // len <= 64, start + len <= 64
+    const uint64_t m = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
+    return m << start;
+}
+
+// Ascending bitonic sort of one 32-bit key per lane.  18 of the 21 compare-exchange steps reach their partner (lane ^ 1, 2, 4, 8)
+// with DPP modifiers -- no trip through the LDS crossbar, which the probing waves of the CU's other workgroup keep busy; lane ^ 16
+// is a ds_swizzle, lane ^ 32 a ds_bpermute.  (First form: 64-bit keys exchanged with two ds_bpermute per step -- 42 crossbar
+// operations per batch of 64 labels; the sort phase took 26 of the kernel's 60 ms per 2*10^9 labels.)
+template <int J2>
+__device__ __forceinline__ uint32_t ll_lane_xor(uint32_t x) {
+    if (J2 == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true);           // quad_perm:[1,0,3,2]
+    if (J2 == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, true);           // quad_perm:[2,3,0,1]
+    if (J2 == 4) {                                                                                       // banks 0, 2 read lane + 4, banks 1, 3 lane - 4
+        const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xf, 0x5, false);               // row_shl:4
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xf, 0xa, false);                 // row_shr:4
+    }
+    if (J2 == 8) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false);    // row_ror:8
+    if (J2 == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);                           // and 0x1f, or 0, xor 0x10
+    return (uint32_t)__shfl_xor((int)x, 32);
+}
+template <int K2, int J2>
+__device__ __forceinline__ uint32_t ll_cmpx(uint32_t key, uint32_t lane) {
+    const uint32_t other = ll_lane_xor<J2>(key);
+    const bool take_min = ((lane & (uint32_t)K2) == 0u) == ((lane & (uint32_t)J2) == 0u);
+    const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
+    return take_min ? mn : mx;
+}
+__device__ __forceinline__ uint32_t ll_wave_sort(uint32_t key, uint32_t lane) {
+    key = ll_cmpx<2, 1>(key, lane);
+    key = ll_cmpx<4, 2>(key, lane); key = ll_cmpx<4, 1>(key, lane);
+    key = ll_cmpx<8, 4>(key, lane); key = ll_cmpx<8, 2>(key, lane); key = ll_cmpx<8, 1>(key, lane);
+    key = ll_cmpx<16, 8>(key, lane); key = ll_cmpx<16, 4>(key, lane); key = ll_cmpx<16, 2>(key, lane); key = ll_cmpx<16, 1>(key, lane);
+    key = ll_cmpx<32, 16>(key, lane); key = ll_cmpx<32, 8>(key, lane); key = ll_cmpx<32, 4>(key, lane); key = ll_cmpx<32, 2>(key, lane);
+    key = ll_cmpx<32, 1>(key, lane);
+    key = ll_cmpx<64, 32>(key, lane); key = ll_cmpx<64, 16>(key, lane); key = ll_cmpx<64, 8>(key, lane); key = ll_cmpx<64, 4>(key, lane);
+    key = ll_cmpx<64, 2>(key, lane); key = ll_cmpx<64, 1>(key, lane);
+    return key;
+}
+// inclusive maximum over the lanes at or below this one (the DPP ladder of wave_inclusive_scan_u32 with max for +)
+__device__ __forceinline__ uint32_t ll_wave_max_scan(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    const uint32_t a = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);
+    v = mx(mx(v, a), mx(b, c));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
+// A segment of more than 64 labels, sorted and de-duplicated in place by one wavefront: bitonic network in the all-ascending form
+// (the first step of every merge mirrors, the others shift), so that positions >= n simply count as +infinity and are never
+// touched.  The labels live in global memory (a k-mer seen thousands of times); steps are separated by WORKGROUP-scope fences: the
+// waves of a workgroup share their CU's write-through L1, so a wait for the outstanding stores is all the ordering needs -- a
+// device-scope fence writes the XCD's L2 back and invalidates it (__threadfence() after the append sweep made that sweep 2.4x
+// slower and the stores another 50 ms per 2*10^9 labels).  Returns the number of distinct labels.
+__device__ __forceinline__ uint32_t ll_wave_sort_unique_global(uint32_t* __restrict__ a, uint32_t n, uint32_t lane) {
+    uint32_t P = 128;
+    while (P < n) P <<= 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+        for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            const bool mirror = j2 == (k2 >> 1);
+            for (uint32_t t = lane; t < (P >> 1); t += 64) {
+                const uint32_t i = ((t / j2) * 2u * j2) + (t % j2);
+                const uint32_t q = mirror ? (i ^ (k2 - 1u)) : (i + j2);
+                if (q < n) {                                                     // (i < q always)
+                    const uint32_t x = a[i], y = a[q];
+                    if (y < x) { a[i] = y; a[q] = x; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    uint32_t out_n = 0, carry = 0;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+        const bool act = c0 + lane < n;
+        const uint32_t v = act ? a[c0 + lane] : 0u;
+        uint32_t pv = (uint32_t)__shfl_up((int)v, 1);
+        if (lane == 0) pv = carry;
+        const bool first = act && (c0 + lane == 0u || v != pv);
+        const uint64_t fm = __ballot(first);
+        carry = (uint32_t)__shfl((int)v, 63);
+        if (first) a[out_n + (uint32_t)__popcll(fm & lt)] = v;                   // at or below its own position: never ahead of a read
+        out_n += (uint32_t)__popcll(fm);
+    }
+    return out_n;
+}
+
+// DBG_LL_ABL = n (measurement builds, WRONG results): 1 stop after the counting sweep, 2 after the segment offsets, 3 no sort of the
+// segments, 4 the append sweep without its global stores (and no sort)
+#ifndef DBG_LL_ABL
+#define DBG_LL_ABL 0
+#endif
+template <int KW, int NBW, int NT, int T>
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt,
+                                                       const uint32_t* __restrict__ labs, const uint32_t* __restrict__ labs_alt, uint32_t alt_from,
+                                                       const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
+                                                       uint32_t n_src, uint64_t seg_stride,
+                                                       int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
+                                                       unsigned long long* __restrict__ out_cursor, ListOut lo, uint32_t* __restrict__ gflags) {
+    constexpr int RW = NBW;
+    constexpr int NWV = NT / 64;
+    constexpr uint32_t CH = 4;
+    constexpr uint32_t CAPC = (NBW == 4 ? 3 : 4) * NT;       // chunk-map capacity per round (k >= 56: keeps two workgroups per CU)
+    __shared__ __attribute__((aligned(16))) uint32_t s_tag[T];
+    __shared__ __attribute__((aligned(16))) uint64_t s_key[KW * T];
+    __shared__ uint32_t s_cnt[T];                           // observations; after phase D: distinct labels (0 = not valid)
+    __shared__ uint32_t s_cur[T];                           // phase C: next free place of the slot's segment; after D: the segment's offset
+    __shared__ uint32_t s_ex4[T / 4];                       // Exts, one byte per entry
+    __shared__ uint64_t s_slab[RW * NT];                    // staged batch of records, word-major
+    __shared__ uint32_t s_lab[NT];                          // ... and their labels
+    __shared__ __attribute__((aligned(4))) uint16_t s_cmap[CAPC];   // chunk -> record slot | chunk index << 10
+    __shared__ uint32_t s_m, s_cproc, s_nextq;
+    __shared__ uint32_t s_wsum[NWV];
+    __shared__ uint32_t s_flag[2];                          // [0] table overflow, [1] claimed entries
+    __shared__ unsigned long long s_base, s_base_all, s_lbase;
+    __shared__ uint32_t s_st[24];
+    __shared__ uint32_t s_segpre[66];
+    __shared__ uint64_t s_segbeg[64];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        uint32_t len = 0;
+        if (tid < n_src) {
+            const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)blockIdx.x], b = seg_end[tid * seg_stride + (uint64_t)blockIdx.x];
+            len = (uint32_t)(b - a);
+            s_segbeg[tid] = a;
+        }
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += o;
+        }
+        if (tid < n_src) s_segpre[tid] = incl - len;
+        if (tid == 63) s_segpre[n_src] = incl;
+    }
+    __syncthreads();
+    const uint32_t total_recs = s_segpre[n_src];
+    if (total_recs == 0) return;
+    const K128 kmask = k128_mask(k);
+    const uint64_t lt_mask = lanemask_lt();
+
+    int sp = 1;
+    for (uint32_t guard = 0;; guard++) {
+        if (sp == 0) break;
+        if (guard > 20000u) { if (tid == 0) atomicOr(&gflags[3], 2u); break; }
+        const uint32_t ent = guard == 0 ? 1u : s_st[sp - 1];
+        const uint32_t P = ent & 0xffffu, pr = ent >> 16;
+        sp--;
+        if (tid == 0 && P > 1) { atomicMax(&gflags[1], P); atomicAdd(&gflags[2], 1u); }
+        for (int i = tid; i < T; i += NT) { s_tag[i] = 0; s_cnt[i] = 0; s_cur[i] = 0; }
+        for (int i = tid; i < T / 4; i += NT) s_ex4[i] = 0;
+        if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+        __syncthreads();
+
+        unsigned long long lbase = 0;                       // start of this pass's stretch of the label buffer (phase C)
+        // ---- one sweep over the bin's records.  MODE 0: insert + count; MODE 1: look up + append the label ----
+        auto stream = [&](const int MODE) -> bool {
+            for (uint32_t r0 = 0; r0 < total_recs; r0 += NT) {
+                const uint32_t nb = total_recs - r0 < (uint32_t)NT ? total_recs - r0 : (uint32_t)NT;
+                uint32_t nkr = 0;
+                if (tid < nb) {
+                    const uint32_t ridx = r0 + tid;
+                    uint32_t sg = 0;
+                    while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
+                    const uint64_t ri = s_segbeg[sg] + (ridx - s_segpre[sg]);
+                    const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + ri * RW;
+                    uint64_t a[RW];
+#pragma unroll
+                    for (int q = 0; q < RW; q++) a[q] = g[q];
+#pragma unroll
+                    for (int q = 0; q < RW; q++) s_slab[q * NT + tid] = a[q];
+                    if (MODE == 1) s_lab[tid] = (sg >= alt_from ? labs_alt : labs)[ri];
+                    const uint32_t rl = (uint32_t)(a[RW - 1] & 0x7f);
+                    if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - (META_BITS + 1) / 2)) atomicOr(&gflags[3], 4u);   // not a record of the scan
+                    else nkr = rl - (uint32_t)k + 1u;
+                }
+                const uint32_t nch = (nkr + CH - 1) / CH;
+                for (uint32_t base = 0; base < nb;) {
+                    if (tid == 0) { s_m = nb; s_cproc = 0; s_nextq = 0; }
+                    uint32_t tot;
+                    const uint32_t mine = tid >= base ? nch : 0u;
+                    const uint32_t incl = block_inclusive_scan<NT>(mine, s_wsum, &tot);      // barriers inside (also: the batch is staged)
+                    if (incl <= CAPC) {
+                        if (mine) atomicMax(&s_cproc, incl);
+                        for (uint32_t c = 0; c < mine; c++) s_cmap[incl - mine + c] = (uint16_t)(tid | (c << 10));
+                    } else if (tid >= base && tid < nb) atomicMin(&s_m, tid);
+                    __syncthreads();
+                    const uint32_t mend = s_m, cproc = s_cproc;
+                    for (;;) {
+                        uint32_t q0 = 0;
+                        if (lane == 0) q0 = atomicAdd(&s_nextq, 64u);
+                        q0 = __shfl(q0, 0);
+                        if (q0 >= cproc) break;
+                        const uint32_t q = q0 + lane;
+                        const bool act = q < cproc;
+                        const uint32_t e = act ? (uint32_t)s_cmap[q] : 0u;
+                        const uint32_t r = e & 1023u, c = e >> 10;
+                        uint64_t W0 = s_slab[r], W1 = s_slab[NT + r], W2 = 0, W3 = 0;
+                        if (NBW > 2) W2 = s_slab[2 * NT + r];
+                        if (NBW > 3) W3 = s_slab[3 * NT + r];
+                        uint64_t meta;
+                        {
+                            uint64_t& WL = NBW == 2 ? W1 : (NBW == 3 ? W2 : W3);
+                            meta = WL & ((1ull << META_BITS) - 1);
+                            WL &= ~((1ull << META_BITS) - 1);
+                        }
+                        const uint32_t label = MODE == 1 ? s_lab[r] : 0u;
+                        const uint32_t rlen = (uint32_t)(meta & 0x7f), rexts = (uint32_t)(meta >> 7) & 0xffu;
+                        const uint32_t rnk = rlen - (uint32_t)k + 1u, rnch = (rnk + 3u) >> 2;
+                        const uint32_t cbase = rnk < 4u ? rnk : (rnk == 5u ? 2u : ((rnk & 3u) ? 3u : 4u)), crem = rnk - cbase * rnch;
+                        uint32_t j = c * cbase + (c < crem ? c : crem);
+                        const uint32_t jend = act ? j + cbase + (c < crem ? 1u : 0u) : j;
+                        auto base_at = [&](uint32_t qq) -> uint32_t {
+                            const uint64_t wd = qq < 32 ? W0 : (qq < 64 ? W1 : (NBW > 2 && qq < 96 ? W2 : (NBW > 3 ? W3 : (NBW > 2 ? W2 : W1))));
+                            return (uint32_t)(wd >> (62 - 2 * (qq & 31))) & 3u;
+                        };
+                        K128 fw;
+                        {
+                            const uint32_t sft = 2 * j, ws = sft >> 6, bs = sft & 63;
+                            const uint64_t A = ws == 0 ? W0 : W1, B = ws == 0 ? W1 : (NBW > 2 ? W2 : 0ull),
+                                           C = ws == 0 ? (NBW > 2 ? W2 : 0ull) : (NBW > 3 ? W3 : 0ull);
+                            const uint64_t h = bs ? (A << bs) | (B >> (64 - bs)) : A, l = bs ? (B << bs) | (C >> (64 - bs)) : B;
+                            fw = k128_shr(K128{h, l}, 128 - 2 * k);
+                        }
+                        K128 rcw = kmer_rc(fw, k);
+                        uint32_t lb = j ? base_at(j - 1) : 0u;
+                        uint32_t nx;
+                        {
+                            const uint32_t sft = 2 * (j + (uint32_t)k), ws = sft >> 6, bs = sft & 63;
+                            const uint64_t A = ws == 0 ? W0 : (ws == 1 ? W1 : (NBW > 2 && ws == 2 ? W2 : (NBW > 3 && ws == 3 ? W3 : 0ull)));
+                            const uint64_t B = ws == 0 ? W1 : (NBW > 2 && ws == 1 ? W2 : (NBW > 3 && ws == 2 ? W3 : 0ull));
+                            const uint64_t v = bs ? (A << bs) | (B >> (64 - bs)) : A;
+                            nx = (uint32_t)(v >> 32);
+                        }
+                        while (__any(j < jend)) {
+                            if (j < jend) {
+                                const uint32_t nbase = nx >> 30;
+                                nx <<= 2;
+                                uint32_t left = j == 0 ? (rexts & 0xfu) : (1u << lb);
+                                uint32_t right = (j + (uint32_t)k == rlen) ? (rexts & 0xf0u) : (16u << nbase);
+                                uint32_t ex = left | right;
+                                K128 km = fw;
+                                if (!stranded && !k128_lt(fw, rcw)) { km = rcw; ex = __brev(ex) >> 24; }   // ties flip (lib.rs:226-230)
+                                const uint64_t h = hash_key(km.hi, km.lo);
+                                if (P == 1 || ((uint32_t)(h >> 16) & (P - 1)) == pr) {
+                                    const uint32_t mytag = ((uint32_t)(h >> 32) & 0x7fffffffu) | 1u;
+                                    uint32_t bkt = (uint32_t)h & (T / 4 - 1);
+                                    uint32_t slot = 0, tried = 0, nprobe = 0;
+                                    const uint32_t rot = (uint32_t)(h >> 12) & 3u;
+                                    bool hit = false;
+                                    for (;;) {
+                                        asm volatile("" ::: "memory");
+                                        const uint4 t4 = *reinterpret_cast<const uint4*>(&s_tag[bkt * 4]);
+                                        const uint32_t mm = ((t4.x == mytag ? 1u : 0u) | (t4.y == mytag ? 2u : 0u) | (t4.z == mytag ? 4u : 0u) |
+                                                             (t4.w == mytag ? 8u : 0u)) & ~tried;
+                                        const uint32_t em = (t4.x == 0u ? 1u : 0u) | (t4.y == 0u ? 2u : 0u) | (t4.z == 0u ? 4u : 0u) | (t4.w == 0u ? 8u : 0u);
+                                        if (mm) {
+                                            const uint32_t i = (uint32_t)__ffs((int)mm) - 1u, sl = bkt * 4 + i;
+                                            bool same;
+                                            if (KW == 2) {
+                                                const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s_key[2 * sl]);
+                                                same = kk.x == km.lo && kk.y == km.hi;
+                                            } else same = s_key[sl] == km.lo;
+                                            if (same) { hit = true; slot = sl; break; }
+                                            tried |= 1u << i;
+                                            continue;
+                                        }
+                                        if (MODE == 0) {
+                                            const uint32_t bz = mytag | TAG_BUSY;
+                                            if (t4.x == bz || t4.y == bz || t4.z == bz || t4.w == bz) continue;      // a claimer is writing its key
+                                            if (em) {
+                                                const uint32_t emr = ((em >> rot) | (em << (4u - rot))) & 15u;
+                                                const uint32_t sl = bkt * 4 + (((uint32_t)__ffs((int)emr) - 1u + rot) & 3u);
+                                                if (atomicCAS(&s_tag[sl], 0u, bz) == 0u) {
+                                                    if (KW == 2) *reinterpret_cast<ulonglong2*>(&s_key[2 * sl]) = make_ulonglong2(km.lo, km.hi);
+                                                    else s_key[sl] = km.lo;
+                                                    asm volatile("" ::: "memory");
+                                                    __hip_atomic_store(&s_tag[sl], mytag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                                    atomicAdd(&s_flag[1], 1u);
+                                                    hit = true; slot = sl;
+                                                    break;
+                                                }
+                                                continue;
+                                            }
+                                        } else if (em) break;                    // a key of the table sits before the first free slot of its chain
+                                        bkt = (bkt + 1) & (T / 4 - 1);
+                                        tried = 0;
+                                        if (++nprobe >= (uint32_t)(T / 4)) break;
+                                    }
+                                    if (MODE == 0) {
+                                        if (hit) {
+                                            atomicAdd(&s_cnt[slot], 1u);
+                                            atomicOr(&s_ex4[slot >> 2], ex << (8u * (slot & 3u)));
+                                        } else __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    } else if (hit && (uint64_t)s_cnt[slot] >= min_obs) {
+                                        const uint32_t pos = atomicAdd(&s_cur[slot], 1u);
+                                        if (DBG_LL_ABL != 4 || label == 0x12345u) lo.lab[lbase + pos] = label;
+                                    }
+                                }
+                                if (KW == 2) {
+                                    const int sh = 2 * (k - 1) - 64;
+                                    lb = (uint32_t)(fw.hi >> sh) & 3u;
+                                    fw.hi = ((fw.hi << 2) | (fw.lo >> 62)) & kmask.hi;
+                                    fw.lo = (fw.lo << 2) | nbase;
+                                    rcw.lo = (rcw.lo >> 2) | (rcw.hi << 62);
+                                    rcw.hi = (rcw.hi >> 2) | ((uint64_t)(3u - nbase) << sh);
+                                } else {
+                                    const int sh = 2 * (k - 1);
+                                    lb = (uint32_t)(fw.lo >> sh) & 3u;
+                                    fw.lo = ((fw.lo << 2) | nbase) & kmask.lo;
+                                    rcw.lo = (rcw.lo >> 2) | ((uint64_t)(3u - nbase) << sh);
+                                }
+                                j++;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    base = mend;
+                }
+                if (MODE == 0) {
+                    // a table more than 7/8 full with records still to come: give up early and re-split the pass
+                    if (r0 + NT < total_recs && tid == 0 && s_flag[1] > (uint32_t)(T - T / 8)) s_flag[0] = 1;
+                    __syncthreads();
+                    if (__hip_atomic_load(&s_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return true;
+                }
+            }
+            return false;
+        };
+
+        // ---- A: count ----
+        const bool ovf = stream(0);
+        if (DBG_LL_ABL == 1) break;
+        bool room = true;
+        if (!ovf) {
+            // ---- B: segments of the valid k-mers (four consecutive slots per thread) ----
+            static_assert(T == 4 * NT, "four slots per thread");
+            uint32_t v4[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i = tid * 4 + q;
+                const uint32_t c = s_cnt[i];
+                v4[q] = (s_tag[i] != 0u && (uint64_t)c >= min_obs) ? c : 0u;
+                sum += v4[q];
+            }
+            uint32_t tot;
+            const uint32_t incl = block_inclusive_scan<NT>(sum, s_wsum, &tot);
+            uint32_t o = incl - sum;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { s_cur[tid * 4 + q] = o; o += v4[q]; }
+            if (tid == 0) s_lbase = tot ? atomicAdd(lo.cursor, (unsigned long long)tot) : 0ull;
+            __syncthreads();
+            lbase = s_lbase;
+            room = lbase + tot <= lo.cap;
+            if (!room && tid == 0) atomicOr(&gflags[0], 16u);
+            if (DBG_LL_ABL == 2) break;
+            if (room && tot) {
+                // ---- C: append ----
+                (void)stream(1);
+                __syncthreads();                            // (workgroup scope: the appended labels are visible to the waves that sort them)
+                // ---- D: sort + de-duplicate every segment; each wave takes its own T / NWV slots ----
+                uint32_t* const L = lo.lab + lbase;
+                for (uint32_t blk = 0; blk < (uint32_t)(T / NWV / 64) && DBG_LL_ABL < 3; blk++) {
+                    const uint32_t i = wave * (T / NWV) + blk * 64 + lane;
+                    const uint32_t c = s_cnt[i];
+                    const bool valid = s_tag[i] != 0u && (uint64_t)c >= min_obs;
+                    const uint32_t off = valid ? s_cur[i] - c : 0u;
+                    const uint32_t v = (valid && c <= 64u) ? c : 0u;
+                    const uint64_t bigm = __ballot(valid && c > 64u);
+                    const uint32_t incl = wave_inclusive_scan_u32(v);
+                    uint32_t nl = valid ? c : 0u;
+                    // per-wave scratch in the (idle) record staging area: element -> slot lane marks, and the slot lanes' numbers
+                    uint32_t* const WS = reinterpret_cast<uint32_t*>(s_slab) + wave * 256;
+                    WS[64 + lane] = incl - v; WS[128 + lane] = off; WS[192 + lane] = v;
+                    uint32_t g0 = 0, sbase = 0;
+                    while (g0 < 64u) {
+                        const uint64_t fit = __ballot(lane >= g0 && incl - sbase <= 64u);    // incl is monotone: the lanes [g0, g1)
+                        const uint32_t g1 = g0 + (uint32_t)__popcll(fit);
+                        const uint32_t n_el = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(g1 - 1u)) - sbase;
+                        if (n_el) {
+                            // element e of the batch belongs to the last slot lane whose segment starts at or before e: the slot
+                            // lanes mark their first element, a maximum scan spreads the marks
+                            WS[lane] = 0u;
+                            if (lane >= g0 && lane < g1 && v) WS[incl - v - sbase] = lane + 1u;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const bool act = lane < n_el;
+                            const uint32_t ms = ll_wave_max_scan(WS[lane]);
+                            const uint32_t j = act ? ms - 1u : g0;
+                            const uint32_t excl_j = WS[64 + j] - sbase, off_j = WS[128 + j], v_j = WS[192 + j];
+                            const uint32_t idx = act ? lane - excl_j : 0u;
+                            const uint32_t label = act ? L[off_j + idx] : 0u;
+                            // (segment in the batch, label): labels are < 2^24 (checked by the host side), at most 64 segments
+                            uint32_t key = act ? (((j - g0) << 24) | label) : 0xffffffffu;
+                            key = ll_wave_sort(key, lane);
+                            // the segments keep their lane ranges: lane e still belongs to slot lane j after the sort
+                            const uint32_t pk = (uint32_t)__shfl_up((int)key, 1);
+                            const bool first = act && (lane == 0u || pk != key);
+                            const uint64_t fm = __ballot(first);
+                            if (first) L[off_j + (uint32_t)__popcll(fm & ll_range_mask(excl_j, v_j) & lt_mask)] = key & 0xffffffu;
+                            if (lane >= g0 && lane < g1 && v) nl = (uint32_t)__popcll(fm & ll_range_mask(incl - v - sbase, v));
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        }
+                        sbase = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(g1 - 1u));
+                        g0 = g1;
+                    }
+                    uint64_t bm = bigm;
+                    while (bm) {
+                        const uint32_t jj = (uint32_t)__ffsll((long long)bm) - 1u;
+                        bm &= bm - 1;
+                        const uint32_t c_j = (uint32_t)__shfl((int)c, (int)jj), off_j = (uint32_t)__shfl((int)off, (int)jj);
+                        const uint32_t n = ll_wave_sort_unique_global(L + off_j, c_j, lane);
+                        if (lane == jj) nl = n;
+                    }
+                    s_cnt[i] = nl;
+                    s_cur[i] = off;
+                }
+            } else if (room) {
+                // no valid k-mer in this pass: nothing to append; counts of invalid slots must read as "no labels"
+                for (int i = tid; i < T; i += NT) s_cnt[i] = 0;
+            }
+            __syncthreads();
+        }
+        if (!ovf && room) {
+            // ---- E: emit (bin_count_kernel's scheme; valid = has labels) ----
+            constexpr int EMIT_IT = T / NWV / 64;
+            const uint32_t slot0 = wave * (T / NWV) + lane;
+            uint64_t vb[EMIT_IT], ab[EMIT_IT];
+            uint32_t nv = 0, na = 0;
+#pragma unroll
+            for (int it = 0; it < EMIT_IT; it++) {
+                const uint32_t i = slot0 + it * 64;
+                const bool occ = s_tag[i] != 0u;
+                vb[it] = __ballot(occ && s_cnt[i] != 0u); ab[it] = __ballot(occ);
+                nv += (uint32_t)__popcll(vb[it]); na += (uint32_t)__popcll(ab[it]);
+            }
+            if (lane == 0) s_wsum[wave] = nv | (na << 16);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NWV; w++) { const uint32_t x = s_wsum[w]; before += (uint32_t)w < wave ? x : 0u; total += x; }
+            const uint32_t tot_valid = total & 0xffffu, tot_all = total >> 16;
+            if (tid == 0) {
+                s_base = tot_valid ? atomicAdd(out_cursor, (unsigned long long)tot_valid) : 0ull;
+                s_base_all = (out.all_lo && tot_all) ? atomicAdd(out.all_cursor, (unsigned long long)tot_all) : 0ull;
+            }
+            __syncthreads();
+            const unsigned long long base = s_base + (before & 0xffffu), base_all = s_base_all + (before >> 16);
+            const bool fit = !(tot_valid && s_base + tot_valid > out_cap);
+            const bool fit_all = !(out.all_lo && tot_all && s_base_all + tot_all > out.all_cap);
+            if (!fit && tid == 0) atomicOr(&gflags[0], 1u);
+            if (!fit_all && tid == 0) atomicOr(&gflags[0], 8u);
+            if (fit && fit_all) {
+                uint64_t o = base, oa = base_all;
+#pragma unroll
+                for (int it = 0; it < EMIT_IT; it++) {
+                    const uint32_t i = slot0 + it * 64;
+                    if (out.all_lo && ((ab[it] >> lane) & 1ull)) {
+                        const uint64_t q = oa + (uint32_t)__popcll(ab[it] & lt_mask);
+                        if (KW == 2) { out.all_hi[q] = s_key[2 * i + 1]; out.all_lo[q] = s_key[2 * i]; }
+                        else out.all_lo[q] = s_key[i];
+                    }
+                    if ((vb[it] >> lane) & 1ull) {
+                        const uint64_t q = o + (uint32_t)__popcll(vb[it] & lt_mask);
+                        const unsigned long long goff = lbase + s_cur[i];
+                        out.w_rec[q] = make_uint4((uint32_t)goff, (uint32_t)(goff >> 32), s_cnt[i], (s_ex4[i >> 2] >> (8u * (i & 3u))) & 0xffu);
+                        const uint32_t pay = (uint32_t)q;
+                        if (out.rec16) {
+                            const uint64_t klo = KW == 2 ? s_key[2 * i] : s_key[i], khi = KW == 2 ? s_key[2 * i + 1] : 0ull;
+                            out.rec16[q] = make_uint4((uint32_t)klo, (uint32_t)(klo >> 32), (uint32_t)khi, pay);
+                        } else {
+                            if (KW == 2) { out.hi[q] = s_key[2 * i + 1]; out.lo[q] = s_key[2 * i]; }
+                            else out.lo[q] = s_key[i];
+                            out.pay[q] = pay;
+                        }
+                    }
+                    o += (uint32_t)__popcll(vb[it]); oa += (uint32_t)__popcll(ab[it]);
+                }
+            }
+        } else if (ovf) {
+            if (P >= 4096u || sp + 2 >= 24) { if (tid == 0) atomicOr(&gflags[0], 2u); break; }
+            if (tid == 0) { s_st[sp] = (2 * P) | (pr << 16); s_st[sp + 1] = (2 * P) | ((pr + P) << 16); }
+            sp += 2;
+        }
+        if (sp != 0) __syncthreads();
+    }
+}
+
+// after the order-restoring sort: the payload columns spell the record's position in the unsorted output (Exts column = low byte,
+// mask column = the other 24 bits); Exts, the number of labels and the segment's place are fetched from there
+__global__ void __launch_bounds__(256) ll_meta_kernel(uint32_t n, uint8_t* __restrict__ exts_io, const uint32_t* __restrict__ q_hi24,
+                                                      const uint4* __restrict__ w_rec, uint32_t* __restrict__ setn, uint64_t* __restrict__ seg_off) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t q = (uint32_t)exts_io[i] | (q_hi24[i] << 8);
+    const uint4 r = w_rec[q];
+    exts_io[i] = (uint8_t)r.w;
+    setn[i] = r.z;
+    seg_off[i] = (uint64_t)r.x | ((uint64_t)r.y << 32);
+}
+
+// label lists in table order: a wavefront takes 64 consecutive keys, whose lists form one contiguous stretch of set_val; lane e of a
+// round writes element e of the stretch (consecutive lanes, consecutive words) and finds its key by a binary search over the 64
+// offsets (shuffles); the reads run along the segments (a list is ~80 contiguous bytes at 30x coverage)
+__global__ void __launch_bounds__(256) ll_csr_kernel(uint32_t n, const uint64_t* __restrict__ set_off, const uint64_t* __restrict__ seg_off,
+                                                     const uint32_t* __restrict__ lab, uint32_t* __restrict__ set_val) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t k0 = (blockIdx.x * 4 + wave) * 64;
+    if (k0 >= n) return;
+    const uint32_t i = k0 + lane < n ? k0 + lane : n - 1;
+    const uint64_t base = set_off[k0];
+    const uint64_t end = set_off[k0 + 64 < n ? k0 + 64 : n];
+    const uint32_t mine = (uint32_t)(set_off[i] - base);                 // my list's offset inside the wave's stretch (< 2^32: 64 lists)
+    const uint64_t so = seg_off[i];
+    const uint32_t nkeys = n - k0 < 64u ? n - k0 : 64u;
+    const uint64_t len = end - base;
+    for (uint64_t e0 = 0; e0 < len; e0 += 64) {
+        const uint64_t e = e0 + lane;
+        // last key whose offset is <= e (lists may be empty only for keys past the end: every valid k-mer has a label)
+        uint32_t lo_ = 0, hi_ = nkeys - 1u;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const uint32_t mid = (lo_ + hi_ + 1u) >> 1;
+            const uint32_t val = (uint32_t)__shfl((int)mine, (int)mid);
+            if (lo_ < hi_) { if ((uint64_t)val <= e) lo_ = mid; else hi_ = mid - 1u; }
+        }
+        const uint32_t mo = (uint32_t)__shfl((int)mine, (int)lo_);
+        const uint32_t slo = (uint32_t)__shfl((int)(uint32_t)so, (int)lo_), shi = (uint32_t)__shfl((int)(uint32_t)(so >> 32), (int)lo_);
+        if (e < len) set_val[base + e] = lab[(((uint64_t)shi << 32) | slo) + (e - mo)];
+    }
+}
+
+// *used = false (and nothing written): not enough device memory for the label buffers -- the caller takes the generic path
+static int filter_kmers_fast_lists(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out, bool* used) {
+    *used = false;
+    const int k = (int)prm->k;
+    FastPlan pl;
+    if (!fast_make_plan(c, k, prm->stranded != 0, true, n_kmers, 0, &pl)) return 0;
+    pl.lists = true;
+    pl.wide = true;                                     // (payload = output position, side records: the WIDE plumbing of the count state)
+    pl.lmap = nullptr; pl.linv.on = 0;
+    const bool report_all = prm->report_all_kmers != 0;
+    {   // the segment sort packs (segment, label) into 32 bits: labels < 2^24, as the C ABI demands (dbg_mi355x.h)
+        uint32_t mx = 0;
+        DBG_TRY(seq_max_label(c, s, &mx));
+        if (mx >= (1u << 24)) return c->fail(17, "D1 values must be < 2^24");
+    }
+    DBuf<uint32_t> lab_out;
+    if (!lab_out.alloc(c, std::max<uint64_t>(n_kmers, 1))) return 0;        // every instance of a valid k-mer appends one label
+    if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: %llu k-mer instances, label buffer %.2f GB\n", (unsigned long long)n_kmers, n_kmers * 4e-9);
+
+    FastScan st;
+    DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
+    const uint32_t nb = pl.nbins * NCLS;
+    DBuf<uint64_t> ovf_off, ovf_recs, seg;
+    DBuf<uint32_t> ovf_lab;
+    DBuf<unsigned long long> total, lab_cursor;
+    ALLOC_OR_FAIL(c, ovf_off, (size_t)nb + 1);
+    DBG_TRY(fast_bin_offsets(c, &st, ovf_off.p, false));
+    ALLOC_OR_FAIL(c, ovf_recs, std::max<uint64_t>(st.n_recs * pl.rw, 1));
+    ALLOC_OR_FAIL(c, ovf_lab, std::max<uint64_t>(st.n_recs, 1));
+    DBuf<uint64_t> slab;
+    DBuf<uint32_t> cursor, slab_lab;
+    std::swap(slab, st.slab); std::swap(cursor, st.cursor); std::swap(slab_lab, st.slab_lab);
+    const uint32_t slab_cap = st.slab_cap;
+    DBG_TRY(fast_scatter(c, &st, ovf_off.p, ovf_recs.p, ovf_lab.p));
+    ALLOC_OR_FAIL(c, seg, (size_t)nb * 4);
+    ALLOC_OR_FAIL(c, total, 1);
+    ALLOC_OR_FAIL(c, lab_cursor, 1);
+    HIP_TRY(c, hipMemsetAsync(total.p, 0, 8, c->stream));
+    slab_bounds_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(cursor.p, slab_cap, ovf_off.p, nb, seg.p, seg.p + 2 * (size_t)nb, total.p);
+    LAUNCH_CHECK(c, "slab_bounds");
+    unsigned long long n_recs_total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_recs_total, total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->t_begin("sk_records", n_recs_total);
+    c->t_end();
+
+    FastCountState cs;
+    DBG_TRY(fast_count_begin(c, pl, prm->min_kmer_obs, n_kmers, &cs, report_all));
+    const uint64_t* seg_beg = seg.p;
+    const uint64_t* seg_end = seg.p + 2 * (size_t)nb;
+    const uint32_t n_src = st.n_recs ? 2u : 1u;
+    unsigned long long n_labels_raw = 0;
+    for (int attempt = 0;; attempt++) {
+        unsigned long long zero = 0;
+        HIP_TRY(c, hipMemcpyAsync(cs.out_cursor.p, &zero, 8, hipMemcpyHostToDevice, c->stream));
+        if (report_all) HIP_TRY(c, hipMemcpyAsync(cs.all_cursor.p, &zero, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemsetAsync(lab_cursor.p, 0, 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(cs.gflags.p, 0, 64, c->stream));
+        FastOut fo{cs.u_hi.p, cs.u_lo.p, cs.u_pay.p, cs.use16 ? cs.u16.p : nullptr, cs.w_rec.p,
+                   report_all ? cs.a_hi.p : nullptr, report_all ? cs.a_lo.p : nullptr, report_all ? cs.all_cursor.p : nullptr, cs.all_cap};
+        ListOut lo{lab_out.p, n_kmers, lab_cursor.p};
+        c->t_begin("bin_labels", n_kmers);
+#define ARGS_ slab.p, ovf_recs.p, slab_lab.p, ovf_lab.p, 1u, seg_beg, seg_end, n_src, (uint64_t)nb, k, pl.stranded ? 1 : 0, (uint64_t)prm->min_kmer_obs, fo, cs.cap, cs.out_cursor.p, lo, cs.gflags.p
+        if (!pl.has_hi) bin_labels_kernel<1, 2, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
+        else if (pl.nbw == 2) bin_labels_kernel<2, 2, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
+        else if (pl.nbw == 3) bin_labels_kernel<2, 3, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
+        else bin_labels_kernel<2, 4, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
+#undef ARGS_
+        c->t_end();
+        LAUNCH_CHECK(c, "bin_labels");
+        unsigned long long cur = 0, cur_all = 0;
+        uint32_t flv[16] = {0};
+        HIP_TRY(c, hipMemcpyAsync(&cur, cs.out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        if (report_all) HIP_TRY(c, hipMemcpyAsync(&cur_all, cs.all_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&n_labels_raw, lab_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(flv, cs.gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: bins=%u recs=%llu valid=%llu labels appended=%llu flags=%u maxP=%u split_passes=%u wd=%u\n",
+                                         pl.nbins, n_recs_total, cur, n_labels_raw, flv[0], flv[1], flv[2], flv[3]);
+        if (flv[3] & 4u) return c->fail(134, "fast path: corrupt super-k-mer record (record buffer or segment table of the counting stage is wrong)");
+        if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
+        if (flv[0] & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
+        if (flv[0] & 16u) return c->fail(138, "fast path: the label buffer is smaller than the observations of the valid k-mers");
+        if (flv[0] & 9u) {
+            if (attempt >= 3 || cur >= (1ull << 32) || cur_all >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 k-mers in one table");
+            if (flv[0] & 1u) DBG_TRY(fast_count_alloc(c, &cs, cur + cur / 16 + 1024));
+            if (flv[0] & 8u) DBG_TRY(fast_count_alloc_all(c, &cs, cur_all + cur_all / 16 + 1024));
+            continue;
+        }
+        cs.n_out = cur;
+        cs.n_all = cur_all;
+        break;
+    }
+    slab.release(); slab_lab.release(); ovf_recs.release(); ovf_lab.release();
+
+    // order-restoring sort, then the lists in table order
+    const uint64_t n_out = cs.n_out;
+    const size_t na = std::max<uint64_t>(n_out, 1);
+    DBuf<uint64_t> seg_off;
+    DBuf<uint32_t> setn;
+    ALLOC_OR_FAIL(c, seg_off, na); ALLOC_OR_FAIL(c, setn, na);
+    // (fast_count_finish gathers colour masks; the lists need their own gather, so the sort is driven here)
+    {
+        const bool has_hi = pl.has_hi;
+        DBuf<uint32_t> t_pay, msk_sorted;
+        DBuf<uint64_t> t_hi, t_lo, o_hi, o_lo, o_set_off;
+        DBuf<uint8_t> o_exts;
+        DBuf<uint32_t> o_set_val;
+        if (!cs.use16) {
+            ALLOC_OR_FAIL(c, t_pay, na); ALLOC_OR_FAIL(c, t_lo, na);
+            if (has_hi) ALLOC_OR_FAIL(c, t_hi, na);
+        }
+        ALLOC_OR_FAIL(c, o_hi, na); ALLOC_OR_FAIL(c, o_lo, na); ALLOC_OR_FAIL(c, o_exts, na);
+        ALLOC_OR_FAIL(c, msk_sorted, na); ALLOC_OR_FAIL(c, o_set_off, na + 1);
+        if (cs.use16) {
+            DBuf<uint4> t16;
+            ALLOC_OR_FAIL(c, t16, na);
+            DBG_TRY(sort_table_hybrid16(c, n_out, cs.u16.p, t16.p, 2 * k, true, !c->opt("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, nullptr, nullptr, msk_sorted.p));
+        } else {
+            RecArrays A{has_hi ? cs.u_hi.p : nullptr, cs.u_lo.p, cs.u_pay.p}, B{has_hi ? t_hi.p : nullptr, t_lo.p, t_pay.p};
+            DBG_TRY(sort_table_hybrid(c, n_out, A, B, 2 * k, true, !c->opt("DBG_NO_HYBRID_SORT"), o_hi.p, o_lo.p, o_exts.p, nullptr, nullptr, msk_sorted.p));
+        }
+        uint64_t n_setval = 0;
+        if (n_out) {
+            c->t_begin("list_meta", n_out);
+            ll_meta_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, o_exts.p, msk_sorted.p, cs.w_rec.p, setn.p, seg_off.p);
+            c->t_end();
+            LAUNCH_CHECK(c, "ll_meta");
+            DBG_TRY(scan_exclusive_u32_u64(c, setn.p, o_set_off.p, n_out));
+            HIP_TRY(c, hipMemcpyAsync(&n_setval, o_set_off.p + n_out, 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else HIP_TRY(c, hipMemsetAsync(o_set_off.p, 0, 8, c->stream));
+        ALLOC_OR_FAIL(c, o_set_val, std::max<uint64_t>(n_setval, 1));
+        if (n_out) {
+            c->t_begin("set_csr", n_out);
+            ll_csr_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, o_set_off.p, seg_off.p, lab_out.p, o_set_val.p);
+            c->t_end();
+            LAUNCH_CHECK(c, "ll_csr");
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memset(out, 0, sizeof(*out));
+        out->n = n_out;
+        out->key_hi = o_hi.take(); out->key_lo = o_lo.take(); out->exts = o_exts.take();
+        out->set_off = o_set_off.take(); out->set_val = o_set_val.take(); out->n_set_val = n_setval;
+        out->n_kmer_instances = n_kmers; out->n_passes = 1; out->on_device = 1;
+    }
+    if (report_all) {
+        const uint64_t n_all = cs.n_all;
+        const size_t naa = std::max<uint64_t>(n_all, 1);
+        const bool has_hi = pl.has_hi;
+        DBuf<uint64_t> b_hi, b_lo, f_hi, f_lo;
+        DBuf<uint32_t> a_pay, b_pay;
+        DBuf<uint8_t> x_exts;
+        DBuf<uint16_t> x_count;
+        ALLOC_OR_FAIL(c, a_pay, naa); ALLOC_OR_FAIL(c, b_pay, naa); ALLOC_OR_FAIL(c, b_lo, naa);
+        ALLOC_OR_FAIL(c, f_hi, naa); ALLOC_OR_FAIL(c, f_lo, naa); ALLOC_OR_FAIL(c, x_exts, naa); ALLOC_OR_FAIL(c, x_count, naa);
+        if (has_hi) ALLOC_OR_FAIL(c, b_hi, naa);
+        HIP_TRY(c, hipMemsetAsync(a_pay.p, 0, naa * 4, c->stream));
+        RecArrays A2{has_hi ? cs.a_hi.p : nullptr, cs.a_lo.p, a_pay.p}, B2{has_hi ? b_hi.p : nullptr, b_lo.p, b_pay.p};
+        DBG_TRY(sort_table_hybrid(c, n_all, A2, B2, 2 * k, false, !c->opt("DBG_NO_HYBRID_SORT"), f_hi.p, f_lo.p, x_exts.p, x_count.p, nullptr, nullptr));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        out->n_all = n_all;
+        out->all_hi = f_hi.take(); out->all_lo = f_lo.take();
+    }
+    *used = true;
+    return 0;
+}

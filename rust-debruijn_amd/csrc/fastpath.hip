@@ -36,6 +36,10 @@ struct FastCfg {
     uint32_t nbins;
     const uint8_t* lmap;        // D1 label -> dense colour index (sparse label alphabets), or null: the label is the index
     int strand_norm;            // store every piece as the smaller of (piece, reverse complement): non-stranded counting with odd k
+    // label lists (fast_labellists.hpp): the read's full D1 label goes to a side array at the record's index -- lab_slab next to
+    // the slabs (bin * slab_cap + slot), lab_tmp next to the read-order buffer; null = the 6-bit colour in the record is all there is
+    uint32_t* lab_slab = nullptr;
+    uint32_t* lab_tmp = nullptr;
 };
 
 // p-mer from the two words that hold it (w1 is ignored when the p-mer ends inside w0): no branches
@@ -257,7 +261,10 @@ struct PieceEmitter {
         if (DIRECT) {
             to_tmp = act && r >= slab_cap;
 #ifndef DBG_ABL_NO_STORE
-            if (act && !to_tmp) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
+            if (act && !to_tmp) {
+                store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
+                if (c.lab_slab) c.lab_slab[(uint64_t)b * slab_cap + r] = d1;
+            }
 #else
             if (act && !to_tmp && rv[0] == 0x123456789ull) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
 #endif
@@ -278,6 +285,7 @@ struct PieceEmitter {
             atomicAdd(&hist[b], 1u);
             store_rec(tmp_recs + idx * RW);
             tmp_bin[idx] = b;
+            if (c.lab_tmp) c.lab_tmp[idx] = d1;
         }
     }
 };
@@ -632,13 +640,15 @@ __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, u
 template <int NBW>
 __global__ void __launch_bounds__(256) sk_scatter_kernel(const uint64_t* __restrict__ tmp_recs, const uint32_t* __restrict__ tmp_bin,
                                                          uint64_t n_recs, const uint64_t* __restrict__ bin_off,
-                                                         uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs) {
+                                                         uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs,
+                                                         const uint32_t* __restrict__ tmp_lab = nullptr, uint32_t* __restrict__ lab_out = nullptr) {
     constexpr int RW = NBW;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_recs) return;
     uint32_t b = tmp_bin[i];
     if (b == BIN_INVALID) return;
     uint64_t r = bin_off[b] + atomicAdd(&cursor[b], 1u);
+    if (tmp_lab) lab_out[r] = tmp_lab[i];
     const uint64_t* src = tmp_recs + i * RW;
     uint64_t* dst = recs + r * RW;
     if (RW % 2 == 0) {                                   // 32-byte records: two 16-byte moves
@@ -1487,6 +1497,7 @@ struct FastPlan {
     bool stranded, is_set, has_hi;
     bool wide = false;                                  // colour sets of 25..64 colours: two mask words per table entry, payload gathered after the sort
     bool weighted = false;                              // sharded flow: records may carry a weight (sender-side duplicate merge) in the WEIGHT_BITS above the meta bits
+    bool lists = false;                                 // label lists (fast_labellists.hpp): the scan keeps every record's full D1 label in a side array
     uint32_t nbins;
     LabelInv linv = {};
     const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
@@ -1526,6 +1537,7 @@ struct FastScan {
     DBuf<uint64_t> slab;
     DBuf<uint32_t> cursor;
     uint32_t slab_cap = 0;
+    DBuf<uint32_t> slab_lab, tmp_lab;                   // pl.lists: labels of the records in the slabs / in the read-order buffer
 };
 
 // which D1 labels (< 65536) occur: one bit each; bitmap[2048] != 0 when a label >= 65536 was seen
@@ -1647,7 +1659,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     st->pl = pl; st->n_kmers = n_kmers;
     const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
     const uint32_t nbins = pl.nbins * NCLS;                      // sub-bins (bin, length class)
-    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap, (!pl.stranded && (k & 1) && !c->opt("DBG_NO_STRAND_NORM")) ? 1 : 0};
+    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap, (!pl.stranded && (k & 1) && !c->opt("DBG_NO_STRAND_NORM")) ? 1 : 0, nullptr, nullptr};
     SeqDev sd = s;
     if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
     DBuf<uint32_t> sflags;
@@ -1665,7 +1677,8 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
         if (const char* e = c->opt("DBG_SLAB_CAP")) st->slab_cap = (uint32_t)std::max(4, atoi(e)) & ~3u;      // measurement: records per slab
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
+        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw) &&
+            (!pl.lists || st->slab_lab.alloc(c, (uint64_t)nbins * st->slab_cap))) tmp_cap = tmp_cap / 16 + 4096;
         else {
             // not enough memory for slabs (1.3x the records + slack): every record takes the read-order buffer and the
             // scatter pass instead -- slab capacity 0 routes them all there
@@ -1679,6 +1692,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     for (int attempt = 0;; attempt++) {
         ALLOC_OR_FAIL(c, st->tmp_recs, tmp_cap * rw);
         ALLOC_OR_FAIL(c, st->tmp_bin, tmp_cap);
+        if (pl.lists) { ALLOC_OR_FAIL(c, st->tmp_lab, tmp_cap); cfg.lab_slab = st->slab_cap ? st->slab_lab.p : nullptr; cfg.lab_tmp = st->tmp_lab.p; }
         HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)nbins * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(tmp_cursor.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 8, c->stream));
@@ -1771,7 +1785,7 @@ static int fast_bin_offsets(dbg_ctx* c, FastScan* st, uint64_t* bin_off_out, boo
     }
     return 0;
 }
-static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out) {
+static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out, uint32_t* lab_out = nullptr) {
     const uint32_t nbins = st->pl.nbins * NCLS;
     DBuf<uint32_t> cursor;
     ALLOC_OR_FAIL(c, cursor, nbins);
@@ -1779,13 +1793,14 @@ static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint6
     if (st->n_tmp) {
         const uint64_t n_tmp = st->n_tmp;
         c->t_begin("sk_scatter", st->n_recs);
-        if (st->pl.nbw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
-        else if (st->pl.nbw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
-        else sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
+        const uint32_t* tl = lab_out ? st->tmp_lab.p : nullptr;
+        if (st->pl.nbw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out, tl, lab_out);
+        else if (st->pl.nbw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out, tl, lab_out);
+        else sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out, tl, lab_out);
         c->t_end();
         LAUNCH_CHECK(c, "sk_scatter");
     }
-    st->tmp_recs.release(); st->tmp_bin.release(); st->hist.release();
+    st->tmp_recs.release(); st->tmp_bin.release(); st->hist.release(); st->tmp_lab.release();
     return 0;
 }
 
@@ -2251,6 +2266,7 @@ static int fast_run(dbg_ctx* c, const SeqDev& s, FastPlan pl, uint64_t min_obs, 
 }
 
 #include "fast_manylabels.hpp"
+#include "fast_labellists.hpp"
 
 // returns 0 and sets *used = true when the fast path produced the table; *used = false means the
 // caller must take the generic path (unsupported shape), nothing was written.
@@ -2267,9 +2283,18 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         std::vector<uint32_t> many;                 // more than 64 distinct labels (all < 65536): the label-group passes
         DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok, &many));
         if (!ok) {
-            if (many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS")) return 0;
+            // more than 64 distinct labels, or labels >= 65536: label lists (any alphabet, one pass: fast_labellists.hpp); 65..1024
+            // labels may also run as label groups (fast_manylabels.hpp).  DBG_LABEL_LISTS = 0: never lists, 1: lists wherever they apply
+            const char* ll = c->opt("DBG_LABEL_LISTS");
+            const bool groups_ok = !(many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS"));
+            const bool lists_ok = !(ll && !strcmp(ll, "0"));
+            if (groups_ok && !(lists_ok && ll && !strcmp(ll, "1"))) {
+                DBG_TRY(c->wait_all_reads());
+                return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
+            }
+            if (!lists_ok) return 0;
             DBG_TRY(c->wait_all_reads());
-            return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
+            return filter_kmers_fast_lists(c, s, prm, n_kmers, out, used);
         }
     }
     // the WIDE colour-set layout keeps two more words per table entry: with 1024-entry tables two workgroups still share a CU's

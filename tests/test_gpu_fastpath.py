@@ -111,14 +111,19 @@ def test_fast_equals_generic_on_synthetic_stream(ctx):
 
 
 def test_fast_path_refuses_unsupported_shapes(ctx):
+    """more than 1024 distinct labels: label lists (fast_labellists.hpp) since round 5; with DBG_LABEL_LISTS=0 the fast path
+    refuses the shape and the default dispatch takes the generic (sort-based) CountFilterSet"""
     rng = np.random.default_rng(1)
     seqs = random_reads(rng, 1100, 1000, 150, False)
     ss = O.SeqSet.from_byte_seqs(seqs, data=np.arange(1100) * 7 + 40, sizeof_d1=2)
-    with pytest.raises(dbg.DbgError):           # more than 1024 distinct labels need the generic (sort-based) CountFilterSet
-        dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
-    ctx.set_option("DBG_PATH", "auto")
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
     got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+    assert_tables_equal(got, want, True)
+    with ctx.options(DBG_LABEL_LISTS="0"):
+        with pytest.raises(dbg.DbgError):
+            dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+        ctx.set_option("DBG_PATH", "auto")
+        got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     assert_tables_equal(got, want, True)
 
 
