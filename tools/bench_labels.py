@@ -10,6 +10,7 @@ ap.add_argument("--reads", type=int, default=100_000_000)
 ap.add_argument("--k", type=int, default=47)
 ap.add_argument("--lists", default="auto")
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--small", action="store_true", help="labels below 65536 (label groups apply for 65..1024 of them)")
 ap.add_argument("labels", type=int, nargs="+")
 a = ap.parse_args()
 dbg = importlib.import_module("rust-debruijn_amd"); capi = importlib.import_module("rust-debruijn_amd._capi")
@@ -26,7 +27,7 @@ ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), words.data_ptr(), start.dat
 del colour
 g = torch.Generator(device=dev); g.manual_seed(7)
 for L in a.labels:
-    alphabet = torch.randperm(1 << 24, device=dev, generator=g)[:L].to(torch.int32)
+    alphabet = torch.randperm(65536 if a.small else 1 << 24, device=dev, generator=g)[:L].to(torch.int32)
     lab = alphabet[torch.randint(0, L, (N,), device=dev, generator=g)].contiguous()
     ss = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, lab.data_ptr(), 4, N)
     fp = capi.FilterParams(a.k, 0, 1, 2, 0, 4)
