@@ -370,12 +370,16 @@ def main():
             # the shapes the crate is used with day to day, on the same reads (BASELINE configs 4 / 5 per-GPU k, Kmer32's neighbourhood,
             # the plain counter): two timed steps each after one warm-up, per-kernel ms included
             other = {}
-            for nm, k2, set2 in (("k31_set", 31, 1), ("k63_set", 63, 1), ("k47_count", 47, 0), ("k24_set", 24, 1)):
-                if k2 == k and bool(set2) == is_set:
+            # (k47_set_5000_labels: 5000 distinct u32 labels spread over [0, 2^24), one per read at random -- the label-list route)
+            gen = torch.Generator(device=dev); gen.manual_seed(7)
+            lab5k = torch.randperm(1 << 24, device=dev, generator=gen)[:5000].to(torch.int32)[
+                torch.randint(0, 5000, (reads_per_gpu,), device=dev, generator=gen)].contiguous()
+            for nm, k2, set2 in (("k31_set", 31, 1), ("k63_set", 63, 1), ("k47_count", 47, 0), ("k24_set", 24, 1), ("k47_set_5000_labels", 47, 2)):
+                if k2 == k and bool(set2) == is_set and set2 != 2:
                     continue
-                fp2 = capi.FilterParams(k2, 0, set2, args.min_obs, 0, 4)
-                ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, colour.data_ptr() if set2 else None,
-                                  1 if set2 else 0, reads_per_gpu)
+                fp2 = capi.FilterParams(k2, 0, 1 if set2 else 0, args.min_obs, 0, 4)
+                ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None,
+                                  lab5k.data_ptr() if set2 == 2 else (colour.data_ptr() if set2 else None), 4 if set2 == 2 else (1 if set2 else 0), reads_per_gpu)
                 kt2, ni2 = {}, 0
                 for rep in range(3):
                     if rep == 1:
@@ -395,6 +399,9 @@ def main():
                 kt2.pop("sk_records", None)
                 other[nm] = {"k": k2, "summarizer": "CountFilterSet" if set2 else "CountFilter", "value": round(ni2 / odt / 1e9, 3), "unit": "Gkmer/s",
                              "ms_per_step": round(odt * 1e3, 3), "valid_kmers": int(nv2), "kernel_ms_per_step": {n_: round(v / 2, 3) for n_, v in kt2.items()}}
+                if set2 == 2:
+                    other[nm]["labels"] = "5000 distinct u32 labels in [0, 2^24), one per read at random"
+            del lab5k
         cpu = None
         if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
             import oracle_lib as O

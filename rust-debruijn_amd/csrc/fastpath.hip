@@ -2283,18 +2283,18 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
         std::vector<uint32_t> many;                 // more than 64 distinct labels (all < 65536): the label-group passes
         DBG_TRY(fast_labels_prepare(c, s, &pl, &lmap_buf, &ok, &many));
         if (!ok) {
-            // more than 64 distinct labels, or labels >= 65536: label lists (any alphabet, one pass: fast_labellists.hpp); 65..1024
-            // labels may also run as label groups (fast_manylabels.hpp).  DBG_LABEL_LISTS = 0: never lists, 1: lists wherever they apply
+            // more than 64 distinct labels, or labels >= 65536: label lists (any alphabet, one pass, 33 Gkmer/s at the C2 shape whatever
+            // the alphabet: fast_labellists.hpp).  Label groups (fast_manylabels.hpp: 65..1024 labels < 65536; 26 / 21 / 12.6 Gkmer/s at
+            // 65 / 100 / 250 labels) stay for DBG_LABEL_LISTS=0 and for a device too full for the label buffer.
             const char* ll = c->opt("DBG_LABEL_LISTS");
             const bool groups_ok = !(many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS"));
-            const bool lists_ok = !(ll && !strcmp(ll, "0"));
-            if (groups_ok && !(lists_ok && ll && !strcmp(ll, "1"))) {
-                DBG_TRY(c->wait_all_reads());
-                return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
-            }
-            if (!lists_ok) return 0;
             DBG_TRY(c->wait_all_reads());
-            return filter_kmers_fast_lists(c, s, prm, n_kmers, out, used);
+            if (!(ll && !strcmp(ll, "0"))) {
+                DBG_TRY(filter_kmers_fast_lists(c, s, prm, n_kmers, out, used));
+                if (*used) return 0;
+            }
+            if (!groups_ok) return 0;
+            return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
         }
     }
     // the WIDE colour-set layout keeps two more words per table entry: with 1024-entry tables two workgroups still share a CU's

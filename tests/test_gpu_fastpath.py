@@ -139,7 +139,7 @@ def test_fast_label_groups(ctx, n_labels, k, stranded, min_obs, report_all):
     lab[:n_labels] = alphabet                                      # every label occurs
     ss = O.SeqSet(hs.words, hs.start, hs.length, None, lab, 2)
     want = O.filter_kmers(ss, k, O.COUNT_FILTER_SET, min_obs, stranded=stranded, report_all=report_all)
-    with ctx.options(DBG_DEBUG="1"):
+    with ctx.options(DBG_DEBUG="1", DBG_LABEL_LISTS="0"):          # (label lists are the default since round 5: test_gpu_labellists.py)
         got, allk = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), stranded, report_all, 4, k=k, ctx=ctx)
     assert len(got) > 1000
     assert_tables_equal(got, want, True)
@@ -166,9 +166,10 @@ def test_label_groups_threshold_above_the_saturated_count(ctx):
     for min_obs in (70000, 65536, 72801):
         want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, min_obs, stranded=False)
         assert want.n == (1 if min_obs <= 72800 else 0)
-        with ctx.options(DBG_PATH="auto"):
-            got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), False, False, 4, k=47, ctx=ctx)
-        assert_tables_equal(got, want, True)
+        for lists in ("0", "1"):
+            with ctx.options(DBG_PATH="auto", DBG_LABEL_LISTS=lists):
+                got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), False, False, 4, k=47, ctx=ctx)
+            assert_tables_equal(got, want, True)
 
 
 def test_fast_label_groups_uneven(ctx):
@@ -188,8 +189,10 @@ def test_fast_label_groups_uneven(ctx):
     ss = O.SeqSet.from_byte_seqs(seqs, data=np.array(lab), sizeof_d1=2)
     for min_obs in (1, 2, 40):
         want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, min_obs, stranded=False)
-        got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), False, False, 4, k=47, ctx=ctx)
-        assert_tables_equal(got, want, True)
+        for lists in ("0", "1"):
+            with ctx.options(DBG_LABEL_LISTS=lists):
+                got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(min_obs), False, False, 4, k=47, ctx=ctx)
+            assert_tables_equal(got, want, True)
 
 
 @pytest.mark.parametrize("k,stranded,kind", [(47, False, 0), (31, True, 0), (64, False, 0), (47, False, 1), (16, False, 0)])
@@ -353,18 +356,22 @@ def test_fast_wide_colour_sets(ctx, k, width, labels):
         assert int(got.set_val.max()) >= 24                                   # the wide layout was needed
 
 
-def test_more_than_1024_labels_take_the_generic_path(ctx):
-    """(65..1024 distinct labels run as label groups on the fast path: test_fast_label_groups)"""
+def test_more_than_1024_labels(ctx):
+    """more than 1024 distinct labels: label lists on the fast path (round 5, test_gpu_labellists.py); with DBG_LABEL_LISTS=0 the generic
+    path under the default dispatch, and DBG_PATH=fast must not fall back silently"""
     rng = np.random.default_rng(3)
     seqs = random_reads(rng, 1500, 2000, 150, False)
     data = rng.permutation(1500) * 40 + 7
     ss = O.SeqSet.from_byte_seqs(seqs, data=data, sizeof_d1=2)
     want = O.filter_kmers(ss, 47, O.COUNT_FILTER_SET, 1, stranded=False)
-    with ctx.options(DBG_PATH="auto"):
-        got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+    got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
     assert_tables_equal(got, want, True)
-    with pytest.raises(dbg.DbgError):                                           # DBG_PATH=fast must not fall back silently
-        dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+    with ctx.options(DBG_LABEL_LISTS="0"):
+        with ctx.options(DBG_PATH="auto"):
+            got, _ = dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
+        assert_tables_equal(got, want, True)
+        with pytest.raises(dbg.DbgError):
+            dbg.filter_kmers(to_host_seqs(ss, 2), dbg.CountFilterSet(1), False, False, 4, k=47, ctx=ctx)
 
 
 @pytest.mark.parametrize("k", [64, 63, 48, 32])

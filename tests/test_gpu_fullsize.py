@@ -464,8 +464,11 @@ def test_fullsize_wide_colour_sets(env):
     assert np.array_equal(g_off, want.set_off) and np.array_equal(g_val, want.set_val)
 
 
-def test_fullsize_label_groups(env):
-    """More than 64 distinct labels at full size (fast_manylabels.hpp: one CountFilter run for the valid k-mers, one 64-colour run
+@pytest.mark.parametrize("route", ["lists", "groups"])
+def test_fullsize_label_groups(env, route):
+    """More than 64 distinct labels at full size, by both routes -- label lists (fast_labellists.hpp, the default since round 5: one
+    pass, every instance's label appended to its k-mer's segment, segments sorted + de-duplicated) and label groups
+    (fast_manylabels.hpp: one CountFilter run for the valid k-mers, one 64-colour run
     per label group joined into it): 192 labels, label = i mod 64 + 64 * ((i div 64) mod 3) for read i.  Same valid key set as
     CountFilter(2); every label list strictly ascending within 0..191; against the 64-colour run with label = i mod 64 (the
     projection of these labels): every k-mer has at least as many labels and at most three times as many; a 10^5-read prefix
@@ -495,8 +498,10 @@ def test_fullsize_label_groups(env):
     torch.cuda.synchronize()                                         # (torch's copy must be done before the library frees its arrays)
     lib.dbg_free_table(ctx.h, C.byref(t64))
     ctx.trim()
-    tm = run(N_READS, lab192, 1, 2)
-    assert tm.n_passes == 4                                          # CountFilter + three label groups
+    route_opt = dict(DBG_LABEL_LISTS="0" if route == "groups" else "1")
+    with ctx.options(**route_opt):
+        tm = run(N_READS, lab192, 1, 2)
+    assert tm.n_passes == (4 if route == "groups" else 1)            # CountFilter + three label groups / one pass of label lists
     sm = table_stats(e, tm)
     assert sm["ascending"] and s64["ascending"] and sm["n"] == s64["n"] and sm["keysum"] == s64["keysum"]
     off = dev_view(tm.set_off, tm.n + 1)
@@ -525,7 +530,8 @@ def test_fullsize_label_groups(env):
     ctx.trim()
     # prefix of the stream, bit-exact
     m = min(100_000, N_READS)
-    t = run(m, lab192, 1, 1)
+    with ctx.options(**route_opt):
+        t = run(m, lab192, 1, 1)
     h = capi.KmerTable()
     ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))
     lib.dbg_free_table(ctx.h, C.byref(t))

@@ -55,7 +55,10 @@ def draw_case(rng):
                     1: np.arange(int(rng.integers(25, 64))),                                 # wide layout
                     2: np.sort(rng.choice(np.arange(200 if width == 1 else 60000), size=int(rng.integers(2, 60)), replace=False)),  # sparse alphabet
                     3: np.arange(int(rng.integers(70, 120))),                                # label groups (k >= 16), else the generic path
-                    4: np.sort(rng.choice(np.arange(256 if width == 1 else 65536), size=int(rng.integers(65, 250)), replace=False))}[int(rng.integers(0, 5))]
+                    4: np.sort(rng.choice(np.arange(256 if width == 1 else 65536), size=int(rng.integers(65, 250)), replace=False)),
+                    # large alphabets (label lists for k >= 16, else the generic path)
+                    5: np.sort(rng.choice(np.arange(256 if width == 1 else (65536 if width == 2 else 1 << 24)),
+                                          size=int(rng.integers(65, 256 if width == 1 else 2000)), replace=False))}[int(rng.integers(0, 6))]
         data = alphabet[rng.integers(0, len(alphabet), size=n_reads)]
     min_obs = int(rng.choice([1, 1, 2, 3]))
     report_all = bool(rng.integers(0, 2))
@@ -63,10 +66,10 @@ def draw_case(rng):
     # tables, slab overflow), no slabs, the three-array sort form, the plain LSD sort, the wave-per-read scanner
     knobs = [{}, {}, {}, {}, {"DBG_FAST_TARGET": "600"}, {"DBG_FAST_TARGET": "50000"}, {"DBG_FAST_NO_SLAB": "1"},
              {"DBG_NO_REC16": "1"}, {"DBG_NO_HYBRID_SORT": "1"}, {"DBG_SCAN": "wave"}, {"DBG_FAST_TARGET": "300"},
-             {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}, {"DBG_NO_LABEL_GROUPS": "1"}, {"DBG_NO_STRAND_NORM": "1"},
+             {"DBG_SORT": "bytealigned"}, {"DBG_ONESWEEP": "0"}, {"DBG_NO_LABEL_GROUPS": "1"}, {"DBG_NO_STRAND_NORM": "1"}, {"DBG_LABEL_LISTS": "0"},
              # (k <= 15: the directly addressed table whatever the input's size -- k >= 9 partitions its k-mer instances, in one batch or in many)
              {"DBG_PATH": "dense"}, {"DBG_PATH": "dense", "DBG_DENSE_BATCH": "3000"}, {"DBG_PATH": "dense", "DBG_DENSE_PART": "0"},
-             {"DBG_PATH": "dense", "DBG_DENSE_RAW": "0"}][int(rng.integers(0, 19))]
+             {"DBG_PATH": "dense", "DBG_DENSE_RAW": "0"}][int(rng.integers(0, 20))]
     if knobs.get("DBG_PATH") == "dense" and (k > 15 or (is_set and data is not None and int(np.max(data)) >= 64)):
         knobs = {}                                               # (DBG_PATH=dense insists: other shapes are refused, test_gpu_dense.py)
     return dict(k=k, stranded=stranded, is_set=is_set, seqs=seqs, exts=exts, data=data, width=width, min_obs=min_obs, report_all=report_all,

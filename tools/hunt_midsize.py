@@ -15,17 +15,22 @@ for i in range(n_cases):
     n = int(rng.choice([150_000, 400_000, 1_000_000, 2_000_000]))
     k = int(rng.choice([20, 31, 33, 47, 48, 49, 55, 63, 64, 13]))
     kind = int(rng.integers(0, 2))
-    colours = int(rng.choice([4, 24, 40, 100, 200])) if kind else 4      # 100, 200: label groups (fast_manylabels.hpp)
+    colours = int(rng.choice([4, 24, 40, 100, 200, 3000, 50000])) if kind else 4      # > 64: label lists (fast_labellists.hpp)
     cov = int(rng.choice([3, 30, 100]))
     err = float(rng.choice([0.0, 0.001, 0.01]))
     stranded = bool(rng.integers(0, 2))
     min_obs = int(rng.choice([1, 2, 3]))
-    hs = dbg.synth_reads_host(n_reads=n, read_len=150, genome_len=n * 150 // cov, error_rate=err, stranded=stranded, n_colours=colours)
+    hs = dbg.synth_reads_host(n_reads=n, read_len=150, genome_len=n * 150 // cov, error_rate=err, stranded=stranded, n_colours=min(colours, 255))
+    lab, width = hs.data, 1
+    if colours > 255:                                                    # u32 labels spread over [0, 2^24), one per read at random
+        alphabet = np.unique(rng.integers(0, 1 << 24, size=colours, dtype=np.uint64)).astype(np.uint32)
+        lab, width = alphabet[rng.integers(0, len(alphabet), size=n)], 4
+        hs = dbg.HostSeqs(hs.words, hs.start, hs.length, None, lab, 4)
     t0 = time.time()
     summ = (dbg.CountFilterSet if kind else dbg.CountFilter)(min_obs)
     got, _ = dbg.filter_kmers(hs if kind else dbg.HostSeqs(hs.words, hs.start, hs.length), summ, stranded, False, 4, k=k, ctx=ctx)
     t1 = time.time()
-    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, hs.data if kind else None, 1 if kind else 0), k, kind, min_obs, stranded=stranded)
+    want = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, lab if kind else None, width if kind else 0), k, kind, min_obs, stranded=stranded)
     t2 = time.time()
     ok = (len(got) == want.n and np.array_equal(got.key_hi, want.key_hi) and np.array_equal(got.key_lo, want.key_lo) and np.array_equal(got.exts, want.exts)
           and (np.array_equal(got.count, want.count) if not kind else (np.array_equal(got.set_off, want.set_off) and np.array_equal(got.set_val, want.set_val))))
