@@ -46,12 +46,22 @@ __device__ __forceinline__ uint32_t ll_lane_xor(uint32_t x) {
     if (J2 == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);                           // and 0x1f, or 0, xor 0x10
     return (uint32_t)__shfl_xor((int)x, 32);
 }
+// lanes that keep the smaller key in the (K2, J2) step: a compile-time constant, handed to v_cndmask_b32 as a literal SGPR pair (as
+// values computed from the lane number the 21 masks were kept in SGPRs, spilled to VGPR lanes, and fetched back with two
+// v_readlane per step -- 42 VALU instructions per group of 64 labels)
+constexpr uint64_t ll_min_lanes(uint32_t k2, uint32_t j2) {
+    uint64_t m = 0;
+    for (uint32_t l = 0; l < 64; l++) if (((l & k2) == 0u) == ((l & j2) == 0u)) m |= 1ull << l;
+    return m;
+}
 template <int K2, int J2>
 __device__ __forceinline__ uint32_t ll_cmpx(uint32_t key, uint32_t lane) {
     const uint32_t other = ll_lane_xor<J2>(key);
-    const bool take_min = ((lane & (uint32_t)K2) == 0u) == ((lane & (uint32_t)J2) == 0u);
     const uint32_t mn = key < other ? key : other, mx = key < other ? other : key;
-    return take_min ? mn : mx;
+    constexpr uint64_t M = ll_min_lanes((uint32_t)K2, (uint32_t)J2);
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mx), "v"(mn), "s"(M));
+    return r;
 }
 __device__ __forceinline__ uint32_t ll_wave_sort(uint32_t key, uint32_t lane) {
     key = ll_cmpx<2, 1>(key, lane);
