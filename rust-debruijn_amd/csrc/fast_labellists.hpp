@@ -4,7 +4,7 @@
 // labels; everything beyond -- thousands of sample / transcript ids, labels >= 65536 -- used to take the generic path (sort every
 // k-mer instance: ~4 Gkmer/s).  CountFilterSet::summarize (filter.rs:85-100) collects the labels of a k-mer's observations, sorts
 // and de-duplicates them; here that happens bin by bin, next to the LDS hash table that already groups the bin's k-mers:
-//   * the scan writes every record's full D1 label into a side array at the record's index (FastCfg::lab_slab / lab_tmp);
+//   * the scan's records carry one more word, which holds the read's full D1 label (FastPlan::lists: rw = nbw + 1);
 //   * bin_labels_kernel, one workgroup per bin, streams the bin's records TWICE:
 //       A  count: k-mer -> table slot, count, Exts (the probing scheme of bin_count_kernel);
 //       B  validity (filter.rs:88 compares the unsaturated number of observations) and an exclusive scan of the valid slots'
@@ -134,13 +134,13 @@ __device__ __forceinline__ uint32_t ll_wave_sort_unique_global(uint32_t* __restr
 #define DBG_LL_ABL 0
 #endif
 template <int KW, int NBW, int NT, int T>
-__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt,
-                                                       const uint32_t* __restrict__ labs, const uint32_t* __restrict__ labs_alt, uint32_t alt_from,
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
                                                        unsigned long long* __restrict__ out_cursor, ListOut lo, uint32_t* __restrict__ gflags) {
-    constexpr int RW = NBW;
+    constexpr int RW = NBW;                                 // words of a record's bases + meta bits (staged in LDS)
+    constexpr int RWG = NBW + 1;                            // words of a record in memory: + the label word
     constexpr int NWV = NT / 64;
     constexpr uint32_t CH = 4;
     constexpr uint32_t CAPC = (NBW == 4 ? 3 : 4) * NT;       // chunk-map capacity per round (k >= 56: keeps two workgroups per CU)
@@ -222,10 +222,10 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                     uint32_t sg = 0;
                     while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
                     const uint64_t ri = s_segbeg[sg] + (ridx - s_segpre[sg]);
-                    const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + ri * RW;
+                    const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + ri * RWG;
 #pragma unroll
                     for (int q = 0; q < RW; q++) a[q] = g[q];
-                    if (MODE == 1) label = (sg >= alt_from ? labs_alt : labs)[ri];
+                    if (MODE == 1) label = (uint32_t)g[RW];
                     a[RW - 1] &= ~COLOUR_BITS;
                     const uint32_t rl = (uint32_t)(a[RW - 1] & 0x7f);
                     if (rl < (uint32_t)k || rl > (uint32_t)(32 * NBW - (META_BITS + 1) / 2)) atomicOr(&gflags[3], 4u);   // not a record of the scan
@@ -688,110 +688,112 @@ __global__ void __launch_bounds__(256) ll_csr_kernel(uint32_t n, const uint64_t*
     }
 }
 
-// *used = false (and nothing written): not enough device memory for the label buffers -- the caller takes the generic path
-static int filter_kmers_fast_lists(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out, bool* used) {
-    *used = false;
-    const int k = (int)prm->k;
-    FastPlan pl;
-    if (!fast_make_plan(c, k, prm->stranded != 0, true, n_kmers, 0, &pl)) return 0;
-    pl.lists = true;
-    pl.wide = true;                                     // (payload = output position, side records: the WIDE plumbing of the count state)
-    pl.lmap = nullptr; pl.linv.on = 0;
-    const bool report_all = prm->report_all_kmers != 0;
-    {   // the segment sort packs (segment, label) into 32 bits: labels < 2^24, as the C ABI demands (dbg_mi355x.h)
-        uint32_t mx = 0;
-        DBG_TRY(seq_max_label(c, s, &mx));
-        if (mx >= (1u << 24)) return c->fail(17, "D1 values must be < 2^24");
-    }
-    DBuf<uint32_t> lab_out;
-    if (!lab_out.alloc(c, std::max<uint64_t>(n_kmers, 1))) return 0;        // every instance of a valid k-mer appends one label
-    if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: %llu k-mer instances, label buffer %.2f GB\n", (unsigned long long)n_kmers, n_kmers * 4e-9);
+// ---- host side: counting state of the label-list route (the analogue of FastCountState's begin / bins / finish, so that the sharded
+//      flow can count its exchange rounds one after the other and sort once) ----
+struct ListCountState {
+    FastCountState cs;                      // unsorted (key, output position) records, side records {segment, labels, Exts}, all keys
+    DBuf<uint32_t> lab;                     // label segments
+    uint64_t lab_cap = 0, lab_used = 0;
+    DBuf<unsigned long long> lab_cursor;
+    uint64_t min_obs = 0;
+};
 
-    FastScan st;
-    DBG_TRY(fast_scan(c, s, pl, n_kmers, &st, true));
-    const uint32_t nb = pl.nbins * NCLS;
-    DBuf<uint64_t> ovf_off, ovf_recs, seg;
-    DBuf<uint32_t> ovf_lab;
-    DBuf<unsigned long long> total, lab_cursor;
-    ALLOC_OR_FAIL(c, ovf_off, (size_t)nb + 1);
-    DBG_TRY(fast_bin_offsets(c, &st, ovf_off.p, false));
-    ALLOC_OR_FAIL(c, ovf_recs, std::max<uint64_t>(st.n_recs * pl.rw, 1));
-    ALLOC_OR_FAIL(c, ovf_lab, std::max<uint64_t>(st.n_recs, 1));
-    DBuf<uint64_t> slab;
-    DBuf<uint32_t> cursor, slab_lab;
-    std::swap(slab, st.slab); std::swap(cursor, st.cursor); std::swap(slab_lab, st.slab_lab);
-    const uint32_t slab_cap = st.slab_cap;
-    DBG_TRY(fast_scatter(c, &st, ovf_off.p, ovf_recs.p, ovf_lab.p));
-    ALLOC_OR_FAIL(c, seg, (size_t)nb * 4);
-    ALLOC_OR_FAIL(c, total, 1);
-    ALLOC_OR_FAIL(c, lab_cursor, 1);
-    HIP_TRY(c, hipMemsetAsync(total.p, 0, 8, c->stream));
-    slab_bounds_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(cursor.p, slab_cap, ovf_off.p, nb, seg.p, seg.p + 2 * (size_t)nb, total.p);
-    LAUNCH_CHECK(c, "slab_bounds");
-    unsigned long long n_recs_total = 0;
-    HIP_TRY(c, hipMemcpyAsync(&n_recs_total, total.p, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->t_begin("sk_records", n_recs_total);
-    c->t_end();
+static void lists_plan(FastPlan* pl) {
+    pl->lists = true; pl->rw = pl->nbw + 1;             // the label rides in an extra record word
+    pl->wide = true;                                    // (payload = output position, side records: the WIDE plumbing of the count state)
+    pl->lmap = nullptr; pl->linv.on = 0; pl->weighted = false;
+}
 
-    FastCountState cs;
-    DBG_TRY(fast_count_begin(c, pl, prm->min_kmer_obs, n_kmers, &cs, report_all));
-    const uint64_t* seg_beg = seg.p;
-    const uint64_t* seg_end = seg.p + 2 * (size_t)nb;
-    const uint32_t n_src = st.n_recs ? 2u : 1u;
-    unsigned long long n_labels_raw = 0;
+// labels of a label-list run must be < 2^24: the segment sort packs (segment, label) into 32 bits, and the C ABI demands it (dbg_mi355x.h)
+static int lists_check_labels(dbg_ctx* c, const SeqDev& s) {
+    uint32_t mx = 0;
+    DBG_TRY(seq_max_label(c, s, &mx));
+    if (mx >= (1u << 24)) return c->fail(17, "D1 values must be < 2^24");
+    return 0;
+}
+
+static int lists_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, uint64_t n_kmers_hint, uint64_t lab_cap, bool report_all, ListCountState* st) {
+    st->min_obs = min_obs;
+    st->lab_cap = std::max<uint64_t>(lab_cap, 1); st->lab_used = 0;
+    if (!st->lab.p || st->lab.n < st->lab_cap) ALLOC_OR_FAIL(c, st->lab, st->lab_cap);       // (the caller may have reserved it already)
+    ALLOC_OR_FAIL(c, st->lab_cursor, 1);
+    return fast_count_begin(c, pl, min_obs, n_kmers_hint, &st->cs, report_all);
+}
+
+// bin_labels_kernel over `nbins_local` bins whose records arrive as n_src segments; valid k-mers and their label segments are appended
+// to the state.  An output or label buffer that turns out too small is grown (what earlier calls produced is kept) and the launch redone.
+static int lists_count_bins(dbg_ctx* c, ListCountState* st, const uint64_t* recs, const uint64_t* recs_alt, uint32_t alt_from,
+                            const uint64_t* seg_beg, const uint64_t* seg_end, uint32_t n_src, uint64_t seg_stride, uint32_t nbins_local,
+                            uint64_t n_kmers_units, uint64_t n_recs_hint) {
+    FastCountState& cs = st->cs;
+    const FastPlan& pl = cs.pl;
+    const int k = pl.k;
     for (int attempt = 0;; attempt++) {
-        unsigned long long zero = 0;
-        HIP_TRY(c, hipMemcpyAsync(cs.out_cursor.p, &zero, 8, hipMemcpyHostToDevice, c->stream));
-        if (report_all) HIP_TRY(c, hipMemcpyAsync(cs.all_cursor.p, &zero, 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(lab_cursor.p, 0, 8, c->stream));
+        unsigned long long start = cs.n_out, start_all = cs.n_all, start_lab = st->lab_used;
+        HIP_TRY(c, hipMemcpyAsync(cs.out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
+        if (cs.report_all) HIP_TRY(c, hipMemcpyAsync(cs.all_cursor.p, &start_all, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(st->lab_cursor.p, &start_lab, 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemsetAsync(cs.gflags.p, 0, 64, c->stream));
         FastOut fo{cs.u_hi.p, cs.u_lo.p, cs.u_pay.p, cs.use16 ? cs.u16.p : nullptr, cs.w_rec.p,
-                   report_all ? cs.a_hi.p : nullptr, report_all ? cs.a_lo.p : nullptr, report_all ? cs.all_cursor.p : nullptr, cs.all_cap};
-        ListOut lo{lab_out.p, n_kmers, lab_cursor.p};
-        c->t_begin("bin_labels", n_kmers);
-#define ARGS_ slab.p, ovf_recs.p, slab_lab.p, ovf_lab.p, 1u, seg_beg, seg_end, n_src, (uint64_t)nb, k, pl.stranded ? 1 : 0, (uint64_t)prm->min_kmer_obs, fo, cs.cap, cs.out_cursor.p, lo, cs.gflags.p
-        if (!pl.has_hi) bin_labels_kernel<1, 2, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
-        else if (pl.nbw == 2) bin_labels_kernel<2, 2, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
-        else if (pl.nbw == 3) bin_labels_kernel<2, 3, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
-        else bin_labels_kernel<2, 4, 512, 2048><<<pl.nbins, 512, 0, c->stream>>>(ARGS_);
+                   cs.report_all ? cs.a_hi.p : nullptr, cs.report_all ? cs.a_lo.p : nullptr, cs.report_all ? cs.all_cursor.p : nullptr, cs.all_cap};
+        ListOut lo{st->lab.p, st->lab_cap, st->lab_cursor.p};
+        if (nbins_local) {
+            if ((uint64_t)nbins_local * 512 >= (1ull << 32)) return c->fail(135, "fast path: too many bins for the workgroup counting kernel (a grid holds < 2^32 threads)");
+            c->t_begin("bin_labels", n_kmers_units);
+#define ARGS_ recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, st->min_obs, fo, cs.cap, cs.out_cursor.p, lo, cs.gflags.p
+            if (!pl.has_hi) bin_labels_kernel<1, 2, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
+            else if (pl.nbw == 2) bin_labels_kernel<2, 2, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
+            else if (pl.nbw == 3) bin_labels_kernel<2, 3, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
+            else bin_labels_kernel<2, 4, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
 #undef ARGS_
-        c->t_end();
-        LAUNCH_CHECK(c, "bin_labels");
-        unsigned long long cur = 0, cur_all = 0;
+            c->t_end();
+            LAUNCH_CHECK(c, "bin_labels");
+        }
+        unsigned long long cur = 0, cur_all = 0, cur_lab = 0;
         uint32_t flv[16] = {0};
         HIP_TRY(c, hipMemcpyAsync(&cur, cs.out_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-        if (report_all) HIP_TRY(c, hipMemcpyAsync(&cur_all, cs.all_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&n_labels_raw, lab_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        if (cs.report_all) HIP_TRY(c, hipMemcpyAsync(&cur_all, cs.all_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&cur_lab, st->lab_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(flv, cs.gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: bins=%u recs=%llu valid=%llu labels appended=%llu flags=%u maxP=%u split_passes=%u wd=%u\n",
-                                         pl.nbins, n_recs_total, cur, n_labels_raw, flv[0], flv[1], flv[2], flv[3]);
+        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: bins=%u srcs=%u recs=%llu valid=%llu labels appended=%llu (room for %llu) flags=%u maxP=%u split_passes=%u wd=%u\n",
+                                         nbins_local, n_src, (unsigned long long)n_recs_hint, cur, cur_lab, (unsigned long long)st->lab_cap, flv[0], flv[1], flv[2], flv[3]);
         if (flv[3] & 4u) return c->fail(134, "fast path: corrupt super-k-mer record (record buffer or segment table of the counting stage is wrong)");
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (flv[0] & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
-        if (flv[0] & 16u) return c->fail(138, "fast path: the label buffer is smaller than the observations of the valid k-mers");
-        if (flv[0] & 9u) {
+        if (flv[0] & 25u) {
             if (attempt >= 3 || cur >= (1ull << 32) || cur_all >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 k-mers in one table");
             if (flv[0] & 1u) DBG_TRY(fast_count_alloc(c, &cs, cur + cur / 16 + 1024));
             if (flv[0] & 8u) DBG_TRY(fast_count_alloc_all(c, &cs, cur_all + cur_all / 16 + 1024));
+            if (flv[0] & 16u) {                                  // (the cursor went on counting: it holds what this launch wants)
+                const uint64_t want = cur_lab + cur_lab / 16 + 4096;
+                DBuf<uint32_t> nl;
+                ALLOC_OR_FAIL(c, nl, want);
+                if (st->lab_used) HIP_TRY(c, hipMemcpyAsync(nl.p, st->lab.p, st->lab_used * 4, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                std::swap(st->lab, nl);
+                st->lab_cap = want;
+            }
             continue;
         }
-        cs.n_out = cur;
-        cs.n_all = cur_all;
+        cs.n_out = cur; cs.n_all = cur_all; st->lab_used = cur_lab;
         break;
     }
-    slab.release(); slab_lab.release(); ovf_recs.release(); ovf_lab.release();
+    return 0;
+}
 
-    // order-restoring sort, then the lists in table order
+// order-restoring sort of everything counted so far, then the lists in table order
+static int lists_count_finish(dbg_ctx* c, ListCountState* st, dbg_kmer_table* out) {
+    FastCountState& cs = st->cs;
+    const FastPlan& pl = cs.pl;
+    const int k = pl.k;
+    const bool has_hi = pl.has_hi, report_all = cs.report_all;
     const uint64_t n_out = cs.n_out;
     const size_t na = std::max<uint64_t>(n_out, 1);
     DBuf<uint64_t> seg_off;
     DBuf<uint32_t> setn;
     ALLOC_OR_FAIL(c, seg_off, na); ALLOC_OR_FAIL(c, setn, na);
-    // (fast_count_finish gathers colour masks; the lists need their own gather, so the sort is driven here)
     {
-        const bool has_hi = pl.has_hi;
         DBuf<uint32_t> t_pay, msk_sorted;
         DBuf<uint64_t> t_hi, t_lo, o_hi, o_lo, o_set_off;
         DBuf<uint8_t> o_exts;
@@ -823,7 +825,7 @@ static int filter_kmers_fast_lists(dbg_ctx* c, const SeqDev& s, const dbg_filter
         ALLOC_OR_FAIL(c, o_set_val, std::max<uint64_t>(n_setval, 1));
         if (n_out) {
             c->t_begin("set_csr", n_out);
-            ll_csr_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, o_set_off.p, seg_off.p, lab_out.p, o_set_val.p);
+            ll_csr_kernel<<<cdiv(n_out, 256), 256, 0, c->stream>>>((uint32_t)n_out, o_set_off.p, seg_off.p, st->lab.p, o_set_val.p);
             c->t_end();
             LAUNCH_CHECK(c, "ll_csr");
         }
@@ -832,12 +834,11 @@ static int filter_kmers_fast_lists(dbg_ctx* c, const SeqDev& s, const dbg_filter
         out->n = n_out;
         out->key_hi = o_hi.take(); out->key_lo = o_lo.take(); out->exts = o_exts.take();
         out->set_off = o_set_off.take(); out->set_val = o_set_val.take(); out->n_set_val = n_setval;
-        out->n_kmer_instances = n_kmers; out->n_passes = 1; out->on_device = 1;
+        out->n_kmer_instances = cs.n_kmers_hint; out->n_passes = 1; out->on_device = 1;
     }
     if (report_all) {
         const uint64_t n_all = cs.n_all;
         const size_t naa = std::max<uint64_t>(n_all, 1);
-        const bool has_hi = pl.has_hi;
         DBuf<uint64_t> b_hi, b_lo, f_hi, f_lo;
         DBuf<uint32_t> a_pay, b_pay;
         DBuf<uint8_t> x_exts;
@@ -852,6 +853,49 @@ static int filter_kmers_fast_lists(dbg_ctx* c, const SeqDev& s, const dbg_filter
         out->n_all = n_all;
         out->all_hi = f_hi.take(); out->all_lo = f_lo.take();
     }
+    return 0;
+}
+
+// *used = false (and nothing written): not enough device memory for the label buffer -- the caller takes label groups or the generic path
+static int filter_kmers_fast_lists(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm, uint64_t n_kmers, dbg_kmer_table* out, bool* used) {
+    *used = false;
+    const int k = (int)prm->k;
+    FastPlan pl;
+    if (!fast_make_plan(c, k, prm->stranded != 0, true, n_kmers, 0, &pl)) return 0;
+    lists_plan(&pl);
+    DBG_TRY(lists_check_labels(c, s));
+    ListCountState st;
+    // every instance of a valid k-mer appends one label: n_kmers places always suffice
+    if (!st.lab.alloc(c, std::max<uint64_t>(n_kmers, 1))) return 0;
+    if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: %llu k-mer instances, label buffer %.2f GB\n", (unsigned long long)n_kmers, n_kmers * 4e-9);
+
+    FastScan sc;
+    DBG_TRY(fast_scan(c, s, pl, n_kmers, &sc, true));
+    const uint32_t nb = pl.nbins * NCLS;
+    DBuf<uint64_t> ovf_off, ovf_recs, seg;
+    DBuf<unsigned long long> total;
+    ALLOC_OR_FAIL(c, ovf_off, (size_t)nb + 1);
+    DBG_TRY(fast_bin_offsets(c, &sc, ovf_off.p, false));
+    ALLOC_OR_FAIL(c, ovf_recs, std::max<uint64_t>(sc.n_recs * pl.rw, 1));
+    DBuf<uint64_t> slab;
+    DBuf<uint32_t> cursor;
+    std::swap(slab, sc.slab); std::swap(cursor, sc.cursor);
+    const uint32_t slab_cap = sc.slab_cap;
+    DBG_TRY(fast_scatter(c, &sc, ovf_off.p, ovf_recs.p));
+    ALLOC_OR_FAIL(c, seg, (size_t)nb * 4);
+    ALLOC_OR_FAIL(c, total, 1);
+    HIP_TRY(c, hipMemsetAsync(total.p, 0, 8, c->stream));
+    slab_bounds_kernel<<<cdiv(nb, 256), 256, 0, c->stream>>>(cursor.p, slab_cap, ovf_off.p, nb, seg.p, seg.p + 2 * (size_t)nb, total.p);
+    LAUNCH_CHECK(c, "slab_bounds");
+    unsigned long long n_recs_total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_recs_total, total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->t_begin("sk_records", n_recs_total);
+    c->t_end();
+    DBG_TRY(lists_count_begin(c, pl, prm->min_kmer_obs, n_kmers, n_kmers, prm->report_all_kmers != 0, &st));
+    DBG_TRY(lists_count_bins(c, &st, slab.p, ovf_recs.p, 1, seg.p, seg.p + 2 * (size_t)nb, sc.n_recs ? 2u : 1u, (uint64_t)nb, pl.nbins, n_kmers, n_recs_total));
+    slab.release(); ovf_recs.release();
+    DBG_TRY(lists_count_finish(c, &st, out));
     *used = true;
     return 0;
 }

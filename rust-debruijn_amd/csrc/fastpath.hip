@@ -36,10 +36,6 @@ struct FastCfg {
     uint32_t nbins;
     const uint8_t* lmap;        // D1 label -> dense colour index (sparse label alphabets), or null: the label is the index
     int strand_norm;            // store every piece as the smaller of (piece, reverse complement): non-stranded counting with odd k
-    // label lists (fast_labellists.hpp): the read's full D1 label goes to a side array at the record's index -- lab_slab next to
-    // the slabs (bin * slab_cap + slot), lab_tmp next to the read-order buffer; null = the 6-bit colour in the record is all there is
-    uint32_t* lab_slab = nullptr;
-    uint32_t* lab_tmp = nullptr;
 };
 
 // p-mer from the two words that hold it (w1 is ignored when the p-mer ends inside w0): no branches
@@ -127,9 +123,12 @@ constexpr uint32_t NCLS = 1;                    // length classes per bin: recor
 // bin); only the records of bins that outgrow their slab take the read-order temporary buffer and the scatter kernel.
 constexpr uint32_t PLC = 256;                   // ring slots per wave (wave-per-read kernel: 4 words per piece)
 constexpr uint32_t PLC_PACKED = 128;            // lane-per-read kernel: 2 words per piece {start | end << 11 | lane << 22, hash}
-template <int NBW, bool DIRECT, bool PACKED = false>
+// LAB (label lists, fast_labellists.hpp): the record has one more word, which carries the read's full D1 label -- the 6-bit colour in
+// the meta bits is all there is otherwise.  (First form: a side array at the record's index; the second scattered store cost the
+// scan 8 of 40 ms at the C2 shape, and the exchange of the sharded flow would have had to carry two streams.)
+template <int NBW, bool DIRECT, bool PACKED = false, bool LAB = false>
 struct PieceEmitter {
-    static constexpr int RW = NBW;
+    static constexpr int RW = NBW + (LAB ? 1 : 0);
     static constexpr uint32_t CAP = PACKED ? PLC_PACKED : PLC;
     const SeqDev& s;
     const FastCfg& c;
@@ -247,6 +246,7 @@ struct PieceEmitter {
                 }
             }
             rv[NBW - 1] |= (uint64_t)len | ((uint64_t)((re << 4) | le) << 7) | ((uint64_t)(d1 & 63u) << 15);
+            if (LAB) rv[RW - 1] = (uint64_t)d1;
         }
         auto store_rec = [&](uint64_t* o) {
             if (RW % 2 == 0) {
@@ -261,10 +261,7 @@ struct PieceEmitter {
         if (DIRECT) {
             to_tmp = act && r >= slab_cap;
 #ifndef DBG_ABL_NO_STORE
-            if (act && !to_tmp) {
-                store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
-                if (c.lab_slab) c.lab_slab[(uint64_t)b * slab_cap + r] = d1;
-            }
+            if (act && !to_tmp) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
 #else
             if (act && !to_tmp && rv[0] == 0x123456789ull) store_rec(slab + ((uint64_t)b * slab_cap + r) * RW);
 #endif
@@ -285,13 +282,12 @@ struct PieceEmitter {
             atomicAdd(&hist[b], 1u);
             store_rec(tmp_recs + idx * RW);
             tmp_bin[idx] = b;
-            if (c.lab_tmp) c.lab_tmp[idx] = d1;
         }
     }
 };
 
 // Wave-per-read scan (reads longer than long_min bases: contigs, long reads).
-template <int NBW, bool DIRECT>
+template <int NBW, bool DIRECT, bool LAB = false>
 __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
                                                       uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
                                                       unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
@@ -311,7 +307,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
     const uint64_t gwave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t lt = lanemask_lt();
-    PieceEmitter<NBW, DIRECT> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
+    PieceEmitter<NBW, DIRECT, false, LAB> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
 
     // 64 reads per wave iteration: their metadata arrives in three coalesced loads and is broadcast
     // lane by lane, so the per-read critical path holds a single HBM round trip (the packed words).
@@ -484,7 +480,7 @@ __global__ void __launch_bounds__(256) sk_scan_kernel(SeqDev s, FastCfg c, uint3
 // one LDS round trip serves four steps.
 constexpr uint32_t SCAN_LANE_MAX = 1024;        // longer reads go to the wave-per-read kernel (a wave lasts as long as its longest read)
 __host__ __device__ constexpr uint32_t scan_lane_lds_words(uint32_t W) { return (W + 1) * 64 + 2 * PLC_PACKED; }
-template <int NBW, bool DIRECT>
+template <int NBW, bool DIRECT, bool LAB = false>
 __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, uint32_t* __restrict__ hist,
                                                            uint64_t* __restrict__ tmp_recs, uint32_t* __restrict__ tmp_bin,
                                                            unsigned long long* __restrict__ tmp_cursor, uint64_t tmp_cap,
@@ -502,7 +498,7 @@ __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, u
     const uint64_t last_word = s.n_words ? s.n_words - 1 : 0;
     const uint64_t gwave = blockIdx.x, nwaves = gridDim.x;
     const uint64_t lt = lanemask_lt();
-    PieceEmitter<NBW, DIRECT, true> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
+    PieceEmitter<NBW, DIRECT, true, LAB> E{s, c, hist, tmp_recs, tmp_bin, tmp_cursor, tmp_cap, flags, slab, slab_cap, cursor, PL, lane, lt, last_word};
     const uint32_t pmask = (1u << (2 * p)) - 1u, top = 2u * (uint32_t)(p - 1);      // p <= 15
     const bool stranded = c.stranded != 0;
 
@@ -637,18 +633,15 @@ __global__ void __launch_bounds__(64) sk_scan_lane_kernel(SeqDev s, FastCfg c, u
     }
 }
 
-template <int NBW>
+template <int RW>
 __global__ void __launch_bounds__(256) sk_scatter_kernel(const uint64_t* __restrict__ tmp_recs, const uint32_t* __restrict__ tmp_bin,
                                                          uint64_t n_recs, const uint64_t* __restrict__ bin_off,
-                                                         uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs,
-                                                         const uint32_t* __restrict__ tmp_lab = nullptr, uint32_t* __restrict__ lab_out = nullptr) {
-    constexpr int RW = NBW;
+                                                         uint32_t* __restrict__ cursor, uint64_t* __restrict__ recs) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_recs) return;
     uint32_t b = tmp_bin[i];
     if (b == BIN_INVALID) return;
     uint64_t r = bin_off[b] + atomicAdd(&cursor[b], 1u);
-    if (tmp_lab) lab_out[r] = tmp_lab[i];
     const uint64_t* src = tmp_recs + i * RW;
     uint64_t* dst = recs + r * RW;
     if (RW % 2 == 0) {                                   // 32-byte records: two 16-byte moves
@@ -1497,7 +1490,7 @@ struct FastPlan {
     bool stranded, is_set, has_hi;
     bool wide = false;                                  // colour sets of 25..64 colours: two mask words per table entry, payload gathered after the sort
     bool weighted = false;                              // sharded flow: records may carry a weight (sender-side duplicate merge) in the WEIGHT_BITS above the meta bits
-    bool lists = false;                                 // label lists (fast_labellists.hpp): the scan keeps every record's full D1 label in a side array
+    bool lists = false;                                 // label lists (fast_labellists.hpp): rw = nbw + 1, the extra record word carries the read's full D1 label
     uint32_t nbins;
     LabelInv linv = {};
     const uint8_t* lmap = nullptr;                      // device table label -> colour index (owned by the caller of fast_labels_prepare)
@@ -1537,7 +1530,6 @@ struct FastScan {
     DBuf<uint64_t> slab;
     DBuf<uint32_t> cursor;
     uint32_t slab_cap = 0;
-    DBuf<uint32_t> slab_lab, tmp_lab;                   // pl.lists: labels of the records in the slabs / in the read-order buffer
 };
 
 // which D1 labels (< 65536) occur: one bit each; bitmap[2048] != 0 when a label >= 65536 was seen
@@ -1659,7 +1651,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     st->pl = pl; st->n_kmers = n_kmers;
     const int k = pl.k, p = pl.p, nbw = pl.nbw, rw = pl.rw;
     const uint32_t nbins = pl.nbins * NCLS;                      // sub-bins (bin, length class)
-    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap, (!pl.stranded && (k & 1) && !c->opt("DBG_NO_STRAND_NORM")) ? 1 : 0, nullptr, nullptr};
+    FastCfg cfg{k, p, pl.stranded, pl.nbins, pl.lmap, (!pl.stranded && (k & 1) && !c->opt("DBG_NO_STRAND_NORM")) ? 1 : 0};
     SeqDev sd = s;
     if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
     DBuf<uint32_t> sflags;
@@ -1677,8 +1669,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
         if (const char* e = c->opt("DBG_SLAB_CAP")) st->slab_cap = (uint32_t)std::max(4, atoi(e)) & ~3u;      // measurement: records per slab
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw) &&
-            (!pl.lists || st->slab_lab.alloc(c, (uint64_t)nbins * st->slab_cap))) tmp_cap = tmp_cap / 16 + 4096;
+        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
         else {
             // not enough memory for slabs (1.3x the records + slack): every record takes the read-order buffer and the
             // scatter pass instead -- slab capacity 0 routes them all there
@@ -1692,7 +1683,6 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     for (int attempt = 0;; attempt++) {
         ALLOC_OR_FAIL(c, st->tmp_recs, tmp_cap * rw);
         ALLOC_OR_FAIL(c, st->tmp_bin, tmp_cap);
-        if (pl.lists) { ALLOC_OR_FAIL(c, st->tmp_lab, tmp_cap); cfg.lab_slab = st->slab_cap ? st->slab_lab.p : nullptr; cfg.lab_tmp = st->tmp_lab.p; }
         HIP_TRY(c, hipMemsetAsync(st->hist.p, 0, (size_t)nbins * 4, c->stream));
         HIP_TRY(c, hipMemsetAsync(tmp_cursor.p, 0, 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(sflags.p, 0, 8, c->stream));
@@ -1717,10 +1707,11 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
             const size_t lds = (size_t)scan_lane_lds_words(W) * sizeof(uint32_t) + DBG_SCAN_LDS_PAD;
             uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 63) / 64, 256ull * 16 * 4));
             c->t_begin("sk_scan", n_kmers);
-#define SCANL(NBW_, D_) do { HIP_TRY(c, hipFuncSetAttribute((const void*)sk_scan_lane_kernel<NBW_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            sk_scan_lane_kernel<NBW_, D_><<<lane_blocks, 64, lds, c->stream>>>(SCAN_ARGS); } while (0)
-#define SCANL_GO() do { if (direct) { if (nbw == 2) SCANL(2, true); else if (nbw == 3) SCANL(3, true); else SCANL(4, true); } \
-            else { if (nbw == 2) SCANL(2, false); else if (nbw == 3) SCANL(3, false); else SCANL(4, false); } } while (0)
+#define SCANL(NBW_, D_, L_) do { HIP_TRY(c, hipFuncSetAttribute((const void*)sk_scan_lane_kernel<NBW_, D_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            sk_scan_lane_kernel<NBW_, D_, L_><<<lane_blocks, 64, lds, c->stream>>>(SCAN_ARGS); } while (0)
+#define SCANL_D(NBW_, L_) do { if (direct) SCANL(NBW_, true, L_); else SCANL(NBW_, false, L_); } while (0)
+#define SCANL_GO() do { if (pl.lists) { if (nbw == 2) SCANL_D(2, true); else if (nbw == 3) SCANL_D(3, true); else SCANL_D(4, true); } \
+            else { if (nbw == 2) SCANL_D(2, false); else if (nbw == 3) SCANL_D(3, false); else SCANL_D(4, false); } } while (0)
             if (!gates) SCANL_GO();
             else {
                 uint64_t r0 = 0;
@@ -1740,6 +1731,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
                 cur_reads = sd;
             }
 #undef SCANL_GO
+#undef SCANL_D
 #undef SCANL
             c->t_end();
             LAUNCH_CHECK(c, "sk_scan_lane");
@@ -1750,9 +1742,11 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         if (!lane_scan || sfl[1]) {
             const uint32_t long_min = lane_scan ? SCAN_LANE_MAX : 0u;
             c->t_begin(lane_scan ? "sk_scan_long" : "sk_scan", lane_scan ? 0 : n_kmers);
-#define SCAN(NBW_, D_) sk_scan_kernel<NBW_, D_><<<scan_blocks, 256, 0, c->stream>>>(SCAN_ARGS, long_min)
-            if (direct) { if (nbw == 2) SCAN(2, true); else if (nbw == 3) SCAN(3, true); else SCAN(4, true); }
-            else { if (nbw == 2) SCAN(2, false); else if (nbw == 3) SCAN(3, false); else SCAN(4, false); }
+#define SCAN(NBW_, D_, L_) sk_scan_kernel<NBW_, D_, L_><<<scan_blocks, 256, 0, c->stream>>>(SCAN_ARGS, long_min)
+#define SCAN_D(NBW_, L_) do { if (direct) SCAN(NBW_, true, L_); else SCAN(NBW_, false, L_); } while (0)
+            if (pl.lists) { if (nbw == 2) SCAN_D(2, true); else if (nbw == 3) SCAN_D(3, true); else SCAN_D(4, true); }
+            else { if (nbw == 2) SCAN_D(2, false); else if (nbw == 3) SCAN_D(3, false); else SCAN_D(4, false); }
+#undef SCAN_D
 #undef SCAN
             c->t_end();
             LAUNCH_CHECK(c, "sk_scan");
@@ -1785,7 +1779,7 @@ static int fast_bin_offsets(dbg_ctx* c, FastScan* st, uint64_t* bin_off_out, boo
     }
     return 0;
 }
-static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out, uint32_t* lab_out = nullptr) {
+static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint64_t* recs_out) {
     const uint32_t nbins = st->pl.nbins * NCLS;
     DBuf<uint32_t> cursor;
     ALLOC_OR_FAIL(c, cursor, nbins);
@@ -1793,14 +1787,14 @@ static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint6
     if (st->n_tmp) {
         const uint64_t n_tmp = st->n_tmp;
         c->t_begin("sk_scatter", st->n_recs);
-        const uint32_t* tl = lab_out ? st->tmp_lab.p : nullptr;
-        if (st->pl.nbw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out, tl, lab_out);
-        else if (st->pl.nbw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out, tl, lab_out);
-        else sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out, tl, lab_out);
+        if (st->pl.rw == 2) sk_scatter_kernel<2><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
+        else if (st->pl.rw == 3) sk_scatter_kernel<3><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
+        else if (st->pl.rw == 4) sk_scatter_kernel<4><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
+        else sk_scatter_kernel<5><<<cdiv(n_tmp, 256), 256, 0, c->stream>>>(st->tmp_recs.p, st->tmp_bin.p, n_tmp, bin_off, cursor.p, recs_out);
         c->t_end();
         LAUNCH_CHECK(c, "sk_scatter");
     }
-    st->tmp_recs.release(); st->tmp_bin.release(); st->hist.release(); st->tmp_lab.release();
+    st->tmp_recs.release(); st->tmp_bin.release(); st->hist.release();
     return 0;
 }
 
