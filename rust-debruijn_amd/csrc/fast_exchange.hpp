@@ -125,6 +125,8 @@ struct XRun {
     DBuf<unsigned long long>* keep_masks = nullptr;     // label-group runs
     int lrc_in = 0;                                     // status of the rank-local work done before the run
     bool main_run = true;                               // the call's own table (timing records cleared, merge statistics kept)
+    bool lists = false;                                 // CountFilterSet over a large label alphabet: label lists (fast_labellists.hpp) -- the records
+                                                        // carry their read's label in an extra word, the owners run bin_labels_kernel round by round
 };
 
 // scan -> ownership -> layout -> pipelined exchange rounds -> count -> sort, over the plan sp (see the header of this file)
@@ -144,7 +146,12 @@ int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const 
     if (o.main_run) c->t_clear();
     lrc = [&]() -> int {
         if (o.lrc_in) return o.lrc_in;                              // (rank-local work before this run failed: c->err holds its message)
-        DBG_TRY(plan_from(c, &sp, &pl));
+        if (o.lists) {                                              // (no colour layout to agree on: labels travel as they are)
+            dbg_shard_plan spp = sp;
+            spp.max_label = 0; spp.n_labels = 0;
+            DBG_TRY(plan_from(c, &spp, &pl));
+            lists_plan(&pl);
+        } else DBG_TRY(plan_from(c, &sp, &pl));
         nb = pl.nbins * NCLS; rw = (uint32_t)pl.rw;
         if (X.inject("scan")) return X.injected("scan");
         DBG_TRY(shard_scan_core(c, ds, &sp, pl, &sc));
@@ -282,6 +289,7 @@ int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const 
     EventSet events(c);
     std::vector<hipEvent_t> ev_done(R), ev_a(R), ev_b(R), ev_w0(R), ev_w1(R), ev_counted(R);
     std::unique_ptr<FastCountState> cs(new FastCountState());
+    std::unique_ptr<ListCountState> ls(new ListCountState());
     auto compact_round = [&](uint32_t r, hipStream_t stream) -> int {
         for (uint32_t d = 0; d < W; d++) {
             const uint32_t b0 = bounds[d] + cutc[(size_t)d * (R + 1) + r], b1 = bounds[d] + cutc[(size_t)d * (R + 1) + r + 1];
@@ -289,7 +297,7 @@ int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const 
             const uint32_t nbr = b1 - b0, blocks = cdiv((uint64_t)nbr * 64, 256);
             const uint64_t* slab_r = sc.slab.p + (uint64_t)b0 * sc.slab_cap * rw;
 #define COMPACT(RW_) slab_compact_kernel<RW_><<<blocks, 256, 0, stream>>>(slab_r, sc.slab_cap, sc.cursor.p + b0, off.p + b0, nbr, recs.p, ovf_base.p + b0)
-            if (rw == 2) COMPACT(2); else if (rw == 3) COMPACT(3); else COMPACT(4);
+            if (rw == 2) COMPACT(2); else if (rw == 3) COMPACT(3); else if (rw == 4) COMPACT(4); else COMPACT(5);
 #undef COMPACT
             LAUNCH_CHECK(c, "slab_compact");
         }
@@ -360,6 +368,14 @@ int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const 
         if (R > 1) ALLOC_OR_FAIL(c, rbuf[1], std::max<uint64_t>(max_recv * rw, 1));
         for (uint32_t r = 0; r < R; r++) { ev_done[r] = events.get(); ev_a[r] = events.get(); ev_b[r] = events.get(); ev_w0[r] = events.get(); ev_w1[r] = events.get(); ev_counted[r] = events.get(); }
         if (X.inject("count_begin")) return X.injected("count_begin");
+        if (pl.lists) {
+            // room for one label per k-mer instance this rank will count: its records' share of the instances it scanned, with a margin
+            // (lists_count_bins grows the buffer if a round wants more)
+            const double per_rec = n_recs ? (double)std::max<uint64_t>(n_local, 1) / (double)n_recs : 16.0;
+            const uint64_t lab_cap = (uint64_t)((double)owned * per_rec * 1.15) + 65536;
+            DBG_TRY(lists_count_begin(c, pl, sp.min_kmer_obs, std::max<uint64_t>(n_local, 1), lab_cap, false, ls.get()));
+            return 0;
+        }
         DBG_TRY(fast_count_begin(c, pl, sp.min_kmer_obs, std::max<uint64_t>(n_local, 1), cs.get()));
         cs->keep_masks = o.keep_masks;                              // (label-group runs: the sorted 64-bit masks instead of a CSR)
         return 0;
@@ -412,7 +428,10 @@ int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const 
         (void)hipEventRecord(ev_b[r], c->stream);
         const uint32_t nbc = mycut[r + 1] - mycut[r];
         if (!lrc && X.inject("round") && r == std::min<uint32_t>(1, R - 1)) lrc = X.injected("round");
-        if (nbc && !lrc)
+        if (nbc && !lrc && pl.lists)
+            lrc = lists_count_bins(c, ls.get(), recs.p, rbuf[r & 1].p, 1, seg.p + tab_off[r], seg.p + tab_off[r] + 1, W, (uint64_t)nbc + 1, nbc / NCLS,
+                                   std::max<uint64_t>(n_local, 1) / R, 0);
+        else if (nbc && !lrc)
             lrc = fast_count_bins(c, cs.get(), recs.p, rbuf[r & 1].p, 1, seg.p + tab_off[r], seg.p + tab_off[r] + 1, W, (uint64_t)nbc + 1, nbc / NCLS,
                                   std::max<uint64_t>(n_local, 1) / R, 0);
         else (void)hipStreamSynchronize(c->stream);
@@ -437,7 +456,7 @@ int shard_exchange_run(dbg_ctx* c, ShardComm& X, const dbg_transport* tr, const 
 
     // ---- phase "finish": one order-restoring sort of everything counted ----
     if (!lrc && X.inject("finish")) lrc = X.injected("finish");
-    if (!lrc) lrc = fast_count_finish(c, cs.get(), out);
+    if (!lrc) lrc = pl.lists ? lists_count_finish(c, ls.get(), out) : fast_count_finish(c, cs.get(), out);
     const int arc = X.agree(lrc, "finish");
     if (arc) {
         if (!lrc) { dbg_free_table(c, out); memset(out, 0, sizeof(*out)); }    // this rank's table is of no use without the others'
@@ -664,7 +683,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     // Shapes the super-k-mer exchange does not take -- k < 16, more than 64 distinct labels over all ranks, labels >= 65536 -- go
     // the key-range route (shard_generic.hip): decided from values every rank holds alike.  DBG_PATH=generic insists on it.
     bool key_range_route = p->k < 16 || (c->opt("DBG_PATH") && !strcmp(c->opt("DBG_PATH"), "generic"));
-    bool label_groups = false;
+    bool label_groups = false, label_lists = false;
     std::vector<uint32_t> label_list;                            // the distinct labels of all ranks, ascending (labels >= 64 only)
 
     dbg_shard_plan sp;
@@ -686,8 +705,12 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
         for (uint32_t v = 0; v < 65536; v++) if (pres[v]) { if (nl < 64) sp.labels[nl] = v; nl++; label_list.push_back(v); }
         // 65 .. 1024 distinct labels (all < 65536): label groups of 64, as on one GPU (fast_manylabels.hpp); beyond that, or labels
         // >= 65536, or a threshold the u16 counts cannot decide: the key-range route
-        label_groups = !pres[65536] && nl > 64 && nl <= 64u * ML_MAX_GROUPS && p->min_kmer_obs <= 65535 && !c->opt("DBG_NO_LABEL_GROUPS");
-        if (pres[65536] || (nl > 64 && !label_groups)) key_range_route = true;
+        // More than 64 distinct labels over all ranks, or labels >= 65536: label lists (round 5; every value is one all ranks hold alike).
+        // With DBG_LABEL_LISTS=0: label groups for 65 .. 1024 labels < 65536, the key-range route beyond.
+        label_lists = (pres[65536] || nl > 64) && max_label < (1u << 24) && !(c->opt("DBG_LABEL_LISTS") && !strcmp(c->opt("DBG_LABEL_LISTS"), "0"));
+        label_groups = !label_lists && !pres[65536] && nl > 64 && nl <= 64u * ML_MAX_GROUPS && p->min_kmer_obs <= 65535 && !c->opt("DBG_NO_LABEL_GROUPS");
+        if (label_lists) {}
+        else if (pres[65536] || (nl > 64 && !label_groups)) key_range_route = true;
         else if (nl <= 64) sp.n_labels = nl;
     }
     if (key_range_route) {
@@ -709,6 +732,7 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     for (uint32_t v = 0; v < (uint32_t)label_list.size(); v++) labels_all.push_back(label_list[v]);
     XRun o;
     o.n_rounds = p->n_rounds; o.balance = p->balance != 0; o.merge = merge; o.n_local = n_local; o.n_max = n_max; o.total = total;
+    if (label_lists) { o.lists = true; o.merge = 0; }                    // (records with different labels must stay apart: no sender-side merge)
     if (label_groups) return shard_filter_label_groups(c, X, tr, ds, p, sp, o, labels_all, out, S, t_setup);
     return shard_exchange_run(c, X, tr, ds, sp, o, out, S, t_setup);
 }

@@ -2374,7 +2374,8 @@ extern "C" int dbg_shard_plan_make(dbg_ctx* c, dbg_shard_plan* sp) {
 static int shard_scan_core(dbg_ctx* c, const dbg_seqset* ds, const dbg_shard_plan* sp, FastPlan pl, FastScan* st) {
     SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, ds->data ? ds->data_width : 0u, ds->n_seqs, ds->n_words};
     DBuf<uint8_t> lmap_buf;                          // label -> colour index (sparse alphabets); lives until the scan is done
-    if (pl.is_set && sp->n_labels) {
+    if (pl.lists) {}                                 // (label lists: the labels travel as they are, checked < 2^24 by the caller)
+    else if (pl.is_set && sp->n_labels) {
         std::vector<uint32_t> hb;
         DBG_TRY(seq_label_bitmap(c, s, &hb));
         const uint32_t top = sp->labels[sp->n_labels - 1];

@@ -81,7 +81,7 @@ def make_reads(seed, k, n_reads=900, kind=0, n_labels=5):
 class Job:
     """world contexts + one in-process group, kept across calls (the point: they stay usable after an agreed failure)"""
 
-    def __init__(self, world, k, kind, seed, n_labels=5, n_reads=900):
+    def __init__(self, world, k, kind, seed, n_labels=5, n_reads=900, lists=True):
         self.world, self.k, self.kind = world, k, kind
         self.lib = capi.load()
         self.keep = make_group(world)
@@ -89,6 +89,8 @@ class Job:
         self.ctxs = [dbg.Context(0) for _ in range(world)]
         for c in self.ctxs:
             c.set_option("DBG_COMPRESS", "device")
+            if not lists:                                             # alphabets beyond 64 colours: label groups / the key-range route instead of label lists
+                c.set_option("DBG_LABEL_LISTS", "0")
         self.seqs, self.data = make_reads(seed, k, n_reads=n_reads, kind=kind, n_labels=n_labels)
         n = len(self.seqs)
         self.bounds = [n * r // world for r in range(world + 1)]
@@ -163,13 +165,18 @@ class Job:
             self.lib.dbg_transport_destroy(self.keep[r])
 
 
-@pytest.mark.parametrize("world,k,kind,n_labels", [(3, 31, 0, 5), (2, 47, 1, 5), (3, 33, 1, 150), (2, 12, 1, 5), (3, 40, 1, 60000)])
-def test_injected_failure_in_shard_filter_fails_all_ranks_together(world, k, kind, n_labels):
-    """(the last three shapes: label groups -- 150 distinct labels, one CountFilter run + three group runs, failures in the
-    rank-local steps between the runs included -- and the key-range route for k < 16 and for > 1024 distinct labels)"""
-    job = Job(world, k, kind, seed=5100 + world, n_labels=n_labels, n_reads=2600 if n_labels > 1024 else 900)
+@pytest.mark.parametrize("world,k,kind,n_labels,lists", [(3, 31, 0, 5, True), (2, 47, 1, 5, True), (3, 33, 1, 150, False), (2, 12, 1, 5, True), (3, 40, 1, 60000, False),
+                                                         (3, 33, 1, 150, True), (2, 40, 1, 60000, True)])
+def test_injected_failure_in_shard_filter_fails_all_ranks_together(world, k, kind, n_labels, lists):
+    """(shapes 3-5: label groups -- 150 distinct labels with DBG_LABEL_LISTS=0, one CountFilter run + three group runs, failures in the
+    rank-local steps between the runs included -- and the key-range route for k < 16 and, with DBG_LABEL_LISTS=0, for > 1024 distinct
+    labels; the last two: label lists, the default beyond 64 colours -- the sites of the super-k-mer exchange, with bin_labels_kernel
+    counting the rounds)"""
+    job = Job(world, k, kind, seed=5100 + world, n_labels=n_labels, n_reads=2600 if n_labels > 1024 else 900, lists=lists)
     sites = FILTER_SITES
-    if n_labels == 150:
+    if n_labels > 64 and lists:
+        sites = FILTER_SITES + ["labels"]
+    elif n_labels == 150:
         sites = ["count", "labels", "scan", "groups", "round", "join", "finish"]
     elif k < 16 or n_labels > 1024:
         sites = ["count", "histogram", "extract", "reduce"]

@@ -59,7 +59,8 @@ def run_ranks(world, fn):
 
 
 def draw(rng):
-    # (round 5: k below 16 and label alphabets beyond 64 colours / 65535 take the key-range route of the rank-spanning call)
+    # (round 5: k below 16 takes the key-range route of the rank-spanning call; label alphabets beyond 64 colours / 65535 the label lists,
+    #  or label groups / the key-range route with DBG_LABEL_LISTS=0)
     k = int(rng.choice([int(rng.integers(16, 33)), int(rng.integers(33, 49)), int(rng.integers(49, 65)), 47, 63, int(rng.integers(4, 16))]))
     stranded = bool(rng.random() < 0.3)
     kind = int(rng.integers(0, 2))
@@ -100,7 +101,9 @@ def draw(rng):
     return dict(k=k, stranded=stranded, kind=kind, world=world, seqs=seqs, data=data, width=width, bounds=bounds,
                 min_obs=int(rng.choice([1, 2, 2, 3])), rounds=int(rng.choice([0, 0, 1, 2, 5])), balance=bool(rng.integers(0, 2)),
                 merge=[int(rng.choice([-1, 0, 1])) for _ in range(world)], force=bool(world == 1 and rng.random() < 0.7),
-                tree=bool(rng.random() < 0.4))
+                tree=bool(rng.random() < 0.4),
+                # alphabets beyond 64 colours: label lists (fast_labellists.hpp) by default, label groups / the key-range route with the knob
+                lists_off=bool(rng.random() < 0.3))
 
 
 def masks_to_classes(off, val):
@@ -122,6 +125,8 @@ def test_fuzz_rank_spanning_entry_points(seed):
         ctx = dbg.Context(0)
         try:
             ctx.set_option("DBG_COMPRESS", "device")
+            if c["lists_off"]:
+                ctx.set_option("DBG_LABEL_LISTS", "0")
             lo, hi = c["bounds"][r], c["bounds"][r + 1]
             ss_o = O.SeqSet.from_byte_seqs(c["seqs"][lo:hi], data=(c["data"][lo:hi] if kind else None), sizeof_d1=c["width"] if kind else 0)
             hs = dbg.HostSeqs(ss_o.words, ss_o.start, ss_o.length, None, ss_o.data if kind else None, c["width"] if kind else 0)
