@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=0, help="exchange rounds (0 = the library's default: 8 from four ranks on)")
     ap.add_argument("--colours", type=int, default=4, help="distinct D1 labels of the synthetic reads (read index mod colours; at most 255)")
     ap.add_argument("--no-label-groups", action="store_true", help="DBG_NO_LABEL_GROUPS=1 on every ctx: 65..1024 labels take the key-range route")
+    ap.add_argument("--labels", type=int, default=0, help="CountFilterSet with this many distinct u32 labels spread over [0, 2^24), one per read by a hash of its index (overrides --colours)")
+    ap.add_argument("--lists", default=None, help="DBG_LABEL_LISTS on every ctx (0: label groups / the key-range route beyond 64 colours)")
     ap.add_argument("--no-compress", action="store_true")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -142,16 +144,27 @@ def main():
                  length=torch.empty(n, dtype=torch.int32, device=dev), colour=torch.empty(n, dtype=torch.uint8, device=dev))
         ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), t["words"].data_ptr(), t["start"].data_ptr(), t["length"].data_ptr(), t["colour"].data_ptr()))
         torch.cuda.synchronize()
+        if args.labels and is_set:
+            g = torch.Generator(device=dev); g.manual_seed(11)
+            alphabet = torch.randperm(1 << 24, device=dev, generator=g)[:args.labels].to(torch.int32)
+            idx = torch.arange(first, first + n, device=dev, dtype=torch.int64)
+            t["label"] = alphabet[((idx * 2654435761) % 4294967291) % args.labels].contiguous()
+            del idx
+            torch.cuda.synchronize()
+            return capi.SeqSet(t["words"].data_ptr(), nw, t["start"].data_ptr(), t["length"].data_ptr(), None, t["label"].data_ptr(), 4, n), t
         ss = capi.SeqSet(t["words"].data_ptr(), nw, t["start"].data_ptr(), t["length"].data_ptr(), None,
                          t["colour"].data_ptr() if is_set else None, 1 if is_set else 0, n)
         return ss, t
 
     spec = dbg.SimpleCompress("saturating_add")
     say("# rehearse_shard: %d thread-ranks x %d reads (%d in all), k = %d, %s(2), %d labels%s, one GPU, in-process transport"
-        % (W, per, total_reads, k, "CountFilterSet" if is_set else "CountFilter", args.colours, " (label groups off)" if args.no_label_groups else ""))
+        % (W, per, total_reads, k, "CountFilterSet" if is_set else "CountFilter", args.labels or args.colours,
+           (" (label groups off)" if args.no_label_groups else "") + (" DBG_LABEL_LISTS=%s" % args.lists if args.lists is not None else "")))
 
     # ---- the single-GPU calls over the same reads ----
     ctx0 = dbg.Context(0)
+    if args.lists is not None:
+        ctx0.set_option("DBG_LABEL_LISTS", args.lists)
     ss, keep = synth(ctx0, total_reads, 0)
     fp = capi.FilterParams(k, 0, 1 if is_set else 0, 2, 0, 4)
     t1 = capi.KmerTable()
@@ -192,6 +205,9 @@ def main():
     if args.no_label_groups:
         for c_ in ctxs:
             c_.set_option("DBG_NO_LABEL_GROUPS", "1")
+    if args.lists is not None:
+        for c_ in ctxs:
+            c_.set_option("DBG_LABEL_LISTS", args.lists)
     res = [None] * W
     err = [None] * W
 
