@@ -86,10 +86,11 @@ typedef struct {
                                    Kmer::get(3) of a shorter k-mer underflows `k - 1 - pos` (kmer.rs:254-257, :515-518) -- a panic in
                                    the reference's debug builds, reproduced here as an error */
     int32_t  stranded;          /* filter.rs:142 */
-    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min).  Label sets of any D1 values are served; how fast
-                                   depends on the alphabet: up to 64 distinct labels (< 65536) one pass of the counting kernel,
-                                   65..1024 distinct labels one extra pass per 64 labels (n_passes = 1 + groups), beyond that (or
-                                   labels >= 65536) the sort-based generic path */
+    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min).  Label sets of any D1 values (< 2^24) are served:
+                                   up to 64 distinct labels (< 65536) as colour masks in the counting kernel; any larger alphabet as
+                                   label lists (one pass: every observation's label appended to its k-mer's segment, segments sorted
+                                   and de-duplicated -- about a third of the colour-mask rate, whatever the alphabet); the sort-based
+                                   generic path for k < 16 or when the label buffer (4 bytes per k-mer instance) does not fit */
     uint64_t min_kmer_obs;      /* filter.rs:41,69 */
     int32_t  report_all_kmers;  /* filter.rs:143 */
     uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero).  Otherwise IGNORED: in the
@@ -436,8 +437,8 @@ int  dbg_shard_round_cuts(const uint32_t* bounds, uint32_t world, uint32_t bin_g
 typedef struct {
     uint32_t k;
     int32_t  stranded;
-    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (up to 64 distinct labels < 65536 over all ranks on the
-                                   super-k-mer route; larger alphabets and labels up to 2^24 - 1 on the key-range route) */
+    int32_t  summarizer;        /* DBG_COUNT_FILTER | DBG_COUNT_FILTER_SET (any labels < 2^24: up to 64 distinct ones < 65536 over all
+                                   ranks as colour masks, larger alphabets as label lists -- both on the super-k-mer route) */
     uint64_t min_kmer_obs;
     uint32_t n_rounds;          /* exchange rounds; 0 = 4 (8 from 4 ranks on), more when a round's receive buffer would pass 8 GiB */
     int32_t  merge_dups;        /* sender-side duplicate merge: 1 on, 0 off, -1 = the library decides (on at 2 ranks, where one link
@@ -469,8 +470,10 @@ typedef struct {
  * is the table dbg_filter_kmers_dev returns for the concatenated reads.  Collective: every rank calls it with the same
  * parameters.  Scan -> ownership -> slab compaction in (round, destination, bin) order -> pipelined all-to-all rounds on a
  * communication stream ordered against the ctx's stream with events (no host synchronisation per round) -> per-bin counting
- * -> one order-restoring sort.  Shapes that exchange cannot carry -- k < 16, more than 64 distinct labels over all ranks, labels >=
- * 65536 -- take the key-range route instead (round 5): ownership by ranges of the canonical k-mer's top byte from the all-reduced
+ * -> one order-restoring sort.  Label alphabets beyond 64 colours travel as label lists: the records carry their read's label in an
+ * extra word, the owners append, sort and de-duplicate per k-mer (round 5; DBG_LABEL_LISTS=0: label groups up to 1024 labels, the
+ * key-range route beyond).  Shapes that exchange cannot carry -- k < 16 -- take the key-range route instead (round 5): ownership by
+ * ranges of the canonical k-mer's top byte from the all-reduced
  * byte histogram, k-mer records exchanged per round, sort + segmented reduce on the owner (the rank-spanning form of the generic
  * path; SURVEY.md section 8(e) "non-MSP variant"), so the call covers every shape dbg_filter_kmers_dev covers.  stats may be NULL. */
 int  dbg_shard_filter_kmers_dev(dbg_ctx* ctx, const dbg_transport* tr, const dbg_seqset* dev_seqs, const dbg_shard_params* p,
