@@ -460,11 +460,12 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
         bool room = true;
         if (!ovf) {
             // ---- B: segments of the valid k-mers (four consecutive slots per thread) ----
-            static_assert(T == 4 * NT, "four slots per thread");
-            uint32_t v4[4], sum = 0;
+            constexpr int SPT = T / NT;                     // consecutive slots per thread
+            static_assert(T == SPT * NT && SPT >= 1, "whole slots per thread");
+            uint32_t v4[SPT], sum = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t i = tid * 4 + q;
+            for (int q = 0; q < SPT; q++) {
+                const uint32_t i = tid * SPT + q;
                 const uint32_t c = s_cnt[i];
                 v4[q] = (s_tag[i] != 0u && (uint64_t)c >= min_obs) ? c : 0u;
                 sum += v4[q];
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
             const uint32_t incl = block_inclusive_scan<NT>(sum, s_wsum, &tot);
             uint32_t o = incl - sum;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { s_cur[tid * 4 + q] = o; o += v4[q]; }
+            for (int q = 0; q < SPT; q++) { s_cur[tid * SPT + q] = o; o += v4[q]; }
             if (tid == 0) s_lbase = tot ? atomicAdd(lo.cursor, (unsigned long long)tot) : 0ull;
             __syncthreads();
             lbase = s_lbase;
@@ -702,6 +703,10 @@ static void lists_plan(FastPlan* pl) {
     pl->lists = true; pl->rw = pl->nbw + 1;             // the label rides in an extra record word
     pl->wide = true;                                    // (payload = output position, side records: the WIDE plumbing of the count state)
     pl->lmap = nullptr; pl->linv.on = 0; pl->weighted = false;
+    // 4-word records (k >= 56): the staging area and the duplicate filter leave room for two workgroups per CU only next to 1024-entry
+    // tables, so the bins are half the size (as for the WIDE colour layout); with 2048 entries and one workgroup per CU the kernel took
+    // 349 ms against 200 at k = 47 (C2 shape, 5000 labels)
+    if (pl->nbw == 4) pl->nbins = (uint32_t)std::min<uint64_t>((uint64_t)pl->nbins * 2, (1ull << 23) - 1);
 }
 
 // labels of a label-list run must be < 2^24: the segment sort packs (segment, label) into 32 bits, and the C ABI demands it (dbg_mi355x.h)
@@ -744,7 +749,7 @@ static int lists_count_bins(dbg_ctx* c, ListCountState* st, const uint64_t* recs
             if (!pl.has_hi) bin_labels_kernel<1, 2, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
             else if (pl.nbw == 2) bin_labels_kernel<2, 2, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
             else if (pl.nbw == 3) bin_labels_kernel<2, 3, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
-            else bin_labels_kernel<2, 4, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
+            else bin_labels_kernel<2, 4, 512, 1024><<<nbins_local, 512, 0, c->stream>>>(ARGS_);       // (k >= 56: see lists_plan)
 #undef ARGS_
             c->t_end();
             LAUNCH_CHECK(c, "bin_labels");

@@ -10,6 +10,7 @@ ap.add_argument("--reads", type=int, default=100_000_000)
 ap.add_argument("--k", type=int, default=47)
 ap.add_argument("--lists", default="auto")
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--target", default=None, help="DBG_FAST_TARGET: k-mer instances per bin")
 ap.add_argument("--small", action="store_true", help="labels below 65536 (label groups apply for 65..1024 of them)")
 ap.add_argument("labels", type=int, nargs="+")
 a = ap.parse_args()
@@ -17,6 +18,8 @@ dbg = importlib.import_module("rust-debruijn_amd"); capi = importlib.import_modu
 ctx = dbg.Context(0); lib = ctx.lib; dev = torch.device("cuda", 0)
 if a.lists != "auto":
     ctx.set_option("DBG_LABEL_LISTS", a.lists)
+if a.target:
+    ctx.set_option("DBG_FAST_TARGET", a.target)
 N = a.reads
 ctx.enable_timing(True)
 p = dbg.synth_params(n_reads=N, read_len=150, genome_len=N * 150 // 30, error_rate=0.001, stranded=False, n_colours=4, first_read=0)
