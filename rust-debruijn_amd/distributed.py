@@ -306,7 +306,15 @@ def table_digest(tab, device):
     d = int(row.sum().item()) if n else 0
     if tab.set_off and n:
         off = _dev_tensor(tab.set_off, n + 1, "<i8", device)
-        val = _dev_tensor(tab.set_val, int(tab.n_set_val), "<i4", device).to(torch.int64)
-        owner = torch.repeat_interleave(_mix(lo, 6364136223846793005) + hi, off[1:] - off[:-1])
-        d += int(_mix(owner + (val + 1) * 1442695040888963407, -7046029254386353131).sum().item())
+        val32 = _dev_tensor(tab.set_val, int(tab.n_set_val), "<i4", device)
+        own = _mix(lo, 6364136223846793005) + hi
+        # in stretches of keys (label lists hold ~10^10 labels at full size: one repeat_interleave of all of them is 80 GB)
+        step = 1 << 24
+        for a in range(0, n, step):
+            b = min(a + step, n)
+            o0, o1 = int(off[a].item()), int(off[b].item())
+            owner = torch.repeat_interleave(own[a:b], off[a + 1:b + 1] - off[a:b])
+            val = val32[o0:o1].to(torch.int64)
+            d += int(_mix(owner + (val + 1) * 1442695040888963407, -7046029254386353131).sum().item())
+            del owner, val
     return d & ((1 << 64) - 1)
