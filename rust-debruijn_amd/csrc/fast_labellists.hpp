@@ -74,6 +74,19 @@ __device__ __forceinline__ uint32_t ll_wave_sort(uint32_t key, uint32_t lane) {
     key = ll_cmpx<64, 2>(key, lane); key = ll_cmpx<64, 1>(key, lane);
     return key;
 }
+// two independent networks step by step (a step's three instructions depend on one another, and a DPP operand wants its producer
+// several cycles old): -10 % of the sort phase's time, -1 % of the kernel's -- the CU as a whole is bound by VALU issue, what one
+// phase leaves idle the other workgroup's phases take
+#define LL_STEP2(K2, J2) do { a = ll_cmpx<K2, J2>(a, lane); b = ll_cmpx<K2, J2>(b, lane); } while (0)
+__device__ __forceinline__ void ll_wave_sort2(uint32_t& a, uint32_t& b, uint32_t lane) {
+    LL_STEP2(2, 1);
+    LL_STEP2(4, 2); LL_STEP2(4, 1);
+    LL_STEP2(8, 4); LL_STEP2(8, 2); LL_STEP2(8, 1);
+    LL_STEP2(16, 8); LL_STEP2(16, 4); LL_STEP2(16, 2); LL_STEP2(16, 1);
+    LL_STEP2(32, 16); LL_STEP2(32, 8); LL_STEP2(32, 4); LL_STEP2(32, 2); LL_STEP2(32, 1);
+    LL_STEP2(64, 32); LL_STEP2(64, 16); LL_STEP2(64, 8); LL_STEP2(64, 4); LL_STEP2(64, 2); LL_STEP2(64, 1);
+}
+#undef LL_STEP2
 // inclusive maximum over the lanes at or below this one (the DPP ladder of wave_inclusive_scan_u32 with max for +)
 __device__ __forceinline__ uint32_t ll_wave_max_scan(uint32_t v) {
     auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
@@ -133,6 +146,13 @@ __device__ __forceinline__ uint32_t ll_wave_sort_unique_global(uint32_t* __restr
 #ifndef DBG_LL_ABL
 #define DBG_LL_ABL 0
 #endif
+// -DDBG_LL_PHASE_TIMES (measurement builds): 100 MHz ticks of thread 0 per phase, summed over bins; printed by the host under DBG_DEBUG
+#ifdef DBG_LL_PHASE_TIMES
+__device__ unsigned long long g_ll_phase[8];
+#define LLPH(i) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_ll_phase[i], now_ - t_prev_); t_prev_ = now_; } } while (0)
+#else
+#define LLPH(i) do {} while (0)
+#endif
 template <int KW, int NBW, int NT, int T>
 __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
@@ -171,6 +191,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
     __shared__ uint64_t s_segbeg[64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DBG_LL_PHASE_TIMES
+    unsigned long long t_prev_ = wall_clock64();
+#endif
     if (tid < 64) {
         uint32_t len = 0;
         if (tid < n_src) {
@@ -189,6 +212,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
     }
     __syncthreads();
     const uint32_t total_recs = s_segpre[n_src];
+    LLPH(0);
     if (total_recs == 0) return;
     const K128 kmask = k128_mask(k);
     const uint64_t lt_mask = lanemask_lt();
@@ -456,6 +480,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
 
         // ---- A: count ----
         const bool ovf = stream(0);
+        LLPH(1);
         if (DBG_LL_ABL == 1) break;
         bool room = true;
         if (!ovf) {
@@ -480,11 +505,13 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
             lbase = s_lbase;
             room = lbase + tot <= lo.cap;
             if (!room && tid == 0) atomicOr(&gflags[0], 16u);
+            LLPH(2);
             if (DBG_LL_ABL == 2) break;
             if (room && tot) {
                 // ---- C: append ----
                 (void)stream(1);
                 __syncthreads();                            // (workgroup scope: the appended labels are visible to the waves that sort them)
+                LLPH(3);
                 // ---- D: sort + de-duplicate every segment; each wave takes its own T / NWV slots ----
                 uint32_t* const L = lo.lab + lbase;
                 for (uint32_t blk = 0; blk < (uint32_t)(T / NWV / 64) && DBG_LL_ABL < 3; blk++) {
@@ -528,18 +555,23 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                         G.label = act ? L[G.off_j + (lane - G.excl_j)] : 0u;
                         return G;
                     };
-                    auto process = [&](const Grp& G) {
-                        if (!G.n_el) return;
+                    // (two groups at a time, no branches: an empty group has no active lane)
+                    auto finish = [&](const Grp& G, uint32_t key) {
                         const bool act = lane < G.n_el;
-                        // (segment in the batch, label): labels are < 2^24 (checked by the host side), at most 64 segments
-                        uint32_t key = act ? (((G.j - G.g0) << 24) | G.label) : 0xffffffffu;
-                        key = ll_wave_sort(key, lane);
                         // the segments keep their lane ranges: lane e still belongs to slot lane j after the sort
                         const uint32_t pk = (uint32_t)__shfl_up((int)key, 1);
                         const bool first = act && (lane == 0u || pk != key);
                         const uint64_t fm = __ballot(first);
                         if (first) L[G.off_j + (uint32_t)__popcll(fm & ll_range_mask(G.excl_j, G.v_j) & lt_mask)] = key & 0xffffffu;
                         if (lane >= G.g0 && lane < G.g1 && v) nl = (uint32_t)__popcll(fm & ll_range_mask(incl - v - G.sbase, v));
+                    };
+                    auto process2 = [&](const Grp& GA, const Grp& GB) {
+                        // (segment in the batch, label): labels are < 2^24 (checked by the host side), at most 64 segments
+                        uint32_t ka = lane < GA.n_el ? (((GA.j - GA.g0) << 24) | GA.label) : 0xffffffffu;
+                        uint32_t kb = lane < GB.n_el ? (((GB.j - GB.g0) << 24) | GB.label) : 0xffffffffu;
+                        ll_wave_sort2(ka, kb, lane);
+                        finish(GA, ka);
+                        finish(GB, kb);
                     };
                     uint32_t g0 = 0, sbase = 0;
                     while (g0 < 64u) {
@@ -551,7 +583,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                             sbase = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(g0 - 1u));
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; q++) process(G[q]);
+                        for (int q = 0; q < 4; q += 2) process2(G[q], G[q + 1]);
                     }
                     uint64_t bm = bigm;
                     while (bm) {
@@ -569,6 +601,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                 for (int i = tid; i < T; i += NT) s_cnt[i] = 0;
             }
             __syncthreads();
+            LLPH(4);
         }
         if (!ovf && room) {
             // ---- E: emit (bin_count_kernel's scheme; valid = has labels) ----
@@ -632,6 +665,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
             sp += 2;
         }
         if (sp != 0) __syncthreads();
+        LLPH(5);
     }
 }
 
@@ -761,6 +795,16 @@ static int lists_count_bins(dbg_ctx* c, ListCountState* st, const uint64_t* recs
         HIP_TRY(c, hipMemcpyAsync(&cur_lab, st->lab_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(flv, cs.gflags.p, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+#ifdef DBG_LL_PHASE_TIMES
+        if (c->opt("DBG_DEBUG")) {
+            unsigned long long ph[8];
+            (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_ll_phase), sizeof(ph));
+            fprintf(stderr, "[label-lists phases] (100 MHz ticks of thread 0, summed over bins) prologue=%llu count=%llu segments=%llu append=%llu sort=%llu emit=%llu\n",
+                    ph[0], ph[1], ph[2], ph[3], ph[4], ph[5]);
+            unsigned long long z[8] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ll_phase), z, sizeof(z));
+        }
+#endif
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] label lists: bins=%u srcs=%u recs=%llu valid=%llu labels appended=%llu (room for %llu) flags=%u maxP=%u split_passes=%u wd=%u\n",
                                          nbins_local, n_src, (unsigned long long)n_recs_hint, cur, cur_lab, (unsigned long long)st->lab_cap, flv[0], flv[1], flv[2], flv[3]);
         if (flv[3] & 4u) return c->fail(134, "fast path: corrupt super-k-mer record (record buffer or segment table of the counting stage is wrong)");
