@@ -121,3 +121,21 @@ def test_label_lists_equal_label_groups_and_generic(ctx):
         assert np.array_equal(t.key_hi, tabs[0].key_hi) and np.array_equal(t.key_lo, tabs[0].key_lo) and np.array_equal(t.exts, tabs[0].exts)
         assert np.array_equal(t.set_off, tabs[0].set_off) and np.array_equal(t.set_val, tabs[0].set_val)
     assert len(tabs[0]) > 10000
+
+
+@pytest.mark.parametrize("knobs", [dict(DBG_SCAN="wave"), dict(DBG_FAST_NO_SLAB="1"), dict(DBG_SLAB_CAP="4"), dict(DBG_NO_REC16="1"),
+                                   dict(DBG_FAST_TARGET="400"), dict(DBG_NO_STRAND_NORM="1")])
+def test_label_lists_other_routes_of_the_scan_and_sort(ctx, knobs):
+    """the record's label word through every way a record can take: the wave-per-read scanner, reads longer than the lane-per-read
+    scanner takes (1024 bases), no slabs / tiny slabs (read-order buffer + scatter of 4- and 5-word records), the three-array sort,
+    tiny bins"""
+    rng = np.random.default_rng(31)
+    seqs = random_reads(rng, 900, 3000, 150, False)
+    genome = R.random_dna(rng, 5000)
+    seqs += [genome[a:a + int(rng.integers(1100, 1700))] for a in rng.integers(0, 3000, size=40)]          # long reads
+    lab = rng.integers(0, 1 << 24, size=len(seqs))
+    lab[:300] = rng.integers(0, 7, size=300) * 65537                   # some labels shared by many reads
+    ss = O.SeqSet.from_byte_seqs(seqs, data=lab, sizeof_d1=4)
+    with ctx.options(**knobs):
+        for k in (31, 47, 63):
+            check(ctx, ss, k, 1, False, 4)
