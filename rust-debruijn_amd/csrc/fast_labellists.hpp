@@ -63,18 +63,7 @@ __device__ __forceinline__ uint32_t ll_cmpx(uint32_t key, uint32_t lane) {
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mx), "v"(mn), "s"(M));
     return r;
 }
-__device__ __forceinline__ uint32_t ll_wave_sort(uint32_t key, uint32_t lane) {
-    key = ll_cmpx<2, 1>(key, lane);
-    key = ll_cmpx<4, 2>(key, lane); key = ll_cmpx<4, 1>(key, lane);
-    key = ll_cmpx<8, 4>(key, lane); key = ll_cmpx<8, 2>(key, lane); key = ll_cmpx<8, 1>(key, lane);
-    key = ll_cmpx<16, 8>(key, lane); key = ll_cmpx<16, 4>(key, lane); key = ll_cmpx<16, 2>(key, lane); key = ll_cmpx<16, 1>(key, lane);
-    key = ll_cmpx<32, 16>(key, lane); key = ll_cmpx<32, 8>(key, lane); key = ll_cmpx<32, 4>(key, lane); key = ll_cmpx<32, 2>(key, lane);
-    key = ll_cmpx<32, 1>(key, lane);
-    key = ll_cmpx<64, 32>(key, lane); key = ll_cmpx<64, 16>(key, lane); key = ll_cmpx<64, 8>(key, lane); key = ll_cmpx<64, 4>(key, lane);
-    key = ll_cmpx<64, 2>(key, lane); key = ll_cmpx<64, 1>(key, lane);
-    return key;
-}
-// two independent networks step by step (a step's three instructions depend on one another, and a DPP operand wants its producer
+// The network, for two independent keys per lane, step by step (a step's three instructions depend on one another, and a DPP operand wants its producer
 // several cycles old): -10 % of the sort phase's time, -1 % of the kernel's -- the CU as a whole is bound by VALU issue, what one
 // phase leaves idle the other workgroup's phases take
 #define LL_STEP2(K2, J2) do { a = ll_cmpx<K2, J2>(a, lane); b = ll_cmpx<K2, J2>(b, lane); } while (0)
@@ -811,7 +800,8 @@ static int lists_count_bins(dbg_ctx* c, ListCountState* st, const uint64_t* recs
         if (flv[3]) return c->fail(132, "fast path: internal watchdog fired");
         if (flv[0] & 6u) return c->fail(130, "fast path: a bin exceeded the multi-pass limit");
         if (flv[0] & 25u) {
-            if (attempt >= 3 || cur >= (1ull << 32) || cur_all >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 k-mers in one table");
+            if (cur >= (1ull << 32) || cur_all >= (1ull << 32)) return c->fail(131, "fast path: more than 2^32-1 k-mers in one table");
+            if (attempt >= 4) return c->fail(138, "fast path: the output buffers of the label-list run kept turning out too small");
             if (flv[0] & 1u) DBG_TRY(fast_count_alloc(c, &cs, cur + cur / 16 + 1024));
             if (flv[0] & 8u) DBG_TRY(fast_count_alloc_all(c, &cs, cur_all + cur_all / 16 + 1024));
             if (flv[0] & 16u) {                                  // (the cursor went on counting: it holds what this launch wants)
