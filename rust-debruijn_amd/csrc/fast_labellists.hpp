@@ -675,7 +675,9 @@ __global__ void __launch_bounds__(256) ll_meta_kernel(uint32_t n, uint8_t* __res
 // round writes element e of the stretch (consecutive lanes, consecutive words).  Which key an element belongs to: the keys whose
 // lists start inside the round mark their first element in the wave's LDS row, a maximum scan (DPP) spreads the marks, elements before
 // the first mark belong to the key the previous round ended in.  (First form: a binary search over the 64 offsets with shuffles, nine
-// ds_bpermute per round: 31.5 ms for 9.9e9 labels.)  The reads run along the segments (a list is ~80 contiguous bytes at 30x).
+// ds_bpermute per round: 31.5 ms for 9.9e9 labels.)  The reads run along the segments (a list is ~80 contiguous bytes at 30x):
+// 84-byte runs at random alignment touch 2-3 sectors of 64 bytes, so the 29.6 ms are ~120 GB of traffic for 79 GB of labels moved --
+// bandwidth, not latency (four rounds' loads in flight together: 29.9 ms).
 __global__ void __launch_bounds__(256) ll_csr_kernel(uint32_t n, const uint64_t* __restrict__ set_off, const uint64_t* __restrict__ seg_off,
                                                      const uint32_t* __restrict__ lab, uint32_t* __restrict__ set_val) {
     __shared__ uint32_t s_ws[4][256];
