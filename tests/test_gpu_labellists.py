@@ -139,3 +139,38 @@ def test_label_lists_other_routes_of_the_scan_and_sort(ctx, knobs):
     with ctx.options(**knobs):
         for k in (31, 47, 63):
             check(ctx, ss, k, 1, False, 4)
+
+
+def test_label_lists_into_scmap_compress(ctx):
+    """the pipeline of BASELINE config 5 with a large alphabet: filter_kmers(CountFilterSet) as label lists, table left in HBM ->
+    dbg_compress_table_dev with ScmapCompress (label lists -> class ids by verified hash, compression.rs:68-98) -> the oracle's
+    compress_kmers over the same table with the classes numbered alike"""
+    import ctypes as C
+    from graph_canon import graphs_equal
+    from pkg import capi
+    k = 47
+    hs = dbg.synth_reads_host(n_reads=30000, read_len=150, genome_len=120000, error_rate=0.002, stranded=False, n_colours=4)
+    lab = ((np.arange(len(hs.start)) // 40) * 4099 + 70000).astype(np.uint32)          # 750 labels >= 65536, 40 reads each
+    seqs = dbg.HostSeqs(hs.words, hs.start, hs.length, None, lab, 4)
+    ss, keep = dbg.upload_seqs(seqs, 0)
+    with ctx.options(DBG_COMPRESS="device"):
+        t = dbg.filter_kmers_dev(ss, dbg.CountFilterSet(2), False, k, ctx=ctx)
+        try:
+            got = dbg.compress_table_dev(False, dbg.ScmapCompress(), t, k, ctx=ctx)
+            h = capi.KmerTable()
+            ctx.check(ctx.lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))
+            th = dbg._table_from_c(h, k)
+            ctx.lib.dbg_free_table(ctx.h, C.byref(h))
+        finally:
+            ctx.lib.dbg_free_table(ctx.h, C.byref(t))
+    want_t = O.filter_kmers(O.SeqSet(hs.words, hs.start, hs.length, None, lab, 4), k, O.COUNT_FILTER_SET, 2, stranded=False)
+    assert_tables_equal(th, want_t, True)
+    sets = [tuple(int(x) for x in th.set_val[int(th.set_off[i]):int(th.set_off[i + 1])]) for i in range(len(th))]
+    glob = sorted(set(sets))
+    pos = {s: i for i, s in enumerate(glob)}
+    og = O.compress_kmers(k, False, O.SPEC_SCMAP_EQ, th.key_hi, th.key_lo, th.exts, np.array([pos[s] for s in sets], dtype=np.uint32))
+    assert sorted(got.classes) == glob and len(glob) > 500
+    ga = dict(got.arrays())
+    ga["data"] = np.array([pos[got.classes[int(c)]] for c in got.data], dtype=np.uint32)
+    assert graphs_equal(ga, og.arrays())
+    assert 100 < len(got) < len(th)
