@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t ll_wave_sort_unique_global(uint32_t* __restr
 }
 
 // DBG_LL_ABL = n (measurement builds, WRONG results): 1 stop after the counting sweep, 2 after the segment offsets, 3 no sort of the
-// segments, 4 the append sweep without its global stores (and no sort)
+// segments, 4 the append sweep without its global stores (and no sort), 5 one label per merged record only (and no sort)
 #ifndef DBG_LL_ABL
 #define DBG_LL_ABL 0
 #endif
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                                         } else __hip_atomic_store(&s_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                     } else if (hit && (uint64_t)s_cnt[slot] >= min_obs) {
                                         const uint32_t pos = atomicAdd(&s_cur[slot], wgt);
-                                        for (uint32_t t = 0; t < wgt; t++) {
+                                        for (uint32_t t = 0; t < (DBG_LL_ABL == 5 ? 1u : wgt); t++) {
                                             const uint32_t label = s_lab[lstart + t];
                                             if (DBG_LL_ABL != 4 || label == 0x12345u) lo.lab[lbase + pos + t] = label;
                                         }
