@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t ll_wave_sort_unique_global(uint32_t* __restr
 }
 
 // DBG_LL_ABL = n (measurement builds, WRONG results): 1 stop after the counting sweep, 2 after the segment offsets, 3 no sort of the
-// segments, 4 the append sweep without its global stores (and no sort), 5 one label per merged record only (and no sort)
+// segments, 4 the append sweep without its global stores (and no sort), 5 one label per merged record only (and no sort), 6 the sort phase without its networks
 #ifndef DBG_LL_ABL
 #define DBG_LL_ABL 0
 #endif
@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                         // (segment in the batch, label): labels are < 2^24 (checked by the host side), at most 64 segments
                         uint32_t ka = lane < GA.n_el ? (((GA.j - GA.g0) << 24) | GA.label) : 0xffffffffu;
                         uint32_t kb = lane < GB.n_el ? (((GB.j - GB.g0) << 24) | GB.label) : 0xffffffffu;
-                        ll_wave_sort2(ka, kb, lane);
+                        if (DBG_LL_ABL != 6) ll_wave_sort2(ka, kb, lane);
                         finish(GA, ka);
                         finish(GB, kb);
                     };
