@@ -63,11 +63,11 @@ __device__ __forceinline__ uint32_t ll_cmpx(uint32_t key, uint32_t lane) {
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mx), "v"(mn), "s"(M));
     return r;
 }
-// The network, for two independent keys per lane, step by step (a step's three instructions depend on one another, and a DPP operand wants its producer
+// The network, for four independent keys per lane, step by step (a step's three instructions depend on one another, and a DPP operand wants its producer
 // several cycles old): -10 % of the sort phase's time, -1 % of the kernel's -- the CU as a whole is bound by VALU issue, what one
 // phase leaves idle the other workgroup's phases take
-#define LL_STEP2(K2, J2) do { a = ll_cmpx<K2, J2>(a, lane); b = ll_cmpx<K2, J2>(b, lane); } while (0)
-__device__ __forceinline__ void ll_wave_sort2(uint32_t& a, uint32_t& b, uint32_t lane) {
+#define LL_STEP2(K2, J2) do { a = ll_cmpx<K2, J2>(a, lane); b = ll_cmpx<K2, J2>(b, lane); c = ll_cmpx<K2, J2>(c, lane); d = ll_cmpx<K2, J2>(d, lane); } while (0)
+__device__ __forceinline__ void ll_wave_sort4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t lane) {
     LL_STEP2(2, 1);
     LL_STEP2(4, 2); LL_STEP2(4, 1);
     LL_STEP2(8, 4); LL_STEP2(8, 2); LL_STEP2(8, 1);
@@ -251,9 +251,9 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                 uint32_t myslot = 0;
                 const bool have = pend;
                 {
-                    uint64_t ha = a[0], hb = NBW == 2 ? a[1] : a[1];
-                    if (NBW == 3) ha += a[2] * 0x9E3779B97F4A7C15ull;
-                    if (NBW == 4) { ha += a[2] * 0x9E3779B97F4A7C15ull; hb += a[3] * 0xC2B2AE3D27D4EB4Full; }
+                    uint64_t ha = a[0], hb = a[1];
+                    if constexpr (NBW == 3) ha += a[2] * 0x9E3779B97F4A7C15ull;
+                    if constexpr (NBW == 4) { ha += a[2] * 0x9E3779B97F4A7C15ull; hb += a[3] * 0xC2B2AE3D27D4EB4Full; }
                     const uint64_t h = hash_key(ha, hb);
                     const uint32_t mytag = (uint32_t)(h >> 42) << 10;
                     uint32_t sl = (uint32_t)h & (DD - 1);
@@ -554,13 +554,14 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                         if (first) L[G.off_j + (uint32_t)__popcll(fm & ll_range_mask(G.excl_j, G.v_j) & lt_mask)] = key & 0xffffffu;
                         if (lane >= G.g0 && lane < G.g1 && v) nl = (uint32_t)__popcll(fm & ll_range_mask(incl - v - G.sbase, v));
                     };
-                    auto process2 = [&](const Grp& GA, const Grp& GB) {
+                    auto process4 = [&](const Grp& GA, const Grp& GB, const Grp& GC, const Grp& GD) {
                         // (segment in the batch, label): labels are < 2^24 (checked by the host side), at most 64 segments
                         uint32_t ka = lane < GA.n_el ? (((GA.j - GA.g0) << 24) | GA.label) : 0xffffffffu;
                         uint32_t kb = lane < GB.n_el ? (((GB.j - GB.g0) << 24) | GB.label) : 0xffffffffu;
-                        if (DBG_LL_ABL != 6) ll_wave_sort2(ka, kb, lane);
-                        finish(GA, ka);
-                        finish(GB, kb);
+                        uint32_t kc = lane < GC.n_el ? (((GC.j - GC.g0) << 24) | GC.label) : 0xffffffffu;
+                        uint32_t kd = lane < GD.n_el ? (((GD.j - GD.g0) << 24) | GD.label) : 0xffffffffu;
+                        if (DBG_LL_ABL != 6) ll_wave_sort4(ka, kb, kc, kd, lane);
+                        finish(GA, ka); finish(GB, kb); finish(GC, kc); finish(GD, kd);
                     };
                     uint32_t g0 = 0, sbase = 0;
                     while (g0 < 64u) {
@@ -571,8 +572,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
                             g0 = G[q].g1;
                             sbase = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(g0 - 1u));
                         }
-#pragma unroll
-                        for (int q = 0; q < 4; q += 2) process2(G[q], G[q + 1]);
+                        process4(G[0], G[1], G[2], G[3]);
                     }
                     uint64_t bm = bigm;
                     while (bm) {
