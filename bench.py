@@ -188,11 +188,13 @@ def main():
     t0 = time.perf_counter()
     n_valid = n_inst = digest = 0
     ktimes = {}
+    kseries = {}                                        # per-step HIP-event ms of each kernel: a bimodal scan shows here, not in a mean
     for _ in range(args.steps):
         n_valid, n_inst, digest = step()
         for kt in ctx.timings():
             a = ktimes.setdefault(kt["name"], dict(ms=0.0, launches=0, units=0))
             a["ms"] += kt["ms"]; a["launches"] += kt["launches"]; a["units"] += kt["units"]
+            kseries.setdefault(kt["name"], []).append(round(kt["ms"], 3))
     barrier()
     dt = time.perf_counter() - t0
     ctx.enable_timing(False)
@@ -238,6 +240,19 @@ def main():
         balance = None
     ms_per_step = dt / args.steps * 1e3
     value = n_inst_total * args.steps / dt / 1e9
+    # how the scan's slab is backed and how fast it takes random record writes (after the timed region: the slab sits in the pool)
+    slab = None
+    try:
+        cst = ctx.stats()
+        pr = ctx.probe_slab()
+        slab = {"backing": cst["slab_backing_name"], "gb": round(cst["slab_bytes"] / 2**30, 2), "mb_per_handle": cst["slab_piece_bytes"] >> 20,
+                "handles": cst["slab_pieces"], "note": cst["slab_note"] or None,
+                "probe_ms": round(pr[0], 3) if pr else None, "probe_writes": pr[1] if pr else None,
+                "probe_note": "2^27 record-sized random writes into the pooled slab, best of 3 (fast placement kind at 26 GB / 24-byte records: 5.6-5.9 ms; slow: 7.0-7.5)",
+                "alloc": {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in cst.items()
+                          if kk.startswith(("n_", "s_", "pooled"))}}
+    except Exception as e:                               # (never let a diagnostic take the bench line down)
+        slab = {"error": str(e)}
 
     out = None
     if rank == 0:
@@ -364,7 +379,9 @@ def main():
                     "traffic_source": os.path.basename(tf[-1]) if tf else None, "traffic_stale": traffic_stale if tf else None,
                     "kernel_source_sha16": src_sha,
                     "kernels": rows,
-                    "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()}}
+                    "kernel_ms_per_step": {n: round(v["ms"] / args.steps, 3) for n, v in ktimes.items()},
+                    "kernel_ms_min_med_max": {n: [min(v), sorted(v)[len(v) // 2], max(v)] for n, v in kseries.items() if n != "sk_records" and v},
+                    "kernel_ms_by_step": {n: v for n, v in kseries.items() if n in ("sk_scan", "bin_count")}}
         other = None
         if world == 1 and not args.force_sharded and not args.no_other_shapes:
             # the shapes the crate is used with day to day, on the same reads (BASELINE configs 4 / 5 per-GPU k, Kmer32's neighbourhood,
@@ -542,6 +559,7 @@ def main():
                           "transport": xstats.get("transport"), "transport_fallback": xstats.get("transport_fallback"),
                           "setup_ms_per_step_rank0": round(xstats.get("setup_ms", 0.0) / max(args.steps, 1), 3)} if (world > 1 or args.force_exchange) else None),
             "balance": balance,
+            "slab": slab,
             "roofline": roof, "other_shapes": other, "cpu_baseline": cpu, "cpu_baseline_all_cores": (cpu or {}).get("all_cores"),
             "host_boundary": hostb, "compress": comp,
         }

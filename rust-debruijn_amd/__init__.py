@@ -292,6 +292,26 @@ class Context:
     def set_stream(self, hip_stream_ptr):
         self.check(self.lib.dbg_ctx_set_stream(self.h, C.c_void_p(hip_stream_ptr)))
 
+    def stats(self):
+        """dbg_ctx_get_stats: allocation account of the ctx (what a cold call pays) and how the scan's slab is backed"""
+        st = _capi.CtxStats()
+        st.struct_size = C.sizeof(st)
+        self.check(self.lib.dbg_ctx_get_stats(self.h, C.byref(st)))
+        d = {n: getattr(st, n) for n, _ in st._fields_ if n not in ("struct_size", "slab_note")}
+        d["slab_note"] = st.slab_note.decode(errors="replace")
+        d["slab_backing_name"] = _capi.SLAB_BACKING_NAMES.get(st.slab_backing, "?")
+        return d
+
+    def probe_slab(self, n_writes=0):
+        """dbg_ctx_probe_slab: random record-sized writes into the pooled slab -> (ms, writes per launch); None if there is none"""
+        ms, nw = C.c_float(), C.c_uint64()
+        if self.lib.dbg_ctx_probe_slab(self.h, n_writes, C.byref(ms), C.byref(nw)):
+            return None
+        return ms.value, nw.value
+
+    def warm(self, slab_bytes=0, pinned_bytes=0):
+        self.check(self.lib.dbg_ctx_warm(self.h, slab_bytes, pinned_bytes))
+
 
 _default_ctx = None
 

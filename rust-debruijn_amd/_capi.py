@@ -98,6 +98,19 @@ class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("launches", C.c_uint32), ("units", C.c_uint64)]
 
 
+class CtxStats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("slab_backing", C.c_uint32), ("slab_bytes", C.c_uint64), ("slab_piece_bytes", C.c_uint64),
+                ("slab_pieces", C.c_uint32), ("slab_pooled", C.c_uint32), ("pooled_bytes", C.c_uint64), ("pooled_high_water", C.c_uint64),
+                ("n_hipmalloc", C.c_uint64), ("n_vmm_blocks", C.c_uint64), ("n_pool_hits", C.c_uint64), ("n_trims", C.c_uint64),
+                ("n_oom_retries", C.c_uint64), ("n_raw_free", C.c_uint64), ("n_pinned_alloc", C.c_uint64),
+                ("s_hipmalloc", C.c_double), ("s_vmm_map", C.c_double), ("s_free", C.c_double), ("s_pinned_alloc", C.c_double),
+                ("slab_note", C.c_char * 96)]
+
+
+SLAB_BACKING_NAMES = {0: "none", 1: "vmm", 2: "plain (slab < 4 GB)", 3: "plain (DBG_SLAB_VMM=0)", 4: "plain (piecewise mapping failed)",
+                      5: "no slabs (read-order buffer + scatter)"}
+
+
 # every symbol include/dbg_mi355x.h declares
 EXPORTS = [
     "dbg_ctx_create", "dbg_ctx_destroy", "dbg_last_error", "dbg_version", "dbg_ctx_set_stream",
@@ -105,6 +118,7 @@ EXPORTS = [
     "dbg_remove_censored_exts", "dbg_msp_sequence", "dbg_msp_sequence_dev", "dbg_free_pieces",
     "dbg_compress_kmers_with_hash", "dbg_compress_kmers_with_hash_dev", "dbg_kmer_set_exts", "dbg_compress_kmers_no_exts", "dbg_free_graph", "dbg_label_classes_dev", "dbg_free_label_classes", "dbg_compress_table_dev", "dbg_synth_words", "dbg_synth_reads_dev",
     "dbg_synth_reads_host", "dbg_ctx_enable_timing", "dbg_ctx_get_timings",
+    "dbg_ctx_get_stats", "dbg_ctx_probe_slab", "dbg_ctx_warm", "dbg_abi_version",
     "dbg_count_kmer_instances_dev", "dbg_shard_plan_make", "dbg_shard_scan_dev", "dbg_shard_scatter_dev",
     "dbg_shard_count_dev", "dbg_shard_count_begin", "dbg_shard_count_bins_dev", "dbg_shard_count_finish", "dbg_graph_combine", "dbg_compress_graph",
     "dbg_graph_edges", "dbg_free_edges", "dbg_graph_to_gfa", "dbg_graph_write_gfa", "dbg_free_text",
@@ -224,5 +238,10 @@ def load():
                                            C.c_int32, C.c_int32, C.POINTER(Graph), C.POINTER(Graph), C.POINTER(LabelClasses)]
     lib.dbg_ctx_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.dbg_ctx_get_timings.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.dbg_ctx_get_stats.argtypes = [C.c_void_p, C.POINTER(CtxStats)]
+    lib.dbg_ctx_probe_slab.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    lib.dbg_ctx_warm.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.dbg_abi_version.restype = C.c_uint32
+    lib.dbg_abi_version.argtypes = []
     _lib = lib
     return lib

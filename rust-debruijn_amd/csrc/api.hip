@@ -81,6 +81,98 @@ extern "C" int dbg_ctx_trim(dbg_ctx* c, uint64_t* freed_bytes) {
     return 0;
 }
 
+extern "C" uint32_t dbg_abi_version(void) { return DBG_ABI_VERSION; }
+
+extern "C" int dbg_ctx_get_stats(dbg_ctx* c, dbg_ctx_stats* out) {
+    if (!out || out->struct_size < 8) return c->fail(10, "dbg_ctx_get_stats: struct_size not set");
+    dbg_ctx_stats st;
+    memset(&st, 0, sizeof(st));
+    st.slab_backing = c->slab_backing; st.slab_bytes = c->slab_bytes; st.slab_piece_bytes = c->slab_piece_bytes;
+    st.slab_pieces = c->slab_piece_bytes ? (uint32_t)((c->slab_bytes + c->slab_piece_bytes - 1) / c->slab_piece_bytes) : 0;
+    if (c->slab_ptr) for (auto& kv : c->free_blocks) if (kv.second == c->slab_ptr) st.slab_pooled = 1;
+    st.pooled_bytes = c->pooled_bytes; st.pooled_high_water = c->pooled_high_water;
+    st.n_hipmalloc = c->n_hipmalloc; st.n_vmm_blocks = c->n_vmm_blocks; st.n_pool_hits = c->n_pool_hits; st.n_trims = c->n_trims;
+    st.n_oom_retries = c->n_oom_retries; st.n_raw_free = c->n_raw_free; st.n_pinned_alloc = c->n_pinned_alloc;
+    st.s_hipmalloc = c->s_hipmalloc; st.s_vmm_map = c->s_vmm_map; st.s_free = c->s_free; st.s_pinned_alloc = c->s_pinned_alloc;
+    memcpy(st.slab_note, c->slab_note, sizeof(st.slab_note));
+    const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(st));
+    st.struct_size = n;
+    memcpy(out, &st, n);
+    return 0;
+}
+
+// record-sized writes at random record slots of a block (tools/micro/slab_probe5.hip's pattern: what the scan does to its slab)
+template <int RW>
+__global__ void __launch_bounds__(256) slab_write_probe_kernel(uint64_t* __restrict__ slab, uint64_t n_rec, uint32_t per_thread) {
+    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; };
+    uint32_t h = mix(blockIdx.x * 1024u + threadIdx.x);
+    for (uint32_t i = 0; i < per_thread; i++) {
+        h = mix(h + i);
+        const uint32_t h2 = mix(h ^ 0x9E3779B9u);
+        const uint64_t r = (uint64_t)(((unsigned __int128)(((uint64_t)h << 32) | h2) * n_rec) >> 64);
+        uint64_t* o = slab + r * RW;
+#pragma unroll
+        for (int q = 0; q < RW; q++) o[q] = h + q;
+    }
+}
+
+extern "C" int dbg_ctx_probe_slab(dbg_ctx* c, uint64_t n_writes, float* ms_out, uint64_t* writes_out) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    bool pooled = false;
+    size_t bytes = 0;
+    if (c->slab_ptr) for (auto& kv : c->free_blocks) if (kv.second == c->slab_ptr) { pooled = true; bytes = std::min(kv.first, c->slab_bytes); }
+    if (!pooled || bytes < 4096) return c->fail(19, "dbg_ctx_probe_slab: no pooled slab (no fast-path call yet, the block is in use, or the pool was trimmed)");
+    const int rw = c->slab_rec_words >= 2 && c->slab_rec_words <= 5 ? (int)c->slab_rec_words : 3;
+    if (!n_writes) n_writes = 1ull << 27;
+    const uint32_t per_thread = 16;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_writes / (256ull * per_thread), 1u << 20));
+    const uint64_t n_rec = bytes / (8ull * rw);
+    hipEvent_t a = c->get_event(), b = c->get_event();
+    float best = 1e30f;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(a, c->stream);
+        uint64_t* sp = (uint64_t*)c->slab_ptr;
+        if (rw == 2) slab_write_probe_kernel<2><<<blocks, 256, 0, c->stream>>>(sp, n_rec, per_thread);
+        else if (rw == 3) slab_write_probe_kernel<3><<<blocks, 256, 0, c->stream>>>(sp, n_rec, per_thread);
+        else if (rw == 4) slab_write_probe_kernel<4><<<blocks, 256, 0, c->stream>>>(sp, n_rec, per_thread);
+        else slab_write_probe_kernel<5><<<blocks, 256, 0, c->stream>>>(sp, n_rec, per_thread);
+        (void)hipEventRecord(b, c->stream);
+        HIP_TRY(c, hipEventSynchronize(b));
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, a, b));
+        best = std::min(best, ms);
+    }
+    c->event_pool.push_back(a); c->event_pool.push_back(b);
+    if (ms_out) *ms_out = best;
+    if (writes_out) *writes_out = (uint64_t)blocks * 256ull * per_thread;
+    return 0;
+}
+
+void* ctx_halloc(dbg_ctx* c, size_t bytes);
+void ctx_hfree(dbg_ctx* c, void* p);
+extern "C" int dbg_ctx_warm(dbg_ctx* c, uint64_t slab_bytes, uint64_t pinned_bytes) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (slab_bytes) {
+        const char* knob = c->opt("DBG_SLAB_VMM");
+        void* p = nullptr;
+        if (slab_bytes >= (4ull << 30) && !(knob && !strcmp(knob, "0"))) {
+            const size_t piece = knob && atoll(knob) > 0 ? (size_t)atoll(knob) << 20 : (size_t)256 << 20;
+            p = c->dalloc_pieces(slab_bytes, piece);
+        }
+        if (!p) p = c->dalloc(slab_bytes);
+        if (!p) return c->fail(101, "dbg_ctx_warm: device allocation failed");
+        c->dfree(p);
+    }
+    if (pinned_bytes) {
+        // result arrays come in several blocks (keys, Exts, counts / label sets): four quarters serve the usual split
+        void* q[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < 4; i++) q[i] = ctx_halloc(c, (size_t)(pinned_bytes / 4));
+        for (int i = 0; i < 4; i++) ctx_hfree(c, q[i]);
+    }
+    return 0;
+}
+
 extern "C" int dbg_ctx_set_scratch_budget(dbg_ctx* c, uint64_t bytes) { c->scratch_budget = bytes; return 0; }
 
 extern "C" int dbg_ctx_enable_timing(dbg_ctx* c, int on) { c->timing = on != 0; c->t_clear(); return 0; }

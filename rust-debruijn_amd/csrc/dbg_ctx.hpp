@@ -10,7 +10,16 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include "../../include/dbg_mi355x.h"
+
+// host seconds spent inside the driver's allocation calls (dbg_ctx_get_stats: the cold-call account)
+struct HostTimer {
+    double* acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit HostTimer(double* a) : acc(a) {}
+    ~HostTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 struct dbg_timing_rec {
     const char* name;
@@ -113,6 +122,16 @@ struct dbg_ctx {
     std::multimap<size_t, void*> free_blocks;
     std::map<void*, size_t> live_blocks;
     size_t pooled_bytes = 0;
+    // ---- allocation account (dbg_ctx_get_stats): what a cold call pays, and how the scan's slab is backed ----
+    size_t pooled_high_water = 0;
+    uint64_t n_hipmalloc = 0, n_vmm_blocks = 0, n_pool_hits = 0, n_trims = 0, n_oom_retries = 0, n_raw_free = 0, n_pinned_alloc = 0;
+    double s_hipmalloc = 0, s_vmm_map = 0, s_free = 0, s_pinned_alloc = 0;
+    uint32_t slab_backing = 0;                     // DBG_SLAB_* of the last slab the scan took
+    void* slab_ptr = nullptr;                      // ... the block (it sits in free_blocks between calls)
+    size_t slab_bytes = 0, slab_piece_bytes = 0;
+    uint32_t slab_rec_words = 0;                   // words per record of the scan that used it
+    char slab_note[96] = {0};
+    void note_pool() { if (pooled_bytes > pooled_high_water) pooled_high_water = pooled_bytes; }
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
 
@@ -124,11 +143,14 @@ struct dbg_ctx {
             void* p = it->second;
             live_blocks[p] = it->first;
             free_blocks.erase(it);
+            n_pool_hits++;
             return p;
         }
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
+        hipError_t e;
+        { HostTimer t_(&s_hipmalloc); e = hipMalloc(&p, bytes); n_hipmalloc++; }
         if (e != hipSuccess) {
+            n_oom_retries++;
             (void)hipGetLastError();            // (the failure is sticky: the next launch check would report it as its own)
             // the device is full: a pooled block of up to twice the size serves before everything pooled is given back (trim() also
             // unmaps the piecewise-mapped slabs, which the next call then maps again: seconds at 100 GB -- label lists at k = 20 and
@@ -140,11 +162,12 @@ struct dbg_ctx {
                 return q;
             }
             trim();
-            e = hipMalloc(&p, bytes);
+            { HostTimer t_(&s_hipmalloc); e = hipMalloc(&p, bytes); n_hipmalloc++; }
             if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         live_blocks[p] = bytes;
         pooled_bytes += bytes;
+        note_pool();
         return p;
     }
     void dfree(void* p) {
@@ -172,51 +195,60 @@ struct dbg_ctx {
         (void)hipMemAddressFree(va, b.bytes);
         (void)hipGetLastError();
     }
-    void* dalloc_pieces(size_t bytes, size_t piece = 2ull << 30) {
+    void* dalloc_pieces(size_t bytes, size_t piece = 2ull << 30, std::string* why = nullptr) {
+        auto say = [&](const char* what, hipError_t e) { if (why) *why = std::string(what) + ": " + hipGetErrorString(e); };
         bytes = (bytes + 255) & ~(size_t)255;
         auto it = free_blocks.lower_bound(bytes);                    // a pooled block of this size (a slab of an earlier call) first
         if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
             void* p = it->second;
             live_blocks[p] = it->first;
             free_blocks.erase(it);
+            n_pool_hits++;
             return p;
         }
+        HostTimer t_(&s_vmm_map);
         hipMemAllocationProp prop = {};
         prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
         size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return nullptr; }
+        if (hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended); e != hipSuccess || !gran) { say("hipMemGetAllocationGranularity", e); (void)hipGetLastError(); return nullptr; }
         piece = (piece + gran - 1) / gran * gran;
         const size_t total = (bytes + gran - 1) / gran * gran;
         void* va = nullptr;
-        if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipError_t e = hipMemAddressReserve(&va, total, 0, nullptr, 0); e != hipSuccess) { say("hipMemAddressReserve", e); (void)hipGetLastError(); return nullptr; }
         VmmBlock b{total, {}};
         size_t mapped = 0;
         bool ok = true;
         for (size_t o = 0; o < total && ok; o += piece) {
             const size_t n = std::min(piece, total - o);
             hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, n, &prop, 0) != hipSuccess) { ok = false; break; }
+            if (hipError_t e = hipMemCreate(&h, n, &prop, 0); e != hipSuccess) { say("hipMemCreate", e); ok = false; break; }
             b.pieces.push_back({h, n});
-            if (hipMemMap((char*)va + o, n, 0, h, 0) != hipSuccess) { ok = false; break; }
+            if (hipError_t e = hipMemMap((char*)va + o, n, 0, h, 0); e != hipSuccess) { say("hipMemMap", e); ok = false; break; }
             mapped = o + n;
         }
         hipMemAccessDesc acc = {};
         acc.location.type = hipMemLocationTypeDevice; acc.location.id = device; acc.flags = hipMemAccessFlagsProtReadWrite;
-        if (ok && hipMemSetAccess(va, total, &acc, 1) != hipSuccess) ok = false;
+        if (ok) if (hipError_t e = hipMemSetAccess(va, total, &acc, 1); e != hipSuccess) { say("hipMemSetAccess", e); ok = false; }
         if (!ok) { (void)hipGetLastError(); vmm_release(va, b, mapped); return nullptr; }
         vmm_blocks[va] = std::move(b);
         live_blocks[va] = total;
         pooled_bytes += total;
+        n_vmm_blocks++;
+        note_pool();
         return va;
     }
     // give a block back to the driver, whichever way it was obtained
     void raw_free(void* p) {
+        HostTimer t_(&s_free);
+        n_raw_free++;
+        if (p == slab_ptr) slab_ptr = nullptr;
         auto it = vmm_blocks.find(p);
         if (it == vmm_blocks.end()) { (void)hipFree(p); return; }
         vmm_release(p, it->second, it->second.bytes);
         vmm_blocks.erase(it);
     }
     void trim() {
+        n_trims++;
         (void)hipStreamSynchronize(stream);
         for (auto& kv : free_blocks) { raw_free(kv.second); pooled_bytes -= kv.first; }
         free_blocks.clear();

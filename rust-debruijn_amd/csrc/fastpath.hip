@@ -1628,20 +1628,37 @@ int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out) {
 // (profiles/r05_slab_vmm_probe.txt, tools/micro/slab_probe5.hip; k = 31 over nine processes: scan 59.0-59.5 ms with 256 MB
 // handles, 59.3-62.3 with 2 GB, 58.8-63.3 plain -- profiles/r05_k31_vmm_ab.txt), so slabs of 4 GB and more are allocated that way
 // (dbg_ctx::dalloc_pieces; DBG_SLAB_VMM=0: plain pool blocks, as smaller slabs always are).
-static bool slab_alloc(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words) {
+static bool slab_alloc(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words, uint32_t rec_words) {
     const size_t bytes = words * 8;
     const char* knob = c->opt("DBG_SLAB_VMM");
+    // what the scan runs on is recorded in the ctx (dbg_ctx_get_stats): a slab that lost its piecewise mapping is never silent
+    c->slab_ptr = nullptr; c->slab_bytes = bytes; c->slab_piece_bytes = 0; c->slab_rec_words = rec_words; c->slab_note[0] = 0;
+    c->slab_backing = bytes < (4ull << 30) ? DBG_SLAB_PLAIN_SMALL : DBG_SLAB_PLAIN_KNOB;
     if (bytes >= (4ull << 30) && !(knob && !strcmp(knob, "0"))) {
         (void)hipStreamSynchronize(c->stream);                           // (a pooled block may still be in use by queued work of its previous owner)
         const size_t piece = knob && atoll(knob) > 0 ? (size_t)atoll(knob) << 20 : (size_t)256 << 20;    // (DBG_SLAB_VMM=<MB per handle>: measurements)
-        if (void* p = c->dalloc_pieces(bytes, piece)) {
+        std::string why;
+        if (void* p = c->dalloc_pieces(bytes, piece, &why)) {
             slab->release();
             slab->ctx = c; slab->p = (uint64_t*)p; slab->n = words;
+            auto vb = c->vmm_blocks.find(p);
+            if (vb != c->vmm_blocks.end()) {
+                c->slab_backing = DBG_SLAB_VMM;
+                c->slab_piece_bytes = vb->second.pieces.empty() ? 0 : vb->second.pieces[0].second;
+            } else {                                                     // a pooled plain block of matching size served (an earlier fallback)
+                c->slab_backing = DBG_SLAB_PLAIN_FALLBACK;
+                snprintf(c->slab_note, sizeof(c->slab_note), "pooled plain block reused");
+            }
+            c->slab_ptr = p;
             return true;
         }
-        if (c->opt("DBG_DEBUG")) fprintf(stderr, "[fastpath] slab of %zu bytes: no piecewise mapping, plain allocation\n", bytes);
+        c->slab_backing = DBG_SLAB_PLAIN_FALLBACK;
+        snprintf(c->slab_note, sizeof(c->slab_note), "%s", why.c_str());
+        fprintf(stderr, "[dbg_mi355x] slab of %zu bytes: no piecewise mapping (%s); plain allocation\n", bytes, why.c_str());
     }
-    return slab->alloc(c, words);
+    const bool ok = slab->alloc(c, words);
+    if (ok) c->slab_ptr = slab->p;
+    return ok;
 }
 
 static bool lane_scan_wanted(dbg_ctx* c) { return !(c->opt("DBG_SCAN") && !strcmp(c->opt("DBG_SCAN"), "wave")); }
@@ -1669,8 +1686,11 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
         if (const char* e = c->opt("DBG_SLAB_CAP")) st->slab_cap = (uint32_t)std::max(4, atoi(e)) & ~3u;      // measurement: records per slab
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw)) tmp_cap = tmp_cap / 16 + 4096;
+        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw, (uint32_t)rw)) tmp_cap = tmp_cap / 16 + 4096;
         else {
+            if (!c->opt("DBG_FAST_NO_SLAB")) fprintf(stderr, "[dbg_mi355x] no device memory for per-bin slabs: records take the read-order buffer and the scatter pass\n");
+            c->slab_backing = DBG_SLAB_RECORD_ORDER; c->slab_ptr = nullptr;
+            snprintf(c->slab_note, sizeof(c->slab_note), "%s", c->opt("DBG_FAST_NO_SLAB") ? "DBG_FAST_NO_SLAB" : "slab allocation failed");
             // not enough memory for slabs (1.3x the records + slack): every record takes the read-order buffer and the
             // scatter pass instead -- slab capacity 0 routes them all there
             st->slab_cap = 0;

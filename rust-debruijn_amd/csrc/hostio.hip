@@ -61,6 +61,7 @@ Stager* get_stager(dbg_ctx* c) {
     const unsigned nt = host_threads();
     s->lanes.resize(nt);
     bool ok = hipStreamCreateWithFlags(&s->dma, hipStreamNonBlocking) == hipSuccess;
+    HostTimer t_(&c->s_pinned_alloc);
     for (auto& l : s->lanes) {
         for (int b = 0; b < 2 && ok; b++)
             ok = hipHostMalloc(&l.buf[b], STAGE_CHUNK, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&l.ev[b], hipEventDisableTiming) == hipSuccess;
@@ -150,6 +151,8 @@ void* ctx_halloc(dbg_ctx* c, size_t bytes) {
         return p;
     }
     void* p = nullptr;
+    HostTimer t_(&c->s_pinned_alloc);
+    c->n_pinned_alloc++;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         { std::lock_guard<std::mutex> g(g_pin_mu); for (auto& kv : c->hfree_blocks) g_pin_owner.erase(kv.second); }

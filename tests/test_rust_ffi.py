@@ -17,7 +17,8 @@ spec.loader.exec_module(G)
 MIRROR = {"dbg_seqset": capi.SeqSet, "dbg_filter_params": capi.FilterParams, "dbg_kmer_table": capi.KmerTable, "dbg_msp_params": capi.MspParams,
           "dbg_msp_pieces": capi.MspPieces, "dbg_graph": capi.Graph, "dbg_label_classes": capi.LabelClasses, "dbg_edges": capi.Edges,
           "dbg_shard_plan": capi.ShardPlan, "dbg_transport": capi.Transport, "dbg_shard_params": capi.ShardParams,
-          "dbg_shard_stats": capi.ShardStats, "dbg_synth_params": capi.SynthParams, "dbg_kernel_time": capi.KernelTime}
+          "dbg_shard_stats": capi.ShardStats, "dbg_synth_params": capi.SynthParams, "dbg_kernel_time": capi.KernelTime,
+          "dbg_ctx_stats": capi.CtxStats}
 
 
 def parsed():

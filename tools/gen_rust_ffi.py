@@ -18,8 +18,8 @@ HEADER = os.path.join(ROOT, "include", "dbg_mi355x.h")
 OUT = os.path.join(ROOT, "integration", "dbg_mi355x_sys.rs")
 
 PRIM = {"uint64_t": "u64", "uint32_t": "u32", "uint16_t": "u16", "uint8_t": "u8", "int32_t": "i32", "int64_t": "i64", "int": "c_int",
-        "double": "f64", "char": "c_char", "void": "c_void", "size_t": "usize"}
-SIZES = {"u64": 8, "u32": 4, "u16": 2, "u8": 1, "i32": 4, "i64": 8, "c_int": 4, "f64": 8, "c_char": 1, "usize": 8}
+        "double": "f64", "float": "f32", "char": "c_char", "void": "c_void", "size_t": "usize"}
+SIZES = {"u64": 8, "u32": 4, "u16": 2, "u8": 1, "i32": 4, "i64": 8, "c_int": 4, "f64": 8, "f32": 4, "c_char": 1, "usize": 8}
 
 
 def strip_comments(text):
@@ -57,7 +57,8 @@ def parse(text):
             fp = re.match(r"^(\w[\w\s\*]*?)\(\s*\*\s*(\w+)\s*\)\s*\((.*)\)$", part, flags=re.S)
             if fp:
                 args = [split_decl(a) for a in fp.group(3).split(",")]
-                fields.append(dict(name=fp.group(2), fnptr=True, ret=rust_type(fp.group(1)), args=[(n, rust_type(t)) for t, n, _ in args]))
+                # (a `void` return is no return type in Rust: `c_void` is only ever a pointee)
+                fields.append(dict(name=fp.group(2), fnptr=True, ret=None if fp.group(1).strip() == "void" else rust_type(fp.group(1)), args=[(n, rust_type(t)) for t, n, _ in args]))
                 continue
             ctype, first, arr = split_decl(part.split(",")[0])
             names = [(first, arr)]
@@ -72,6 +73,9 @@ def parse(text):
             if "=" in item:
                 k, v = item.split("=")
                 enums.append((k.strip(), int(v.strip())))
+    for m in re.finditer(r"(?m)^#define\s+(DBG_[A-Z0-9_]+)\s+(\d+)\b", text):
+        if m.group(1) != "DBG_MI355X_H":
+            enums.append((m.group(1), int(m.group(2))))
     body = re.sub(r"typedef\s+struct\s*\w*\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
     for m in re.finditer(r"(?m)^\s*((?:const\s+)?\w+\s*\**)\s*(dbg_\w+)\s*\(([^;{]*?)\)\s*;", body, flags=re.S):
         ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
@@ -108,7 +112,7 @@ def emit(structs, enums, funcs):
         for f in fields:
             if f["fnptr"]:
                 args = ", ".join("%s: %s" % (ident(n), t) for n, t in f["args"])
-                o.append("    pub %s: Option<unsafe extern \"C\" fn(%s) -> %s>," % (ident(f["name"]), args, f["ret"]))
+                o.append("    pub %s: Option<unsafe extern \"C\" fn(%s)%s>," % (ident(f["name"]), args, " -> %s" % f["ret"] if f["ret"] else ""))
             elif f["array"]:
                 o.append("    pub %s: [%s; %d]," % (ident(f["name"]), f["rtype"], f["array"]))
             else:
