@@ -245,10 +245,12 @@ def main():
     try:
         cst = ctx.stats()
         pr = ctx.probe_slab()
-        slab = {"backing": cst["slab_backing_name"], "gb": round(cst["slab_bytes"] / 2**30, 2), "mb_per_handle": cst["slab_piece_bytes"] >> 20,
-                "handles": cst["slab_pieces"], "note": cst["slab_note"] or None,
+        slab = {"backing": cst["slab_backing_name"], "gb": round(cst["slab_bytes"] / 2**30, 2), "note": cst["slab_note"] or None,
+                # slab tournament: first-scan ms of the candidate blocks the first calls tried; the fastest one stayed (it needs DBG_SLAB_TRIALS = 4
+                # calls: --warmup >= 4 keeps the trials out of the timed steps)
+                "tournament_scan_ms": cst["slab_trial_ms"], "tournament_settled": cst["slab_candidates_pooled"] <= 1 and cst["slab_trials_done"] >= 4,
                 "probe_ms": round(pr[0], 3) if pr else None, "probe_writes": pr[1] if pr else None,
-                "probe_note": "2^27 record-sized random writes into the pooled slab, best of 3 (fast placement kind at 26 GB / 24-byte records: 5.6-5.9 ms; slow: 7.0-7.5)",
+                "probe_note": "2^27 record-sized random writes into the pooled slab, best of 3 (26 GB, 24-byte records: 5.4 ms in a well-placed block .. 7.4 in a badly placed one)",
                 "alloc": {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in cst.items()
                           if kk.startswith(("n_", "s_", "pooled"))}}
     except Exception as e:                               # (never let a diagnostic take the bench line down)
@@ -398,7 +400,8 @@ def main():
                 ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None,
                                   lab5k.data_ptr() if set2 == 2 else (colour.data_ptr() if set2 else None), 4 if set2 == 2 else (1 if set2 else 0), reads_per_gpu)
                 kt2, ni2 = {}, 0
-                for rep in range(3):
+                # (four untimed calls: the slab tournament of the shape -- the library tries four slab blocks and keeps the fastest)
+                for rep in range(-3, 3):
                     if rep == 1:
                         ctx.enable_timing(True)
                         torch.cuda.synchronize()
@@ -419,6 +422,7 @@ def main():
                 if set2 == 2:
                     other[nm]["labels"] = "5000 distinct u32 labels in [0, 2^24), one per read at random"
             del lab5k
+            ctx.trim()                                               # (one tournament winner per shape sits in the pool)
         cpu = None
         if not args.no_cpu_baseline and world == 1:                # timed on rank 0 at N = 1 only
             import oracle_lib as O
@@ -534,6 +538,49 @@ def main():
                                               "kmers_per_s": round(nk / ddt, 1), "boundary": "index in HBM, host BaseGraph out"}}
             lib.dbg_free_graph(ctx.h, C.byref(g))
             lib.dbg_free_table(ctx.h, C.byref(h2))
+            # (c) the pipeline real callers run (filter.rs:233-306, test.rs:236-254): filter_kmers -> remove_censored_exts ->
+            # compress_kmers_with_hash.  Extensions towards k-mers that did not pass the filter are dropped first, so the valid
+            # k-mers join into few, long unitigs (10^5 of ~4 kb instead of 2*10^7 short ones): another regime for the chain walks.
+            # Warm (the bench ctx) and FIRST CALL (a fresh ctx: nothing pooled, nothing pinned), the latter itemised from the
+            # ctx's allocation account.
+            t3 = capi.KmerTable()
+            ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss2), C.byref(fp2), C.byref(t3)))
+            ctx.enable_timing(True)
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            ctx.check(lib.dbg_remove_censored_exts(ctx.h, k, 0, C.byref(t3), 0))
+            torch.cuda.synchronize()
+            cens_dt = time.perf_counter() - c0
+
+            def censored_compress(cx):
+                gg = capi.Graph()
+                cx.enable_timing(True)
+                torch.cuda.synchronize()
+                q0 = time.perf_counter()
+                cx.check(lib.dbg_compress_kmers_with_hash_dev(cx.h, k, 0, 0, t3.n, t3.key_hi, t3.key_lo, t3.exts, None, t3.count, C.byref(gg)))
+                qdt = time.perf_counter() - q0
+                kt = {x["name"]: round(x["ms"], 3) for x in cx.timings()}
+                cx.enable_timing(False)
+                nn = int(gg.n_nodes)
+                ln = np.ctypeslib.as_array(C.cast(gg.length, C.POINTER(C.c_uint32)), shape=(max(nn, 1),))[:nn]
+                info = {"seconds": round(qdt, 4), "unitigs": nn, "unitigs_per_s": round(nn / qdt, 1), "kmers_per_s": round(t3.n / qdt, 1),
+                        "longest_unitig_bases": int(ln.max()) if nn else 0, "mean_unitig_bases": round(float(ln.mean()), 1) if nn else 0.0,
+                        "chain_route": ("chain walk (unitig_chain_scan)" if "unitig_chain_scan" in kt and "unitig_pointer_jump" not in kt and "unitig_walk_ends" not in kt
+                                        else ("pointer jumping" if "unitig_pointer_jump" in kt else ("end walks" if "unitig_walk_ends" in kt else "host walk"))),
+                        "kernel_ms": kt}
+                lib.dbg_free_graph(cx.h, C.byref(gg))
+                return info
+            censored_compress(ctx)                                   # (pool warm-up of this shape)
+            warm = censored_compress(ctx)
+            ctx.trim()                                               # the bench ctx's pool holds most of the device by now; a second ctx needs room
+            cold_ctx = dbg.Context(local_rank)
+            cold = censored_compress(cold_ctx)
+            cst = cold_ctx.stats()
+            cold["alloc_account"] = {kk: (round(v, 4) if isinstance(v, float) else v) for kk, v in cst.items() if kk.startswith(("n_", "s_", "pooled"))}
+            cold_ctx.close()
+            comp["censored"] = {"pipeline": "dbg_filter_kmers_dev(CountFilter(2)) -> dbg_remove_censored_exts -> dbg_compress_kmers_with_hash_dev (index in HBM, host BaseGraph out)",
+                                "remove_censored_exts_seconds": round(cens_dt, 4), "warm": warm, "first_call_fresh_ctx": cold}
+            lib.dbg_free_table(ctx.h, C.byref(t3))
         out = {
             "metric": "Gkmer/s extracted+counted (k=%d, 150 bp synthetic reads)" % k, "value": round(value, 4),
             "unit": "Gkmer/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -530,41 +530,42 @@ typedef struct {
 int  dbg_ctx_enable_timing(dbg_ctx* ctx, int on);
 int  dbg_ctx_get_timings(dbg_ctx* ctx, dbg_kernel_time* out, uint32_t cap, uint32_t* n_out);
 
-/* ---- allocation account of a ctx + how the scan's slab is backed (round 6) ----------------------------------------
- * What a cold call pays before its first kernel (driver allocations, piecewise mapping of the slab, pinned host blocks) and
- * whether the 26 GB slab the scan writes at random got the piecewise mapping that keeps it of the fast placement kind
- *  -- the library never degrades silently: slab_backing says what the last scan ran on, and why.
+/* ---- allocation account of a ctx + the slab the scan writes (round 6) ---------------------------------------------
+ * What a cold call pays before its first kernel (driver allocations, pinned host blocks), and the slab tournament: a block of
+ * tens of GB takes the scan's random record writes 10 % faster or slower depending on where the driver placed it (DESIGN.md
+ * section 4.1), so the first DBG_SLAB_TRIALS (default 4) fast-path calls of a shape each scan into a fresh block, the scan is
+ * timed, and the fastest block stays.  Nothing degrades silently: slab_backing says what the last scan ran on.
  * The caller sets struct_size = sizeof(dbg_ctx_stats); the library fills at most that many bytes (fields are only ever
  * appended). */
 #define DBG_SLAB_NONE         0   /* no slab taken yet (dense / generic path, or no call so far) */
-#define DBG_SLAB_VMM          1   /* one virtual range mapped from physical handles of slab_piece_bytes (hipMemCreate / hipMemMap) */
-#define DBG_SLAB_PLAIN_SMALL  2   /* below 4 GB: a plain pool block (placement kinds only show on blocks of many GB) */
-#define DBG_SLAB_PLAIN_KNOB   3   /* DBG_SLAB_VMM=0 asked for a plain block */
-#define DBG_SLAB_PLAIN_FALLBACK 4 /* the piecewise mapping failed (slab_note holds the reason): plain block */
+#define DBG_SLAB_PLAIN        1   /* a plain device block of 4 GB or more: takes part in the tournament */
+#define DBG_SLAB_PLAIN_SMALL  2   /* below 4 GB: a pool block (placement kinds only show on blocks of many GB) */
 #define DBG_SLAB_RECORD_ORDER 5   /* no memory for slabs: every record takes the read-order buffer and the scatter pass */
 typedef struct {
     uint32_t struct_size;
     uint32_t slab_backing;          /* DBG_SLAB_* of the last fast-path scan */
     uint64_t slab_bytes;
-    uint64_t slab_piece_bytes;      /* bytes per physical handle (DBG_SLAB_VMM) */
-    uint32_t slab_pieces;
+    uint32_t slab_rec_words;        /* 64-bit words per record of that scan */
     uint32_t slab_pooled;           /* 1: the block is in the ctx pool right now (dbg_ctx_probe_slab can run on it) */
     uint64_t pooled_bytes;          /* device bytes the ctx holds (live + kept for reuse) */
     uint64_t pooled_high_water;
-    uint64_t n_hipmalloc, n_vmm_blocks, n_pool_hits, n_trims, n_oom_retries, n_raw_free, n_pinned_alloc;
+    uint64_t n_hipmalloc, n_fresh_blocks, n_pool_hits, n_trims, n_oom_retries, n_raw_free, n_pinned_alloc;
     double   s_hipmalloc;           /* host seconds inside hipMalloc */
-    double   s_vmm_map;             /* ... creating + mapping physical handles */
-    double   s_free;                /* ... giving blocks back (hipFree, unmap + release) */
+    double   s_free;                /* ... giving blocks back (hipFree) */
     double   s_pinned_alloc;        /* ... hipHostMalloc of staging / result blocks */
     char     slab_note[96];
+    /* slab tournament: slab_trial_ms[i] = scan time of candidate i (milliseconds, first scan into the block) */
+    uint32_t slab_trials_done;
+    uint32_t slab_candidates_pooled;    /* measured candidates still held (1 once the tournament has settled) */
+    float    slab_trial_ms[8];
 } dbg_ctx_stats;
 int  dbg_ctx_get_stats(dbg_ctx* ctx, dbg_ctx_stats* out);
 /* Random-write probe of the slab block the last scan used, while it sits in the pool between calls: n_writes (0 = 2^27)
  * record-sized writes at random record slots, best of three launches, milliseconds in *ms_out (*writes_out: the writes of one
- * launch).  On MI355X the fast placement kind takes 5.6-5.9 ms for 2^27 24-byte writes into 26 GB, the slow kind 7.0-7.5.
+ * launch).  On MI355X 2^27 24-byte writes into 26 GB take 5.4 ms in a well-placed block and up to 7.4 ms in a badly placed one.
  * Returns non-zero when there is no pooled slab to probe. */
 int  dbg_ctx_probe_slab(dbg_ctx* ctx, uint64_t n_writes, float* ms_out, uint64_t* writes_out);
-/* Pays the cold costs of a first call ahead of time: maps a slab of slab_bytes (0 = none) and reserves pinned_bytes of pinned
+/* Pays the cold costs of a first call ahead of time: allocates a device block of slab_bytes (0 = none) and pinned_bytes of pinned
  * host result blocks (0 = none) into the ctx pools.  A later call of matching size then starts like a warm one. */
 int  dbg_ctx_warm(dbg_ctx* ctx, uint64_t slab_bytes, uint64_t pinned_bytes);
 /* ABI revision of this header: structs only grow at their end from one revision to the next, and a host may check

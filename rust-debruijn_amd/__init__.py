@@ -297,7 +297,8 @@ class Context:
         st = _capi.CtxStats()
         st.struct_size = C.sizeof(st)
         self.check(self.lib.dbg_ctx_get_stats(self.h, C.byref(st)))
-        d = {n: getattr(st, n) for n, _ in st._fields_ if n not in ("struct_size", "slab_note")}
+        d = {n: getattr(st, n) for n, _ in st._fields_ if n not in ("struct_size", "slab_note", "slab_trial_ms") and not n.startswith("reserved")}
+        d["slab_trial_ms"] = [round(float(x), 3) for x in st.slab_trial_ms[:min(st.slab_trials_done, 8)]]
         d["slab_note"] = st.slab_note.decode(errors="replace")
         d["slab_backing_name"] = _capi.SLAB_BACKING_NAMES.get(st.slab_backing, "?")
         return d

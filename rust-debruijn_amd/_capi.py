@@ -99,16 +99,15 @@ class KernelTime(C.Structure):
 
 
 class CtxStats(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("slab_backing", C.c_uint32), ("slab_bytes", C.c_uint64), ("slab_piece_bytes", C.c_uint64),
-                ("slab_pieces", C.c_uint32), ("slab_pooled", C.c_uint32), ("pooled_bytes", C.c_uint64), ("pooled_high_water", C.c_uint64),
-                ("n_hipmalloc", C.c_uint64), ("n_vmm_blocks", C.c_uint64), ("n_pool_hits", C.c_uint64), ("n_trims", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("slab_backing", C.c_uint32), ("slab_bytes", C.c_uint64),                 ("slab_rec_words", C.c_uint32), ("slab_pooled", C.c_uint32), ("pooled_bytes", C.c_uint64), ("pooled_high_water", C.c_uint64),
+                ("n_hipmalloc", C.c_uint64), ("n_fresh_blocks", C.c_uint64), ("n_pool_hits", C.c_uint64), ("n_trims", C.c_uint64),
                 ("n_oom_retries", C.c_uint64), ("n_raw_free", C.c_uint64), ("n_pinned_alloc", C.c_uint64),
-                ("s_hipmalloc", C.c_double), ("s_vmm_map", C.c_double), ("s_free", C.c_double), ("s_pinned_alloc", C.c_double),
-                ("slab_note", C.c_char * 96)]
+                ("s_hipmalloc", C.c_double), ("s_free", C.c_double), ("s_pinned_alloc", C.c_double),
+                ("slab_note", C.c_char * 96), ("slab_trials_done", C.c_uint32), ("slab_candidates_pooled", C.c_uint32),
+                ("slab_trial_ms", C.c_float * 8)]
 
 
-SLAB_BACKING_NAMES = {0: "none", 1: "vmm", 2: "plain (slab < 4 GB)", 3: "plain (DBG_SLAB_VMM=0)", 4: "plain (piecewise mapping failed)",
-                      5: "no slabs (read-order buffer + scatter)"}
+SLAB_BACKING_NAMES = {0: "none", 1: "plain block, tournament", 2: "plain (slab < 4 GB)", 5: "no slabs (read-order buffer + scatter)"}
 
 
 # every symbol include/dbg_mi355x.h declares

@@ -87,14 +87,15 @@ extern "C" int dbg_ctx_get_stats(dbg_ctx* c, dbg_ctx_stats* out) {
     if (!out || out->struct_size < 8) return c->fail(10, "dbg_ctx_get_stats: struct_size not set");
     dbg_ctx_stats st;
     memset(&st, 0, sizeof(st));
-    st.slab_backing = c->slab_backing; st.slab_bytes = c->slab_bytes; st.slab_piece_bytes = c->slab_piece_bytes;
-    st.slab_pieces = c->slab_piece_bytes ? (uint32_t)((c->slab_bytes + c->slab_piece_bytes - 1) / c->slab_piece_bytes) : 0;
+    st.slab_backing = c->slab_backing; st.slab_bytes = c->slab_bytes; st.slab_rec_words = c->slab_rec_words;
     if (c->slab_ptr) for (auto& kv : c->free_blocks) if (kv.second == c->slab_ptr) st.slab_pooled = 1;
     st.pooled_bytes = c->pooled_bytes; st.pooled_high_water = c->pooled_high_water;
-    st.n_hipmalloc = c->n_hipmalloc; st.n_vmm_blocks = c->n_vmm_blocks; st.n_pool_hits = c->n_pool_hits; st.n_trims = c->n_trims;
+    st.n_hipmalloc = c->n_hipmalloc; st.n_fresh_blocks = c->n_fresh_blocks; st.n_pool_hits = c->n_pool_hits; st.n_trims = c->n_trims;
     st.n_oom_retries = c->n_oom_retries; st.n_raw_free = c->n_raw_free; st.n_pinned_alloc = c->n_pinned_alloc;
-    st.s_hipmalloc = c->s_hipmalloc; st.s_vmm_map = c->s_vmm_map; st.s_free = c->s_free; st.s_pinned_alloc = c->s_pinned_alloc;
+    st.s_hipmalloc = c->s_hipmalloc; st.s_free = c->s_free; st.s_pinned_alloc = c->s_pinned_alloc;
     memcpy(st.slab_note, c->slab_note, sizeof(st.slab_note));
+    st.slab_trials_done = c->slab_trials_done; st.slab_candidates_pooled = (uint32_t)c->slab_cands.size();
+    memcpy(st.slab_trial_ms, c->slab_trial_ms, sizeof(st.slab_trial_ms));
     const uint32_t n = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(st));
     st.struct_size = n;
     memcpy(out, &st, n);
@@ -149,18 +150,10 @@ extern "C" int dbg_ctx_probe_slab(dbg_ctx* c, uint64_t n_writes, float* ms_out, 
     return 0;
 }
 
-void* ctx_halloc(dbg_ctx* c, size_t bytes);
-void ctx_hfree(dbg_ctx* c, void* p);
 extern "C" int dbg_ctx_warm(dbg_ctx* c, uint64_t slab_bytes, uint64_t pinned_bytes) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (slab_bytes) {
-        const char* knob = c->opt("DBG_SLAB_VMM");
-        void* p = nullptr;
-        if (slab_bytes >= (4ull << 30) && !(knob && !strcmp(knob, "0"))) {
-            const size_t piece = knob && atoll(knob) > 0 ? (size_t)atoll(knob) << 20 : (size_t)256 << 20;
-            p = c->dalloc_pieces(slab_bytes, piece);
-        }
-        if (!p) p = c->dalloc(slab_bytes);
+        void* p = c->dalloc(slab_bytes);
         if (!p) return c->fail(101, "dbg_ctx_warm: device allocation failed");
         c->dfree(p);
     }

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <set>
 #include <algorithm>
 #include <mutex>
 #include <condition_variable>
@@ -42,8 +43,8 @@ struct dbg_state_slot {
 static const char* const DBG_OPTION_NAMES[] = {
     "DBG_PATH", "DBG_COMPRESS", "DBG_FAST_TARGET", "DBG_FAST_NT", "DBG_FAST_TABLE", "DBG_NO_HYBRID_SORT", "DBG_NO_REC16",
     "DBG_FAST_NO_SLAB", "DBG_DEBUG", "DBG_UNITIG_NO_WALK", "DBG_UNITIG_NO_CHAINS", "DBG_NO_KEY_RECORDS", "DBG_NO_NODE_RECORDS",
-    "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_SLAB_VMM", "DBG_NO_LABEL_GROUPS", "DBG_NO_STRAND_NORM", "DBG_SHARD_MERGE", "DBG_LINKS", "DBG_DENSE_RANGES", "DBG_CHAIN_WALKS", "DBG_DENSE_PART", "DBG_DENSE_BATCH", "DBG_DENSE_L1", "DBG_DENSE_RAW",
-    "DBG_FAIL_AT", "DBG_COMM_TIMEOUT_S", "DBG_SHARD_MERGE_COST_MS", "DBG_LABEL_LISTS"};   // (the last two: fault injection and the bound on communication waits of the rank-spanning calls, shard_comm.hpp)   // (DBG_MSP: wave | twopass)
+    "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_NO_LABEL_GROUPS", "DBG_NO_STRAND_NORM", "DBG_SHARD_MERGE", "DBG_LINKS", "DBG_DENSE_RANGES", "DBG_CHAIN_WALKS", "DBG_DENSE_PART", "DBG_DENSE_BATCH", "DBG_DENSE_L1", "DBG_DENSE_RAW",
+    "DBG_FAIL_AT", "DBG_COMM_TIMEOUT_S", "DBG_SHARD_MERGE_COST_MS", "DBG_LABEL_LISTS", "DBG_SLAB_TRIALS"};   // (the last two: fault injection and the bound on communication waits of the rank-spanning calls, shard_comm.hpp)   // (DBG_MSP: wave | twopass)
 
 // Reads whose packed words are still on their way to the device (dbg_filter_kmers: the upload of the caller's words runs in chunks
 // of reads next to the scan of the chunks that have arrived, api.hip).  Chunk g is complete once reads [0, upto[g]) have their words
@@ -119,18 +120,30 @@ struct dbg_ctx {
     std::vector<dbg_timing_rec> trecs;
     std::vector<hipEvent_t> event_pool;
     // pooled device allocations: free blocks by size; live blocks by pointer
-    std::multimap<size_t, void*> free_blocks;
+    // (size, address): among blocks of one size the lowest address serves first, so the same request of the same call sequence gets
+    //  the same block every time -- with insertion order two equal-sized buffers swapped blocks from call to call, and the scan's time
+    //  alternated by 0.9 ms with the block its cursor array sat in, round 6)
+    std::set<std::pair<size_t, void*>> free_blocks;
+    std::set<std::pair<size_t, void*>>::iterator pool_find(size_t bytes) { return free_blocks.lower_bound({bytes, nullptr}); }
     std::map<void*, size_t> live_blocks;
     size_t pooled_bytes = 0;
     // ---- allocation account (dbg_ctx_get_stats): what a cold call pays, and how the scan's slab is backed ----
     size_t pooled_high_water = 0;
-    uint64_t n_hipmalloc = 0, n_vmm_blocks = 0, n_pool_hits = 0, n_trims = 0, n_oom_retries = 0, n_raw_free = 0, n_pinned_alloc = 0;
-    double s_hipmalloc = 0, s_vmm_map = 0, s_free = 0, s_pinned_alloc = 0;
+    uint64_t n_hipmalloc = 0, n_fresh_blocks = 0, n_pool_hits = 0, n_trims = 0, n_oom_retries = 0, n_raw_free = 0, n_pinned_alloc = 0;
+    double s_hipmalloc = 0, s_free = 0, s_pinned_alloc = 0;
     uint32_t slab_backing = 0;                     // DBG_SLAB_* of the last slab the scan took
     void* slab_ptr = nullptr;                      // ... the block (it sits in free_blocks between calls)
-    size_t slab_bytes = 0, slab_piece_bytes = 0;
+    size_t slab_bytes = 0;
     uint32_t slab_rec_words = 0;                   // words per record of the scan that used it
     char slab_note[96] = {0};
+    // Slab tournament (fastpath.hip, slab_alloc): the first calls of a shape each run their scan on a fresh block, the scan is timed,
+    // and the fastest block stays -- a 26 GB block takes the same random 24-byte writes at 31 or 34-36 ms depending on where the driver
+    // placed it, reproducibly per block and differently in every process.
+    struct SlabCand { void* p; size_t bytes; double ns_per_kmer; };
+    std::vector<SlabCand> slab_cands;
+    uint64_t slab_trial_key = 0;
+    uint32_t slab_trials_done = 0;
+    float slab_trial_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void note_pool() { if (pooled_bytes > pooled_high_water) pooled_high_water = pooled_bytes; }
 
     int fail(int code, const std::string& msg) { err = msg; return code; }
@@ -138,7 +151,7 @@ struct dbg_ctx {
     void* dalloc(size_t bytes) {
         if (bytes == 0) bytes = 256;
         bytes = (bytes + 255) & ~(size_t)255;
-        auto it = free_blocks.lower_bound(bytes);
+        auto it = pool_find(bytes);
         if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
             void* p = it->second;
             live_blocks[p] = it->first;
@@ -177,75 +190,31 @@ struct dbg_ctx {
         free_blocks.insert({it->second, p});
         live_blocks.erase(it);
     }
-    // Blocks of several GB that are written at random (the scan's slabs): ONE virtual range mapped from physical handles of 2 GB
-    // (hipMemCreate / hipMemMap).  Round 5 measured why (profiles/r05_slab_modes.txt, r05_slab_vmm_probe.txt): a 26 GB hipMalloc --
-    // and a 26 GB range mapped from a single handle -- comes in two kinds, 5.8 or 7.0-7.5 ms for the same 1.3e8 random 24-byte writes,
-    // the slow kind stalling on DRAM write credits at the L2 with identical traffic; the same range mapped from 13 handles of 2 GB
-    // (or 104 of 256 MB) is always of the fast kind (5.6-5.85 ms).  Such blocks join the pool like any other (live_blocks /
-    // free_blocks); only their release differs (raw_free).
-    struct VmmBlock { size_t bytes; std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> pieces; };
-    std::map<void*, VmmBlock> vmm_blocks;
-    void vmm_release(void* va, VmmBlock& b, size_t mapped) {
-        size_t o = 0;
-        for (auto& pc : b.pieces) {
-            if (o < mapped) (void)hipMemUnmap((char*)va + o, pc.second);
-            (void)hipMemRelease(pc.first);
-            o += pc.second;
-        }
-        (void)hipMemAddressFree(va, b.bytes);
-        (void)hipGetLastError();
-    }
-    void* dalloc_pieces(size_t bytes, size_t piece = 2ull << 30, std::string* why = nullptr) {
-        auto say = [&](const char* what, hipError_t e) { if (why) *why = std::string(what) + ": " + hipGetErrorString(e); };
+    // A block of the asked size straight from the driver, not from the pool (a candidate of the slab tournament, fastpath.hip).
+    // Round 5 mapped slabs piecewise from physical handles (hipMemCreate / hipMemMap) in the belief that this fixed their placement
+    // kind; round 6 measured that it does not (any handle size, 2 MB .. 2 GB, probes at 5.4 .. 7.4 ms like a plain block:
+    // tools/micro/slab_probe6.hip, slab_probe7.hip) and that RELEASING such a block is unsafe on this driver: physical pages that
+    // return to the driver and are mapped again are zero-filled asynchronously, without a fence the user queues wait for, so the clear
+    // lands on top of data kernels have already written into the new mapping (tools/micro/vmm_reuse.hip: 2e7 zeroed words per 26 GB
+    // round; the bench failed with "corrupt super-k-mer record" in 2 of 5 processes).  hipMalloc / hipFree do not show it.
+    void* dalloc_fresh(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
-        auto it = free_blocks.lower_bound(bytes);                    // a pooled block of this size (a slab of an earlier call) first
-        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
-            void* p = it->second;
-            live_blocks[p] = it->first;
-            free_blocks.erase(it);
-            n_pool_hits++;
-            return p;
-        }
-        HostTimer t_(&s_vmm_map);
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
-        size_t gran = 0;
-        if (hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended); e != hipSuccess || !gran) { say("hipMemGetAllocationGranularity", e); (void)hipGetLastError(); return nullptr; }
-        piece = (piece + gran - 1) / gran * gran;
-        const size_t total = (bytes + gran - 1) / gran * gran;
-        void* va = nullptr;
-        if (hipError_t e = hipMemAddressReserve(&va, total, 0, nullptr, 0); e != hipSuccess) { say("hipMemAddressReserve", e); (void)hipGetLastError(); return nullptr; }
-        VmmBlock b{total, {}};
-        size_t mapped = 0;
-        bool ok = true;
-        for (size_t o = 0; o < total && ok; o += piece) {
-            const size_t n = std::min(piece, total - o);
-            hipMemGenericAllocationHandle_t h;
-            if (hipError_t e = hipMemCreate(&h, n, &prop, 0); e != hipSuccess) { say("hipMemCreate", e); ok = false; break; }
-            b.pieces.push_back({h, n});
-            if (hipError_t e = hipMemMap((char*)va + o, n, 0, h, 0); e != hipSuccess) { say("hipMemMap", e); ok = false; break; }
-            mapped = o + n;
-        }
-        hipMemAccessDesc acc = {};
-        acc.location.type = hipMemLocationTypeDevice; acc.location.id = device; acc.flags = hipMemAccessFlagsProtReadWrite;
-        if (ok) if (hipError_t e = hipMemSetAccess(va, total, &acc, 1); e != hipSuccess) { say("hipMemSetAccess", e); ok = false; }
-        if (!ok) { (void)hipGetLastError(); vmm_release(va, b, mapped); return nullptr; }
-        vmm_blocks[va] = std::move(b);
-        live_blocks[va] = total;
-        pooled_bytes += total;
-        n_vmm_blocks++;
+        void* p = nullptr;
+        hipError_t e;
+        { HostTimer t_(&s_hipmalloc); e = hipMalloc(&p, bytes); n_hipmalloc++; }
+        if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        live_blocks[p] = bytes;
+        pooled_bytes += bytes;
         note_pool();
-        return va;
+        return p;
     }
     // give a block back to the driver, whichever way it was obtained
     void raw_free(void* p) {
         HostTimer t_(&s_free);
         n_raw_free++;
         if (p == slab_ptr) slab_ptr = nullptr;
-        auto it = vmm_blocks.find(p);
-        if (it == vmm_blocks.end()) { (void)hipFree(p); return; }
-        vmm_release(p, it->second, it->second.bytes);
-        vmm_blocks.erase(it);
+        for (size_t i = 0; i < slab_cands.size(); i++) if (slab_cands[i].p == p) { slab_cands.erase(slab_cands.begin() + i); break; }
+        (void)hipFree(p);
     }
     void trim() {
         n_trims++;

@@ -681,7 +681,15 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
 // because the kernel waited on LDS; since round 2 it is bound by instruction issue, and dropping the third round is worth 1.8 %
 // with the same probe statistics.  DBG_HASH_1MUL (measurement): the high word folded in by rotations, one multiply.
 __device__ __forceinline__ uint64_t hash_key(uint64_t hi, uint64_t lo) {
-#ifdef DBG_HASH_1MUL
+#if defined(DBG_HASH_FOLD)
+    // Round 6 (measurement): the key's four 32-bit words folded by rotations into one word x (3-4 full-rate instructions), ONE
+    // 32 x 32 -> 64 multiply (v_mad_u64_u32, quarter rate), its halves xor-ed for the bucket / pass bits; the tag is x itself -- it
+    // only has to tell the keys of a bucket apart, and the 128-bit key compare guards every match.  12 issue slots instead of 30.
+    const uint32_t x = (uint32_t)lo ^ rotl32((uint32_t)(lo >> 32), 11) ^ rotl32((uint32_t)hi, 22) ^ rotl32((uint32_t)(hi >> 32), 5);
+    const uint64_t p = (uint64_t)x * 0x9E3779B1ull;
+    const uint32_t m = (uint32_t)p ^ (uint32_t)(p >> 32);
+    return ((uint64_t)(x ^ (x >> 15)) << 32) | m;
+#elif defined(DBG_HASH_1MUL)
     uint64_t h = lo ^ ((hi << 21) | (hi >> 43)) ^ (hi >> 7);
     h ^= h >> 29; h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32;
@@ -1620,41 +1628,61 @@ int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out) {
     return 0;
 }
 
-// The slabs are ~26 GB written 24 bytes at a time at random addresses, and how fast that goes depends on how the block is backed: a
-// plain 26 GB hipMalloc comes in two kinds -- 5.8 or 7.0-7.5 ms for the same 1.3e8 random writes, reproducibly per block, the scan
-// 30.5 or 35 ms -- and the slow kind stalls on DRAM write credits at the L2 with the same requests and hit rates
-// (profiles/r05_slab_modes.txt).  Rounds 3-4 worked around it by timing up to four candidate blocks (slab_probe_kernel); round 5
-// found the cure: the same virtual range mapped from physical handles of 256 MB or 2 GB is always of the fast kind
-// (profiles/r05_slab_vmm_probe.txt, tools/micro/slab_probe5.hip; k = 31 over nine processes: scan 59.0-59.5 ms with 256 MB
-// handles, 59.3-62.3 with 2 GB, 58.8-63.3 plain -- profiles/r05_k31_vmm_ab.txt), so slabs of 4 GB and more are allocated that way
-// (dbg_ctx::dalloc_pieces; DBG_SLAB_VMM=0: plain pool blocks, as smaller slabs always are).
-static bool slab_alloc(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words, uint32_t rec_words) {
+// The slabs are ~26 GB written 24 bytes at a time at random addresses, and how fast that goes depends on where the driver put the
+// block: the same 1.3e8 random writes take 5.4 .. 7.4 ms, the scan 30.8 .. 35.6 ms, steady to 0.3 ms per block and different in every
+// process (profiles/r06_slab_placement.txt).  Rounds 3-4 probed up to four candidate blocks with a synthetic kernel; round 5 mapped the
+// slab piecewise from 256 MB physical handles and believed the matter closed -- round 6 measured that no handle size (2 MB .. 2 GB, any
+// alignment) changes the lottery (every single 256 MB handle is equally fast; it is the COMBINATION of physical ranges a block is made
+// of that decides), and that releasing mapped handles corrupts later mappings on this driver (dbg_ctx::dalloc_fresh).  So the slab is a
+// plain block again, and the lottery is played on purpose: the first DBG_SLAB_TRIALS (default 4) calls of a shape each scan into a
+// FRESH block while the earlier candidates wait in the pool; the scan itself is the probe (timed with events), and from then on only
+// the fastest block stays (the others go back with hipFree).  Six processes: scan 30.9 .. 31.2 ms after the tournament against
+// 30.8 .. 34.2 without.  A trial needs room for one more slab (checked); a change of shape starts over; DBG_SLAB_TRIALS=1: no trials.
+static bool slab_alloc(dbg_ctx* c, DBuf<uint64_t>* slab, size_t words, uint32_t rec_words, int k, bool allow_trial, bool* trial) {
     const size_t bytes = words * 8;
-    const char* knob = c->opt("DBG_SLAB_VMM");
-    // what the scan runs on is recorded in the ctx (dbg_ctx_get_stats): a slab that lost its piecewise mapping is never silent
-    c->slab_ptr = nullptr; c->slab_bytes = bytes; c->slab_piece_bytes = 0; c->slab_rec_words = rec_words; c->slab_note[0] = 0;
-    c->slab_backing = bytes < (4ull << 30) ? DBG_SLAB_PLAIN_SMALL : DBG_SLAB_PLAIN_KNOB;
-    if (bytes >= (4ull << 30) && !(knob && !strcmp(knob, "0"))) {
+    *trial = false;
+    // what the scan runs on is recorded in the ctx (dbg_ctx_get_stats)
+    c->slab_ptr = nullptr; c->slab_bytes = bytes; c->slab_rec_words = rec_words; c->slab_note[0] = 0;
+    c->slab_backing = bytes < (4ull << 30) ? DBG_SLAB_PLAIN_SMALL : DBG_SLAB_PLAIN;
+    uint32_t n_trials = 4;
+    if (const char* e = c->opt("DBG_SLAB_TRIALS")) n_trials = (uint32_t)std::max(1, std::min(8, atoi(e)));
+    if (bytes >= (4ull << 30) && n_trials > 1) {
         (void)hipStreamSynchronize(c->stream);                           // (a pooled block may still be in use by queued work of its previous owner)
-        const size_t piece = knob && atoll(knob) > 0 ? (size_t)atoll(knob) << 20 : (size_t)256 << 20;    // (DBG_SLAB_VMM=<MB per handle>: measurements)
-        std::string why;
-        if (void* p = c->dalloc_pieces(bytes, piece, &why)) {
-            slab->release();
-            slab->ctx = c; slab->p = (uint64_t*)p; slab->n = words;
-            auto vb = c->vmm_blocks.find(p);
-            if (vb != c->vmm_blocks.end()) {
-                c->slab_backing = DBG_SLAB_VMM;
-                c->slab_piece_bytes = vb->second.pieces.empty() ? 0 : vb->second.pieces[0].second;
-            } else {                                                     // a pooled plain block of matching size served (an earlier fallback)
-                c->slab_backing = DBG_SLAB_PLAIN_FALLBACK;
-                snprintf(c->slab_note, sizeof(c->slab_note), "pooled plain block reused");
-            }
-            c->slab_ptr = p;
-            return true;
+        const uint64_t key = (uint64_t)bytes ^ ((uint64_t)k << 48) ^ ((uint64_t)rec_words << 56);
+        if (key != c->slab_trial_key) {
+            c->slab_trial_key = key; c->slab_trials_done = 0; c->slab_cands.clear();
+            for (float& x : c->slab_trial_ms) x = 0.f;
         }
-        c->slab_backing = DBG_SLAB_PLAIN_FALLBACK;
-        snprintf(c->slab_note, sizeof(c->slab_note), "%s", why.c_str());
-        fprintf(stderr, "[dbg_mi355x] slab of %zu bytes: no piecewise mapping (%s); plain allocation\n", bytes, why.c_str());
+        // settle what has been measured so far: only the fastest candidate stays pooled
+        if (c->slab_cands.size() > 1) {
+            auto cands = c->slab_cands;
+            size_t best = 0;
+            for (size_t i = 1; i < cands.size(); i++) if (cands[i].ns_per_kmer < cands[best].ns_per_kmer) best = i;
+            for (size_t i = 0; i < cands.size(); i++) {
+                if (i == best) continue;
+                for (auto it = c->free_blocks.begin(); it != c->free_blocks.end(); ++it)
+                    if (it->second == cands[i].p) { c->pooled_bytes -= it->first; c->free_blocks.erase(it); c->raw_free(cands[i].p); break; }
+            }
+        }
+        bool fresh = allow_trial && c->slab_trials_done >= 1 && c->slab_trials_done < n_trials;
+        if (fresh) {                                                      // room for one more slab next to everything else?
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + bytes / 2) { (void)hipGetLastError(); fresh = false; c->slab_trials_done = n_trials; }
+        }
+        if (fresh) {
+            if (void* p = c->dalloc_fresh(bytes)) {
+                slab->release();
+                slab->ctx = c; slab->p = (uint64_t*)p; slab->n = words;
+                c->n_fresh_blocks++;
+                c->slab_ptr = p;
+                *trial = true;
+                return true;
+            }
+            c->slab_trials_done = n_trials;                              // the device is full: the tournament ends with what it has
+        }
+        const bool ok = slab->alloc(c, words);
+        if (ok) { c->slab_ptr = slab->p; *trial = allow_trial && c->slab_trials_done < n_trials; }
+        return ok;
     }
     const bool ok = slab->alloc(c, words);
     if (ok) c->slab_ptr = slab->p;
@@ -1673,6 +1701,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
     if (!pl.is_set) { sd.data = nullptr; sd.data_width = 0; }   // CountFilter ignores D1 (filter.rs:52-62)
     DBuf<uint32_t> sflags;
     DBuf<unsigned long long> tmp_cursor;
+    bool slab_trial = false;                                     // this call's scan decides whether its (fresh) slab block stays: slab_alloc
     ALLOC_OR_FAIL(c, st->hist, nbins);
     ALLOC_OR_FAIL(c, tmp_cursor, 1);
     ALLOC_OR_FAIL(c, sflags, 2);
@@ -1686,7 +1715,8 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         st->slab_cap = ((uint32_t)std::min<double>(mean * 1.3 + 48.0, 4.0e9) + 3u) & ~3u;
         if (const char* e = c->opt("DBG_SLAB_CAP")) st->slab_cap = (uint32_t)std::max(4, atoi(e)) & ~3u;      // measurement: records per slab
         ALLOC_OR_FAIL(c, st->cursor, nbins);
-        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw, (uint32_t)rw)) tmp_cap = tmp_cap / 16 + 4096;
+        const bool gated_upload = c->read_gates && c->read_gates->upto.size() > 1;     // (the scan's interval would include the waits for the upload)
+        if (!c->opt("DBG_FAST_NO_SLAB") && slab_alloc(c, &st->slab, (uint64_t)nbins * st->slab_cap * rw, (uint32_t)rw, k, !gated_upload, &slab_trial)) tmp_cap = tmp_cap / 16 + 4096;
         else {
             if (!c->opt("DBG_FAST_NO_SLAB")) fprintf(stderr, "[dbg_mi355x] no device memory for per-bin slabs: records take the read-order buffer and the scatter pass\n");
             c->slab_backing = DBG_SLAB_RECORD_ORDER; c->slab_ptr = nullptr;
@@ -1698,7 +1728,9 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
         }
     }
     const uint32_t scan_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 255) / 256, 256ull * 32));
-    const uint64_t chunk_slack = (uint64_t)scan_blocks * 4 * SCAN_CHUNK;      // every wave may strand one partial chunk
+    // every wave may strand one partial chunk -- of every launch: a gated host-boundary scan launches once per upload chunk
+    const bool gated_scan = lane_scan_wanted(c) && direct && c->read_gates && c->read_gates->upto.size() > 1;
+    const uint64_t chunk_slack = (uint64_t)scan_blocks * 4 * SCAN_CHUNK * (gated_scan ? c->read_gates->upto.size() : 1);
     tmp_cap += chunk_slack;
     for (int attempt = 0;; attempt++) {
         ALLOC_OR_FAIL(c, st->tmp_recs, tmp_cap * rw);
@@ -1726,7 +1758,9 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
 #endif
             const size_t lds = (size_t)scan_lane_lds_words(W) * sizeof(uint32_t) + DBG_SCAN_LDS_PAD;
             uint32_t lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((s.n + 63) / 64, 256ull * 16 * 4));
-            c->t_begin("sk_scan", n_kmers);
+            if (!gates) c->t_begin("sk_scan", n_kmers);           // (gated: one interval per launch, without the waits for the upload)
+            hipEvent_t tr_a = nullptr, tr_b = nullptr;
+            if (slab_trial && attempt == 0) { tr_a = c->get_event(); tr_b = c->get_event(); (void)hipEventRecord(tr_a, c->stream); }
 #define SCANL(NBW_, D_, L_) do { HIP_TRY(c, hipFuncSetAttribute((const void*)sk_scan_lane_kernel<NBW_, D_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             sk_scan_lane_kernel<NBW_, D_, L_><<<lane_blocks, 64, lds, c->stream>>>(SCAN_ARGS); } while (0)
 #define SCANL_D(NBW_, L_) do { if (direct) SCANL(NBW_, true, L_); else SCANL(NBW_, false, L_); } while (0)
@@ -1736,7 +1770,7 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
             else {
                 uint64_t r0 = 0;
                 for (size_t g = 0; g < gates->upto.size(); g++) {
-                    if (const int e = gates->wait(g)) { c->t_end(); return c->fail(e, gates->msg); }
+                    if (const int e = gates->wait(g)) return c->fail(e, gates->msg);
                     const uint64_t r1 = std::min<uint64_t>(gates->upto[g], s.n);
                     if (r1 <= r0) continue;
                     cur_reads = sd;
@@ -1744,7 +1778,9 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
                     if (cur_reads.exts) cur_reads.exts += r0;
                     if (cur_reads.data) cur_reads.data = (const uint8_t*)cur_reads.data + r0 * cur_reads.data_width;
                     lane_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((cur_reads.n + 63) / 64, 256ull * 16 * 4));
+                    c->t_begin("sk_scan", (uint64_t)((double)n_kmers * (double)(r1 - r0) / (double)std::max<uint64_t>(s.n, 1)));
                     SCANL_GO();
+                    c->t_end();
                     LAUNCH_CHECK(c, "sk_scan_lane");
                     r0 = r1;
                 }
@@ -1753,11 +1789,23 @@ static int fast_scan(dbg_ctx* c, const SeqDev& s, const FastPlan& pl, uint64_t n
 #undef SCANL_GO
 #undef SCANL_D
 #undef SCANL
-            c->t_end();
+            if (!gates) c->t_end();
+            if (tr_b) (void)hipEventRecord(tr_b, c->stream);
             LAUNCH_CHECK(c, "sk_scan_lane");
             HIP_TRY(c, hipMemcpyAsync(sfl, sflags.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipMemcpyAsync(&cur, tmp_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (tr_b) {                                          // one more candidate of the slab tournament measured
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, tr_a, tr_b) == hipSuccess && ms > 0.f && c->slab_ptr == (void*)st->slab.p) {
+                    if (c->slab_trials_done < 8) c->slab_trial_ms[c->slab_trials_done] = ms;
+                    c->slab_trials_done++;
+                    bool known = false;
+                    for (auto& cd : c->slab_cands) if (cd.p == c->slab_ptr) { cd.ns_per_kmer = std::min(cd.ns_per_kmer, (double)ms * 1e6 / (double)std::max<uint64_t>(n_kmers, 1)); known = true; }
+                    if (!known) c->slab_cands.push_back({c->slab_ptr, c->slab_bytes, (double)ms * 1e6 / (double)std::max<uint64_t>(n_kmers, 1)});
+                } else (void)hipGetLastError();
+                c->event_pool.push_back(tr_a); c->event_pool.push_back(tr_b);
+            }
         }
         if (!lane_scan || sfl[1]) {
             const uint32_t long_min = lane_scan ? SCAN_LANE_MAX : 0u;
@@ -2302,11 +2350,11 @@ int filter_kmers_fast(dbg_ctx* c, const SeqDev& s, const dbg_filter_params* prm,
             // 65 / 100 / 250 labels) stay for DBG_LABEL_LISTS=0 and for a device too full for the label buffer.
             const char* ll = c->opt("DBG_LABEL_LISTS");
             const bool groups_ok = !(many.empty() || many.size() > 64u * ML_MAX_GROUPS || c->opt("DBG_NO_LABEL_GROUPS"));
-            DBG_TRY(c->wait_all_reads());
-            if (!(ll && !strcmp(ll, "0"))) {
+            if (!(ll && !strcmp(ll, "0"))) {                 // (its scan follows the gates of a host-boundary upload like fast_run's)
                 DBG_TRY(filter_kmers_fast_lists(c, s, prm, n_kmers, out, used));
                 if (*used) return 0;
             }
+            DBG_TRY(c->wait_all_reads());
             if (!groups_ok) return 0;
             return filter_kmers_fast_many(c, s, prm, n_kmers, many, out, used);
         }

@@ -1055,9 +1055,14 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             classes->n_classes = glob.size(); classes->n_set_val = nv;
             classes->set_off = (uint64_t*)malloc((glob.size() + 1) * 8);
             classes->set_val = (uint32_t*)malloc(std::max<uint64_t>(nv, 1) * 4);
+            if (!classes->set_off || !classes->set_val) {
+                free(classes->set_off); free(classes->set_val);
+                classes->set_off = nullptr; classes->set_val = nullptr; classes->n_classes = 0; classes->n_set_val = 0;
+                lrc = c->fail(102, "sharded compress: host allocation of the class table failed");
+            }
             uint64_t o = 0;
-            for (size_t i = 0; i < glob.size(); i++) { classes->set_off[i] = o; if (!glob[i].empty()) memcpy(classes->set_val + o, glob[i].data(), glob[i].size() * 4); o += glob[i].size(); }
-            classes->set_off[glob.size()] = o;
+            for (size_t i = 0; i < glob.size() && !lrc; i++) { classes->set_off[i] = o; if (!glob[i].empty()) memcpy(classes->set_val + o, glob[i].data(), glob[i].size() * 4); o += glob[i].size(); }
+            if (!lrc) classes->set_off[glob.size()] = o;
         }
     }
     if (local_out && !lrc) lrc = graph_dev_to_host(c, mine, local_out);
@@ -1065,15 +1070,18 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
     if (int r = X.agree(lrc, "shard")) { release_outputs(); return r; }
 
     // ---- merge the shard graphs ----
+    // (a transport failure cannot be agreed on -- the peers end in their bounded waits -- but this rank's outputs are released like on
+    //  every other failure path: a caller that treats outputs as invalid on error must not leak them)
+#define XFER_TRY(expr) do { if (int r_ = (expr)) { release_outputs(); return r_; } } while (0)
     GraphDev result;
     bool have_result = false;
     if (reduce == DBG_REDUCE_GATHER || W == 1) {
         // phase "gather (sizes)": the sizes go to root, root reserves room for every shard graph
         std::vector<GraphDev> got(W);
         std::vector<GraphMeta> gm(W);
-        if (me != (uint32_t)root) DBG_TRY(graph_send_meta(c, X, mine, root));
+        if (me != (uint32_t)root) XFER_TRY(graph_send_meta(c, X, mine, root));
         else {
-            for (uint32_t r = 0; r < W; r++) if (r != me) DBG_TRY(graph_recv_meta(c, X, &gm[r], (int32_t)r));
+            for (uint32_t r = 0; r < W; r++) if (r != me) XFER_TRY(graph_recv_meta(c, X, &gm[r], (int32_t)r));
             lrc = [&]() -> int {
                 if (W > 1 && X.inject("gather")) return X.injected("gather");
                 for (uint32_t r = 0; r < W; r++) if (r != me) DBG_TRY(graph_dev_reserve(c, gm[r], &got[r]));
@@ -1081,12 +1089,12 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             }();
         }
         if (int r = X.agree(lrc, "gather (sizes)")) { release_outputs(); return r; }
-        if (me != (uint32_t)root) DBG_TRY(graph_send_data(c, X, mine, root));
+        if (me != (uint32_t)root) XFER_TRY(graph_send_data(c, X, mine, root));
         else {
             std::vector<GraphDev*> order(W);
             for (uint32_t r = 0; r < W; r++) {
                 if (r == me) order[r] = &mine;
-                else { DBG_TRY(graph_recv_data(c, X, gm[r], &got[r], (int32_t)r)); order[r] = &got[r]; }
+                else { XFER_TRY(graph_recv_data(c, X, gm[r], &got[r], (int32_t)r)); order[r] = &got[r]; }
             }
             phase_done("gather_transfer", 0);
             lrc = [&]() -> int {
@@ -1112,18 +1120,18 @@ extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint3
             GraphMeta gm{0, 0, 0, 0};
             // (a rank whose own merge failed at the level below still exchanges sizes, so that its partner is not left waiting; the
             //  status is agreed right after)
-            if (sender) DBG_TRY(graph_send_meta(c, X, mine, (int32_t)to));
+            if (sender) XFER_TRY(graph_send_meta(c, X, mine, (int32_t)to));
             else if (receiver) {
-                DBG_TRY(graph_recv_meta(c, X, &gm, (int32_t)from));
+                XFER_TRY(graph_recv_meta(c, X, &gm, (int32_t)from));
                 if (!lrc) lrc = (X.inject("tree") && st == 1) ? X.injected("tree") : graph_dev_reserve(c, gm, &other);
             }
             if (int r = X.agree(lrc, "tree (sizes)")) { release_outputs(); return r; }
             if (sender) {
-                DBG_TRY(graph_send_data(c, X, mine, (int32_t)to));
+                XFER_TRY(graph_send_data(c, X, mine, (int32_t)to));
                 graph_dev_clear(&mine);
                 active = false;
             } else if (receiver) {
-                DBG_TRY(graph_recv_data(c, X, gm, &other, (int32_t)from));
+                XFER_TRY(graph_recv_data(c, X, gm, &other, (int32_t)from));
                 phase_done("tree_transfer", other.n_nodes);
                 lrc = [&]() -> int {
                     GraphDev comb, merged;

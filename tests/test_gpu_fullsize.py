@@ -255,18 +255,24 @@ def _lookup(torch, hi_t, lo_t, qhi, qlo):
     return out.cpu().numpy()
 
 
+@pytest.mark.parametrize("censored", [False, True], ids=["as-filtered", "censored"])
 @pytest.mark.parametrize("env", [CASES[0], CASES[1]], ids=[CASE_IDS[0], CASE_IDS[1]], indirect=True)
-def test_fullsize_compress_invariants(env):
-    """BASELINE config 3 at full size: CountFilter(2) table -> compress_kmers_with_hash on the device (index left in HBM).
+def test_fullsize_compress_invariants(env, censored):
+    """BASELINE config 3 at full size: CountFilter(2) table [-> remove_censored_exts, the pipeline real callers run,
+    filter.rs:233-306 / test.rs:236-254] -> compress_kmers_with_hash on the device (index left in HBM).
     Size-independent properties of the reference's result (compression.rs:355-583; the tests of test.rs:236-349 check the
     same on small graphs): the nodes partition the valid k-mers (the k-mer counts add up, sampled nodes consist of table
     k-mers only and no k-mer of two different sampled nodes coincides), a node's data is the saturating sum of its
-    k-mers' counts, its Exts are the outward Exts of its end k-mers, and inside a node every k-mer has exactly the one
-    neighbour the path takes."""
+    k-mers' counts, its Exts are the outward Exts of its end k-mers, inside a node every k-mer has exactly the one
+    neighbour the path takes, and no sampled node could have been extended (BaseGraph::is_compressed, graph.rs:296-334,
+    at the k-mer level: an end with exactly one extension leads to a k-mer that does not have exactly one extension back,
+    unless the path bites its own tail).  The censored table is the long-unitig regime: 10^5 unitigs of kilobases."""
     torch, capi, ctx, lib = env["torch"], env["capi"], env["ctx"], env["lib"]
     K, N_READS = env["k"], env["n_reads"]
     torch.cuda.empty_cache()
     t = run_filter(env, 0, N_READS, 0, 2)
+    if censored:
+        ctx.check(lib.dbg_remove_censored_exts(ctx.h, K, 0, C.byref(t), 0))
     g = capi.Graph()
     ctx.check(lib.dbg_compress_kmers_with_hash_dev(ctx.h, K, 0, 0, t.n, t.key_hi, t.key_lo, t.exts, None, t.count, C.byref(g)))
     n_nodes = int(g.n_nodes)
@@ -281,29 +287,37 @@ def test_fullsize_compress_invariants(env):
     assert int(length.min()) >= K
     assert int((length.astype(np.int64) - (K - 1)).sum()) == int(t.n)                 # every valid k-mer sits in exactly one node
     assert np.array_equal(start[1:], np.cumsum(length[:-1], dtype=np.uint64) + start[0]) and int(start[0]) == 0
+    if censored:                                                                       # few, long unitigs
+        assert n_nodes * 20 < int(t.n) // (150 - K) and int(length.max()) > 20 * 150
     hi_t, lo_t = dev_view(t.key_hi, t.n), dev_view(t.key_lo, t.n)
     ex_t, cn_t = dev_view(t.exts, t.n, "|u1"), dev_view(t.count, t.n, "<i2")      # int16 view: uint16 cannot be indexed on the device
     rng = np.random.default_rng(3)
-    # a sample of ordinary nodes plus the longest ones
-    pick = np.unique(np.concatenate([rng.integers(0, n_nodes, 300), np.argsort(length)[-20:]]))
+    # a sample of ordinary nodes plus the longest ones (fewer of them when they are kilobases long)
+    pick = np.unique(np.concatenate([rng.integers(0, n_nodes, 80 if censored else 300), np.argsort(length)[-(6 if censored else 20):]]))
     mask = (1 << (2 * K)) - 1
+    top = 2 * (K - 1)
+    def rc_of(v):
+        r = 0
+        for _ in range(K):
+            r = (r << 2) | (3 - (v & 3)); v >>= 2
+        return r
+    def orient(e, f):                                                              # Exts::rc = byte bit-reversal
+        return int(f"{int(e):08b}"[::-1], 2) if f else int(e)
     seen = set()
+    n_end_checks = 0
     for u in pick:
         s0, ln = int(start[u]), int(length[u])
         bases = [int((int(words[(s0 + i) >> 5]) >> (62 - 2 * ((s0 + i) & 31))) & 3) for i in range(ln)]
-        qhi, qlo, flips = [], [], []
-        v = 0
+        qhi, qlo, flips, mine = [], [], [], set()
+        v = rcv = 0
         for i, b in enumerate(bases):
             v = ((v << 2) | b) & mask
+            rcv = (rcv >> 2) | ((3 - b) << top)
             if i >= K - 1:
-                rc = 0
-                x = v
-                for _ in range(K):
-                    rc = (rc << 2) | (3 - (x & 3)); x >>= 2
-                c = min(v, rc)
-                flips.append(rc < v)
+                c = min(v, rcv)
+                flips.append(rcv < v)
                 assert c not in seen                                               # no k-mer in two places
-                seen.add(c)
+                seen.add(c); mine.add(c)
                 qhi.append(c >> 64); qlo.append(c & 0xFFFFFFFFFFFFFFFF)
         pos = _lookup(torch, hi_t, lo_t, qhi, qlo)
         assert (pos >= 0).all()                                                    # only valid k-mers
@@ -311,12 +325,32 @@ def test_fullsize_compress_invariants(env):
         ex = ex_t[idx].cpu().numpy()
         cn = cn_t[idx].cpu().numpy().view(np.uint16).astype(np.int64)
         assert int(gdata[u]) == min(int(cn.sum()), 65535)                          # SimpleCompress(saturating_add)
-        def orient(e, f):                                                          # Exts::rc = byte bit-reversal
-            return int(f"{int(e):08b}"[::-1], 2) if f else int(e)
         oe = [orient(e, f) for e, f in zip(ex, flips)]
         assert (int(gexts[u]) & 0x0f) == (oe[0] & 0x0f) and (int(gexts[u]) & 0xf0) == (oe[-1] & 0xf0)
         for i in range(len(oe) - 1):                                               # the path follows the unique extensions
             assert (oe[i] >> 4) == 1 << bases[i + K] and (oe[i + 1] & 0x0f) == 1 << bases[i]
+        # the node could not have been extended at either end (is_compressed at the k-mer level)
+        first = last = 0
+        for b in bases[:K]:
+            first = (first << 2) | b
+        for b in bases[-K:]:
+            last = (last << 2) | b
+        for end_kmer, e_out, right in ((last, oe[-1] >> 4, True), (first, oe[0] & 0x0f, False)):
+            if bin(e_out).count("1") != 1:
+                continue
+            b = e_out.bit_length() - 1
+            y = ((end_kmer << 2) | b) & mask if right else (end_kmer >> 2) | (b << top)
+            yr = rc_of(y)
+            yc, yf = min(y, yr), yr < y
+            p1 = _lookup(torch, hi_t, lo_t, [yc >> 64], [yc & 0xFFFFFFFFFFFFFFFF])
+            if p1[0] < 0:
+                assert not censored                                                # censoring leaves extensions to valid k-mers only
+                continue
+            ye = orient(int(ex_t[int(p1[0])].item()), yf)
+            back = (ye & 0x0f) if right else (ye >> 4)                              # y's extensions back towards this node
+            n_end_checks += 1
+            assert bin(back).count("1") != 1 or yc in mine, (int(u), right)        # ... or the path bites its own tail
+    assert n_end_checks > 0
     lib.dbg_free_graph(ctx.h, C.byref(g))
     lib.dbg_free_table(ctx.h, C.byref(t))
 
