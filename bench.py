@@ -38,6 +38,65 @@ def alg_bytes_per_kmer(k, read_len, is_set, u_over_n):
     return b_in + 2 * r + u_over_n * b_out
 
 
+# the files that hold the kernels of the timed path and of the shapes reported next to it (host-side files -- api, transports, graph,
+# the rank-spanning flows -- do not change what the counters measured); tools/pmc_traffic.py hashes the same list
+KERNEL_SOURCES = ("dbg_device.hpp", "dbg_msp_device.hpp", "fast_manylabels.hpp", "fastpath.hip", "radix.hip", "scan.hip",
+                  "fast_labellists.hpp", "densepath.hip")
+
+
+def kernel_source_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    cdir = os.path.join(ROOT, "rust-debruijn_amd", "csrc")
+    for f_ in KERNEL_SOURCES:
+        h.update(f_.encode()); h.update(open(os.path.join(cdir, f_), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_kernel_names(k):
+    """timing name of the library -> kernel name(s) in a rocprofv3 counter file"""
+    return {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
+            # (round 3: look-back passes -- one up-front histogram kernel, the scatter kernel does its own offsets; the classic
+            #  kernels remain as DBG_ONESWEEP=0 and as the fall-back)
+            "radix_hist": (("radix16_global_hist_kernel", "radix16_hist_kernel") if 2 * k <= 96
+                           else ("radix_global_hist_kernel", "radix_hist_kernel")),
+            "radix_scatter": (("radix16_onesweep_kernel", "radix16_scatter_kernel") if 2 * k <= 96 else ("radix_scatter_kernel",)),
+            "span_sort": (("span_sort16_groups_kernel", "span_sort16_kernel") if 2 * k <= 96
+                          else ("span_sort_groups_kernel", "span_sort_kernel")), "set_csr": ("csr_apply_kernel", "ll_csr_kernel"),
+            "sk_scatter": "sk_scatter_kernel", "slab_compact": "slab_compact_kernel", "bin_labels": "bin_labels_kernel",
+            "list_meta": "ll_meta_kernel"}
+
+
+def shape_kernel_rows(shape, k, kernel_ms, n_inst, n_recs, src_sha):
+    """other_shapes: per-kernel rows with the counter evidence of profiles/r*_pmc_shape_<shape>.json (tools/r06_pmc_shapes.sh: measured HBM bytes, VALU busy, the binding
+    resource), hash-guarded like the main rows"""
+    import glob
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_shape_%s.json" % shape)))
+    tj = json.load(open(tf[-1])) if tf else {}
+    stale = bool(tj) and tj.get("_kernel_source_sha16") != src_sha
+    names = pmc_kernel_names(k)
+    rows = []
+    for nm, ms in sorted(kernel_ms.items(), key=lambda kv: -kv[1]):
+        pn = names.get(nm, nm)
+        ent = next((tj[c] for c in (pn if isinstance(pn, tuple) else (pn,)) if c in tj), None)
+        r = {"kernel": nm, "ms_per_step": ms, "measured_hbm_frac": None, "bound_resource": None, "bound_frac": None}
+        if nm in ("sk_scan", "sk_scan_long") and n_recs and ms > 0:
+            r["bound_resource"] = "global slot atomics (%.1e/s device rate)" % ATOMIC_PEAK_PER_S
+            r["bound_frac"] = round(n_recs / (ms * 1e-3) / ATOMIC_PEAK_PER_S, 4)
+        if ent and ms > 0:
+            tb = ent["bytes_per_instance"] * n_inst
+            r["traffic_bytes_per_step"] = round(tb, 0)
+            r["measured_hbm_frac"] = round(tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if r["bound_resource"] is None:
+                if ent.get("valu_busy") is not None and r["measured_hbm_frac"] < 0.25:
+                    r["valu_busy"], r["lds_active"], r["wave_wait_share"] = ent.get("valu_busy"), ent.get("lds_active"), ent.get("wave_wait_share")
+                    r["bound_resource"], r["bound_frac"] = "VALU issue next to dependent LDS round trips / barriers", ent.get("valu_busy")
+                else:
+                    r["bound_resource"], r["bound_frac"] = "HBM bandwidth", r["measured_hbm_frac"]
+        rows.append(r)
+    return {"kernels": rows, "traffic_source": os.path.basename(tf[-1]) if tf else None, "traffic_stale": stale if tf else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,7 +342,6 @@ def main():
             # HBM traffic per k-mer instance from the PMC passes (tools/pmc.sh: separate --pmc runs of this same bench at
             # 10M reads; FETCH_SIZE doubled per the gfx950 correction): newest profiles/r*_pmc_traffic*.json
             import glob
-            import hashlib
             tj, tf = {}, sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
             if args.pmc_json:
                 tf = [args.pmc_json]
@@ -291,23 +349,9 @@ def main():
                 tj = json.load(open(tf[-1]))
             # the counter passes cannot run inside the timed bench (rocprofv3 wraps the process): the traffic file carries the hash
             # of the kernel sources it was measured on, and a file from other sources is reported as stale
-            hsrc = hashlib.sha256()
-            cdir = os.path.join(ROOT, "rust-debruijn_amd", "csrc")
-            # (the files that hold the kernels of the timed path; host-side files -- api, transports, graph, the rank-spanning flows --
-            #  do not change what the counters measured.  tools/pmc_traffic.py hashes the same list)
-            for f_ in ("dbg_device.hpp", "dbg_msp_device.hpp", "fast_manylabels.hpp", "fastpath.hip", "radix.hip", "scan.hip"):
-                hsrc.update(f_.encode()); hsrc.update(open(os.path.join(cdir, f_), "rb").read())
-            src_sha = hsrc.hexdigest()[:16]
+            src_sha = kernel_source_sha16()
             traffic_stale = bool(tj) and tj.get("_kernel_source_sha16") != src_sha
-            pmc_name = {"sk_scan": "sk_scan_lane_kernel", "sk_scan_long": "sk_scan_kernel", "bin_count": "bin_count_kernel",
-                        # (round 3: look-back passes -- one up-front histogram kernel, the scatter kernel does its own offsets; the classic
-                        #  kernels remain as DBG_ONESWEEP=0 and as the fall-back)
-                        "radix_hist": (("radix16_global_hist_kernel", "radix16_hist_kernel") if 2 * k <= 96
-                                       else ("radix_global_hist_kernel", "radix_hist_kernel")),
-                        "radix_scatter": (("radix16_onesweep_kernel", "radix16_scatter_kernel") if 2 * k <= 96 else ("radix_scatter_kernel",)),
-                        "span_sort": (("span_sort16_groups_kernel", "span_sort16_kernel") if 2 * k <= 96
-                                      else ("span_sort_groups_kernel", "span_sort_kernel")), "set_csr": "csr_apply_kernel",
-                        "sk_scatter": "sk_scatter_kernel", "slab_compact": "slab_compact_kernel"}
+            pmc_name = pmc_kernel_names(k)
 
             def row(name, a):
                 per_unit = alg.get(name, 2 * rbytes)
@@ -399,7 +443,7 @@ def main():
                 fp2 = capi.FilterParams(k2, 0, 1 if set2 else 0, args.min_obs, 0, 4)
                 ss2 = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None,
                                   lab5k.data_ptr() if set2 == 2 else (colour.data_ptr() if set2 else None), 4 if set2 == 2 else (1 if set2 else 0), reads_per_gpu)
-                kt2, ni2 = {}, 0
+                kt2, kt_units, ni2 = {}, {}, 0
                 # (four untimed calls: the slab tournament of the shape -- the library tries four slab blocks and keeps the fastest)
                 for rep in range(-3, 3):
                     if rep == 1:
@@ -413,12 +457,16 @@ def main():
                     if rep >= 1:
                         for kt in ctx.timings():
                             kt2[kt["name"]] = kt2.get(kt["name"], 0.0) + kt["ms"]
+                            kt_units[kt["name"]] = kt_units.get(kt["name"], 0) + kt["units"]
                 torch.cuda.synchronize()
                 odt = (time.perf_counter() - o0) / 2
                 ctx.enable_timing(False)
+                nrec2 = kt_units.get("sk_records", 0) / 2
                 kt2.pop("sk_records", None)
                 other[nm] = {"k": k2, "summarizer": "CountFilterSet" if set2 else "CountFilter", "value": round(ni2 / odt / 1e9, 3), "unit": "Gkmer/s",
                              "ms_per_step": round(odt * 1e3, 3), "valid_kmers": int(nv2), "kernel_ms_per_step": {n_: round(v / 2, 3) for n_, v in kt2.items()}}
+                other[nm]["superkmer_records_per_step"] = nrec2
+                other[nm]["roofline"] = shape_kernel_rows(nm, k2, other[nm]["kernel_ms_per_step"], ni2, nrec2, kernel_source_sha16())
                 if set2 == 2:
                     other[nm]["labels"] = "5000 distinct u32 labels in [0, 2^24), one per read at random"
             del lab5k

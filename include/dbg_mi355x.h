@@ -15,7 +15,9 @@
  *         (src/dna_string.rs:762-767): one packed u64 stream (32 bases/word,
  *         base i at bits [63-2(i%32), 62-2(i%32)] of word i/32,
  *         src/dna_string.rs:383-399) + start[] (BASE offsets) + length[].
- *   D1  : none | u8 | u16 | u32 (values must be < 2^24).
+ *   D1  : none | u8 | u16 | u32.  dbg_filter_kmers[_dev] take every u32 value: a call whose largest label is 2^24 or more runs on
+ *         an order-preserving dictionary of its distinct labels (at most 2^24 - 1 of them; round 6).  The rank-spanning
+ *         dbg_shard_filter_kmers_dev takes labels < 2^24.
  *   S   : CountFilter (src/filter.rs:40-63) | CountFilterSet (:68-101).
  *   spec: SimpleCompress with saturating_add / (a+b)%65535 / max / wrapping add,
  *         or ScmapCompress (src/compression.rs:40-98).
@@ -86,11 +88,12 @@ typedef struct {
                                    Kmer::get(3) of a shorter k-mer underflows `k - 1 - pos` (kmer.rs:254-257, :515-518) -- a panic in
                                    the reference's debug builds, reproduced here as an error */
     int32_t  stranded;          /* filter.rs:142 */
-    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min).  Label sets of any D1 values (< 2^24) are served:
+    int32_t  summarizer;        /* DBG_COUNT_FILTER(min) | DBG_COUNT_FILTER_SET(min).  Label sets of any D1 values are served:
                                    up to 64 distinct labels (< 65536) as colour masks in the counting kernel; any larger alphabet as
                                    label lists (one pass: every observation's label appended to its k-mer's segment, segments sorted
                                    and de-duplicated -- about a third of the colour-mask rate, whatever the alphabet); the sort-based
-                                   generic path for k < 16 or when the label buffer (4 bytes per k-mer instance) does not fit */
+                                   generic path for k < 16 or when the label buffer (4 bytes per k-mer instance) does not fit; labels of
+                                   2^24 and more are ranked among the call's distinct labels first and translated back at the end */
     uint64_t min_kmer_obs;      /* filter.rs:41,69 */
     int32_t  report_all_kmers;  /* filter.rs:143 */
     uint64_t memory_size;       /* filter.rs:144, GB; 0 is rejected (reference divides by zero).  Otherwise IGNORED: in the

@@ -254,9 +254,43 @@ int join_reduce_parts(dbg_ctx* c, std::vector<ReduceOut>& parts, bool is_set, bo
     return 0;
 }
 
+int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out);                                       // fastpath.hip
+int label_dict_build(dbg_ctx* c, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out, DBuf<uint32_t>* dict_out, uint32_t* n_distinct);   // labeldict.hip
+int label_dict_translate(dbg_ctx* c, uint32_t* set_val, uint64_t n, const uint32_t* dict, uint32_t n_dict);
+static int filter_kmers_dev_impl(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out);
+
 extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out) {
     DBG_TRY(validate_filter(c, ds, p));
     HIP_TRY(c, hipSetDevice(c->device));
+    c->t_clear();
+    memset(out, 0, sizeof(*out));
+    // Full-width D1 (CountFilterSet<D: Ord> takes any u32, filter.rs:68-101): the device routes hold labels in 24 bits, so a call whose
+    // largest label does not fit runs on the labels' ranks among the call's distinct labels and gets its set_val translated back
+    // (labeldict.hip).  Smaller labels take the routes as they are.
+    if (p->summarizer == DBG_COUNT_FILTER_SET && ds->data && ds->data_width == 4 && ds->n_seqs) {
+        SeqDev s{ds->words, ds->start, ds->length, ds->exts, ds->data, 4u, ds->n_seqs, ds->n_words};
+        uint32_t mx = 0;
+        DBG_TRY(seq_max_label(c, s, &mx));
+        if (mx >= (1u << 24)) {
+            DBuf<uint32_t> rank, dict;
+            uint32_t nd = 0;
+            DBG_TRY(label_dict_build(c, (const uint32_t*)ds->data, ds->n_seqs, &rank, &dict, &nd));
+            dbg_seqset ranked = *ds;
+            ranked.data = rank.p;
+            auto kept = std::move(c->trecs);                             // (the impl clears the timing records: keep the dictionary's)
+            c->trecs.clear();
+            const int r = filter_kmers_dev_impl(c, &ranked, p, out);
+            c->trecs.insert(c->trecs.begin(), kept.begin(), kept.end());
+            if (r) return r;
+            const int t = label_dict_translate(c, out->set_val, out->n_set_val, dict.p, nd);
+            if (t) { dbg_free_table(c, out); return t; }
+            return 0;
+        }
+    }
+    return filter_kmers_dev_impl(c, ds, p, out);
+}
+
+static int filter_kmers_dev_impl(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out) {
     c->t_clear();
     memset(out, 0, sizeof(*out));
     const int k = (int)p->k;
@@ -441,7 +475,7 @@ int upload_seqset(dbg_ctx* c, const dbg_seqset* hs, DevSeqSet* d) { return uploa
 // read of that or an earlier chunk; *monotone = the reads' start offsets never decrease (PackedDnaStringSet::add appends, so they do
 // not in practice): then the words a chunk of reads needs are a prefix of the array
 static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs, uint32_t n_chunks = 0, uint64_t* chunk_end = nullptr, bool* monotone = nullptr) {
-    // bounds + D1 range checks that would be undefined behaviour on the device (on the host threads the container is granted)
+    // bounds checks that would be undefined behaviour on the device (on the host threads the container is granted)
     std::atomic<int> bad{0};
     std::vector<std::atomic<uint64_t>> cend(n_chunks);
     for (auto& v : cend) v = 0;
@@ -461,7 +495,6 @@ static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs, uint32_t n_chunks
         for (uint64_t i = a; i < b; i++) {
             const uint64_t st = hs->start[i], end = st + hs->length[i];
             if ((end + 31) / 32 > hs->n_words && hs->length[i]) f |= 1;
-            if (hs->data && hs->data_width == 4 && ((const uint32_t*)hs->data)[i] >= (1u << 24)) f |= 2;
             if (n_chunks) {
                 if (i >= upto[g]) { flush(); while (g + 1 < n_chunks && i >= upto[g]) g++; }
                 if (st < prev) f |= 4;
@@ -478,7 +511,6 @@ static int check_host_seqset(dbg_ctx* c, const dbg_seqset* hs, uint32_t n_chunks
         *monotone = !(bad & 4);
     }
     if (bad & 1) return c->fail(16, "sequence runs past n_words");
-    if (bad & 2) return c->fail(17, "D1 values must be < 2^24");
     return 0;
 }
 

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) walk_ends_kernel(const uint32_t* __restri
                                                         const uint32_t* __restrict__ weight, const uint8_t* __restrict__ avail, uint32_t n,
                                                         const uint32_t* __restrict__ ends, uint32_t n_ends, Jump* __restrict__ J,
                                                         uint32_t* __restrict__ next, unsigned long long* __restrict__ written,
-                                                        uint32_t* __restrict__ capped) {
+                                                        uint32_t* __restrict__ capped, uint32_t walk_cap) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t wpos = 0, wend = 0;                                   // this wave's reserved range of `ends` (wave-uniform)
@@ -220,12 +220,45 @@ __global__ void __launch_bounds__(256) walk_ends_kernel(const uint32_t* __restri
                 J[2 * j + (1u - nd)] = o;                          // j's state that faces back
                 total++;
                 cur = j; side = nd;
-                if (++steps > WALK_CAP) { atomicOr(capped, 1u); active = false; }
+                if (++steps > walk_cap) { atomicOr(capped, 1u); active = false; }
             }
         }
     }
     for (int d = 32; d > 0; d >>= 1) total += __shfl_down(total, d, 64);
     if (lane == 0 && total) atomicAdd(written, (unsigned long long)total);
+}
+
+// Chains longer than WALK_CAP (the censored graphs real callers compress: 10^5 unitigs of kilobases, the longest 10^5 k-mers) leave the
+// middle of the chain unwritten: the table was filled with UNWRITTEN before the walk, the states the walkers reached hold their final
+// values, and only the others -- a few per cent of the states -- go through the doubling, starting from their one-step links.  (The
+// doubling used to start over from all 2n states: 465 of the 670 ms of a censored config-3 graph.)
+constexpr uint32_t J_UNWRITTEN = 0xFFFFFFFFu;                      // Jump::dist of a state no walker reached (a chain has fewer than 2^32 - 1 k-mers)
+__global__ void __launch_bounds__(1024) init_unwritten_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ weight,
+                                                              const uint8_t* __restrict__ avail, uint32_t n, Jump* __restrict__ J,
+                                                              uint32_t* __restrict__ live_out, uint32_t* __restrict__ n_live) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool todo = false;
+    if (s < 2 * n && J[s].dist == J_UNWRITTEN) {
+        const uint32_t i = s >> 1, p = s & 1;
+        const uint32_t L = link[(uint64_t)p * n + i];
+        Jump o;
+        const bool usable = link_valid(L, i) && (!avail || (avail[i] && avail[(L & 0x7FFFFFFFu) >> 1]));
+        if (usable) { const uint32_t j = L >> 1, nd = L & 1; o.nxt = 2 * j + nd; o.dist = weight ? weight[j] : 1u; o.minr = rank ? rank[j] : j; o.endst = ST_NONE; todo = true; }
+        else { o.nxt = ST_NONE; o.dist = 0; o.minr = R_INF; o.endst = s; }           // (a terminal state of an unavailable element: nobody walks from it)
+        J[s] = o;
+    }
+    __shared__ uint32_t s_cnt[16], s_base;
+    const uint64_t km = __ballot(todo);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(km);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; w++) { uint32_t x = s_cnt[w]; s_cnt[w] = tot; tot += x; }
+        s_base = tot ? atomicAdd(n_live, tot) : 0u;
+    }
+    __syncthreads();
+    if (todo) live_out[s_base + s_cnt[wave] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = s;
 }
 
 // after the doubling has covered 2n steps, any state still walking sits on a cycle; cut it at its seed's right side
@@ -699,13 +732,16 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         uint32_t n_ends = 0;
         HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // long chains (a censored graph: thousands of k-mers per chain) are not for this route -- its two walks per chain are as long
+        // as the longest chain, and they give up at WALK_CAP: straight to the table routes
+        const bool long_chains = n_ends && (uint64_t)n2 / n_ends > 512u;
         DBuf<uint32_t> done_bits;
         const bool one_walk = !(c->opt("DBG_CHAIN_WALKS") && !strcmp(c->opt("DBG_CHAIN_WALKS"), "2"));
         if (n_ends && one_walk) {
             ALLOC_OR_FAIL(c, done_bits, (size_t)(n2 + 31) / 32 + 1);
             HIP_TRY(c, hipMemsetAsync(done_bits.p, 0, ((size_t)(n2 + 31) / 32 + 1) * 4, c->stream));
         }
-        if (n_ends) {
+        if (n_ends && !long_chains) {
             chain_scan_kernel<<<std::min<uint32_t>(cdiv(n_ends, 256), 2048), 256, 0, c->stream>>>(
                 link_dev, rank_dev, n, LA.p, n_ends, k, flag_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p,
                 counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, links_checked ? nullptr : nrec, flags.p, done_bits.p);
@@ -721,7 +757,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             DBG_TRY(links_bad(&bad));
             if (bad) return 0;
         }
-        const bool ok = res[1] == 0 && seen == n;                  // no walker gave up, every k-mer sits on an open chain
+        const bool ok = !long_chains && res[1] == 0 && seen == n;  // no walker gave up, every k-mer sits on an open chain
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
                                          ok ? "" : " -> general route");
         if (ok) {
@@ -803,8 +839,10 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     ALLOC_OR_FAIL(c, JA, n2);
     Jump* cur = nullptr;
     bool walked = false;
+    bool partial = false;                                          // the walk filled a part of the table: the doubling takes the rest only
     if (!c->opt("DBG_UNITIG_NO_WALK")) {
         HIP_TRY(c, hipMemsetAsync(counters.p, 0, 24, c->stream));
+        HIP_TRY(c, hipMemsetAsync(JA.p, 0xFF, (size_t)n2 * sizeof(Jump), c->stream));      // every state UNWRITTEN
         c->t_begin("unitig_walk_ends", n);
         collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, avail, n, LA.p, counters.p);
         LAUNCH_CHECK(c, "collect_ends");
@@ -813,8 +851,12 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (n_ends) {
             const uint32_t wblocks = std::min<uint32_t>(cdiv(n_ends, 256), 2048);        // 8 resident blocks per CU
+            // the table walk goes twice as far as the chain route's: at config-3 size (censored: 1.3e5 chains of ~3900 k-mers, the longest 1e5)
+            // 2^14 left 16 % of the states to the doubling (156 ms), 2^15 leaves 3 % (30 ms) for 10 ms more of walking, 2^16 nothing for 36 more
+            uint32_t walk_cap = 2 * WALK_CAP;
+            if (const char* e = c->opt("DBG_WALK_CAP")) walk_cap = (uint32_t)std::max(16, atoi(e));       // measurement / tests
             walk_ends_kernel<<<wblocks, 256, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, LA.p, n_ends, JA.p, counters.p + 4,
-                                                             (unsigned long long*)(counters.p + 2), counters.p + 1);
+                                                             (unsigned long long*)(counters.p + 2), counters.p + 1, walk_cap);
             LAUNCH_CHECK(c, "walk_ends");
         }
         uint32_t res[4] = {0, 0, 0, 0};
@@ -826,17 +868,30 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends wrote %llu of %u states%s\n", n_ends, (unsigned long long)written, n2,
                                          walked ? "" : " -> doubling");
         if (walked) cur = JA.p;
+        else partial = !c->opt("DBG_UNITIG_FULL_DOUBLING");
     }
     if (!walked) {
         ALLOC_OR_FAIL(c, JB, n2);
         ALLOC_OR_FAIL(c, LB, n2);
     }
     for (int phase = 0; phase < 2 && !walked; phase++) {
-        init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, JA.p);
-        LAUNCH_CHECK(c, "init_states");
         Jump *a = JA.p, *b = JB.p;
         uint32_t *la = nullptr, *lb = LB.p;                         // round 0 visits every state
         uint32_t n_live = n2;
+        if (phase == 0 && partial) {
+            // the states the walkers did not reach start from their one-step links; everything else is final already, in both buffers
+            HIP_TRY(c, hipMemsetAsync(counters.p, 0, 4, c->stream));
+            init_unwritten_kernel<<<cdiv(n2, 1024), 1024, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, JA.p, LA.p, counters.p);
+            LAUNCH_CHECK(c, "init_unwritten");
+            HIP_TRY(c, hipMemcpyAsync(JB.p, JA.p, (size_t)n2 * sizeof(Jump), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&n_live, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            la = LA.p;
+            if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] doubling over the %u states the walkers left (%.1f %% of %u)\n", n_live, 100.0 * n_live / n2, n2);
+        } else {
+            init_states_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, JA.p);
+            LAUNCH_CHECK(c, "init_states");
+        }
         bool walking = true;
         int rounds = 0;
         const int max_rounds = 34;                                 // 2^33 steps > any chain (+ the finalising round)
@@ -853,6 +908,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             n_live = cnt[0];
             walking = cnt[1] != 0;
             rounds++;
+            if (c->opt("DBG_DEBUG") && partial) fprintf(stderr, "[unitig]   round %d: %u states live\n", rounds, n_live);
         }
         c->t_end();
         // every state's final value is in the buffer written last; states that finished earlier were copied into both

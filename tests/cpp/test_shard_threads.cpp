@@ -55,8 +55,11 @@ int main(int argc, char** argv) {
     dbg_graph fin_gather{}, fin_tree{};
     dbg_ctx* ctx0 = nullptr;
     std::vector<dbg_ctx*> ctxs(W, nullptr);
+    // argv[2] = number of devices to spread the thread-ranks over (1: all on device 0; on a multi-GPU node rank r drives device
+    // r % n, and the in-process transport's copies are real peer copies)
+    const int n_dev = argc > 2 ? std::max(1, atoi(argv[2])) : 1;
     for (int r = 0; r < W; r++)
-        if (dbg_ctx_create(0, &ctxs[r])) FAIL(3, "dbg_ctx_create: %s", dbg_last_error(nullptr));
+        if (dbg_ctx_create(r % n_dev, &ctxs[r])) FAIL(3, "dbg_ctx_create: %s", dbg_last_error(nullptr));
     ctx0 = ctxs[0];
 
     auto rank_main = [&](int r) {

@@ -222,9 +222,18 @@ def test_compress_long_chains(ctx, compress_mode, k, stranded, spec_i):
     contigs = [genome[a:a + 3000] for a in range(0, 60000 - 3000 + 1, 1000)]      # overlapping pieces: every k-mer 3 times
     if not stranded:
         contigs = [c if i % 2 else (3 - c)[::-1].copy() for i, c in enumerate(contigs)]
+    # (round 6) an isolated cycle longer than the walkers' cap next to the long chains: no walker reaches it, the doubling finds it
+    cyc = R.random_dna(rng, 20000)
+    contigs.append(np.concatenate([cyc, cyc[:k - 1]]))
+    contigs.append(np.concatenate([cyc[10000:], cyc[:10000 + k - 1]]))
     t = gpu_table(ctx, contigs, k, 2, stranded)
     got, want = compare(ctx, t, k, stranded, SPECS[spec_i])
     assert max(int(x) for x in got.arrays()["length"]) > (1 << 14) + k
+    # the doubling over the states the walkers left (default since round 6) against the doubling over every state
+    with ctx.options(DBG_UNITIG_FULL_DOUBLING="1"):
+        compare(ctx, t, k, stranded, SPECS[spec_i])
+    order = rng.permutation(len(t)).astype(np.uint64)
+    compare(ctx, t, k, stranded, SPECS[spec_i], seed_order=order)
 
 
 def test_compress_non_mutual_links(ctx, compress_mode):

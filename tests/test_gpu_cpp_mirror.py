@@ -53,6 +53,18 @@ def test_shard_threads_runs(world):
     assert r.returncode == 0 and "shard threads ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.gpu
+def test_shard_threads_one_rank_per_device():
+    """multi-GPU node only: every thread-rank drives its own device, the in-process transport copies between devices"""
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("needs two GPUs")
+    build_shard_threads()
+    r = subprocess.run([BIN_THREADS, str(nd), str(nd)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "shard threads ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_cpp_mirror_compiles():
     """CPU check: the C++ mirror header and its test program compile and link against the C ABI library."""
     build_cpp_mirror()

@@ -65,6 +65,25 @@ def test_rccl_table_operations_world1(rccl1):
     assert torch.equal(dst[8:1008], src[96:1096]) and int(dst[:8].sum()) == 0 and int(dst[1008:].sum()) == 0
 
 
+def test_rccl_table_pieces_above_one_gib_world1(rccl1):
+    """a pair's message of more than 1 GiB is cut into <= 1 GiB pieces, one send/recv group per piece (transport.hip:
+    rccl_all_to_allv, rccl_send / rccl_recv): 2.5 GiB from an odd offset to an odd offset, every byte checked"""
+    import torch
+    dev = torch.device("cuda", 0)
+    tab = rccl1.table
+    n = (5 << 29) + 12345                                        # 2.5 GiB and a bit: three pieces
+    src = torch.empty(n + 4096, dtype=torch.uint8, device=dev)
+    src.view(torch.int64)[: (n + 4096) // 8].copy_(torch.arange((n + 4096) // 8, dtype=torch.int64, device=dev) * -7046029254386353131)
+    dst = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)
+    u = C.c_uint64 * 1
+    torch.cuda.synchronize()
+    assert tab.all_to_allv(tab.self, src.data_ptr(), u(40), u(n), dst.data_ptr(), u(1000), u(n), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst[1000:1000 + n], src[40:40 + n]) and int(dst[:1000].sum()) == 0 and int(dst[1000 + n:].sum()) == 0
+    del src, dst
+    torch.cuda.empty_cache()
+
+
 def _table(ctx, t, k):
     h = capi.KmerTable()
     ctx.check(ctx.lib.dbg_table_to_host(ctx.h, C.byref(t), C.byref(h)))

@@ -86,7 +86,12 @@ class Job:
         self.lib = capi.load()
         self.keep = make_group(world)
         self.trs = [_Tr(self.keep[r], r) for r in range(world)]
-        self.ctxs = [dbg.Context(0) for _ in range(world)]
+        # DBG_TEST_PER_DEVICE=1 (tools/first_contact_8gpu.sh on a multi-GPU node): thread-rank r drives device r, so that the in-process
+        # transport's copies are real peer copies
+        import os
+        import torch
+        nd = torch.cuda.device_count() if os.environ.get("DBG_TEST_PER_DEVICE") else 1
+        self.ctxs = [dbg.Context(r % max(nd, 1)) for r in range(world)]
         for c in self.ctxs:
             c.set_option("DBG_COMPRESS", "device")
             if not lists:                                             # alphabets beyond 64 colours: label groups / the key-range route instead of label lists

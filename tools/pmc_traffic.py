@@ -10,7 +10,8 @@ def kernel_source_sha():
     measured on other kernels as stale (.git does not travel to the GPU box, so a commit id is not available there)"""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust-debruijn_amd", "csrc")
     h = hashlib.sha256()
-    for f in ("dbg_device.hpp", "dbg_msp_device.hpp", "fast_manylabels.hpp", "fastpath.hip", "radix.hip", "scan.hip"):   # = bench.py's list
+    for f in ("dbg_device.hpp", "dbg_msp_device.hpp", "fast_manylabels.hpp", "fastpath.hip", "radix.hip", "scan.hip",
+              "fast_labellists.hpp", "densepath.hip"):   # = bench.py's KERNEL_SOURCES
         h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

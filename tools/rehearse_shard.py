@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--labels", type=int, default=0, help="CountFilterSet with this many distinct u32 labels spread over [0, 2^24), one per read by a hash of its index (overrides --colours)")
     ap.add_argument("--lists", default=None, help="DBG_LABEL_LISTS on every ctx (0: label groups / the key-range route beyond 64 colours)")
     ap.add_argument("--no-compress", action="store_true")
+    ap.add_argument("--per-device", action="store_true", help="thread-rank r drives device r %% device_count (a multi-GPU node: real peer copies)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     os.environ.setdefault("DBG_INPROC_TIMEOUT_S", "600")
@@ -126,6 +127,8 @@ def main():
     D = importlib.import_module("rust-debruijn_amd.distributed")
     lib = capi.load()
     dev = torch.device("cuda", 0)
+    n_dev = torch.cuda.device_count() if args.per_device else 1
+    rank_dev = lambda r: torch.device("cuda", r % n_dev)
     W, per, k, L = args.ranks, args.reads_per_rank, args.k, 150
     is_set = args.summarizer == "set"
     total_reads = W * per
@@ -137,7 +140,7 @@ def main():
         print(line, flush=True)
         log.write(line + "\n")
 
-    def synth(ctx, n, first):
+    def synth(ctx, n, first, dev=dev):
         p = dbg.synth_params(n_reads=n, read_len=L, genome_len=genome_len, error_rate=0.001, stranded=False, n_colours=args.colours, first_read=first)
         nw = lib.dbg_synth_words(C.byref(p))
         t = dict(words=torch.empty(nw, dtype=torch.int64, device=dev), start=torch.empty(n, dtype=torch.int64, device=dev),
@@ -201,7 +204,22 @@ def main():
     # ---- the same over W thread-ranks ----
     arr_t = (C.POINTER(capi.Transport) * W)()
     assert lib.dbg_transport_inprocess_create(W, arr_t) == 0
-    ctxs = [dbg.Context(0) for _ in range(W)]
+    ctxs = [dbg.Context(r % n_dev) for r in range(W)]
+
+    def account(what):
+        """the ctxs' allocation accounts (dbg_ctx_get_stats) since the last call of this function: where wall time that no kernel
+        explains went -- driver allocations, pool trims after a failed allocation (eight ctx pools share ONE device here)"""
+        tot = {}
+        for c_ in ctxs:
+            st_ = c_.stats()
+            last = getattr(c_, "_acct", {})
+            for kk in ("s_hipmalloc", "s_free", "n_hipmalloc", "n_trims", "n_oom_retries", "n_raw_free"):
+                tot[kk] = tot.get(kk, 0) + st_[kk] - last.get(kk, 0)
+            tot["pooled_high_water_max"] = max(tot.get("pooled_high_water_max", 0), st_["pooled_high_water"])
+            c_._acct = st_
+        say("  allocation account of %s, summed over the %d ctxs: hipMalloc %.3f s (%d calls), hipFree %.3f s (%d blocks), %d pool trims after %d failed "
+            "allocations; largest pool of a ctx %.1f GB" % (what, W, tot["s_hipmalloc"], tot["n_hipmalloc"], tot["s_free"], tot["n_raw_free"], tot["n_trims"],
+                                                           tot["n_oom_retries"], tot["pooled_high_water_max"] / 1e9))
     if args.no_label_groups:
         for c_ in ctxs:
             c_.set_option("DBG_NO_LABEL_GROUPS", "1")
@@ -228,7 +246,7 @@ def main():
                 raise SystemExit("rank %d: %r" % (r, e))
         return time.perf_counter() - t0
 
-    reads = [synth(ctxs[r], per, r * per) for r in range(W)]
+    reads = [synth(ctxs[r], per, r * per, rank_dev(r)) for r in range(W)]
 
     def do_filter(r):
         p = capi.ShardParams(k, 0, 1 if is_set else 0, 2, args.rounds, -1, 1, 0)
@@ -238,7 +256,7 @@ def main():
     secs = run(do_filter)
     tabs = [x[0] for x in res]
     stats = [x[1] for x in res]
-    dsum = sum(D.table_digest(t, dev) for t in tabs) & M64
+    dsum = sum(D.table_digest(t, rank_dev(r_)) for r_, t in enumerate(tabs)) & M64
     vsum = sum(int(t.n) for t in tabs)
     owned = [int(s.records_owned) for s in stats]
     say("dbg_shard_filter_kmers_dev x %d ranks: %.3f s wall (all ranks on one GPU), rounds %d, sender merge %d, valid %d, digest sum %016x -> %s"
@@ -246,6 +264,9 @@ def main():
     say("  records owned per rank: min %d max %d (max / mean %.4f); bytes sent per rank: %s"
         % (min(owned), max(owned), max(owned) / (sum(owned) / W), [int(s.bytes_sent) for s in stats]))
     ok = dsum == single_digest and vsum == single_valid
+    account("dbg_shard_filter_kmers_dev")
+    say("  kernel + transfer time per rank inside the call (HIP events; setup / exposed exchange): setup %s ms, exposed %s ms"
+        % ([round(float(s.setup_ms), 1) for s in stats], [round(float(s.exposed_ms), 1) for s in stats]))
     del reads
     torch.cuda.empty_cache()
 
@@ -294,6 +315,7 @@ def main():
             kt = sorted(ctxs[0].timings(), key=lambda t: -t["ms"])
             ctxs[0].enable_timing(False)
             say("    root's kernels (HIP events, ms): " + ", ".join("%s %.1f" % (t["name"], t["ms"]) for t in kt[:14]))
+            account("dbg_shard_compress_dev %s" % name)
             for r in range(W):
                 lib.dbg_free_graph(ctxs[r].h, C.byref(res[r]))
     for r in range(W):
