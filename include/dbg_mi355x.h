@@ -16,8 +16,8 @@
  *         base i at bits [63-2(i%32), 62-2(i%32)] of word i/32,
  *         src/dna_string.rs:383-399) + start[] (BASE offsets) + length[].
  *   D1  : none | u8 | u16 | u32.  dbg_filter_kmers[_dev] take every u32 value: a call whose largest label is 2^24 or more runs on
- *         an order-preserving dictionary of its distinct labels (at most 2^24 - 1 of them; round 6).  The rank-spanning
- *         dbg_shard_filter_kmers_dev takes labels < 2^24.
+ *         an order-preserving dictionary of its distinct labels (at most 2^24 - 1 of them; round 6); the rank-spanning
+ *         dbg_shard_filter_kmers_dev builds that dictionary job-wide (every rank then passes u32 labels).
  *   S   : CountFilter (src/filter.rs:40-63) | CountFilterSet (:68-101).
  *   spec: SimpleCompress with saturating_add / (a+b)%65535 / max / wrapping add,
  *         or ScmapCompress (src/compression.rs:40-98).

@@ -255,8 +255,6 @@ int join_reduce_parts(dbg_ctx* c, std::vector<ReduceOut>& parts, bool is_set, bo
 }
 
 int seq_max_label(dbg_ctx* c, const SeqDev& s, uint32_t* out);                                       // fastpath.hip
-int label_dict_build(dbg_ctx* c, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out, DBuf<uint32_t>* dict_out, uint32_t* n_distinct);   // labeldict.hip
-int label_dict_translate(dbg_ctx* c, uint32_t* set_val, uint64_t n, const uint32_t* dict, uint32_t n_dict);
 static int filter_kmers_dev_impl(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out);
 
 extern "C" int dbg_filter_kmers_dev(dbg_ctx* c, const dbg_seqset* ds, const dbg_filter_params* p, dbg_kmer_table* out) {

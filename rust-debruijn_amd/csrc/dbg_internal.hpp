@@ -159,3 +159,16 @@ struct GraphDev {
             return (ctx)->fail(102, _b);                                                        \
         }                                                                                       \
     } while (0)
+
+// order-preserving dictionary of the distinct u32 labels of a call (labeldict.hip): labels of 2^24 and more run as their ranks
+struct LabelDict {
+    DBuf<unsigned long long> bm;        // presence bitmap over the 2^32 values
+    DBuf<uint32_t> base;                // rank of the first value of every block of 1024 values
+    DBuf<uint32_t> dict;                // rank -> label, ascending
+    uint32_t n = 0;
+};
+int label_dict_make(dbg_ctx* c, const uint32_t* labels, uint64_t n, LabelDict* d);
+int label_dict_rank(dbg_ctx* c, const LabelDict& d, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out);
+int label_dict_build(dbg_ctx* c, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out, DBuf<uint32_t>* dict_out, uint32_t* n_distinct);
+int label_dict_translate(dbg_ctx* c, uint32_t* set_val, uint64_t n, const uint32_t* dict, uint32_t n_dict);
+

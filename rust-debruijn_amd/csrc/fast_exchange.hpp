@@ -671,6 +671,65 @@ extern "C" int dbg_shard_filter_kmers_dev(dbg_ctx* c, const dbg_transport* tr, c
     vote = mx3[2];
     S->total_kmers = total; S->local_kmers = n_local;
 
+    if (collective && is_set && max_label >= (1u << 24)) {
+        // ---- full-width D1 (round 6; CountFilterSet<D: Ord> takes any u32, filter.rs:68-101) ----
+        // The exchange and the counting hold a label in 24 bits.  Every rank ranks its distinct labels (labeldict.hip), the ranks' lists
+        // are gathered, every rank builds the same job-wide dictionary from them, the call runs once more on the ranks (their maximum is
+        // below 2^24, so this branch is not taken again) and the owner translates its table's set_val back.  Decided from max_label, which
+        // all ranks hold alike.
+        if (!tr->all_gather) return c->fail(161, "sharded flow: labels of 2^24 and more need the transport's all_gather");
+        LabelDict local, glob;
+        DBuf<uint32_t> send, recv, compact, rank;
+        DBuf<uint64_t> cnt_mine, cnt_all;
+        uint64_t nd[1] = {0};
+        lrc = [&]() -> int {
+            if (X.inject("labeldict")) return X.injected("labeldict");
+            if (ds->n_seqs && (!ds->data || ds->data_width != 4)) return c->fail(14, "sharded flow: a rank holds labels of 2^24 and more, so every rank must pass u32 labels (data_width 4)");
+            DBG_TRY(label_dict_make(c, (const uint32_t*)ds->data, ds->n_seqs, &local));
+            nd[0] = local.n;
+            return 0;
+        }();
+        DBG_TRY(X.agree(lrc, "label dictionary (local)", nd, 1));
+        const uint64_t nmax = std::max<uint64_t>(nd[0], 1);
+        lrc = [&]() -> int {
+            ALLOC_OR_FAIL(c, send, nmax); ALLOC_OR_FAIL(c, recv, nmax * W); ALLOC_OR_FAIL(c, compact, nmax * W);
+            ALLOC_OR_FAIL(c, cnt_mine, 1); ALLOC_OR_FAIL(c, cnt_all, W);
+            HIP_TRY(c, hipMemsetAsync(send.p, 0, nmax * 4, c->stream));
+            if (local.n) HIP_TRY(c, hipMemcpyAsync(send.p, local.dict.p, (size_t)local.n * 4, hipMemcpyDeviceToDevice, c->stream));
+            const uint64_t mine = local.n;
+            HIP_TRY(c, hipMemcpyAsync(cnt_mine.p, &mine, 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            return 0;
+        }();
+        DBG_TRY(X.agree(lrc, "label dictionary (buffers)"));
+        if (tr->all_gather(tr->self, cnt_mine.p, cnt_all.p, 8, c->stream)) return X.op_failed("all_gather (distinct-label counts)");
+        if (tr->all_gather(tr->self, send.p, recv.p, nmax * 4, c->stream)) return X.op_failed("all_gather (distinct labels)");
+        DBG_TRY(X.wait_stream(c->stream, "the gathered label lists"));
+        lrc = [&]() -> int {
+            std::vector<uint64_t> cnt(W);
+            HIP_TRY(c, hipMemcpyAsync(cnt.data(), cnt_all.p, (size_t)W * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            uint64_t tot = 0;
+            for (uint32_t r = 0; r < W; r++) {
+                if (cnt[r] > nmax) return c->fail(166, "label dictionary: a rank reports more distinct labels than the agreed maximum");
+                if (cnt[r]) HIP_TRY(c, hipMemcpyAsync(compact.p + tot, recv.p + (uint64_t)r * nmax, (size_t)cnt[r] * 4, hipMemcpyDeviceToDevice, c->stream));
+                tot += cnt[r];
+            }
+            DBG_TRY(label_dict_make(c, compact.p, tot, &glob));              // the same on every rank: the union of all lists
+            DBG_TRY(label_dict_rank(c, glob, (const uint32_t*)ds->data, ds->n_seqs, &rank));
+            return 0;
+        }();
+        DBG_TRY(X.agree(lrc, "label dictionary (job-wide)"));
+        local.bm.release(); local.base.release(); local.dict.release(); glob.bm.release(); glob.base.release();
+        send.release(); recv.release(); compact.release();
+        dbg_seqset ranked = *ds;
+        ranked.data = rank.p;
+        DBG_TRY(dbg_shard_filter_kmers_dev(c, tr, &ranked, p, out, stats));
+        lrc = label_dict_translate(c, out->set_val, out->n_set_val, glob.dict.p, glob.n);
+        if (int r = X.agree(lrc, "label dictionary (translation)")) { dbg_free_table(c, out); return r; }
+        return 0;
+    }
+
     if (!collective) {
         // one rank: the sharded table is the whole table
         dbg_filter_params fp{p->k, p->stranded, p->summarizer, p->min_kmer_obs, 0, 4};

@@ -65,34 +65,51 @@ __global__ void __launch_bounds__(256) ld_translate_kernel(uint32_t* __restrict_
 }
 }  // namespace
 
-// ranks of the n labels (u32) among the distinct labels of the call, and the dictionary rank -> label
-int label_dict_build(dbg_ctx* c, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out, DBuf<uint32_t>* dict_out, uint32_t* n_distinct) {
-    DBuf<unsigned long long> bm;
-    DBuf<uint32_t> cnt, base;
-    ALLOC_OR_FAIL(c, bm, LD_WORDS);
+// the dictionary of a label array: presence bitmap, block bases, rank -> label table
+int label_dict_make(dbg_ctx* c, const uint32_t* labels, uint64_t n, LabelDict* d) {
+    DBuf<uint32_t> cnt;
+    ALLOC_OR_FAIL(c, d->bm, LD_WORDS);
     ALLOC_OR_FAIL(c, cnt, LD_BLOCKS);
-    ALLOC_OR_FAIL(c, base, (size_t)LD_BLOCKS + 1);
-    ALLOC_OR_FAIL(c, *rank_out, std::max<uint64_t>(n, 1));
-    HIP_TRY(c, hipMemsetAsync(bm.p, 0, LD_WORDS * 8, c->stream));
+    ALLOC_OR_FAIL(c, d->base, (size_t)LD_BLOCKS + 1);
+    HIP_TRY(c, hipMemsetAsync(d->bm.p, 0, LD_WORDS * 8, c->stream));
     c->t_begin("label_dict", n);
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n, 256), 256ull * 32));
-    ld_mark_kernel<<<grid, 256, 0, c->stream>>>(labels, n, bm.p);
-    LAUNCH_CHECK(c, "ld_mark");
-    ld_block_count_kernel<<<cdiv(LD_BLOCKS, 256), 256, 0, c->stream>>>(bm.p, cnt.p);
+    if (n) { ld_mark_kernel<<<grid, 256, 0, c->stream>>>(labels, n, d->bm.p); LAUNCH_CHECK(c, "ld_mark"); }
+    ld_block_count_kernel<<<cdiv(LD_BLOCKS, 256), 256, 0, c->stream>>>(d->bm.p, cnt.p);
     LAUNCH_CHECK(c, "ld_block_count");
-    DBG_TRY(scan_exclusive_u32(c, cnt.p, base.p, LD_BLOCKS));
+    DBG_TRY(scan_exclusive_u32(c, cnt.p, d->base.p, LD_BLOCKS));
     uint32_t nd = 0;
-    HIP_TRY(c, hipMemcpyAsync(&nd, base.p + LD_BLOCKS, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&nd, d->base.p + LD_BLOCKS, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (nd >= (1u << 24)) { c->t_end(); return c->fail(17, "CountFilterSet: more than 2^24 - 1 distinct D1 values in one call"); }
-    ALLOC_OR_FAIL(c, *dict_out, std::max<uint32_t>(nd, 1));
-    ld_fill_kernel<<<cdiv(LD_BLOCKS, 256), 256, 0, c->stream>>>(bm.p, base.p, dict_out->p);
-    LAUNCH_CHECK(c, "ld_fill");
-    ld_rank_kernel<<<grid, 256, 0, c->stream>>>(labels, n, bm.p, base.p, rank_out->p);
-    LAUNCH_CHECK(c, "ld_rank");
+    ALLOC_OR_FAIL(c, d->dict, std::max<uint32_t>(nd, 1));
+    ld_fill_kernel<<<cdiv(LD_BLOCKS, 256), 256, 0, c->stream>>>(d->bm.p, d->base.p, d->dict.p);
     c->t_end();
-    HIP_TRY(c, hipStreamSynchronize(c->stream));                   // (bm / cnt / base go back to the pool)
-    *n_distinct = nd;
+    LAUNCH_CHECK(c, "ld_fill");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                   // (cnt goes back to the pool)
+    d->n = nd;
+    return 0;
+}
+
+// rank_out[i] = index of labels[i] among the dictionary's labels (every label must be in the dictionary)
+int label_dict_rank(dbg_ctx* c, const LabelDict& d, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out) {
+    ALLOC_OR_FAIL(c, *rank_out, std::max<uint64_t>(n, 1));
+    if (!n) return 0;
+    c->t_begin("label_dict_rank", n);
+    ld_rank_kernel<<<(uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n, 256), 256ull * 32)), 256, 0, c->stream>>>(labels, n, d.bm.p, d.base.p, rank_out->p);
+    c->t_end();
+    LAUNCH_CHECK(c, "ld_rank");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ranks of the n labels (u32) among the distinct labels of the call, and the dictionary rank -> label
+int label_dict_build(dbg_ctx* c, const uint32_t* labels, uint64_t n, DBuf<uint32_t>* rank_out, DBuf<uint32_t>* dict_out, uint32_t* n_distinct) {
+    LabelDict d;
+    DBG_TRY(label_dict_make(c, labels, n, &d));
+    DBG_TRY(label_dict_rank(c, d, labels, n, rank_out));
+    *dict_out = std::move(d.dict);
+    *n_distinct = d.n;
     return 0;
 }
 

@@ -80,3 +80,57 @@ def test_full_width_labels_compact_sets_and_device_entry(ctx):
     sv = np.ctypeslib.as_array(C.cast(t.set_val, C.POINTER(C.c_uint32)), shape=(int(t.n_set_val),)).copy()
     ctx.lib.dbg_free_table(ctx.h, C.byref(t))
     assert np.array_equal(sv, want.set_val)
+
+
+@pytest.mark.parametrize("world,k,lists_off", [(3, 47, False), (2, 31, True), (4, 63, False), (2, 11, False)])
+def test_full_width_labels_rank_spanning(world, k, lists_off):
+    """dbg_shard_filter_kmers_dev with labels of 2^24 and more: the ranks' distinct labels are gathered into ONE job-wide dictionary, the
+    exchange and the counting run on the ranks, every owner translates its rows back -- the union of the ranks' tables is the oracle's
+    table over all reads, label lists included.  One rank holds labels below 2^24 only, one rank holds no reads at all (world 4)."""
+    import ctypes as C
+    from pkg import capi, D
+    from test_gpu_shard_fuzz import make_group, run_ranks, masks_to_classes
+    hs = dbg.synth_reads_host(n_reads=3000, read_len=150, error_rate=0.003, stranded=False, n_colours=4)
+    ss, alphabet = labelled(hs, 400, 1234 + k)
+    lab = ss.data.copy()
+    n = len(hs.start)
+    bounds = [n * r // world for r in range(world + 1)]
+    if world == 4:
+        bounds[2] = bounds[1]                                      # rank 1 holds nothing
+    lab[bounds[0]:bounds[1]] = lab[bounds[0]:bounds[1]] % (1 << 20)     # rank 0: small labels only
+    ss_all = O.SeqSet(hs.words, hs.start, hs.length, None, lab, 4)
+    want = O.filter_kmers(ss_all, k, O.COUNT_FILTER_SET, 2, stranded=False)
+    assert int(want.set_val.max()) >= 1 << 24
+    trs, keep = make_group(world)
+    lib = capi.load()
+
+    def rank_main(r):
+        ctx = dbg.Context(0)
+        try:
+            if lists_off:
+                ctx.set_option("DBG_LABEL_LISTS", "0")
+            lo, hi = bounds[r], bounds[r + 1]
+            st0 = int(hs.start[lo]) if lo < hi else 0
+            part = dbg.HostSeqs(hs.words, (hs.start[lo:hi]).copy(), hs.length[lo:hi].copy(), None, lab[lo:hi].copy(), 4)
+            dev, hc = capi.SeqSet(), part.c_struct()
+            ctx.check(lib.dbg_seqset_to_device(ctx.h, C.byref(hc), C.byref(dev)))
+            tab, st = D.shard_filter_kmers_c(ctx, trs[r], dev, k, False, 1, 2)
+            lib.dbg_seqset_free_device(ctx.h, C.byref(dev))
+            h = capi.KmerTable()
+            ctx.check(lib.dbg_table_to_host(ctx.h, C.byref(tab), C.byref(h)))
+            th = dbg._table_from_c(h, k)
+            lib.dbg_free_table(ctx.h, C.byref(h))
+            lib.dbg_free_table(ctx.h, C.byref(tab))
+            return th
+        finally:
+            ctx.close()
+
+    tabs = run_ranks(world, rank_main)
+    for t in trs:
+        lib.dbg_transport_destroy(t.ptr)
+    hi_ = np.concatenate([t.key_hi for t in tabs]); lo_ = np.concatenate([t.key_lo for t in tabs])
+    order = np.lexsort((lo_, hi_))
+    assert len(order) == want.n and np.array_equal(hi_[order], want.key_hi) and np.array_equal(lo_[order], want.key_lo)
+    assert np.array_equal(np.concatenate([t.exts for t in tabs])[order], want.exts)
+    got_sets = [s for t in tabs for s in masks_to_classes(t.set_off, t.set_val)]
+    assert [got_sets[i] for i in order] == masks_to_classes(want.set_off, want.set_val)

@@ -72,9 +72,9 @@ def test_rccl_table_pieces_above_one_gib_world1(rccl1):
     dev = torch.device("cuda", 0)
     tab = rccl1.table
     n = (5 << 29) + 12345                                        # 2.5 GiB and a bit: three pieces
-    src = torch.empty(n + 4096, dtype=torch.uint8, device=dev)
-    src.view(torch.int64)[: (n + 4096) // 8].copy_(torch.arange((n + 4096) // 8, dtype=torch.int64, device=dev) * -7046029254386353131)
-    dst = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)
+    tot = (n + 4096 + 7) // 8 * 8
+    src = (torch.arange(tot // 8, dtype=torch.int64, device=dev) * -7046029254386353131).view(torch.uint8)
+    dst = torch.zeros(tot, dtype=torch.uint8, device=dev)
     u = C.c_uint64 * 1
     torch.cuda.synchronize()
     assert tab.all_to_allv(tab.self, src.data_ptr(), u(40), u(n), dst.data_ptr(), u(1000), u(n), None) == 0

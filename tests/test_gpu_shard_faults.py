@@ -81,7 +81,7 @@ def make_reads(seed, k, n_reads=900, kind=0, n_labels=5):
 class Job:
     """world contexts + one in-process group, kept across calls (the point: they stay usable after an agreed failure)"""
 
-    def __init__(self, world, k, kind, seed, n_labels=5, n_reads=900, lists=True):
+    def __init__(self, world, k, kind, seed, n_labels=5, n_reads=900, lists=True, wide=False):
         self.world, self.k, self.kind = world, k, kind
         self.lib = capi.load()
         self.keep = make_group(world)
@@ -97,13 +97,16 @@ class Job:
             if not lists:                                             # alphabets beyond 64 colours: label groups / the key-range route instead of label lists
                 c.set_option("DBG_LABEL_LISTS", "0")
         self.seqs, self.data = make_reads(seed, k, n_reads=n_reads, kind=kind, n_labels=n_labels)
+        w = self.width = 4 if wide else 2
+        if wide and kind:                                           # full-width u32 labels: the job-wide label dictionary (round 6)
+            self.data = (self.data.astype(np.uint64) * 1000003 + (1 << 24)) % (1 << 32)
         n = len(self.seqs)
         self.bounds = [n * r // world for r in range(world + 1)]
         self.devs = []
         for r in range(world):
             lo, hi = self.bounds[r], self.bounds[r + 1]
-            ss_o = O.SeqSet.from_byte_seqs(self.seqs[lo:hi], data=(self.data[lo:hi] if kind else None), sizeof_d1=2 if kind else 0)
-            hs = dbg.HostSeqs(ss_o.words, ss_o.start, ss_o.length, None, ss_o.data if kind else None, 2 if kind else 0)
+            ss_o = O.SeqSet.from_byte_seqs(self.seqs[lo:hi], data=(self.data[lo:hi] if kind else None), sizeof_d1=w if kind else 0)
+            hs = dbg.HostSeqs(ss_o.words, ss_o.start, ss_o.length, None, ss_o.data if kind else None, w if kind else 0)
             dev, hc = capi.SeqSet(), hs.c_struct()
             self.ctxs[r].check(self.lib.dbg_seqset_to_device(self.ctxs[r].h, C.byref(hc), C.byref(dev)))
             self.devs.append(dev)
@@ -138,7 +141,7 @@ class Job:
         return rc, g, err
 
     def oracle_table(self):
-        ss = O.SeqSet.from_byte_seqs(self.seqs, data=self.data if self.kind else None, sizeof_d1=2 if self.kind else 0)
+        ss = O.SeqSet.from_byte_seqs(self.seqs, data=self.data if self.kind else None, sizeof_d1=self.width if self.kind else 0)
         return O.filter_kmers(ss, self.k, O.COUNT_FILTER_SET if self.kind else O.COUNT_FILTER, 2, stranded=False)
 
     def check_tables(self, tabs):
@@ -171,15 +174,17 @@ class Job:
 
 
 @pytest.mark.parametrize("world,k,kind,n_labels,lists", [(3, 31, 0, 5, True), (2, 47, 1, 5, True), (3, 33, 1, 150, False), (2, 12, 1, 5, True), (3, 40, 1, 60000, False),
-                                                         (3, 33, 1, 150, True), (2, 40, 1, 60000, True)])
+                                                         (3, 33, 1, 150, True), (2, 40, 1, 60000, True), (3, 47, 1, 900, "wide")])
 def test_injected_failure_in_shard_filter_fails_all_ranks_together(world, k, kind, n_labels, lists):
     """(shapes 3-5: label groups -- 150 distinct labels with DBG_LABEL_LISTS=0, one CountFilter run + three group runs, failures in the
     rank-local steps between the runs included -- and the key-range route for k < 16 and, with DBG_LABEL_LISTS=0, for > 1024 distinct
     labels; the last two: label lists, the default beyond 64 colours -- the sites of the super-k-mer exchange, with bin_labels_kernel
     counting the rounds)"""
-    job = Job(world, k, kind, seed=5100 + world, n_labels=n_labels, n_reads=2600 if n_labels > 1024 else 900, lists=lists)
+    job = Job(world, k, kind, seed=5100 + world, n_labels=n_labels, n_reads=2600 if n_labels > 1024 else 900, lists=bool(lists), wide=lists == "wide")
     sites = FILTER_SITES
-    if n_labels > 64 and lists:
+    if lists == "wide":                                              # labels of 2^24 and more: the dictionary phase, then the label-list run on the ranks
+        sites = ["count", "labeldict", "labels", "scan", "round", "finish"]
+    elif n_labels > 64 and lists:
         sites = FILTER_SITES + ["labels"]
     elif n_labels == 150:
         sites = ["count", "labels", "scan", "groups", "round", "join", "finish"]

@@ -91,7 +91,10 @@ def draw(rng):
                     2: np.sort(rng.choice(np.arange(250 if width == 1 else 60000), size=int(rng.integers(2, 60)), replace=False)),
                     # more than 64 distinct labels; with 4-byte labels also values beyond 65535 (up to 2^24 - 1)
                     3: np.sort(rng.choice(np.arange(256 if width == 1 else (65536 if width == 2 else 1 << 24)),
-                                          size=int(rng.integers(65, 250 if width == 1 else 2000)), replace=False))}[int(rng.integers(0, 4))]
+                                          size=int(rng.integers(65, 250 if width == 1 else 2000)), replace=False)),
+                    # (round 6) full-width u32 labels: hashes / 32-bit ids, 2^32 - 1 included -- the job-wide label dictionary
+                    4: np.unique(np.concatenate([rng.integers(0, 1 << 32, size=int(rng.integers(2, 300)), dtype=np.uint64),
+                                                 np.array([(1 << 32) - 1, 1 << 24], dtype=np.uint64)]))}[int(rng.integers(0, 5 if width == 4 else 4))]
         data = alphabet[rng.integers(0, len(alphabet), size=n_reads)]
     # uneven split of the reads over the ranks; now and then a rank holds nothing
     cuts = np.sort(rng.integers(0, n_reads + 1, size=world - 1)) if world > 1 else np.zeros(0, np.int64)
