@@ -5,7 +5,7 @@ KS=${KS:-"16 18 20 22 24 28 31 32 40 47 56 64"}
 OUT=gpurun_out/${R}_k_sweep.json
 : > $OUT
 for k in $KS; do
-  timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes --k $k "$@" 2>&1 | grep '^{' | python -c "
+  timeout 300 python bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes --k $k "$@" 2>&1 | grep '^{' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 n = d['config']['kmer_instances_per_step']

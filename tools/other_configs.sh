@@ -3,7 +3,7 @@
 R=${1:-r02}
 OUT=gpurun_out/${R}_other_configs.json
 : > $OUT
-run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes "$@" 2>&1 | grep '^{' | python -c "
+run() { timeout 300 python bench.py --steps 3 --warmup 4 --no-cpu-baseline --no-host-boundary --compress-reads 0 --no-other-shapes "$@" 2>&1 | grep '^{' | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 print(json.dumps({'args': '$*', 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'workload': d['config']['workload'], 'kernel_ms_per_step': d['roofline']['kernel_ms_per_step']}))" >> $OUT; }
