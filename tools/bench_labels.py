@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=100_000_000)
 ap.add_argument("--k", type=int, default=47)
 ap.add_argument("--lists", default="auto")
-ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--iters", type=int, default=6, help="calls per alphabet (the first four are the slab tournament of the shape); the last one is reported")
 ap.add_argument("--target", default=None, help="DBG_FAST_TARGET: k-mer instances per bin")
 ap.add_argument("--small", action="store_true", help="labels below 65536 (label groups apply for 65..1024 of them)")
 ap.add_argument("labels", type=int, nargs="+")
