@@ -218,7 +218,8 @@ __global__ void censor_kernel(KeysDev valid, KeysDev all, uint8_t* __restrict__ 
             if (!((e >> (4 * dir + b)) & 1u)) continue;
             K128 x = dir == 0 ? kmer_extend_left(kmer, k, b) : kmer_extend_right(kmer, k, b);
             if (!stranded) { K128 rc = kmer_rc(x, k); if (!k128_lt(x, rc)) x = rc; }   // min_rc (lib.rs:234-241)
-            bool is_valid = find_key(valid, x) >= 0;
+            uint32_t unused;
+            bool is_valid = (valid.rec ? find_key_rec(valid, x, &unused) : find_key(valid, x)) >= 0;   // (packed records: one 16-byte load per step)
             bool keep = sharded ? (is_valid || find_key(all, x) < 0) : is_valid;       // filter.rs:259-269 / :295-299
             if (keep) ne |= 1u << (4 * dir + b);
         }
@@ -636,7 +637,9 @@ extern "C" int dbg_remove_censored_exts(dbg_ctx* c, uint32_t k_, int stranded, d
         ex = d_exts.p;
     }
     DBuf<uint32_t> pi_valid, pi_all;
+    DBuf<ulonglong2> valid_recs;                                       // the link builder's packed {key, Exts} records serve these probes too
     if (n < (1ull << 32)) DBG_TRY(attach_prefix_index(c, &valid, k, &pi_valid));
+    DBG_TRY(attach_key_records(c, &valid, k, ex, &valid_recs));
     if (na && na < (1ull << 32)) DBG_TRY(attach_prefix_index(c, &all, k, &pi_all));
     c->t_begin("remove_censored_exts", n);
     censor_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(valid, all, ex, k, stranded, sharded);
