@@ -509,7 +509,8 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ next, unsigned long long* __restrict__ kmers_seen,
                                                          uint32_t* __restrict__ capped,
                                                          const NodeRec* __restrict__ nrec /* or null */, uint32_t* __restrict__ link_flags,
-                                                         uint32_t* __restrict__ done_bits = nullptr /* one bit per state: its chain has been walked from the other end */) {
+                                                         uint32_t* __restrict__ done_bits /* one bit per state: its chain has been walked from the other end; or null */,
+                                                         uint32_t chain_cap) {
     // With node records both links of a k-mer arrive in the one line a step reads, so the walk itself verifies that every link
     // it takes is answered by the facing link of its target (check_links_kernel's test; every link of an open chain is taken
     // by one of the chain's two walkers): *link_flags |= 2 on a mismatch.
@@ -568,7 +569,7 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
                 active = false;
             } else {
                 cur = L >> 1; face = 1u - (L & 1u);
-                if (m > WALK_CAP) { atomicOr(capped, 1u); active = false; }
+                if (m > chain_cap) { atomicOr(capped, 1u); active = false; }
             }
         }
     }
@@ -734,7 +735,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // long chains (a censored graph: thousands of k-mers per chain) are not for this route -- its two walks per chain are as long
         // as the longest chain, and they give up at WALK_CAP: straight to the table routes
-        const bool long_chains = n_ends && (uint64_t)n2 / n_ends > 512u;
+        uint32_t chain_cap = WALK_CAP;
+        if (const char* e = c->opt("DBG_CHAIN_CAP")) chain_cap = (uint32_t)std::max(16, atoi(e));     // measurement / tests
+        const bool long_chains = n_ends && (uint64_t)n2 / n_ends > 512u && !c->opt("DBG_CHAIN_CAP");
         DBuf<uint32_t> done_bits;
         const bool one_walk = !(c->opt("DBG_CHAIN_WALKS") && !strcmp(c->opt("DBG_CHAIN_WALKS"), "2"));
         if (n_ends && one_walk) {
@@ -744,7 +747,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         if (n_ends && !long_chains) {
             chain_scan_kernel<<<std::min<uint32_t>(cdiv(n_ends, 256), 2048), 256, 0, c->stream>>>(
                 link_dev, rank_dev, n, LA.p, n_ends, k, flag_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p,
-                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, links_checked ? nullptr : nrec, flags.p, done_bits.p);
+                counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, links_checked ? nullptr : nrec, flags.p, done_bits.p, chain_cap);
             LAUNCH_CHECK(c, "chain_scan");
         }
         uint32_t res[4] = {0, 0, 0, 0};
