@@ -845,7 +845,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     bool partial = false;                                          // the walk filled a part of the table: the doubling takes the rest only
     if (!c->opt("DBG_UNITIG_NO_WALK")) {
         HIP_TRY(c, hipMemsetAsync(counters.p, 0, 24, c->stream));
+        c->t_begin("unitig_table_init", n);
         HIP_TRY(c, hipMemsetAsync(JA.p, 0xFF, (size_t)n2 * sizeof(Jump), c->stream));      // every state UNWRITTEN
+        c->t_end();
         c->t_begin("unitig_walk_ends", n);
         collect_ends_kernel<<<cdiv(n2, 1024 * ENDS_ITEMS), 1024, 0, c->stream>>>(link_dev, avail, n, LA.p, counters.p);
         LAUNCH_CHECK(c, "collect_ends");
@@ -884,9 +886,11 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         if (phase == 0 && partial) {
             // the states the walkers did not reach start from their one-step links; everything else is final already, in both buffers
             HIP_TRY(c, hipMemsetAsync(counters.p, 0, 4, c->stream));
+            c->t_begin("unitig_table_init", n);
             init_unwritten_kernel<<<cdiv(n2, 1024), 1024, 0, c->stream>>>(link_dev, rank_dev, weight, avail, n, JA.p, LA.p, counters.p);
             LAUNCH_CHECK(c, "init_unwritten");
             HIP_TRY(c, hipMemcpyAsync(JB.p, JA.p, (size_t)n2 * sizeof(Jump), hipMemcpyDeviceToDevice, c->stream));
+            c->t_end();
             HIP_TRY(c, hipMemcpyAsync(&n_live, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             la = LA.p;
@@ -927,6 +931,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     DBuf<uint8_t> rev_by_rank;
     ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
     ALLOC_OR_FAIL(c, rev_by_rank, n);
+    c->t_begin("unitig_seeds", n);                                  // seeds, node order, offsets, output buffers cleared
     HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
     mark_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, weight, avail, n, k, flag_by_rank.p, len_by_rank.p, rev_by_rank.p);
     LAUNCH_CHECK(c, "mark_seeds");
@@ -950,6 +955,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     HIP_TRY(c, hipMemsetAsync(uacc.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(uexts.p, 0, (size_t)std::max<uint32_t>(n_nodes, 1) * 4, c->stream));
     DBuf<uint32_t> ucnt;
+    c->t_end();
     c->t_begin("unitig_emit", n);
     if (nodes) {
         ALLOC_OR_FAIL(c, ucnt, std::max<uint32_t>(n_nodes, 1));
