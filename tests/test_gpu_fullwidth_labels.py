@@ -134,3 +134,55 @@ def test_full_width_labels_rank_spanning(world, k, lists_off):
     assert np.array_equal(np.concatenate([t.exts for t in tabs])[order], want.exts)
     got_sets = [s for t in tabs for s in masks_to_classes(t.set_off, t.set_val)]
     assert [got_sets[i] for i in order] == masks_to_classes(want.set_off, want.set_val)
+
+
+def test_full_width_labels_full_size_property():
+    """BASELINE configs[1] shape at a fifth of its size (2e7 reads), 5000 labels: the table over full-width u32 labels equals the table over
+    their ranks with every label translated back -- the order-preserving dictionary commutes with CountFilterSet (sorting and
+    de-duplicating ranks = sorting and de-duplicating labels, filter.rs:96-98).  Everything compared on the device."""
+    import ctypes as C
+    import torch
+    from pkg import capi
+    ctx = dbg.Context(0)
+    lib, dev = ctx.lib, torch.device("cuda", 0)
+    n_reads, k = 20_000_000, 47
+    p = dbg.synth_params(n_reads=n_reads, read_len=150, genome_len=n_reads * 150 // 30, error_rate=0.001, stranded=False, n_colours=4, first_read=0)
+    nw = lib.dbg_synth_words(C.byref(p))
+    words = torch.empty(nw, dtype=torch.int64, device=dev)
+    start = torch.empty(n_reads, dtype=torch.int64, device=dev)
+    length = torch.empty(n_reads, dtype=torch.int32, device=dev)
+    colour = torch.empty(n_reads, dtype=torch.uint8, device=dev)
+    ctx.check(lib.dbg_synth_reads_dev(ctx.h, C.byref(p), words.data_ptr(), start.data_ptr(), length.data_ptr(), colour.data_ptr()))
+    del colour
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    small = torch.randint(0, 5000, (n_reads,), device=dev, generator=g, dtype=torch.int64)
+    alphabet = torch.unique(torch.randint(0, 1 << 32, (6000,), device=dev, generator=g, dtype=torch.int64))[:5000]
+    alphabet[-1] = (1 << 32) - 1
+    assert int(alphabet.numel()) == 5000 and bool((alphabet[1:] > alphabet[:-1]).all())
+    big = alphabet[small]
+    lab_small = small.to(torch.int32).contiguous()
+    lab_big = (big - ((big >> 31) << 32)).to(torch.int32).contiguous()      # the u32 bit patterns in an int32 tensor
+    fp = capi.FilterParams(k, 0, 1, 2, 0, 4)
+
+    def run(lab):
+        ss = capi.SeqSet(words.data_ptr(), nw, start.data_ptr(), length.data_ptr(), None, lab.data_ptr(), 4, n_reads)
+        t = capi.KmerTable()
+        ctx.check(lib.dbg_filter_kmers_dev(ctx.h, C.byref(ss), C.byref(fp), C.byref(t)))
+        return t
+    from test_gpu_fullsize import dev_view
+    ts = run(lab_small)
+    n, nsv = int(ts.n), int(ts.n_set_val)
+    keys_s = (dev_view(ts.key_hi, n).clone(), dev_view(ts.key_lo, n).clone())
+    off_s = dev_view(ts.set_off, n + 1).clone()
+    val_s = dev_view(ts.set_val, nsv, "<i4").to(torch.int64)
+    want = alphabet[val_s]                                                    # the translated lists
+    del val_s
+    lib.dbg_free_table(ctx.h, C.byref(ts))
+    tb = run(lab_big)
+    assert int(tb.n) == n and int(tb.n_set_val) == nsv and n > 10_000_000
+    assert torch.equal(dev_view(tb.key_hi, n), keys_s[0]) and torch.equal(dev_view(tb.key_lo, n), keys_s[1])
+    assert torch.equal(dev_view(tb.set_off, n + 1), off_s)
+    got = dev_view(tb.set_val, nsv, "<i4").to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(got, want)
+    lib.dbg_free_table(ctx.h, C.byref(tb))
+    ctx.close()
