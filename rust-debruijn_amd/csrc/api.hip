@@ -23,6 +23,7 @@ extern "C" int dbg_ctx_create(int device, dbg_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return 3; }
     dbg_ctx* c = new dbg_ctx();
     c->device = device;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = cu; else (void)hipGetLastError(); }
     for (const char* name : DBG_OPTION_NAMES)               // the only place the library reads the environment
         if (const char* v = getenv(name)) c->opts[name] = v;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -143,7 +143,7 @@ __device__ unsigned long long g_ll_phase[8];
 #define LLPH(i) do {} while (0)
 #endif
 template <int KW, int NBW, int NT, int T>
-__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
+__device__ __forceinline__ void bin_labels_body(const uint32_t bin_idx, const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
     if (tid < 64) {
         uint32_t len = 0;
         if (tid < n_src) {
-            const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)blockIdx.x], b = seg_end[tid * seg_stride + (uint64_t)blockIdx.x];
+            const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)bin_idx], b = seg_end[tid * seg_stride + (uint64_t)bin_idx];
             len = (uint32_t)(b - a);
             s_segbeg[tid] = a;
         }
@@ -657,6 +657,29 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const
         LLPH(5);
     }
 }
+// resident workgroups take bins from gflags[BIN_TICKET] (bin_count_kernel's scheme, fastpath.hip); n_bins == 0: one workgroup per bin
+template <int KW, int NBW, int NT, int T>
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_labels_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
+                                                       const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
+                                                       uint32_t n_src, uint64_t seg_stride,
+                                                       int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
+                                                       unsigned long long* __restrict__ out_cursor, ListOut lo, uint32_t* __restrict__ gflags, uint32_t n_bins) {
+    if (n_bins == 0) {
+        bin_labels_body<KW, NBW, NT, T>(blockIdx.x, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, stranded, min_obs, out, out_cap, out_cursor, lo, gflags);
+        return;
+    }
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&gflags[BIN_TICKET], 1u);
+    __syncthreads();
+    for (;;) {
+        const uint32_t bin = s_ticket;
+        __syncthreads();
+        if (bin >= n_bins) break;
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&gflags[BIN_TICKET], 1u);
+        bin_labels_body<KW, NBW, NT, T>(bin, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, stranded, min_obs, out, out_cap, out_cursor, lo, gflags);
+        __syncthreads();
+    }
+}
 
 // after the order-restoring sort: the payload columns spell the record's position in the unsorted output (Exts column = low byte,
 // mask column = the other 24 bits); Exts, the number of labels and the segment's place are fetched from there
@@ -763,18 +786,24 @@ static int lists_count_bins(dbg_ctx* c, ListCountState* st, const uint64_t* recs
         HIP_TRY(c, hipMemcpyAsync(cs.out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
         if (cs.report_all) HIP_TRY(c, hipMemcpyAsync(cs.all_cursor.p, &start_all, 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(st->lab_cursor.p, &start_lab, 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(cs.gflags.p, 0, 64, c->stream));
+        HIP_TRY(c, hipMemsetAsync(cs.gflags.p, 0, 128, c->stream));
         FastOut fo{cs.u_hi.p, cs.u_lo.p, cs.u_pay.p, cs.use16 ? cs.u16.p : nullptr, cs.w_rec.p,
                    cs.report_all ? cs.a_hi.p : nullptr, cs.report_all ? cs.a_lo.p : nullptr, cs.report_all ? cs.all_cursor.p : nullptr, cs.all_cap};
         ListOut lo{st->lab.p, st->lab_cap, st->lab_cursor.p};
         if (nbins_local) {
             if ((uint64_t)nbins_local * 512 >= (1ull << 32)) return c->fail(135, "fast path: too many bins for the workgroup counting kernel (a grid holds < 2^32 threads)");
             c->t_begin("bin_labels", n_kmers_units);
-#define ARGS_ recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, st->min_obs, fo, cs.cap, cs.out_cursor.p, lo, cs.gflags.p
-            if (!pl.has_hi) bin_labels_kernel<1, 2, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
-            else if (pl.nbw == 2) bin_labels_kernel<2, 2, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
-            else if (pl.nbw == 3) bin_labels_kernel<2, 3, 512, 2048><<<nbins_local, 512, 0, c->stream>>>(ARGS_);
-            else bin_labels_kernel<2, 4, 512, 1024><<<nbins_local, 512, 0, c->stream>>>(ARGS_);       // (k >= 56: see lists_plan)
+const bool resident = !(c->opt("DBG_FAST_PERSIST") && atoi(c->opt("DBG_FAST_PERSIST")) == 0);
+            const uint32_t n_bins_arg = resident ? nbins_local : 0u;
+#define ARGS_ recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, st->min_obs, fo, cs.cap, cs.out_cursor.p, lo, cs.gflags.p, n_bins_arg
+#define LK(...) do { auto kern = bin_labels_kernel<__VA_ARGS__>; \
+            const uint32_t grid_wg = resident ? std::min(nbins_local, resident_grid(c, (const void*)kern, 512, 0, c->opt("DBG_FAST_PERSIST"))) : nbins_local; \
+            kern<<<grid_wg, 512, 0, c->stream>>>(ARGS_); } while (0)
+            if (!pl.has_hi) LK(1, 2, 512, 2048);
+            else if (pl.nbw == 2) LK(2, 2, 512, 2048);
+            else if (pl.nbw == 3) LK(2, 3, 512, 2048);
+            else LK(2, 4, 512, 1024);       // (k >= 56: see lists_plan)
+#undef LK
 #undef ARGS_
             c->t_end();
             LAUNCH_CHECK(c, "bin_labels");

@@ -802,7 +802,7 @@ __device__ unsigned long long g_phase_cycles[8];
 #define MARK(t) do {} while (0)
 #endif
 template <int KW, int NBW, bool IS_SET, int NT, int T, bool WIDE = false, bool WEIGHTED = false>
-__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
+__device__ __forceinline__ void bin_count_body(const uint32_t bin_idx, const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
                                                        const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
                                                        uint32_t n_src, uint64_t seg_stride,
                                                        int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
     if (tid < 64) {                             // n_src <= 64: one lane per segment, prefix sum by shuffles
         uint32_t len = 0;
         if (tid < n_src) {
-            const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)blockIdx.x * NCLS], b = seg_end[tid * seg_stride + (uint64_t)(blockIdx.x + 1) * NCLS - 1];
+            const uint64_t a = seg_beg[tid * seg_stride + (uint64_t)bin_idx * NCLS], b = seg_end[tid * seg_stride + (uint64_t)(bin_idx + 1) * NCLS - 1];
             len = (uint32_t)(b - a);
             if (HAVE_SEGBEG) s_segbeg[tid] = a;
         }
@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
             if (ridx < total_recs) {
                 uint32_t sg = 0;
                 while (sg + 1 < n_src && ridx >= s_segpre[sg + 1]) sg++;
-                const uint64_t sbase = HAVE_SEGBEG ? s_segbeg[sg] : seg_beg[sg * seg_stride + (uint64_t)blockIdx.x * NCLS];   // first record of the segment
+                const uint64_t sbase = HAVE_SEGBEG ? s_segbeg[sg] : seg_beg[sg * seg_stride + (uint64_t)bin_idx * NCLS];   // first record of the segment
                 const uint64_t* g = (sg >= alt_from ? recs_alt : recs) + (sbase + (ridx - s_segpre[sg])) * RW;
                 A0 = g[0]; A1 = g[1];
                 if (NBW > 2) A2 = g[2];
@@ -1362,6 +1362,34 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
     __syncthreads();
     if (threadIdx.x >= 4 && threadIdx.x < 16 && s_stat[threadIdx.x]) atomicAdd(&gflags[threadIdx.x], s_stat[threadIdx.x]);
 #endif
+}
+
+// The kernel.  Resident workgroups (as many as the chip holds at once, fast_count_bins) take bins from a counter, gflags[BIN_TICKET]; the
+// number of the next bin is requested while the current one is counted.  One workgroup per bin in launch order (n_bins == 0: bin =
+// blockIdx.x, kept for measurements, DBG_FAST_PERSIST=0) pins every eighth bin to one XCD and pays a workgroup launch per bin:
+// 52.9 -> 49.2 ms on the default shape (profiles/r06_bin_count_resident.txt).
+constexpr int BIN_TICKET = 16;
+template <int KW, int NBW, bool IS_SET, int NT, int T, bool WIDE = false, bool WEIGHTED = false>
+__global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const uint64_t* __restrict__ recs, const uint64_t* __restrict__ recs_alt, uint32_t alt_from,
+                                                       const uint64_t* __restrict__ seg_beg, const uint64_t* __restrict__ seg_end,
+                                                       uint32_t n_src, uint64_t seg_stride,
+                                                       int k, int stranded, uint64_t min_obs, FastOut out, uint64_t out_cap,
+                                                       unsigned long long* __restrict__ out_cursor, uint32_t* __restrict__ gflags, uint32_t n_bins) {
+    if (n_bins == 0) {
+        bin_count_body<KW, NBW, IS_SET, NT, T, WIDE, WEIGHTED>(blockIdx.x, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, stranded, min_obs, out, out_cap, out_cursor, gflags);
+        return;
+    }
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&gflags[BIN_TICKET], 1u);
+    __syncthreads();
+    for (;;) {
+        const uint32_t bin = s_ticket;
+        __syncthreads();
+        if (bin >= n_bins) break;
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&gflags[BIN_TICKET], 1u);          // in flight while this bin is counted
+        bin_count_body<KW, NBW, IS_SET, NT, T, WIDE, WEIGHTED>(bin, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, stranded, min_obs, out, out_cap, out_cursor, gflags);
+        __syncthreads();
+    }
 }
 
 // CSR helper for the order-restoring stage
@@ -1866,6 +1894,13 @@ static int fast_scatter(dbg_ctx* c, FastScan* st, const uint64_t* bin_off, uint6
     return 0;
 }
 
+// Workgroups of `kern` the device holds at once (the grid of a kernel whose workgroups take their work from a counter).
+static uint32_t resident_grid(dbg_ctx* c, const void* kern, int nt, size_t dyn_lds, const char* forced) {
+    if (forced && atoi(forced) > 0) return (uint32_t)atoi(forced);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nt, dyn_lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; }
+    return (uint32_t)per_cu * (uint32_t)std::max(1, c->n_cu);
+}
 // per-bin LDS hash tables over `nbins_local` bins whose records arrive as n_src segments, then the
 // order-restoring sort and the output table
 // Counting state that outlives one bin_count launch: the unsorted (key, payload) records of the valid k-mers found so
@@ -1950,7 +1985,7 @@ static int fast_count_begin(dbg_ctx* c, const FastPlan& pl, uint64_t min_obs, ui
         ALLOC_OR_FAIL(c, st->all_cursor, 1);
         DBG_TRY(fast_count_alloc_all(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 4, 1u << 20)), 1)));
     }
-    ALLOC_OR_FAIL(c, st->gflags, 16);
+    ALLOC_OR_FAIL(c, st->gflags, 32);
     HIP_TRY(c, hipMemsetAsync(st->out_cursor.p, 0, 8, c->stream));
     return fast_count_alloc(c, st, std::max<uint64_t>(std::min<uint64_t>(n_kmers_hint, std::max<uint64_t>(n_kmers_hint / 8, 1u << 20)), 1));
 }
@@ -1969,7 +2004,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
         unsigned long long start = st->n_out, start_all = st->n_all;
         HIP_TRY(c, hipMemcpyAsync(st->out_cursor.p, &start, 8, hipMemcpyHostToDevice, c->stream));
         if (st->report_all) HIP_TRY(c, hipMemcpyAsync(st->all_cursor.p, &start_all, 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemsetAsync(st->gflags.p, 0, 64, c->stream));
+        HIP_TRY(c, hipMemsetAsync(st->gflags.p, 0, 128, c->stream));
         FastOut fo{st->u_hi.p, st->u_lo.p, st->u_pay.p, st->use16 ? st->u16.p : nullptr, st->w_rec.p,
                    st->report_all ? st->a_hi.p : nullptr, st->report_all ? st->a_lo.p : nullptr,
                    st->report_all ? st->all_cursor.p : nullptr, st->all_cap};
@@ -1981,11 +2016,18 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
             const int nt_env = c->opt("DBG_FAST_NT") ? atoi(c->opt("DBG_FAST_NT")) : 512;
             const int tb_env = c->opt("DBG_FAST_TABLE") ? atoi(c->opt("DBG_FAST_TABLE")) : 2048;
             const size_t dyn_lds = c->opt("DBG_DYN_LDS") ? (size_t)atoi(c->opt("DBG_DYN_LDS")) : 0;   // measurement: extra LDS per workgroup (8192 leaves room for only one per CU)
-#define ARGS_ recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p
-#define L(KW, NBW, SET, NTT, TT) do { if (pl.weighted && NTT == 512) bin_count_kernel<KW, NBW, SET, 512, TT, false, true><<<nbins_local, 512, dyn_lds, c->stream>>>(ARGS_); \
-            else bin_count_kernel<KW, NBW, SET, NTT, TT><<<nbins_local, NTT, dyn_lds, c->stream>>>(ARGS_); } while (0)
-#define LW(KW, NBW) do { if (pl.weighted) bin_count_kernel<KW, NBW, true, 512, 1024, true, true><<<nbins_local, 512, dyn_lds, c->stream>>>(ARGS_); \
-            else bin_count_kernel<KW, NBW, true, 512, 1024, true><<<nbins_local, 512, dyn_lds, c->stream>>>(ARGS_); } while (0)
+            // resident workgroups: as many as the device holds at once (DBG_FAST_PERSIST=<n>: that many; 0: one workgroup per bin)
+            const bool resident = !(c->opt("DBG_FAST_PERSIST") && atoi(c->opt("DBG_FAST_PERSIST")) == 0);
+            uint32_t grid_wg = nbins_local;
+            const uint32_t n_bins_persist = resident ? nbins_local : 0u;
+#define ARGS_ recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, pl.stranded ? 1 : 0, min_obs, fo, cap, out_cursor_p, gflags_p, n_bins_persist
+#define LK(NTT, ...) do { auto kern = bin_count_kernel<__VA_ARGS__>; \
+            if (resident) grid_wg = std::min(nbins_local, resident_grid(c, (const void*)kern, NTT, dyn_lds, c->opt("DBG_FAST_PERSIST"))); \
+            kern<<<grid_wg, NTT, dyn_lds, c->stream>>>(ARGS_); } while (0)
+#define L(KW, NBW, SET, NTT, TT) do { if (pl.weighted && NTT == 512) LK(512, KW, NBW, SET, 512, TT, false, true); \
+            else LK(NTT, KW, NBW, SET, NTT, TT); } while (0)
+#define LW(KW, NBW) do { if (pl.weighted) LK(512, KW, NBW, true, 512, 1024, true, true); \
+            else LK(512, KW, NBW, true, 512, 1024, true); } while (0)
 #define GO(KW, NBW, SET) do { \
             if (SET && pl.wide) LW(KW, NBW); \
             else if (tb_env == 1024 && nt_env == 256 && !pl.weighted) L(KW, NBW, SET, 256, 1024); \
@@ -1997,6 +2039,7 @@ static int fast_count_bins(dbg_ctx* c, FastCountState* st, const uint64_t* recs,
 #undef GO
 #undef LW
 #undef L
+#undef LK
 #undef ARGS_
             c->t_end();
             LAUNCH_CHECK(c, "bin_count");
