@@ -149,6 +149,8 @@ struct GraphDev {
     bool filled = false;
 };
 
+int graph_dev_join_segments(struct dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, GraphDev* out);   // graph.hip
+
 // ---- launch helpers -----------------------------------------------------------------------
 #define LAUNCH_CHECK(ctx, name)                                                                 \
     do {                                                                                        \

@@ -952,6 +952,12 @@ int gather_blobs(dbg_ctx* c, ShardComm& X, int lrc, const std::vector<uint8_t>& 
 
 }  // namespace
 
+// compress_graph's device route on a device-resident graph without either fix_exts: the second level of unitig.hip's segment route
+// (segments of long chains -> unitigs; a segment end whose extension leads into no node end is a chain end, as at the k-mer level)
+int graph_dev_join_segments(dbg_ctx* c, int k, int stranded, int spec, GraphDev* in, GraphDev* out) {
+    return graph_dev_compress(c, k, stranded, spec, in, out, true);
+}
+
 extern "C" int dbg_shard_compress_dev(dbg_ctx* c, const dbg_transport* tr, uint32_t k, int stranded, int spec, int second_spec,
                                       const dbg_kmer_table* table, int32_t reduce, int32_t root, dbg_graph* final_out, dbg_graph* local_out,
                                       dbg_label_classes* classes) {

@@ -667,6 +667,30 @@ __global__ void __launch_bounds__(256) chain_emit_kernel(const uint32_t* __restr
     }
 }
 
+// ---- segment route: long chains in two levels -----------------------------------------------------------------------------
+// A censored graph (what real callers compress) has 10^5 chains of thousands of k-mers, the longest 10^5: one walker per chain end keeps
+// 2.6e5 lanes busy for as long as the longest walk (92 ms of walking + 33 ms of doubling + a 16 GB table at config-3 size).  Here every
+// `every`-th k-mer (by id: ids are in key order, unrelated to the position in a chain) cuts the link on its right side.  The pieces
+// (~`every` k-mers, the longest ~20 x that) go through the chain route like any short chains, and the resulting BaseGraph of
+// segments is joined by compress_graph's device route (graph.hip), whose rules at a cut -- one extension each way, mutual, same
+// join_test -- are the k-mer rules, and at a real chain end see the same Exts the k-mer walk saw.  Seeds carry over: segments are
+// numbered by their seed's rank and stored in their seed's orientation, the unitig's seed segment holds the unitig's seed.  What does
+// not carry over is the cut of a CYCLE (at its seed k-mer's right side): every open chain has two ends, so unitigs != ends / 2 means
+// a cycle somewhere and the caller takes the table route on the untouched links.
+__global__ void cut_links_kernel(const uint32_t* __restrict__ link_in, uint32_t* __restrict__ link, NodeRec* __restrict__ nrec, uint32_t n, uint32_t every,
+                                 uint32_t* __restrict__ flags) {
+    const uint64_t i64 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * every;
+    if (i64 >= n) return;
+    const uint32_t i = (uint32_t)i64;
+    const uint32_t L = link_in[(uint64_t)n + i];                  // side 1 of k-mer i
+    if (!link_valid(L, i)) return;
+    const uint32_t j = L >> 1, q = 1u - (L & 1u);                 // the side of j that faces i (check_links_kernel)
+    if (link_in[(uint64_t)q * n + j] != (i << 1)) { atomicOr(flags, 2u); return; }   // not mutual: the walks below check every link they take, this one they no longer see
+    link[(uint64_t)n + i] = U_TERM;
+    link[(uint64_t)q * n + j] = U_TERM;
+    if (nrec) { nrec[i].link[1] = U_TERM; nrec[j].link[q] = U_TERM; }
+}
+
 }  // namespace
 
 // Builds the BaseGraph on the device from the neighbour links.  rank_dev: seed rank of every (sorted) k-mer id,
@@ -687,7 +711,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
     // the chain route with node records checks the links while it walks them; everything else checks them first
     bool links_checked = false;
     auto check_links = [&]() -> int {
+        c->t_begin("unitig_check_links", n);
         check_links_kernel<<<cdiv(n2, 256), 256, 0, c->stream>>>(link_dev, avail, n, flags.p);
+        c->t_end();
         LAUNCH_CHECK(c, "check_links");
         links_checked = true;
         return 0;
@@ -763,6 +789,58 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         const bool ok = !long_chains && res[1] == 0 && seen == n;  // no walker gave up, every k-mer sits on an open chain
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
                                          ok ? "" : " -> general route");
+        if (!ok && c->segment_depth > 0) return 0;                  // first level of the segment route: a cycle among the pieces, the caller takes the table route
+        // ---- segment route: long chains are cut into pieces, the pieces are compressed, the pieces are joined ----
+        // (also when the chain route met a chain beyond its cap among short ones: a few very long chains in an ordinary graph)
+        if (!ok && (long_chains || res[1] != 0) && !(c->opt("DBG_SEGMENTS") && atoi(c->opt("DBG_SEGMENTS")) == 0)) {
+            // (links: with node records the pieces' walks check every link they take, as the chain route does, and the cutter checks the
+            //  links it removes; without records check_links_kernel has run above)
+            const uint32_t every = c->opt("DBG_SEGMENTS") ? (uint32_t)std::max(2, atoi(c->opt("DBG_SEGMENTS"))) : 128u;   // 32 / 64 / 128 / 256: 112 / 102 / 98 / 103 ms at config-3 size
+            // this level's chain-route buffers go back to the pool: the first level below asks for the same sizes
+            flag_by_rank.release(); len_by_rank.release(); uidx_by_rank.release(); start_by_rank.release(); seed_by_rank.release(); done_bits.release();
+            DBuf<uint32_t> link_cut;
+            ALLOC_OR_FAIL(c, link_cut, n2);
+            c->t_begin("unitig_segments", n);
+            HIP_TRY(c, hipMemcpyAsync(link_cut.p, link_dev, (size_t)n2 * 4, hipMemcpyDeviceToDevice, c->stream));
+            cut_links_kernel<<<cdiv(cdiv(n, every), 256), 256, 0, c->stream>>>(link_dev, link_cut.p, const_cast<NodeRec*>(nrec), n, every, flags.p);   // (the records are this call's own)
+            c->t_end();
+            LAUNCH_CHECK(c, "cut_links");
+            GraphDev pieces, joined;
+            GraphDev* outer_sink = c->graph_sink;
+            c->graph_sink = &pieces;
+            c->segment_depth++;
+            dbg_graph sizes_only;
+            bool pieces_done = false;
+            int r = compress_links_device(c, k, n, key_hi, key_lo, exts, data, link_cut.p, rank_dev, spec, stranded, &sizes_only, &pieces_done, nullptr, nrec);
+            c->segment_depth--;
+            c->graph_sink = outer_sink;
+            if (r) return r;
+            link_cut.release();
+            {
+                bool bad = false;                                  // a cut link that was not mutual
+                DBG_TRY(links_bad(&bad));
+                if (bad) return 0;
+            }
+            bool joined_ok = false;
+            if (pieces_done) {
+                const uint64_t n_pieces = pieces.n_nodes;
+                c->graph_sink = nullptr;                           // (graph_dev_compress installs its own)
+                r = graph_dev_join_segments(c, k, stranded, spec, &pieces, &joined);
+                c->graph_sink = outer_sink;
+                if (r && r != 48) return r;                        // 48: node links not mutual -- the table route decides what that means
+                joined_ok = r == 0 && joined.filled && joined.n_nodes * 2 == (uint64_t)n_ends;
+                if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: %llu pieces (every %u) -> %llu unitigs, %u chain ends%s\n", (unsigned long long)n_pieces, every,
+                                                 (unsigned long long)joined.n_nodes, n_ends, joined_ok ? "" : " -> table route");
+            } else if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: the pieces hold a cycle -> table route\n");
+            if (joined_ok) {
+                words = std::move(joined.words); ustart = std::move(joined.start); ulen = std::move(joined.length);
+                o_exts = std::move(joined.exts); o_data = std::move(joined.data);
+                n_nodes = (uint32_t)joined.n_nodes; n_words = joined.n_words; total_bases = joined.n_bases;
+                emitted = true;
+                c->t_begin("unitig_segments_joined", n_nodes);     // (a marker in the timing list: the route ran to its end)
+                c->t_end();
+            }
+        }
         if (ok) {
             DBG_TRY(scan_exclusive_u32(c, flag_by_rank.p, uidx_by_rank.p, n));
             HIP_TRY(c, hipMemcpyAsync(&n_nodes, uidx_by_rank.p + n, 4, hipMemcpyDeviceToHost, c->stream));

@@ -236,6 +236,73 @@ def test_compress_long_chains(ctx, compress_mode, k, stranded, spec_i):
     compare(ctx, t, k, stranded, SPECS[spec_i], seed_order=order)
 
 
+@pytest.mark.parametrize("k,stranded,spec_i,every", [(47, False, 0, None), (31, True, 2, "7"), (63, False, 1, "2"), (32, False, 3, "16"), (64, True, 0, "64"),
+                                                    (21, False, 1, "33")])
+def test_compress_segment_route(ctx, compress_mode, k, stranded, spec_i, every):
+    """Long open chains (round 6: the segment route of unitig.hip): every n-th k-mer cuts the link on its right side, the pieces go through
+    the chain route, compress_graph's device route joins them.  Two haplotypes that differ every few kilobases (branches: real chain ends
+    with more than one extension), palindromic k-mers for even k, data folds of every spec, an explicit seed order -- the BaseGraph must
+    be the oracle's, and the route must have run to its end (no fall-back to the table route)."""
+    if compress_mode != "device":
+        pytest.skip("device route")
+    rng = np.random.default_rng(4200 + k)
+    genome = R.random_dna(rng, 70000)
+    if k % 2 == 0:                                                   # palindromes: x + rc(x)
+        for at in (9000, 33000, 51000):
+            x = genome[at:at + k // 2]
+            genome[at + k // 2:at + k] = (3 - x)[::-1]
+    hap = genome.copy()
+    for at in range(2500, 70000, 6000):
+        hap[at] = (hap[at] + 1 + rng.integers(0, 3)) % 4             # a SNP: a bubble, four chain ends with a branch behind them
+    contigs = []
+    for g in (genome, hap):
+        contigs += [g[a:a + 3000] for a in range(0, 70000 - 3000 + 1, 1000)]
+    if not stranded:
+        contigs = [c if i % 2 else (3 - c)[::-1].copy() for i, c in enumerate(contigs)]
+    t = gpu_table(ctx, contigs, k, 2, stranded)
+    opts = {"DBG_SEGMENTS": every} if every else {}
+    with ctx.options(**opts):
+        ctx.enable_timing(True)
+        got, want = compare(ctx, t, k, stranded, SPECS[spec_i])
+        names = [x["name"] for x in ctx.timings()]
+        assert "unitig_segments_joined" in names, names
+        assert max(int(x) for x in got.arrays()["length"]) > 3000
+        order = rng.permutation(len(t)).astype(np.uint64)
+        ctx.enable_timing(True)                                      # (clears the list)
+        compare(ctx, t, k, stranded, SPECS[spec_i], seed_order=order)
+        assert "unitig_segments_joined" in [x["name"] for x in ctx.timings()]
+        data = rng.integers(0, 65536, len(t)).astype(np.uint32)     # folds that saturate / wrap
+        ctx.enable_timing(True)
+        compare(ctx, t, k, stranded, SPECS[spec_i], data=data)
+        assert "unitig_segments_joined" in [x["name"] for x in ctx.timings()]
+        ctx.enable_timing(False)
+    with ctx.options(DBG_SEGMENTS="0"):                              # the table route on the same input
+        ctx.enable_timing(True)
+        compare(ctx, t, k, stranded, SPECS[spec_i])
+        assert "unitig_segments_joined" not in [x["name"] for x in ctx.timings()]
+        ctx.enable_timing(False)
+
+
+def test_compress_segment_route_few_long_chains(ctx, compress_mode):
+    """An ordinary graph (thousands of short chains) with two chains beyond the chain route's cap: the chain route gives up on them,
+    the segment route takes the whole graph (before round 6: the table route)."""
+    if compress_mode != "device":
+        pytest.skip("device route")
+    k, stranded = 31, False
+    rng = np.random.default_rng(77)
+    contigs = [R.random_dna(rng, 40 + int(rng.integers(0, 60))) for _ in range(4000)]
+    for _ in range(2):
+        g = R.random_dna(rng, 30000)
+        contigs += [g[a:a + 4000] for a in range(0, 30000 - 4000 + 1, 2000)]
+    t = gpu_table(ctx, contigs, k, 1, stranded)
+    ctx.enable_timing(True)
+    got, want = compare(ctx, t, k, stranded, SPECS[0])
+    names = [x["name"] for x in ctx.timings()]
+    ctx.enable_timing(False)
+    assert "unitig_segments_joined" in names, names
+    assert max(int(x) for x in got.arrays()["length"]) > (1 << 14) + k and len(got.arrays()["length"]) > 3000
+
+
 def test_compress_non_mutual_links(ctx, compress_mode):
     """Inconsistent Exts: A's only right extension leads to B and B has a single left extension, but to a k-mer that is
     not A.  The reference walks such input in visiting order (compression.rs:450-541); the device routes refuse it
