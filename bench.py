@@ -613,7 +613,7 @@ def main():
                 ln = np.ctypeslib.as_array(C.cast(gg.length, C.POINTER(C.c_uint32)), shape=(max(nn, 1),))[:nn]
                 info = {"seconds": round(qdt, 4), "unitigs": nn, "unitigs_per_s": round(nn / qdt, 1), "kmers_per_s": round(t3.n / qdt, 1),
                         "longest_unitig_bases": int(ln.max()) if nn else 0, "mean_unitig_bases": round(float(ln.mean()), 1) if nn else 0.0,
-                        "chain_route": ("chain walk (unitig_chain_scan)" if "unitig_chain_scan" in kt and "unitig_pointer_jump" not in kt and "unitig_walk_ends" not in kt
+                        "chain_route": ("segments (pieces through the chain walk, joined by compress_graph's device route)" if "unitig_segments_joined" in kt else "chain walk (unitig_chain_scan)" if "unitig_chain_scan" in kt and "unitig_pointer_jump" not in kt and "unitig_walk_ends" not in kt
                                         else ("pointer jumping" if "unitig_pointer_jump" in kt else ("end walks" if "unitig_walk_ends" in kt else "host walk"))),
                         "kernel_ms": kt}
                 lib.dbg_free_graph(cx.h, C.byref(gg))
