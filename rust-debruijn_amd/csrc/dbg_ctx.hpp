@@ -44,7 +44,7 @@ static const char* const DBG_OPTION_NAMES[] = {
     "DBG_PATH", "DBG_COMPRESS", "DBG_FAST_TARGET", "DBG_FAST_NT", "DBG_FAST_TABLE", "DBG_NO_HYBRID_SORT", "DBG_NO_REC16",
     "DBG_FAST_NO_SLAB", "DBG_DEBUG", "DBG_UNITIG_NO_WALK", "DBG_UNITIG_NO_CHAINS", "DBG_NO_KEY_RECORDS", "DBG_NO_NODE_RECORDS",
     "DBG_PIDX_BITS", "DBG_SORT", "DBG_DYN_LDS", "DBG_GENERIC_PASS_MAX", "DBG_FAST_P", "DBG_HOST_STAGING", "DBG_SCAN", "DBG_MSP", "DBG_SLAB_CAP", "DBG_ONESWEEP", "DBG_NO_LABEL_GROUPS", "DBG_NO_STRAND_NORM", "DBG_SHARD_MERGE", "DBG_LINKS", "DBG_DENSE_RANGES", "DBG_CHAIN_WALKS", "DBG_DENSE_PART", "DBG_DENSE_BATCH", "DBG_DENSE_L1", "DBG_DENSE_RAW",
-    "DBG_FAIL_AT", "DBG_COMM_TIMEOUT_S", "DBG_SHARD_MERGE_COST_MS", "DBG_LABEL_LISTS", "DBG_SLAB_TRIALS", "DBG_UNITIG_FULL_DOUBLING", "DBG_WALK_CAP", "DBG_CHAIN_CAP", "DBG_FAST_PERSIST", "DBG_SEGMENTS"};   // (the last two: fault injection and the bound on communication waits of the rank-spanning calls, shard_comm.hpp)   // (DBG_MSP: wave | twopass)
+    "DBG_FAIL_AT", "DBG_COMM_TIMEOUT_S", "DBG_SHARD_MERGE_COST_MS", "DBG_LABEL_LISTS", "DBG_SLAB_TRIALS", "DBG_UNITIG_FULL_DOUBLING", "DBG_WALK_CAP", "DBG_CHAIN_CAP", "DBG_FAST_PERSIST", "DBG_SEGMENTS", "DBG_SEGMENTS_FORCE"};   // (the last two: fault injection and the bound on communication waits of the rank-spanning calls, shard_comm.hpp)   // (DBG_MSP: wave | twopass)
 
 // Reads whose packed words are still on their way to the device (dbg_filter_kmers: the upload of the caller's words runs in chunks
 // of reads next to the scan of the chunks that have arrived, api.hip).  Chunk g is complete once reads [0, upto[g]) have their words

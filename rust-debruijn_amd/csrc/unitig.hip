@@ -763,7 +763,9 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         // as the longest chain, and they give up at WALK_CAP: straight to the table routes
         uint32_t chain_cap = WALK_CAP;
         if (const char* e = c->opt("DBG_CHAIN_CAP")) chain_cap = (uint32_t)std::max(16, atoi(e));     // measurement / tests
-        const bool long_chains = n_ends && (uint64_t)n2 / n_ends > 512u && !c->opt("DBG_CHAIN_CAP");
+        // (DBG_SEGMENTS_FORCE, tests: every graph takes the segment route below, whatever the length of its chains)
+        const bool force_segments = c->opt("DBG_SEGMENTS_FORCE") && c->segment_depth == 0 && n_ends;
+        const bool long_chains = (n_ends && (uint64_t)n2 / n_ends > 512u && !c->opt("DBG_CHAIN_CAP")) || force_segments;
         DBuf<uint32_t> done_bits;
         const bool one_walk = !(c->opt("DBG_CHAIN_WALKS") && !strcmp(c->opt("DBG_CHAIN_WALKS"), "2"));
         if (n_ends && one_walk) {

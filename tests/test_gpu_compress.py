@@ -34,6 +34,22 @@ def compress_mode(request, ctx):
     ctx.set_option("DBG_COMPRESS", old)
 
 
+@pytest.fixture(autouse=True, params=[None, "3", "2"], ids=["", "segments3", "segments2"])
+def forced_segments(request, ctx, compress_mode):
+    """Every test of the device route runs three times: as is, and with the segment route of unitig.hip forced onto every graph
+    (DBG_SEGMENTS_FORCE; every 3rd / 2nd k-mer cuts its right link, the pieces are compressed and joined again by compress_graph's
+    device route; graphs with a cycle fall back to the table route): the random contigs, palindromes, hairpins, degenerate inputs,
+    ScmapCompress data and seed orders of the tests below all cross the cut-and-join."""
+    if request.param is None:
+        yield None
+        return
+    if compress_mode != "device":
+        pytest.skip("device route")
+    o1, o2 = ctx.set_option("DBG_SEGMENTS_FORCE", "1"), ctx.set_option("DBG_SEGMENTS", request.param)
+    yield request.param
+    ctx.set_option("DBG_SEGMENTS_FORCE", o1); ctx.set_option("DBG_SEGMENTS", o2)
+
+
 def gpu_table(ctx, contigs, k, min_obs, stranded, dup=1):
     seqs = []
     for c in contigs:
