@@ -118,13 +118,17 @@ def test_sharded_compress_two_ranks_one_gpu():
     assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("world,reduce", [(3, "gather"), (3, "tree"), (2, "tree"), (4, "tree")])
-def test_sharded_compress_more_shapes_one_gpu(world, reduce):
+@pytest.mark.parametrize("world,reduce,segments", [(3, "gather", False), (3, "tree", False), (2, "tree", False), (4, "tree", False),
+                                                   (3, "gather", True), (2, "tree", True)])
+def test_sharded_compress_more_shapes_one_gpu(world, reduce, segments):
     """dbg_shard_compress_dev with 3 ranks (an odd tree: one rank sits a level out) and the tree merge: gather is compared node for
-    node with the oracle's combine + compress_graph, the tree in canonical form (same unitigs, other order / strand)."""
+    node with the oracle's combine + compress_graph, the tree in canonical form (same unitigs, other order / strand).
+    segments: every rank's per-shard unitig construction takes the segment route (unitig.hip: forced, every 3rd k-mer cut) with the
+    shard graph staying in HBM (dbg_ctx::graph_sink set by the caller)."""
+    env = dict(os.environ, DBG_SEGMENTS_FORCE="1", DBG_SEGMENTS="3") if segments else None
     r = subprocess.run(["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                        "--master-port", str(29741 + world), os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo",
-                        "--one-device", "--reduce", reduce, "--reads", "21000"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                        "--master-port", str(29741 + world + (10 if segments else 0)), os.path.join(ROOT, "tools", "check_sharded_compress.py"), "--backend", "gloo",
+                        "--one-device", "--reduce", reduce, "--reads", "21000"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "sharded compress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
