@@ -87,6 +87,11 @@ struct dbg_ctx {
     // what the last dbg_shard_filter_kmers_dev of this ctx measured: input of the next call's sender-side-merge decision
     bool shard_last_valid = false, shard_last_merge = false;
     double shard_last_exposed_ms = 0.0, shard_last_merge_cost_ms = 0.0, shard_last_wire_ms = 0.0, shard_last_merge_ratio = 1.0;
+    uint32_t* cycle_seed_list = nullptr;    // when set (segment route, second level): cut_cycles_kernel appends the seed element of every cycle it cuts
+    uint32_t* cycle_seed_count = nullptr;
+    uint32_t cycle_seed_cap = 0;
+    uint32_t* segment_outer_links = nullptr;   // first level of the segment route: the call's own link array (cycles no sampled cut fell into are cut there, at their seeds)
+    uint32_t segment_new_cuts = 0;
     int segment_depth = 0;                  // > 0 inside the first level of the segment route (unitig.hip): no further nesting, no general route
     struct GraphDev* graph_sink = nullptr;   // when set, compress_links_device leaves its BaseGraph in HBM there instead of copying it to the host (graph.hip: second stage)
     dbg_state_slot stager;                  // pinned staging ring of the host-boundary uploads (hostio.hip)

@@ -144,6 +144,7 @@ struct GraphDev {
     DBuf<uint64_t> words, start;
     DBuf<uint32_t> length, data;
     DBuf<uint8_t> exts;
+    DBuf<uint32_t> seed;            // (first level of unitig.hip's segment route only) the seed k-mer of every node
     uint64_t n_nodes = 0, n_words = 0, n_bases = 0;
     int stranded = 0;
     bool filled = false;

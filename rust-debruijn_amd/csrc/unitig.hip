@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(1024) init_unwritten_kernel(const uint32_t* __
 }
 
 // after the doubling has covered 2n steps, any state still walking sits on a cycle; cut it at its seed's right side
-__global__ void cut_cycles_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t* __restrict__ link, uint32_t n) {
+__global__ void cut_cycles_kernel(const Jump* __restrict__ J, const uint32_t* __restrict__ rank, uint32_t* __restrict__ link, uint32_t n,
+                                  uint32_t* __restrict__ seed_list = nullptr, uint32_t* __restrict__ seed_count = nullptr, uint32_t seed_cap = 0) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Jump a = J[2 * i];
@@ -273,6 +274,7 @@ __global__ void cut_cycles_kernel(const Jump* __restrict__ J, const uint32_t* __
         uint32_t j = L >> 1, nd = L & 1;
         link[(uint64_t)n + i] = U_TERM;
         link[(uint64_t)(1 - nd) * n + j] = U_TERM;
+        if (seed_count) { const uint32_t at = atomicAdd(seed_count, 1u); if (at < seed_cap) seed_list[at] = i; }
     }
 }
 
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
                                                          uint32_t* __restrict__ capped,
                                                          const NodeRec* __restrict__ nrec /* or null */, uint32_t* __restrict__ link_flags,
                                                          uint32_t* __restrict__ done_bits /* one bit per state: its chain has been walked from the other end; or null */,
-                                                         uint32_t chain_cap) {
+                                                         uint32_t chain_cap, uint32_t* __restrict__ visited = nullptr /* one bit per k-mer, set as the walk passes (or null) */) {
     // With node records both links of a k-mer arrive in the one line a step reads, so the walk itself verifies that every link
     // it takes is answered by the facing link of its target (check_links_kernel's test; every link of an open chain is taken
     // by one of the chain's two walkers): *link_flags |= 2 on a mismatch.
@@ -539,6 +541,7 @@ __global__ void __launch_bounds__(256) chain_scan_kernel(const uint32_t* __restr
             const uint32_t r = rank ? rank[cur] : cur;
             if (r < best) { best = r; seed = cur; seed_left_faces_T = face == 0; }
             m++;
+            if (visited) atomicOr(&visited[cur >> 5], 1u << (cur & 31u));
             uint32_t L;
             bool more;
             if (nrec) {
@@ -691,6 +694,57 @@ __global__ void cut_links_kernel(const uint32_t* __restrict__ link_in, uint32_t*
     if (nrec) { nrec[i].link[1] = U_TERM; nrec[j].link[q] = U_TERM; }
 }
 
+// A cycle NO sampled cut fell into (short ones: 100 k-mers escape every 128th with probability 0.46) has no end, so no walker of the
+// first level passes it: its k-mers are the ones left unmarked after a marking walk.  Every such k-mer walks its cycle once (they are
+// short: 2000 k-mers escape with probability 1.5e-7) and the one that holds the smallest rank cuts the link on its right side, in the
+// call's own links -- the reference's cut.  `gave_up`: a walk that did not come back within the cap (the table route then).
+__global__ void unvisited_cycle_seeds_kernel(const uint32_t* __restrict__ link, const uint32_t* __restrict__ rank, uint32_t n, const uint32_t* __restrict__ visited,
+                                             uint32_t* __restrict__ outer_link, NodeRec* __restrict__ nrec, uint32_t* __restrict__ n_cut, uint32_t* __restrict__ gave_up) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || ((visited[i >> 5] >> (i & 31u)) & 1u)) return;
+    const uint32_t mine = rank ? rank[i] : i;
+    uint32_t cur = i, face = 0;                                    // leave through the side opposite `face`
+    for (uint32_t steps = 0;; steps++) {
+        const uint32_t L = link[(uint64_t)(1u - face) * n + cur];
+        if (!link_valid(L, cur) || steps > (1u << 16)) { atomicOr(gave_up, 1u); return; }
+        cur = L >> 1; face = 1u - (L & 1u);
+        if (cur == i) break;                                       // (either way round: the minimum has been seen over the whole cycle)
+        if ((rank ? rank[cur] : cur) < mine) return;               // not the seed
+    }
+    const uint32_t L = outer_link[(uint64_t)n + i];
+    if (!link_valid(L, i)) return;
+    const uint32_t j = L >> 1, q = 1u - (L & 1u);
+    outer_link[(uint64_t)n + i] = U_TERM;
+    outer_link[(uint64_t)q * n + j] = U_TERM;
+    if (nrec) { nrec[i].link[1] = U_TERM; nrec[j].link[q] = U_TERM; }
+    atomicAdd(n_cut, 1u);
+}
+
+// A cycle with exactly ONE cut is a single piece whose right side leads to its own left side: a self link, terminal for the walk
+// (compression.rs:410-415 at the node level), so no cycle of pieces shows -- it is reported here.
+__global__ void self_loop_seeds_kernel(const uint32_t* __restrict__ link, uint32_t n, uint32_t* __restrict__ seed_list, uint32_t* __restrict__ seed_count, uint32_t seed_cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (link[(uint64_t)n + i] == ((i << 1) | 1u)) { const uint32_t at = atomicAdd(seed_count, 1u); if (at < seed_cap) seed_list[at] = i; }
+}
+
+// A cycle that holds a cut shows up as a cycle of pieces in the second level, which names its seed piece (cut_cycles_kernel's list);
+// the cycle's seed k-mer is that piece's seed.  The link on its right side is removed from the call's links for good -- exactly the
+// cut the reference makes ("an isolated cycle is cut at the right side of its seed") -- and the route runs again on open chains only.
+__global__ void cut_at_piece_seeds_kernel(const uint32_t* __restrict__ seed_pieces, uint32_t n_seeds, const uint32_t* __restrict__ piece_seed,
+                                          uint32_t* __restrict__ link, NodeRec* __restrict__ nrec, uint32_t n, uint32_t* __restrict__ n_cut) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seeds) return;
+    const uint32_t i = piece_seed[seed_pieces[t]];
+    const uint32_t L = link[(uint64_t)n + i];
+    if (!link_valid(L, i)) return;
+    const uint32_t j = L >> 1, q = 1u - (L & 1u);
+    link[(uint64_t)n + i] = U_TERM;
+    link[(uint64_t)q * n + j] = U_TERM;
+    if (nrec) { nrec[i].link[1] = U_TERM; nrec[j].link[q] = U_TERM; }
+    atomicAdd(n_cut, 1u);
+}
+
 }  // namespace
 
 // Builds the BaseGraph on the device from the neighbour links.  rank_dev: seed rank of every (sorted) k-mer id,
@@ -732,11 +786,16 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         if (bad) return 0;
     }
 
+    if (nodes && c->cycle_seed_count) {                             // (second level of the segment route)
+        self_loop_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(link_dev, n, c->cycle_seed_list, c->cycle_seed_count, c->cycle_seed_cap);
+        LAUNCH_CHECK(c, "self_loop_seeds");
+    }
+
     DBuf<uint32_t> LA, counters;
     ALLOC_OR_FAIL(c, LA, n2);
     ALLOC_OR_FAIL(c, counters, 8);
     // results of either route
-    DBuf<uint32_t> flag_by_rank, len_by_rank, uidx_by_rank, ulen, uexts, o_data;
+    DBuf<uint32_t> flag_by_rank, len_by_rank, uidx_by_rank, ulen, uexts, o_data, useed;
     DBuf<uint64_t> ustart, words;
     DBuf<unsigned long long> uacc;
     DBuf<uint8_t> o_exts;
@@ -748,7 +807,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
 
     // ---- chain route (k-mers only): two walks per chain, no per-state table ----
     if (try_chains) {
-        DBuf<uint32_t> start_by_rank, seed_by_rank, ufirst, useed;
+        DBuf<uint32_t> start_by_rank, seed_by_rank, ufirst;
         ALLOC_OR_FAIL(c, flag_by_rank, n); ALLOC_OR_FAIL(c, len_by_rank, n); ALLOC_OR_FAIL(c, uidx_by_rank, (size_t)n + 1);
         ALLOC_OR_FAIL(c, start_by_rank, n); ALLOC_OR_FAIL(c, seed_by_rank, n);
         HIP_TRY(c, hipMemsetAsync(flag_by_rank.p, 0, (size_t)n * 4, c->stream));
@@ -791,7 +850,32 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         const bool ok = !long_chains && res[1] == 0 && seen == n;  // no walker gave up, every k-mer sits on an open chain
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends, chains hold %llu of %u k-mers%s\n", n_ends, (unsigned long long)seen, n,
                                          ok ? "" : " -> general route");
-        if (!ok && c->segment_depth > 0) return 0;                  // first level of the segment route: a cycle among the pieces, the caller takes the table route
+        if (!ok && c->segment_depth > 0) {
+            // first level of the segment route: k-mers no walker passed = cycles without a cut.  Found by a marking walk, cut at their seeds
+            // in the caller's links; the caller runs the route again (or, if nothing could be cut, the table route).
+            c->segment_new_cuts = 0;
+            if (res[1] == 0 && n_ends && c->segment_outer_links) {
+                DBuf<uint32_t> visited, cc;
+                const size_t vw = ((size_t)n + 31) / 32;
+                ALLOC_OR_FAIL(c, visited, vw); ALLOC_OR_FAIL(c, cc, 2);
+                HIP_TRY(c, hipMemsetAsync(visited.p, 0, vw * 4, c->stream));
+                HIP_TRY(c, hipMemsetAsync(cc.p, 0, 8, c->stream));
+                HIP_TRY(c, hipMemsetAsync(counters.p + 1, 0, 20, c->stream));       // the walk's own counters: capped, k-mers seen, next end
+                c->t_begin("unitig_chain_scan", n);
+                chain_scan_kernel<<<std::min<uint32_t>(cdiv(n_ends, 256), 2048), 256, 0, c->stream>>>(
+                    link_dev, rank_dev, n, LA.p, n_ends, k, flag_by_rank.p, len_by_rank.p, start_by_rank.p, seed_by_rank.p,
+                    counters.p + 4, (unsigned long long*)(counters.p + 2), counters.p + 1, nullptr, flags.p, nullptr, chain_cap, visited.p);
+                unvisited_cycle_seeds_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(link_dev, rank_dev, n, visited.p, c->segment_outer_links, const_cast<NodeRec*>(nrec), cc.p, cc.p + 1);
+                c->t_end();
+                LAUNCH_CHECK(c, "unvisited_cycle_seeds");
+                uint32_t h[2] = {0, 0};
+                HIP_TRY(c, hipMemcpyAsync(h, cc.p, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (!h[1]) c->segment_new_cuts = h[0];
+                if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: %llu k-mers on cycles without a cut, %u cycles cut at their seeds%s\n", (unsigned long long)(n - seen), h[0], h[1] ? " (a walk gave up)" : "");
+            }
+            return 0;
+        }
         // ---- segment route: long chains are cut into pieces, the pieces are compressed, the pieces are joined ----
         // (also when the chain route met a chain beyond its cap among short ones: a few very long chains in an ordinary graph)
         if (!ok && (long_chains || res[1] != 0) && !(c->opt("DBG_SEGMENTS") && atoi(c->opt("DBG_SEGMENTS")) == 0)) {
@@ -800,47 +884,74 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
             const uint32_t every = c->opt("DBG_SEGMENTS") ? (uint32_t)std::max(2, atoi(c->opt("DBG_SEGMENTS"))) : 128u;   // 32 / 64 / 128 / 256: 112 / 102 / 98 / 103 ms at config-3 size
             // this level's chain-route buffers go back to the pool: the first level below asks for the same sizes
             flag_by_rank.release(); len_by_rank.release(); uidx_by_rank.release(); start_by_rank.release(); seed_by_rank.release(); done_bits.release();
-            DBuf<uint32_t> link_cut;
-            ALLOC_OR_FAIL(c, link_cut, n2);
-            c->t_begin("unitig_segments", n);
-            HIP_TRY(c, hipMemcpyAsync(link_cut.p, link_dev, (size_t)n2 * 4, hipMemcpyDeviceToDevice, c->stream));
-            cut_links_kernel<<<cdiv(cdiv(n, every), 256), 256, 0, c->stream>>>(link_dev, link_cut.p, const_cast<NodeRec*>(nrec), n, every, flags.p);   // (the records are this call's own)
-            c->t_end();
-            LAUNCH_CHECK(c, "cut_links");
-            GraphDev pieces, joined;
+            DBuf<uint32_t> link_cut, cyc_list, cyc_ctl;
+            constexpr uint32_t CYC_CAP = 1u << 16;
+            ALLOC_OR_FAIL(c, cyc_list, CYC_CAP); ALLOC_OR_FAIL(c, cyc_ctl, 2);
             GraphDev* outer_sink = c->graph_sink;
-            c->graph_sink = &pieces;
-            c->segment_depth++;
-            dbg_graph sizes_only;
-            bool pieces_done = false;
-            int r = compress_links_device(c, k, n, key_hi, key_lo, exts, data, link_cut.p, rank_dev, spec, stranded, &sizes_only, &pieces_done, nullptr, nrec);
-            c->segment_depth--;
-            c->graph_sink = outer_sink;
-            if (r) return r;
-            link_cut.release();
-            {
-                bool bad = false;                                  // a cut link that was not mutual
-                DBG_TRY(links_bad(&bad));
-                if (bad) return 0;
-            }
-            bool joined_ok = false;
-            if (pieces_done) {
+            uint64_t ends_now = n_ends;                            // terminal states of the call's links (two more per cycle cut open below)
+            // A cycle cannot be joined the way an open chain is (its cut belongs at its seed k-mer, not at a sampled one): the second
+            // level reports the seed pieces of the cycles it met, their seed k-mers are cut for good, and the route runs once more.
+            for (int attempt = 0; attempt < 3 && !emitted; attempt++) {
+                ALLOC_OR_FAIL(c, link_cut, n2);
+                c->t_begin("unitig_segments", n);
+                HIP_TRY(c, hipMemcpyAsync(link_cut.p, link_dev, (size_t)n2 * 4, hipMemcpyDeviceToDevice, c->stream));
+                cut_links_kernel<<<cdiv(cdiv(n, every), 256), 256, 0, c->stream>>>(link_dev, link_cut.p, const_cast<NodeRec*>(nrec), n, every, flags.p);   // (the records are this call's own)
+                c->t_end();
+                LAUNCH_CHECK(c, "cut_links");
+                GraphDev pieces, joined;
+                c->graph_sink = &pieces;
+                c->segment_outer_links = link_dev;
+                c->segment_new_cuts = 0;
+                c->segment_depth++;
+                dbg_graph sizes_only;
+                bool pieces_done = false;
+                int r = compress_links_device(c, k, n, key_hi, key_lo, exts, data, link_cut.p, rank_dev, spec, stranded, &sizes_only, &pieces_done, nullptr, nrec);
+                c->segment_depth--;
+                c->graph_sink = outer_sink;
+                c->segment_outer_links = nullptr;
+                if (r) return r;
+                link_cut.release();
+                {
+                    bool bad = false;                              // a cut link that was not mutual
+                    DBG_TRY(links_bad(&bad));
+                    if (bad) return 0;
+                }
+                if (!pieces_done) {                                // cycles without a cut among the pieces (or links the walks rejected)
+                    if (c->segment_new_cuts && attempt < 2) { ends_now += 2ull * c->segment_new_cuts; continue; }   // cut at their seeds below: once more
+                    if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: the pieces hold a cycle that could not be cut -> table route\n");
+                    break;
+                }
                 const uint64_t n_pieces = pieces.n_nodes;
+                HIP_TRY(c, hipMemsetAsync(cyc_ctl.p, 0, 8, c->stream));
                 c->graph_sink = nullptr;                           // (graph_dev_compress installs its own)
+                c->cycle_seed_list = cyc_list.p; c->cycle_seed_count = cyc_ctl.p; c->cycle_seed_cap = CYC_CAP;
                 r = graph_dev_join_segments(c, k, stranded, spec, &pieces, &joined);
+                c->cycle_seed_list = nullptr; c->cycle_seed_count = nullptr; c->cycle_seed_cap = 0;
                 c->graph_sink = outer_sink;
                 if (r && r != 48) return r;                        // 48: node links not mutual -- the table route decides what that means
-                joined_ok = r == 0 && joined.filled && joined.n_nodes * 2 == (uint64_t)n_ends;
-                if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: %llu pieces (every %u) -> %llu unitigs, %u chain ends%s\n", (unsigned long long)n_pieces, every,
-                                                 (unsigned long long)joined.n_nodes, n_ends, joined_ok ? "" : " -> table route");
-            } else if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: the pieces hold a cycle -> table route\n");
-            if (joined_ok) {
-                words = std::move(joined.words); ustart = std::move(joined.start); ulen = std::move(joined.length);
-                o_exts = std::move(joined.exts); o_data = std::move(joined.data);
-                n_nodes = (uint32_t)joined.n_nodes; n_words = joined.n_words; total_bases = joined.n_bases;
-                emitted = true;
-                c->t_begin("unitig_segments_joined", n_nodes);     // (a marker in the timing list: the route ran to its end)
-                c->t_end();
+                const bool joined_ok = r == 0 && joined.filled && joined.n_nodes * 2 == ends_now;
+                uint32_t ctl[2] = {0, 0};
+                HIP_TRY(c, hipMemcpyAsync(ctl, cyc_ctl.p, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] segment route: %llu pieces (every %u) -> %llu unitigs, %llu chain ends, %u cycles of pieces%s\n",
+                                                 (unsigned long long)n_pieces, every, (unsigned long long)joined.n_nodes, (unsigned long long)ends_now, ctl[0],
+                                                 joined_ok ? "" : (r == 0 && ctl[0] && ctl[0] <= CYC_CAP && pieces.seed.p && attempt < 2 ? " -> cycles cut at their seeds, once more" : " -> table route"));
+                if (joined_ok) {
+                    words = std::move(joined.words); ustart = std::move(joined.start); ulen = std::move(joined.length);
+                    o_exts = std::move(joined.exts); o_data = std::move(joined.data);
+                    n_nodes = (uint32_t)joined.n_nodes; n_words = joined.n_words; total_bases = joined.n_bases;
+                    emitted = true;
+                    c->t_begin("unitig_segments_joined", n_nodes); // (a marker in the timing list: the route ran to its end)
+                    c->t_end();
+                    break;
+                }
+                if (r || !ctl[0] || ctl[0] > CYC_CAP || !pieces.seed.p) break;
+                cut_at_piece_seeds_kernel<<<cdiv(ctl[0], 256), 256, 0, c->stream>>>(cyc_list.p, ctl[0], pieces.seed.p, link_dev, const_cast<NodeRec*>(nrec), n, cyc_ctl.p + 1);
+                LAUNCH_CHECK(c, "cut_at_piece_seeds");
+                HIP_TRY(c, hipMemcpyAsync(ctl, cyc_ctl.p, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (!ctl[1]) break;
+                ends_now += 2ull * ctl[1];
             }
         }
         if (ok) {
@@ -1004,7 +1115,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         (void)walking;
         if (phase == 1) return c->fail(150, "unitig construction: cycle cutting did not terminate");
         // cycles: cut each at its seed's right side and redo the doubling
-        cut_cycles_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, link_dev, n);
+        cut_cycles_kernel<<<cdiv(n, 256), 256, 0, c->stream>>>(cur, rank_dev, link_dev, n, c->cycle_seed_list, c->cycle_seed_count, c->cycle_seed_cap);
         LAUNCH_CHECK(c, "cut_cycles");
     }
     // ---- seeds -> node order -> offsets ----
@@ -1068,6 +1179,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         // sizes only, its arrays stay null)
         sink->words = std::move(words); sink->start = std::move(ustart); sink->length = std::move(ulen);
         sink->exts = std::move(o_exts); sink->data = std::move(o_data);
+        if (c->segment_depth > 0) sink->seed = std::move(useed);   // (chain route: the pieces' seed k-mers, for cycles found one level up)
         sink->n_nodes = n_nodes; sink->n_words = n_words; sink->n_bases = total_bases; sink->stranded = stranded ? 1 : 0;
         sink->filled = true;
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -34,11 +34,12 @@ def compress_mode(request, ctx):
     ctx.set_option("DBG_COMPRESS", old)
 
 
-@pytest.fixture(autouse=True, params=[None, "3", "2"], ids=["", "segments3", "segments2"])
+@pytest.fixture(autouse=True, params=[None, "3", "2", "50"], ids=["", "segments3", "segments2", "segments50"])
 def forced_segments(request, ctx, compress_mode):
     """Every test of the device route runs three times: as is, and with the segment route of unitig.hip forced onto every graph
-    (DBG_SEGMENTS_FORCE; every 3rd / 2nd k-mer cuts its right link, the pieces are compressed and joined again by compress_graph's
-    device route; graphs with a cycle fall back to the table route): the random contigs, palindromes, hairpins, degenerate inputs,
+    (DBG_SEGMENTS_FORCE; every 3rd / 2nd / 50th k-mer cuts its right link, the pieces are compressed and joined again by compress_graph's
+    device route; a cycle is cut at its seed k-mer -- named by the second level when it holds a cut, found by a marking walk when it
+    holds none, as with every 50th -- and the route runs once more): the random contigs, palindromes, hairpins, degenerate inputs,
     ScmapCompress data and seed orders of the tests below all cross the cut-and-join."""
     if request.param is None:
         yield None
@@ -242,9 +243,20 @@ def test_compress_long_chains(ctx, compress_mode, k, stranded, spec_i):
     cyc = R.random_dna(rng, 20000)
     contigs.append(np.concatenate([cyc, cyc[:k - 1]]))
     contigs.append(np.concatenate([cyc[10000:], cyc[:10000 + k - 1]]))
+    # ... and a short one, which the segment route's sampled cuts (every 128th k-mer) are likely to miss: found by the marking walk
+    tiny = R.random_dna(rng, 70)
+    contigs.append(np.concatenate([tiny, tiny, tiny[:k - 1]]))
     t = gpu_table(ctx, contigs, k, 2, stranded)
+    ctx.enable_timing(True)
     got, want = compare(ctx, t, k, stranded, SPECS[spec_i])
+    assert "unitig_segments_joined" in [x["name"] for x in ctx.timings()]      # no cycle sends the call to the table route any more
+    ctx.enable_timing(False)
     assert max(int(x) for x in got.arrays()["length"]) > (1 << 14) + k
+    with ctx.options(DBG_SEGMENTS="16"):                             # every cycle holds a cut: cut again at its seed, joined on the second run
+        ctx.enable_timing(True)
+        compare(ctx, t, k, stranded, SPECS[spec_i])
+        assert "unitig_segments_joined" in [x["name"] for x in ctx.timings()]
+        ctx.enable_timing(False)
     # the doubling over the states the walkers left (default since round 6) against the doubling over every state
     with ctx.options(DBG_UNITIG_FULL_DOUBLING="1"):
         compare(ctx, t, k, stranded, SPECS[spec_i])
