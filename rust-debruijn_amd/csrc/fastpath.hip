@@ -1386,8 +1386,12 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 4 : 1) bin_count_kernel(const 
         const uint32_t bin = s_ticket;
         __syncthreads();
         if (bin >= n_bins) break;
-        if (threadIdx.x == 0) s_ticket = atomicAdd(&gflags[BIN_TICKET], 1u);          // in flight while this bin is counted
+        // in flight while this bin is counted; the value stays in a register until the bin is done (stored to LDS right away, the wave
+        // would wait for the round trip here, in front of the segment bounds' loads)
+        uint32_t next_ticket = 0;
+        if (threadIdx.x == 0) next_ticket = atomicAdd(&gflags[BIN_TICKET], 1u);
         bin_count_body<KW, NBW, IS_SET, NT, T, WIDE, WEIGHTED>(bin, recs, recs_alt, alt_from, seg_beg, seg_end, n_src, seg_stride, k, stranded, min_obs, out, out_cap, out_cursor, gflags);
+        if (threadIdx.x == 0) s_ticket = next_ticket;
         __syncthreads();
     }
 }
