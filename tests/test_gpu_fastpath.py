@@ -253,6 +253,25 @@ def test_fast_sort_variants(ctx, env, k, kind):
     assert_tables_equal(got, want, kind == 1)
 
 
+@pytest.mark.parametrize("grid", ["0", "1", "3", "5000"])
+@pytest.mark.parametrize("k,kind,labels", [(47, 1, 4), (31, 0, 0), (63, 1, 40), (47, 1, 3000)], ids=["k47-set4", "k31-count", "k63-set40", "k47-lists"])
+def test_fast_resident_workgroups(ctx, grid, k, kind, labels):
+    """The counting kernels (bin_count, bin_labels) run as resident workgroups that take bins from a ticket counter (round 6).  Whatever the
+    grid -- one workgroup per bin (DBG_FAST_PERSIST=0, the old launch), a single resident workgroup, three, or more than there are bins --
+    the table is the oracle's; many small bins (DBG_FAST_TARGET) so that every workgroup goes round its loop many times."""
+    hs = dbg.synth_reads_host(n_reads=4000, read_len=150, error_rate=0.003, stranded=False, n_colours=max(min(labels, 200), 1))
+    width, data = 0, None
+    if kind:                                                         # 200 distinct 16-bit labels: the label-list kernel
+        width = 1 if labels <= 255 else 2
+        data = np.asarray(hs.data) if width == 1 else (np.asarray(hs.data).astype(np.uint32) * 300 + 7).astype(np.uint16)
+    ss = O.SeqSet(hs.words, hs.start, hs.length, None, data, width)
+    want = O.filter_kmers(ss, k, kind, 2, stranded=False)
+    with ctx.options(DBG_FAST_PERSIST=grid, DBG_FAST_TARGET="600"):
+        summ = dbg.CountFilterSet(2) if kind else dbg.CountFilter(2)
+        got, _ = dbg.filter_kmers(dbg.HostSeqs(hs.words, hs.start, hs.length, None, data, width), summ, False, False, 4, k=k, ctx=ctx)
+    assert_tables_equal(got, want, kind == 1)
+
+
 def _with_env(ctx, env, fn):
     with ctx.options(**env):
         return fn()
