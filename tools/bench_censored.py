@@ -2,7 +2,7 @@
 dbg_compress_kmers_with_hash_dev, three times, with the kernels' HIP-event times (DBG_DEBUG=1 in the environment: the routes' own lines).
     python tools/bench_censored.py [reads] [k]"""
 import importlib, ctypes as C, time, torch, sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 dbg = importlib.import_module("rust-debruijn_amd"); capi = importlib.import_module("rust-debruijn_amd._capi")
 ctx = dbg.Context(0); lib = ctx.lib; dev = torch.device("cuda", 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
