@@ -1045,7 +1045,11 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         uint32_t n_ends = 0;
         HIP_TRY(c, hipMemcpyAsync(&n_ends, counters.p, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (n_ends) {
+        // a handful of ends in front of millions of states (an error-free genome: one chain; its pieces in the segment route's second
+        // level): the walkers would cover n_ends x 2^15 states at one dependent read per microsecond each -- 30 ms for 4 ends -- and
+        // leave nearly everything to the doubling anyway
+        const bool few_ends = n_ends && (uint64_t)n2 / n_ends > 65536u && !c->opt("DBG_WALK_CAP");
+        if (n_ends && !few_ends) {
             const uint32_t wblocks = std::min<uint32_t>(cdiv(n_ends, 256), 2048);        // 8 resident blocks per CU
             // the table walk goes twice as far as the chain route's: at config-3 size (censored: 1.3e5 chains of ~3900 k-mers, the longest 1e5)
             // 2^14 left 16 % of the states to the doubling (156 ms), 2^15 leaves 3 % (30 ms) for 10 ms more of walking, 2^16 nothing for 36 more
@@ -1060,7 +1064,7 @@ int compress_links_device(dbg_ctx* c, int k, uint32_t n, const uint64_t* key_hi,
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->t_end();
         const uint64_t written = (uint64_t)res[2] | ((uint64_t)res[3] << 32);
-        walked = res[1] == 0 && written == n2;                      // no walker gave up, no state on a cycle
+        walked = !few_ends && res[1] == 0 && written == n2;         // no walker gave up, no state on a cycle
         if (c->opt("DBG_DEBUG")) fprintf(stderr, "[unitig] %u chain ends wrote %llu of %u states%s\n", n_ends, (unsigned long long)written, n2,
                                          walked ? "" : " -> doubling");
         if (walked) cur = JA.p;

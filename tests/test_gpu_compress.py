@@ -331,6 +331,27 @@ def test_compress_segment_route_few_long_chains(ctx, compress_mode):
     assert max(int(x) for x in got.arrays()["length"]) > (1 << 14) + k and len(got.arrays()["length"]) > 3000
 
 
+def test_compress_one_chain_few_ends(ctx, compress_mode):
+    """An error-free genome in one piece: two chain ends in front of 4e5 states.  The table route leaves the end walks out (they would
+    cover 2 x 2^15 states at a dependent read each) and doubles over everything; the segment route cuts, joins, and meets the same
+    situation among its pieces when the genome is larger."""
+    if compress_mode != "device":
+        pytest.skip("device route")
+    k = 31
+    rng = np.random.default_rng(5150)
+    g = R.random_dna(rng, 200000)
+    contigs = [g[a:a + 5000] for a in range(0, 200000 - 5000 + 1, 1000)]
+    t = gpu_table(ctx, contigs, k, 2, False)
+    got, want = compare(ctx, t, k, False, SPECS[0])
+    assert len(got.arrays()["length"]) <= 3 and max(int(x) for x in got.arrays()["length"]) > 150000
+    with ctx.options(DBG_SEGMENTS="0"):
+        ctx.enable_timing(True)
+        compare(ctx, t, k, False, SPECS[0])
+        names = [x["name"] for x in ctx.timings()]
+        ctx.enable_timing(False)
+    assert "unitig_pointer_jump" in names and "unitig_segments_joined" not in names
+
+
 def test_compress_non_mutual_links(ctx, compress_mode):
     """Inconsistent Exts: A's only right extension leads to B and B has a single left extension, but to a k-mer that is
     not A.  The reference walks such input in visiting order (compression.rs:450-541); the device routes refuse it
